@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of the batched rollout engine + PPO on N MI355X GPUs.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch: for every environment of the rank, the
+PPO actor-critic forward (AugmentedNatureCNN + heads) samples an action, the macro-step kernel runs
+RobotEnv.step (controller + all physics.step() sub-steps + reward/done), the observation kernel
+renders the 5x64x64 uint8 observation, the transition is stored in the HBM rollout buffer; every
+`--rollout` steps a full PPO update (GAE, `--epochs` epochs of minibatch forward/backward/Adam, one
+flattened-gradient all-reduce per minibatch when N > 1) runs inside the timed region.
+Workload = BASELINE.json configs[1]: acorn_env (labelled stand-in hull: the reference checkout has no
+acorn.stl), 4096 envs per GPU, direction 0, default flags; synthetic = deterministic reset state,
+actions from the randomly initialised policy. Weak scaling: per-GPU work is fixed as N grows.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md)
+# algorithmic bytes per env per macro-step launch of k_macro_step: state in 47 x 4 + action 24,
+# state out 40 x 4, reward 4 + done 1 + goals 16 + info 64
+MACRO_BYTES_PER_ENV = 47 * 4 + 24 + 40 * 4 + 4 + 1 + 16 + 64
+OBS_BYTES_PER_ENV = 5 * 64 * 64 + 14 * 4 + 8
+
+
+def cpu_baseline(obj, seconds_target=15.0):
+    """The C oracle (oracle/, `port`: the reference's own dm_control + SB3 stack is not installable here) timed
+    on this box's host cores over a bounded sample of the same workload (macro step + observation, no policy)."""
+    from oracle import orc
+    threads = orc.lib().orc_num_threads()
+    m = orc.Model(obj)
+    n = 32 * threads
+    b = orc.BatchOracle(m, n)
+    rng = np.random.default_rng(0)
+    obs = np.zeros((n, 5, 64, 64), np.uint8)
+    b.step(np.clip(rng.normal(size=(n, 6)), -1, 1), obs=obs)        # warm-up
+    t0 = time.time(); steps = 0; sub = 0
+    while time.time() - t0 < seconds_target and steps < 64:
+        sub += b.step(np.clip(rng.normal(size=(n, 6)), -1, 1), obs=obs); steps += 1
+    dt = time.time() - t0
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{n} envs x {steps} macro steps incl. observation render, no policy; {sub / dt:.0f} mj-substeps/s",
+            "note": "reference dm_control+SB3 stack cannot be installed here; its recorded whole-training rate is 3.95-12.97 env-steps/s (BASELINE.md)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
+    ap.add_argument("--object", default="acorn")
+    ap.add_argument("--direction", type=int, default=0)
+    ap.add_argument("--rollout", type=int, default=8, help="PPO n_steps (rollout length per env)")
+    ap.add_argument("--epochs", type=int, default=2)
+    ap.add_argument("--minibatch", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ppo", action="store_true", help="diagnostic: rollout only (INVALID as a headline number)")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import BatchedRobotEnv, default_config
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3 import PPO, GpuVecEnv
+    from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
+
+    cfg = default_config(sim_env=f"/xmls/{a.object}_env.xml", direction=a.direction)
+    env = GpuVecEnv(BatchedRobotEnv(cfg, n_envs=a.envs, device_index=local, auto_reset=True))
+    model = PPO("MultiInputPolicy", env, n_steps=a.rollout, batch_size=a.minibatch, n_epochs=a.epochs, seed=1234 + rank,
+                policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]))
+    batch = env.env.batch
+
+    def run(nsteps):
+        """nsteps vec-env steps with a PPO update after every `rollout` of them."""
+        done_steps = 0; subs = 0
+        while done_steps < nsteps:
+            # collect_rollouts always does n_steps steps; trim the last chunk
+            chunk = min(a.rollout, nsteps - done_steps)
+            model.n_steps = chunk; model.rollout_buffer.n_steps = chunk
+            model.collect_rollouts()
+            if not a.no_ppo and chunk == a.rollout:
+                model.train()
+            done_steps += chunk
+        model.n_steps = a.rollout; model.rollout_buffer.n_steps = a.rollout
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(a.warmup)
+    sync()
+    batch.kernel_time(reset=True)
+    sub_before = None
+    # count sub-steps of the timed region on device without host syncs: accumulate n_substeps after each step
+    sub_acc = torch.zeros((), dtype=torch.int64, device=env.device)
+    orig_step = env.step
+
+    def counted_step(actions):
+        r = orig_step(actions)
+        sub_acc.add_(r[3]["n_substeps"].sum())
+        return r
+    env.step = counted_step
+    sync()
+    t0 = time.perf_counter()
+    run(a.steps)
+    sync()
+    dt = time.perf_counter() - t0
+    env.step = orig_step
+    tmax = torch.tensor([dt], dtype=torch.float64, device=env.device)
+    subs = sub_acc.double().reshape(1)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dist.all_reduce(subs, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item()); total_sub = float(subs.item())
+    k_ms, k_n = batch.kernel_time(reset=True)
+
+    if rank == 0:
+        total_env_steps = a.envs * world * a.steps
+        value = total_env_steps / dt
+        macro_bytes = MACRO_BYTES_PER_ENV * a.envs
+        achieved = macro_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "env-steps/sec (whole node), acorn_env 4096 envs/GPU", "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (deterministic reset state, actions sampled from the randomly initialised PPO policy)",
+            "config": {"workload": f"{a.object}_env ({'stand-in hull; ' if a.object == 'acorn' else ''}direction {a.direction}), "
+                                   f"{a.envs} envs/GPU, macro-step + observation + PPO actor-critic fwd each step, "
+                                   f"PPO update every {a.rollout} steps ({a.epochs} epochs, minibatch {a.minibatch})",
+                       "envs_per_gpu": a.envs, "parallelism": f"dp{world}", "ppo_in_timed_region": not a.no_ppo},
+            "mj_substeps_per_s": total_sub / dt, "mean_substeps_per_env_step": total_sub / total_env_steps,
+            "roofline": {"bound": "hbm", "kernel": "k_macro_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms_avg": k_ms, "launches": k_n,
+                         "algorithmic_bytes_per_launch": macro_bytes,
+                         "note": "lane-per-env macro-step kernel is VALU/latency-bound, not HBM-bound (DESIGN.md §4)"},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(a.object)
+            except Exception as ex:      # the oracle is optional test infrastructure
+                out["cpu_baseline"] = {"value": None, "error": str(ex)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,125 @@
+/*
+ * grip_sim.h -- C ABI of the MI355X batched rollout engine (libgrip_sim.so).
+ *
+ * The reference has no FFI of its own: its hot path sits behind Python
+ * surfaces and one implicit operator API, dm_control's `Physics`
+ * (SURVEY.md §8b). Each entry point below names the reference call sites it
+ * replaces. Plain pointers and sizes only; no torch types. All *_dev pointers
+ * are HIP device pointers owned by the caller (torch tensors' data_ptr());
+ * `stream` is a hipStream_t passed as void* (0 = the null stream). Every call
+ * returns 0 on success, <0 on error (text via grip_last_error()); nothing
+ * throws across the ABI. One GripBatch is not re-entrant; distinct batches
+ * are independent. Per-lane numerical faults (NaN, contact overflow) are
+ * reported in GripStepOut.fault, never as a call failure.
+ */
+#ifndef GRIP_SIM_H
+#define GRIP_SIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRIP_NQ 14
+#define GRIP_NV 13
+#define GRIP_NU 7
+#define GRIP_OBS_C 5
+#define GRIP_OBS_H 64
+#define GRIP_OBS_W 64
+#define GRIP_MAXCON 16
+
+typedef struct GripModel GripModel;
+typedef struct GripBatch GripBatch;
+
+/* config/base_config.py:12-54 -- the fields the hot path reads */
+typedef struct {
+    int32_t max_steps;          /* :36  inner-loop cap of robot_env.py:95 */
+    int32_t time_horizon;       /* :45 */
+    int32_t include_roll;       /* :33 */
+    int32_t full_observation;   /* :22 */
+    int32_t her_buffer;         /* :39 */
+    int32_t auto_reset;         /* VecEnv semantics (DummyVecEnv, train_agent.py:22): reset a lane when done */
+    float max_translation;      /* :30 */
+    float max_rotation;         /* :29 */
+    float pos_tolerance;        /* :32 */
+    float grasp_tolerance;      /* :31 */
+    float target_dir[2];        /* robot_env.py:30-33: (1,0) for direction 0, (1,1) for 45 (unnormalised) */
+} GripEnvConfig;
+
+/* Per-env outputs of one macro step: the SoA form of the tuple and `info` dict that
+ * RobotEnv.step returns (robot_env.py:226-241). Any pointer may be NULL to skip it. */
+typedef struct {
+    float *reward;            /* [N]   robot_env.py:188-197 */
+    uint8_t *done;            /* [N]   :201-206 */
+    float *achieved_goal;     /* [N,2] :178 */
+    float *desired_goal;      /* [N,2] :176-177 */
+    int32_t *status;          /* [N]   Status enum :19-22 (value before auto-reset) */
+    int32_t *episode_step;    /* [N]   :222,234 (value before auto-reset) */
+    int32_t *gripper_open;    /* [N]   :231 */
+    int32_t *object_grasped;  /* [N]   :233 */
+    int32_t *position_reached;/* [N]   bit0 target, bit1 initial, bit2 fail (:83-85,239) */
+    float *total_distance;    /* [N]   :209 */
+    float *line_distance;     /* [N]   :213-220 */
+    float *gripper_position;  /* [N,3] :237 */
+    float *object_position;   /* [N,3] :238 */
+    float *init_obj_pos;      /* [N,3] :87 */
+    int32_t *n_substeps;      /* [N]   physics.step() calls this macro step */
+    int32_t *fault;           /* [N]   bit0 NaN state, bit1 contact-list overflow, bit2 solver hit iteration cap */
+} GripStepOut;
+
+const char *grip_last_error(void);
+
+/* mujoco.Physics.from_xml_path (robot_env.py:26): load a compiled model blob
+ * (mujoco_rl_manipulate_unknown_objects_amd/model/compiler.py output). Host only. */
+int grip_model_load(const char *blob_path, GripModel **out);
+void grip_model_free(GripModel *m);
+int grip_model_nvert(const GripModel *m);
+
+/* N environments of one model on one device. RobotEnv.__init__ (robot_env.py:24-44), N times. */
+int grip_batch_create(const GripModel *m, int n_envs, int device_id, GripBatch **out);
+void grip_batch_destroy(GripBatch *b);
+int grip_batch_set_config(GripBatch *b, const GripEnvConfig *cfg);
+int grip_batch_num_envs(const GripBatch *b);
+
+/* RobotEnv.reset (robot_env.py:56-75): physics.reset(), gravity-compensation xfrc, counters.
+ * mask_dev: uint8[N] (reset where != 0) or NULL for all. Goals/pad for the reset state are
+ * written to `out` (achieved_goal, desired_goal = target direction, :71-72). */
+int grip_batch_reset(GripBatch *b, const uint8_t *mask_dev, const GripStepOut *out, void *stream);
+
+/* RobotEnv.step (robot_env.py:77-241) for every env: controller (actuator.py:58-102), the
+ * MOVE / RETURN / OPEN / CLOSE loops of physics.step() (:97-168), reward (reward.py:18-41),
+ * done and info. actions_dev: float32 [N,6] ([N,5] when !include_roll). */
+int grip_batch_step(GripBatch *b, const float *actions_dev, const GripStepOut *out, void *stream);
+
+/* RobotEnv.get_observation (robot_env.py:275-293): RGB + depth render of `gripper_camera`
+ * (sensor.py:56-77), transform_depth (utils.py:11-19) and the sensor pad
+ * (pad[0,0] = check_grasp, pad[0,1] = pheromone_level). obs_dev: uint8 [N,5,64,64] CHW
+ * ([N,4,64,64] when !full_observation). */
+int grip_batch_observe(GripBatch *b, uint8_t *obs_dev, void *stream);
+
+/* ---- low-level hooks (the dm_control Physics surface the reference touches; used by tests) ---- */
+/* physics.data.qpos / qvel / ctrl / qacc_warmstart, env-major float32 [N,14],[N,13],[N,7],[N,13];
+ * host_or_dev = 0: host pointers (synchronous copy), 1: device pointers. NULL skips a field. */
+int grip_batch_get_state(GripBatch *b, float *qpos, float *qvel, float *ctrl, float *warm, int host_or_dev, void *stream);
+int grip_batch_set_state(GripBatch *b, const float *qpos, const float *qvel, const float *ctrl, const float *warm,
+                         int host_or_dev, void *stream);
+int grip_batch_get_flags(GripBatch *b, int32_t *episode_step, int32_t *status, int32_t *gripper_open, void *stream); /* host */
+int grip_batch_set_flags(GripBatch *b, const int32_t *episode_step, const int32_t *status, const int32_t *gripper_open, void *stream);
+/* k calls of physics.step() (robot_env.py:100) with the current ctrl, every env. */
+int grip_batch_substep(GripBatch *b, int k, void *stream);
+/* data.ncon / data.contact[i] (actuator.py:157-176) and derived quantities of the CURRENT state, to host:
+ * ncon int32[N]; con float32 [N,GRIP_MAXCON,10] = pos3, normal3, dist, geom1, geom2, pad;
+ * xpos float32 [N,8,3] (bodies world, ee, base, lk, lf, rk, rf, object); qacc float32 [N,13] of a forward pass. */
+int grip_batch_debug_forward(GripBatch *b, int32_t *ncon, float *con, float *xpos, float *qacc, float *qacc_smooth,
+                             float *M, float *bias, void *stream);
+/* mjlib.mj_jacBody for body `ee` (actuator.py:86-95) + pinv IK: target_qpos float32 [N,5] to host. */
+int grip_batch_target_pose(GripBatch *b, const float *actions_dev, float *target_qpos_host, void *stream);
+
+/* timing of the macro-step kernel on its own stream: average ms per launch since the last call with reset != 0 */
+int grip_batch_kernel_time(GripBatch *b, int reset, float *ms_avg, int *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

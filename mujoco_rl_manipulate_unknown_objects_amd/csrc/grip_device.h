@@ -1,0 +1,138 @@
+// grip_device.h -- device-side model layout and small fp32 vector algebra for the gfx950 kernels.
+//
+// One environment lives in one wavefront lane (64 envs per wave). The articulated system of
+// xmls/<object>_env.xml (reference robot xml :58-99) is folded, at model-load time on the host,
+// into FOUR rigid groups -- G = ee + welded base, L = left knuckle + welded finger, R = right
+// knuckle + finger, O = object -- because welded bodies never move relative to each other.
+// This is a restructuring of the same mechanics the reference gets from MuJoCo, not a port.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GN_GEOM 7          // 0 floor, 1 base, 2 lk, 3 lf, 4 rk, 5 rf, 6 object
+#define GN_HULL 6
+#define GN_PAIR_MAX 16
+#define G_MAXC 16          // contact slots per env (GRIP_MAXCON)
+#define WAVE 64
+
+enum { GRP_G = 0, GRP_L = 1, GRP_R = 2, GRP_O = 3, GRP_WORLD = 4 };
+
+struct DevModel {
+    float timestep, gravity_z, impratio, tolerance;
+    int iterations;
+    float margin;
+    float k_con, b_con, k_lim, b_lim;          // spring/damper of the reference acceleration (solref)
+    float solimp[5], lim_solimp[5];
+    float meaninertia;
+    // rigid groups
+    float grp_mass[4];
+    float grp_com[4][3];                        // COM in the group frame
+    float grp_inertia[4][6];                    // about the COM, group frame: xx yy zz xy xz yz
+    float ee_pos0[3];
+    float base_pos[3], base_R[9];               // base frame in the ee frame
+    float kn_pos[2][3], kn_R[2][9];             // knuckle frames in the base frame (before the hinge)
+    float fin_pos[2][3], fin_R[2][9];           // finger frames in the knuckle frames
+    float armature[13], damping[13];
+    float range[7][2], gear[7], ctrlrange[7][2];
+    float dof_invweight0[7];
+    float qpos0[14];
+    // geoms
+    float geom_center[GN_GEOM][3];              // in the geom's body frame
+    float geom_rbound[GN_GEOM];
+    float geom_friction[GN_GEOM][2];            // sliding, torsional
+    float geom_invweight[GN_GEOM];              // body_invweight0[geom body][0]
+    int geom_group[GN_GEOM];                    // rigid group of the geom's body (GRP_WORLD for the floor)
+    int hull_vadr[GN_HULL], hull_vnum[GN_HULL];
+    int npair;
+    int pairs[GN_PAIR_MAX][2];
+    const float *hull_verts;                    // [nvert][4] xyz + pad, body frame
+    const int *hull_nadr;                       // CSR over all hull vertices
+    const int *hull_nbr;
+    // camera / rendering
+    float cam_pos[3], cam_R[9], cam_fovy;
+    float znear, zfar;
+    float geom_rgba[GN_GEOM][4];
+    float floor_rgb[6], sky_rgb[6];
+    float light_dir[2][3];
+    int hull_padr[GN_HULL], hull_pnum[GN_HULL];
+    const float *hull_planes;                   // [nplane][4] n.x <= d, body frame
+};
+
+struct DevConfig {
+    int max_steps, time_horizon, include_roll, full_observation, her_buffer, auto_reset;
+    float max_translation, max_rotation, pos_tolerance, grasp_tolerance;
+    float dir_x, dir_y;
+};
+
+// ---------------------------------------------------------------- fp32 helpers
+struct V3 { float x, y, z; };
+struct M3 { float m[9]; };                      // row-major
+
+#define DEVI __device__ __forceinline__
+
+DEVI V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+DEVI V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEVI V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEVI V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+DEVI V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+DEVI V3 operator*(float s, V3 a) { return v3(a.x * s, a.y * s, a.z * s); }
+DEVI float dot(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+DEVI V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+DEVI float norm(V3 a) { return sqrtf(dot(a, a)); }
+DEVI V3 normalized(V3 a) {
+    float n = norm(a);
+    if (n < 1e-20f) return v3(1.f, 0.f, 0.f);
+    float inv = 1.0f / n;
+    return a * inv;
+}
+DEVI V3 ldv(const float *p) { return v3(p[0], p[1], p[2]); }
+DEVI V3 mulv(const M3 &R, V3 v) {
+    return v3(R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z, R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z,
+              R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z);
+}
+DEVI V3 multv(const M3 &R, V3 v) {               // R^T v
+    return v3(R.m[0] * v.x + R.m[3] * v.y + R.m[6] * v.z, R.m[1] * v.x + R.m[4] * v.y + R.m[7] * v.z,
+              R.m[2] * v.x + R.m[5] * v.y + R.m[8] * v.z);
+}
+DEVI M3 mulm(const M3 &A, const M3 &B) {
+    M3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
+    return r;
+}
+DEVI M3 ldm(const float *p) { M3 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.m[i] = p[i];
+    return r; }
+DEVI V3 col(const M3 &R, int j) { return v3(R.m[j], R.m[3 + j], R.m[6 + j]); }
+DEVI M3 quat_mat(float w, float x, float y, float z) {
+    M3 R;
+    R.m[0] = 1 - 2 * (y * y + z * z); R.m[1] = 2 * (x * y - w * z); R.m[2] = 2 * (x * z + w * y);
+    R.m[3] = 2 * (x * y + w * z); R.m[4] = 1 - 2 * (x * x + z * z); R.m[5] = 2 * (y * z - w * x);
+    R.m[6] = 2 * (x * z - w * y); R.m[7] = 2 * (y * z + w * x); R.m[8] = 1 - 2 * (x * x + y * y);
+    return R;
+}
+// symmetric 3x3 (xx yy zz xy xz yz) times vector
+DEVI V3 symv(const float *s, V3 v) {
+    return v3(s[0] * v.x + s[3] * v.y + s[4] * v.z, s[3] * v.x + s[1] * v.y + s[5] * v.z, s[4] * v.x + s[5] * v.y + s[2] * v.z);
+}
+// world inertia R S R^T of a symmetric local tensor, returned symmetric-packed
+DEVI void rot_sym(const M3 &R, const float *s, float *out) {
+    // T = R * S
+    float T[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float a = R.m[3 * i], b = R.m[3 * i + 1], c = R.m[3 * i + 2];
+        T[3 * i] = a * s[0] + b * s[3] + c * s[4];
+        T[3 * i + 1] = a * s[3] + b * s[1] + c * s[5];
+        T[3 * i + 2] = a * s[4] + b * s[5] + c * s[2];
+    }
+    out[0] = T[0] * R.m[0] + T[1] * R.m[1] + T[2] * R.m[2];
+    out[1] = T[3] * R.m[3] + T[4] * R.m[4] + T[5] * R.m[5];
+    out[2] = T[6] * R.m[6] + T[7] * R.m[7] + T[8] * R.m[8];
+    out[3] = T[0] * R.m[3] + T[1] * R.m[4] + T[2] * R.m[5];
+    out[4] = T[0] * R.m[6] + T[1] * R.m[7] + T[2] * R.m[8];
+    out[5] = T[3] * R.m[6] + T[4] * R.m[7] + T[5] * R.m[8];
+}

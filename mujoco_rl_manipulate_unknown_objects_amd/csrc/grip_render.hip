@@ -1,0 +1,143 @@
+// grip_render.hip -- observation kernel: RobotEnv.get_observation (robot_env.py:275-293).
+//
+// One 256-thread workgroup per environment, 16 pixels per thread. Rays from `gripper_camera`
+// (robot xml :60) are clipped against the floor plane and the six convex hulls (Cyrus-Beck over
+// the hull face planes, read with workgroup-uniform indices, after a per-ray bounding-sphere
+// test); flat Lambert shading gives RGB (sensor.py:64-66), the distance along the optical axis
+// gives depth (sensor.py:69-72), which goes through transform_depth (utils.py:11-19) with its
+// two whole-image reductions done in LDS. The uint8 CHW observation (5 x 64 x 64 = 20 480 B per
+// env, 98 % of the macro step's algorithmic HBM bytes) is written once, coalesced, together with
+// the sensor pad scalars pad[0,0] = check_grasp, pad[0,1] = pheromone_level (robot_env.py:281-283)
+// that the step kernel left in pad_grasp / pad_pher.
+#include <hip/hip_runtime.h>
+#include "grip_device.h"
+
+#define RW 64
+#define RH 64
+#define RTHREADS 256
+#define RPIX (RW * RH)
+
+struct Frames { float p[6][3]; float R[6][9]; float cam_o[3]; float cam_R[9]; };
+
+__device__ static void compute_frames(const DevModel &m, const float *qpos, int n, int e, Frames &f) {
+    float q[14];
+    for (int i = 0; i < 14; i++) q[i] = qpos[(size_t)i * n + e];
+    V3 pe = v3(m.ee_pos0[0] + q[0], m.ee_pos0[1] + q[1], m.ee_pos0[2] + q[2]);
+    float sr = sinf(q[3]), cr = cosf(q[3]), sy = sinf(q[4]), cy = cosf(q[4]);
+    M3 Re;
+    Re.m[0] = cy; Re.m[1] = -sy; Re.m[2] = 0.f; Re.m[3] = cr * sy; Re.m[4] = cr * cy; Re.m[5] = -sr; Re.m[6] = sr * sy; Re.m[7] = sr * cy; Re.m[8] = cr;
+    auto put = [&](int g, V3 p, const M3 &R) { f.p[g][0] = p.x; f.p[g][1] = p.y; f.p[g][2] = p.z; for (int i = 0; i < 9; i++) f.R[g][i] = R.m[i]; };
+    V3 pb = pe + mulv(Re, ldv(m.base_pos)); M3 Rb = mulm(Re, ldm(m.base_R));
+    put(0, pb, Rb);
+    for (int s = 0; s < 2; s++) {
+        V3 pk = pb + mulv(Rb, ldv(m.kn_pos[s])); M3 Rk0 = mulm(Rb, ldm(m.kn_R[s]));
+        float sq = sinf(q[5 + s]), cq = cosf(q[5 + s]);
+        M3 Ry; Ry.m[0] = cq; Ry.m[1] = 0; Ry.m[2] = sq; Ry.m[3] = 0; Ry.m[4] = 1; Ry.m[5] = 0; Ry.m[6] = -sq; Ry.m[7] = 0; Ry.m[8] = cq;
+        M3 Rk = mulm(Rk0, Ry);
+        put(1 + 2 * s, pk, Rk);
+        put(2 + 2 * s, pk + mulv(Rk, ldv(m.fin_pos[s])), mulm(Rk, ldm(m.fin_R[s])));
+    }
+    float qn = rsqrtf(q[10] * q[10] + q[11] * q[11] + q[12] * q[12] + q[13] * q[13]);
+    put(5, v3(q[7], q[8], q[9]), quat_mat(q[10] * qn, q[11] * qn, q[12] * qn, q[13] * qn));
+    V3 co = pe + mulv(Re, ldv(m.cam_pos)); M3 Rc = mulm(Re, ldm(m.cam_R));
+    f.cam_o[0] = co.x; f.cam_o[1] = co.y; f.cam_o[2] = co.z;
+    for (int i = 0; i < 9; i++) f.cam_R[i] = Rc.m[i];
+}
+
+__device__ static bool ray_hull(const DevModel &m, const Frames &f, int g, V3 o, V3 dir, float &thit, V3 &nrm) {
+    V3 p = ldv(f.p[g - 1]); M3 R = ldm(f.R[g - 1]);
+    V3 c = p + mulv(R, ldv(m.geom_center[g]));
+    V3 oc = o - c;
+    float dd = dot(dir, dir), bq = dot(oc, dir), cq = dot(oc, oc) - m.geom_rbound[g] * m.geom_rbound[g];
+    if (bq * bq - dd * cq < 0.f) return false;
+    V3 ol = multv(R, o - p), dl = multv(R, dir);
+    const float *pl = m.hull_planes + 4 * m.hull_padr[g - 1];
+    int np = m.hull_pnum[g - 1], ent = -1;
+    float tin = -3.0e38f, tout = 3.0e38f;
+    for (int i = 0; i < np; i++) {
+        float nx = pl[4 * i], ny = pl[4 * i + 1], nz = pl[4 * i + 2], dw = pl[4 * i + 3];
+        float den = nx * dl.x + ny * dl.y + nz * dl.z, num = dw - (nx * ol.x + ny * ol.y + nz * ol.z);
+        if (den < 0.f) { float t = num / den; if (t > tin) { tin = t; ent = i; } }
+        else if (den > 0.f) { float t = num / den; if (t < tout) tout = t; }
+        else if (num < 0.f) return false;
+        if (tin > tout) return false;
+    }
+    if (ent < 0 || tin <= 0.f) return false;
+    thit = tin;
+    nrm = mulv(R, v3(pl[4 * ent], pl[4 * ent + 1], pl[4 * ent + 2]));
+    return true;
+}
+
+__device__ static uint8_t to_u8(float v) { v *= 255.f; v = fminf(fmaxf(v, 0.f), 255.f); return (uint8_t)v; }
+
+__global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevConfig cfg, const float *qpos, const int *pad_grasp, const int *pad_pher,
+                                                      int n, uint8_t *obs) {
+    const DevModel &m = *mp;
+    __shared__ Frames fr;
+    __shared__ float sdepth[RPIX];
+    __shared__ float red[RTHREADS];
+    __shared__ int redi[RTHREADS];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) compute_frames(m, qpos, n, e, fr);
+    __syncthreads();
+    const int nch = cfg.full_observation ? 5 : 4;
+    uint8_t *o = obs + (size_t)e * nch * RPIX;
+    const float tanh_ = tanf(0.5f * m.cam_fovy * 0.017453292519943295f);
+    V3 co = ldv(fr.cam_o); M3 Rc = ldm(fr.cam_R);
+    V3 L = normalized(v3(-m.light_dir[0][0], -m.light_dir[0][1], -m.light_dir[0][2]));
+    float lmin = 3.0e38f;
+    for (int k = 0; k < RPIX / RTHREADS; k++) {
+        int px = k * RTHREADS + tid, i = px / RW, j = px % RW;
+        float x = (2.0f * (j + 0.5f) / RW - 1.0f) * tanh_, y = (1.0f - 2.0f * (i + 0.5f) / RH) * tanh_;
+        V3 dir = mulv(Rc, v3(x, y, -1.f));
+        float best = m.zfar; int hit = -1; V3 nrm = v3(0, 0, 1);
+        if (dir.z < 0.f) { float t = -co.z / dir.z; if (t > m.znear && t < best) { best = t; hit = 0; } }
+        for (int g = 1; g < GN_GEOM; g++) {
+            float t; V3 nn;
+            if (ray_hull(m, fr, g, co, dir, t, nn) && t > m.znear && t < best) { best = t; hit = g; nrm = nn; }
+        }
+        float c0, c1, c2;
+        if (hit < 0) {
+            V3 dn = normalized(dir); float f = 0.5f * (dn.z + 1.0f);
+            c0 = m.sky_rgb[3] + f * (m.sky_rgb[0] - m.sky_rgb[3]); c1 = m.sky_rgb[4] + f * (m.sky_rgb[1] - m.sky_rgb[4]); c2 = m.sky_rgb[5] + f * (m.sky_rgb[2] - m.sky_rgb[5]);
+        } else {
+            float b0, b1, b2;
+            if (hit == 0) {
+                float pxw = co.x + best * dir.x, pyw = co.y + best * dir.y;
+                int cx = (int)floorf(pxw * 8.0f), cy = (int)floorf(pyw * 8.0f);
+                int off = ((cx + cy) & 1) ? 3 : 0;
+                b0 = m.floor_rgb[off]; b1 = m.floor_rgb[off + 1]; b2 = m.floor_rgb[off + 2];
+            } else { b0 = m.geom_rgba[hit][0]; b1 = m.geom_rgba[hit][1]; b2 = m.geom_rgba[hit][2]; }
+            float shade = 0.4f + 0.6f * fmaxf(dot(nrm, L), 0.f);
+            c0 = b0 * shade; c1 = b1 * shade; c2 = b2 * shade;
+        }
+        o[px] = to_u8(c0); o[RPIX + px] = to_u8(c1); o[2 * RPIX + px] = to_u8(c2);
+        sdepth[px] = best; lmin = fminf(lmin, best);
+        o[(nch - 1) * RPIX + px] = 0;
+    }
+    // transform_depth (utils.py:11-19): depth -= min; depth /= 2 * mean(depth[depth <= 1]); 255 * clip(depth, 0, 1)
+    red[tid] = lmin; __syncthreads();
+    for (int s = RTHREADS / 2; s > 0; s >>= 1) { if (tid < s) red[tid] = fminf(red[tid], red[tid + s]); __syncthreads(); }
+    float dmin = red[0]; __syncthreads();
+    float lsum = 0.f; int lcnt = 0;
+    for (int k = 0; k < RPIX / RTHREADS; k++) { float d = sdepth[k * RTHREADS + tid] - dmin; if (d <= 1.0f) { lsum += d; lcnt++; } }
+    red[tid] = lsum; redi[tid] = lcnt; __syncthreads();
+    for (int s = RTHREADS / 2; s > 0; s >>= 1) { if (tid < s) { red[tid] += red[tid + s]; redi[tid] += redi[tid + s]; } __syncthreads(); }
+    float scale = 2.0f * (red[0] / (float)redi[0]);
+    if (cfg.full_observation) {
+        for (int k = 0; k < RPIX / RTHREADS; k++) {
+            int px = k * RTHREADS + tid;
+            float v = (sdepth[px] - dmin) / scale; v = fminf(fmaxf(v, 0.f), 1.f);
+            float p = 255.0f * v;
+            o[3 * RPIX + px] = (p != p) ? (uint8_t)0 : (uint8_t)p;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { o[(nch - 1) * RPIX] = (uint8_t)pad_grasp[e]; o[(nch - 1) * RPIX + 1] = (uint8_t)pad_pher[e]; }
+}
+
+extern "C" int grip_render_launch(const DevModel *d_model, DevConfig cfg, const float *qpos, const int *pad_grasp, const int *pad_pher, int n,
+                                  uint8_t *obs, hipStream_t s) {
+    hipLaunchKernelGGL(k_observe, dim3(n), dim3(RTHREADS), 0, s, d_model, cfg, qpos, pad_grasp, pad_pher, n, obs);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -1,0 +1,819 @@
+// grip_sim.hip -- kernels and C ABI (include/grip_sim.h) of the MI355X batched rollout engine.
+//
+// Data layout in HBM: every per-env quantity is a structure of arrays, [field][env] fp32
+// (qpos 14 x N, qvel 13 x N, ctrl 7 x N, qacc_warmstart 13 x N, flags), so that the 64 lanes of a
+// wave load 64 consecutive floats per field: one 256-byte coalesced row per field per wave.
+// One macro step (RobotEnv.step, robot_env.py:77-241) is ONE kernel launch: each lane loads its
+// state once (188 B), runs the controller, the whole MOVE / RETURN / OPEN / CLOSE state machine
+// of physics.step() calls with the state in registers and the contact list in LDS, and writes
+// the state back once (160 B) together with reward / done / info.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/grip_sim.h"
+#include "grip_physics.h"
+
+// ------------------------------------------------------------------------------------------------
+// error handling
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+extern "C" const char *grip_last_error(void) { return g_err.c_str(); }
+static int fail(const std::string &s) { g_err = s; return -1; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// host model
+// ------------------------------------------------------------------------------------------------
+struct Blob {
+    struct Entry { std::string name; unsigned dtype, ndim, dims[4]; size_t off, count; };
+    std::vector<unsigned char> buf; std::vector<Entry> entries;
+    bool load(const char *path) {
+        FILE *f = fopen(path, "rb"); if (!f) return false;
+        fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+        buf.resize(n); bool ok = fread(buf.data(), 1, n, f) == (size_t)n; fclose(f);
+        if (!ok || n < 12 || memcmp(buf.data(), "GRPM", 4) != 0) return false;
+        unsigned cnt; memcpy(&cnt, buf.data() + 8, 4);
+        size_t off = 12;
+        for (unsigned i = 0; i < cnt; i++) {
+            if (off + 48 > buf.size()) return false;
+            Entry e; char nm[25] = {0}; memcpy(nm, buf.data() + off, 24); e.name = nm;
+            memcpy(&e.dtype, buf.data() + off + 24, 4); memcpy(&e.ndim, buf.data() + off + 28, 4); memcpy(e.dims, buf.data() + off + 32, 16);
+            off += 48; e.off = off; e.count = 1; for (unsigned k = 0; k < e.ndim; k++) e.count *= e.dims[k];
+            size_t nb = e.count * (e.dtype == 0 ? 8 : 4); off += nb + ((8 - nb % 8) % 8);
+            entries.push_back(e);
+        }
+        return true;
+    }
+    const Entry *find(const char *name) const { for (auto &e : entries) if (e.name == name) return &e; return nullptr; }
+    bool f64(const char *name, std::vector<double> &out, size_t expect = 0) const {
+        const Entry *e = find(name); if (!e || e->dtype != 0 || (expect && e->count != expect)) return false;
+        out.resize(e->count); memcpy(out.data(), buf.data() + e->off, e->count * 8); return true;
+    }
+    bool i32(const char *name, std::vector<int> &out, size_t expect = 0) const {
+        const Entry *e = find(name); if (!e || e->dtype != 1 || (expect && e->count != expect)) return false;
+        out.resize(e->count); memcpy(out.data(), buf.data() + e->off, e->count * 4); return true;
+    }
+};
+
+struct GripModel {
+    DevModel host;                       // pointer members are filled per device at batch creation
+    std::vector<float> verts4;           // [nvert][4]
+    std::vector<int> nadr, nbr;
+    std::vector<float> planes;           // [nplane][4]
+    int nvert = 0;
+};
+
+namespace hm {   // tiny double-precision helpers for the host-side composite-body build
+struct D3 { double x, y, z; };
+static void qmat(const double *q, double R[9]) {
+    double n = std::sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
+    double w = q[0]/n, x = q[1]/n, y = q[2]/n, z = q[3]/n;
+    R[0] = 1-2*(y*y+z*z); R[1] = 2*(x*y-w*z); R[2] = 2*(x*z+w*y);
+    R[3] = 2*(x*y+w*z); R[4] = 1-2*(x*x+z*z); R[5] = 2*(y*z-w*x);
+    R[6] = 2*(x*z-w*y); R[7] = 2*(y*z+w*x); R[8] = 1-2*(x*x+y*y);
+}
+static void mm(const double A[9], const double B[9], double C[9]) {
+    double t[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) t[3*i+j] = A[3*i]*B[j] + A[3*i+1]*B[3+j] + A[3*i+2]*B[6+j];
+    memcpy(C, t, sizeof t);
+}
+static void mv(const double A[9], const double v[3], double r[3]) {
+    double t[3] = {A[0]*v[0]+A[1]*v[1]+A[2]*v[2], A[3]*v[0]+A[4]*v[1]+A[5]*v[2], A[6]*v[0]+A[7]*v[1]+A[8]*v[2]};
+    memcpy(r, t, sizeof t);
+}
+// inertia of body (iquat, diag) expressed in the frame rotated by Rb: Rb Ri diag Ri^T Rb^T
+static void body_inertia(const double Rb[9], const double *iquat, const double *diag, double I[9]) {
+    double Ri[9], R[9]; qmat(iquat, Ri); mm(Rb, Ri, R);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double s = 0; for (int k = 0; k < 3; k++) s += R[3*i+k] * diag[k] * R[3*j+k];
+        I[3*i+j] = s;
+    }
+}
+}  // namespace hm
+
+// composite of bodies welded together: parts given as (mass, com in group frame, inertia about own com in group frame)
+static void composite(int n, const double *mass, const double (*com)[3], const double (*I)[9], float &m_out, float *com_out, float *I_out) {
+    double M = 0, c[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++) { M += mass[i]; for (int k = 0; k < 3; k++) c[k] += mass[i] * com[i][k]; }
+    for (int k = 0; k < 3; k++) c[k] /= M;
+    double T[9] = {0};
+    for (int i = 0; i < n; i++) {
+        double d[3] = {com[i][0] - c[0], com[i][1] - c[1], com[i][2] - c[2]};
+        double d2 = d[0]*d[0] + d[1]*d[1] + d[2]*d[2];
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) T[3*a+b] += I[i][3*a+b] + mass[i] * ((a == b ? d2 : 0.0) - d[a] * d[b]);
+    }
+    m_out = (float)M; for (int k = 0; k < 3; k++) com_out[k] = (float)c[k];
+    I_out[0] = (float)T[0]; I_out[1] = (float)T[4]; I_out[2] = (float)T[8]; I_out[3] = (float)T[1]; I_out[4] = (float)T[2]; I_out[5] = (float)T[5];
+}
+
+extern "C" int grip_model_load(const char *blob_path, GripModel **out) {
+    Blob b;
+    if (!b.load(blob_path)) return fail(std::string("cannot read model blob ") + blob_path);
+    std::vector<double> opt, margin, solref, solimp, lsolref, lsolimp, bpos, bquat, bmass, bipos, biquat, binert, arm, damp, rng, gear,
+        crange, qpos0, gfric, gcen, grb, grgba, hverts, hplanes, biw, diw, mi, campos, camquat, camfovy, visual, frgb, srgb, ldir;
+    std::vector<int> gbody, hvadr, hvnum, hpadr, hpnum, nadr, nbr, pairs;
+    bool ok = b.f64("opt", opt, 5) && b.f64("geom_margin", margin, 1) && b.f64("geom_solref", solref, 2) && b.f64("geom_solimp", solimp, 5) &&
+              b.f64("lim_solref", lsolref, 2) && b.f64("lim_solimp", lsolimp, 5) && b.f64("body_pos", bpos, 24) && b.f64("body_quat", bquat, 32) &&
+              b.f64("body_mass", bmass, 8) && b.f64("body_ipos", bipos, 24) && b.f64("body_iquat", biquat, 32) && b.f64("body_inertia", binert, 24) &&
+              b.f64("dof_armature", arm, 13) && b.f64("dof_damping", damp, 13) && b.f64("jnt_range", rng, 14) && b.f64("gear", gear, 7) &&
+              b.f64("ctrlrange", crange, 14) && b.f64("qpos0", qpos0, 14) && b.f64("geom_friction", gfric, 21) && b.f64("geom_center", gcen, 21) &&
+              b.f64("geom_rbound", grb, 7) && b.f64("geom_rgba", grgba, 28) && b.f64("hull_verts", hverts) && b.f64("hull_planes", hplanes) &&
+              b.f64("body_invweight0", biw, 16) && b.f64("dof_invweight0", diw, 13) && b.f64("meaninertia", mi, 1) && b.f64("cam_pos", campos, 3) &&
+              b.f64("cam_quat", camquat, 4) && b.f64("cam_fovy", camfovy, 1) && b.f64("visual", visual, 3) && b.f64("floor_rgb", frgb, 6) &&
+              b.f64("sky_rgb", srgb, 6) && b.f64("light_dir", ldir, 6) && b.i32("geom_body", gbody, 7) && b.i32("hull_vadr", hvadr, 6) &&
+              b.i32("hull_vnum", hvnum, 6) && b.i32("hull_padr", hpadr, 6) && b.i32("hull_pnum", hpnum, 6) && b.i32("hull_nadr", nadr) &&
+              b.i32("hull_nbr", nbr) && b.i32("hull_pairs", pairs);
+    if (!ok) return fail(std::string("model blob ") + blob_path + " is missing fields or has the wrong version");
+    GripModel *gm = new GripModel();
+    DevModel &m = gm->host; memset(&m, 0, sizeof m);
+    m.timestep = (float)opt[0]; m.gravity_z = (float)opt[1]; m.impratio = (float)opt[2]; m.iterations = (int)opt[3]; m.tolerance = (float)opt[4];
+    m.margin = (float)margin[0];
+    auto kb = [&](const std::vector<double> &sr, const std::vector<double> &si, float &k, float &bb) {
+        double tc = std::max(sr[0], 2.0 * opt[0]), dr = sr[1], dmax = si[1];
+        k = (float)(1.0 / (dmax * dmax * tc * tc * dr * dr)); bb = (float)(2.0 / (dmax * tc)); };
+    kb(solref, solimp, m.k_con, m.b_con); kb(lsolref, lsolimp, m.k_lim, m.b_lim);
+    for (int i = 0; i < 5; i++) { m.solimp[i] = (float)solimp[i]; m.lim_solimp[i] = (float)lsolimp[i]; }
+    m.meaninertia = (float)mi[0];
+    // ---- composite rigid groups (double), bodies: 1 ee, 2 base, 3 lk, 4 lf, 5 rk, 6 rf, 7 object
+    const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    auto part = [&](int body, const double Rb[9], const double pb[3], double &mass, double com[3], double I[9]) {
+        mass = bmass[body]; double t[3]; hm::mv(Rb, &bipos[3 * body], t);
+        for (int k = 0; k < 3; k++) com[k] = pb[k] + t[k];
+        hm::body_inertia(Rb, &biquat[4 * body], &binert[3 * body], I); };
+    {   // G = ee (frame) + base
+        double mass[2], com[2][3], I[2][9], Rb[9], zero[3] = {0, 0, 0};
+        part(1, I3, zero, mass[0], com[0], I[0]);
+        hm::qmat(&bquat[4 * 2], Rb); part(2, Rb, &bpos[3 * 2], mass[1], com[1], I[1]);
+        composite(2, mass, com, I, m.grp_mass[0], m.grp_com[0], m.grp_inertia[0]);
+        for (int k = 0; k < 3; k++) m.base_pos[k] = (float)bpos[6 + k];
+        for (int k = 0; k < 9; k++) m.base_R[k] = (float)Rb[k];
+    }
+    for (int s = 0; s < 2; s++) {   // L / R = knuckle (frame) + finger
+        int kbody = 3 + 2 * s, fbody = 4 + 2 * s;
+        double mass[2], com[2][3], I[2][9], Rf[9], Rk[9], zero[3] = {0, 0, 0};
+        part(kbody, I3, zero, mass[0], com[0], I[0]);
+        hm::qmat(&bquat[4 * fbody], Rf); part(fbody, Rf, &bpos[3 * fbody], mass[1], com[1], I[1]);
+        composite(2, mass, com, I, m.grp_mass[1 + s], m.grp_com[1 + s], m.grp_inertia[1 + s]);
+        hm::qmat(&bquat[4 * kbody], Rk);
+        for (int k = 0; k < 3; k++) { m.kn_pos[s][k] = (float)bpos[3 * kbody + k]; m.fin_pos[s][k] = (float)bpos[3 * fbody + k]; }
+        for (int k = 0; k < 9; k++) { m.kn_R[s][k] = (float)Rk[k]; m.fin_R[s][k] = (float)Rf[k]; }
+    }
+    {   double mass[1], com[1][3], I[1][9], zero[3] = {0, 0, 0};
+        part(7, I3, zero, mass[0], com[0], I[0]);
+        composite(1, mass, com, I, m.grp_mass[3], m.grp_com[3], m.grp_inertia[3]); }
+    {   double Re[9]; hm::qmat(&bquat[4], Re);
+        for (int k = 0; k < 9; k++) if (std::fabs(Re[k] - I3[k]) > 1e-12) { delete gm; return fail("ee body quat must be identity"); }
+        for (int k = 0; k < 3; k++) m.ee_pos0[k] = (float)bpos[3 + k]; }
+    for (int i = 0; i < 13; i++) { m.armature[i] = (float)arm[i]; m.damping[i] = (float)damp[i]; }
+    for (int j = 0; j < 7; j++) {
+        m.range[j][0] = (float)rng[2*j]; m.range[j][1] = (float)rng[2*j+1]; m.gear[j] = (float)gear[j];
+        m.ctrlrange[j][0] = (float)crange[2*j]; m.ctrlrange[j][1] = (float)crange[2*j+1]; m.dof_invweight0[j] = (float)diw[j];
+    }
+    for (int i = 0; i < 14; i++) m.qpos0[i] = (float)qpos0[i];
+    const int body_group[8] = {GRP_WORLD, GRP_G, GRP_G, GRP_L, GRP_L, GRP_R, GRP_R, GRP_O};
+    for (int g = 0; g < 7; g++) {
+        for (int k = 0; k < 3; k++) m.geom_center[g][k] = (float)gcen[3*g+k];
+        m.geom_rbound[g] = (float)grb[g];
+        m.geom_friction[g][0] = (float)gfric[3*g]; m.geom_friction[g][1] = (float)gfric[3*g+1];
+        m.geom_invweight[g] = (float)biw[2 * gbody[g]];
+        m.geom_group[g] = body_group[gbody[g]];
+        for (int k = 0; k < 4; k++) m.geom_rgba[g][k] = (float)grgba[4*g+k];
+    }
+    for (int h = 0; h < 6; h++) { m.hull_vadr[h] = hvadr[h]; m.hull_vnum[h] = hvnum[h]; m.hull_padr[h] = hpadr[h]; m.hull_pnum[h] = hpnum[h]; }
+    m.npair = (int)pairs.size() / 2;
+    if (m.npair > GN_PAIR_MAX) { delete gm; return fail("too many collision pairs"); }
+    for (int q = 0; q < m.npair; q++) { m.pairs[q][0] = pairs[2*q]; m.pairs[q][1] = pairs[2*q+1]; }
+    gm->nvert = (int)hverts.size() / 3;
+    gm->verts4.resize(4 * (size_t)gm->nvert);
+    for (int i = 0; i < gm->nvert; i++) { for (int k = 0; k < 3; k++) gm->verts4[4*i+k] = (float)hverts[3*i+k]; gm->verts4[4*i+3] = 0.f; }
+    gm->nadr = nadr; gm->nbr = nbr;
+    gm->planes.resize(hplanes.size()); for (size_t i = 0; i < hplanes.size(); i++) gm->planes[i] = (float)hplanes[i];
+    for (int k = 0; k < 3; k++) m.cam_pos[k] = (float)campos[k];
+    {   double Rc[9]; hm::qmat(camquat.data(), Rc); for (int k = 0; k < 9; k++) m.cam_R[k] = (float)Rc[k]; }
+    m.cam_fovy = (float)camfovy[0]; m.znear = (float)visual[1]; m.zfar = (float)visual[2];
+    for (int k = 0; k < 6; k++) { m.floor_rgb[k] = (float)frgb[k]; m.sky_rgb[k] = (float)srgb[k]; m.light_dir[k / 3][k % 3] = (float)ldir[k]; }
+    *out = gm;
+    return 0;
+}
+extern "C" void grip_model_free(GripModel *m) { delete m; }
+extern "C" int grip_model_nvert(const GripModel *m) { return m ? m->nvert : -1; }
+
+// ------------------------------------------------------------------------------------------------
+// batch
+// ------------------------------------------------------------------------------------------------
+struct StepOutDev {     // device copy of GripStepOut (kernel argument)
+    float *reward; uint8_t *done; float *achieved_goal; float *desired_goal; int *status; int *episode_step; int *gripper_open;
+    int *object_grasped; int *position_reached; float *total_distance; float *line_distance; float *gripper_position;
+    float *object_position; float *init_obj_pos; int *n_substeps; int *fault;
+};
+
+struct GripBatch {
+    int n = 0, device = 0;
+    DevModel *d_model = nullptr; float *d_verts = nullptr; int *d_nadr = nullptr, *d_nbr = nullptr; float *d_planes = nullptr;
+    DevConfig cfg;
+    float *qpos = nullptr, *qvel = nullptr, *ctrl = nullptr, *warm = nullptr;     // SoA [field][N]
+    int *episode_step = nullptr, *status = nullptr, *gripper_open = nullptr;
+    int *pad_grasp = nullptr, *pad_pher = nullptr;                              // sensor-pad scalars of the current state
+    float *reset_info = nullptr;                                                // grasp0, pher0, objx0, objy0 of the reset state
+    float *scratch = nullptr; size_t scratch_bytes = 0;
+    float xfrc_z = 0.f;
+    std::vector<hipEvent_t> ev0, ev1; int ev_used = 0;
+    bool reset_info_valid = false;
+};
+
+static constexpr int EV_RING = 1024;
+static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS_PER_LANE * WAVE * sizeof(float);
+
+// ---- state load / store (coalesced SoA)
+struct StatePtrs { float *qpos, *qvel, *ctrl, *warm; int *episode_step, *status, *gripper_open, *pad_grasp, *pad_pher; int n; };
+
+DEVI void ld_state(const StatePtrs &p, int e, LaneState &s) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) s.qpos[i] = p.qpos[(size_t)i * p.n + e];
+#pragma unroll
+    for (int i = 0; i < 13; i++) s.qvel[i] = p.qvel[(size_t)i * p.n + e];
+#pragma unroll
+    for (int i = 0; i < 7; i++) s.ctrl[i] = p.ctrl[(size_t)i * p.n + e];
+#pragma unroll
+    for (int i = 0; i < 13; i++) s.warm[i] = p.warm[(size_t)i * p.n + e];
+}
+DEVI void st_state(const StatePtrs &p, int e, const LaneState &s) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) p.qpos[(size_t)i * p.n + e] = s.qpos[i];
+#pragma unroll
+    for (int i = 0; i < 13; i++) p.qvel[(size_t)i * p.n + e] = s.qvel[i];
+#pragma unroll
+    for (int i = 0; i < 7; i++) p.ctrl[(size_t)i * p.n + e] = s.ctrl[i];
+#pragma unroll
+    for (int i = 0; i < 13; i++) p.warm[(size_t)i * p.n + e] = s.warm[i];
+}
+DEVI void reset_lane(const DevModel &m, LaneState &s) {
+#pragma unroll
+    for (int i = 0; i < 14; i++) s.qpos[i] = m.qpos0[i];
+#pragma unroll
+    for (int i = 0; i < 13; i++) { s.qvel[i] = 0.f; s.warm[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 7; i++) s.ctrl[i] = 0.f;
+}
+
+// utils.py:30-31
+DEVI float project_dir(float x, float y, const DevConfig &c) {
+    float n = sqrtf(c.dir_x * c.dir_x + c.dir_y * c.dir_y);
+    return (x * c.dir_x + y * c.dir_y) / (n * n);
+}
+// actuator.py:198-215
+DEVI int pheromone_level(V3 ee, const DevConfig &c) {
+    float p = project_dir(ee.x, ee.y, c);
+    float dx = p * c.dir_x - ee.x, dy = p * c.dir_y - ee.y;
+    float conc = 1.0f / expf(sqrtf(dx * dx + dy * dy));
+    return conc > 0.82f ? 3 : conc > 0.6f ? 2 : conc > 0.37f ? 1 : 0;
+}
+
+// transformations.py:1035-1090 ('sxyz' non-repeating branch) on a row-major 3x3
+DEVI void euler_from_matrix(const M3 &M, float &ax, float &ay, float &az) {
+    float cy = sqrtf(M.m[0] * M.m[0] + M.m[3] * M.m[3]);
+    if (cy > 4.0f * 1.1920929e-7f) { ax = atan2f(M.m[7], M.m[8]); ay = atan2f(-M.m[6], cy); az = atan2f(M.m[3], M.m[0]); }
+    else { ax = atan2f(-M.m[5], M.m[4]); ay = atan2f(-M.m[6], cy); az = 0.f; }
+}
+// transformations.py:972-1032 ('sxyz')
+DEVI M3 euler_matrix(float ai, float aj, float ak) {
+    float si = sinf(ai), sj = sinf(aj), sk = sinf(ak), ci = cosf(ai), cj = cosf(aj), ck = cosf(ak);
+    float cc = ci * ck, cs = ci * sk, sc = si * ck, ss = si * sk;
+    M3 M;
+    M.m[0] = cj * ck; M.m[1] = sj * sc - cs; M.m[2] = sj * cc + ss;
+    M.m[3] = cj * sk; M.m[4] = sj * ss + cc; M.m[5] = sj * cs - sc;
+    M.m[6] = -sj; M.m[7] = cj * si; M.m[8] = cj * ci;
+    return M;
+}
+
+// Actuator.get_target_pose (actuator.py:58-102) with _normalise_action (:21-44), _clip_translation_vector
+// (:249-264), _enforce_constraints (:266-293); the 6x5 Jacobian pseudo-inverse in closed form (its columns
+// are orthonormal: three world axes, the roll axis x and the yaw axis Rx(roll) z).
+DEVI void target_pose(const DevConfig &c, const float *act, const float (&qpos)[14], const Kin &k, float (&target)[5], float &open_close) {
+    float a[6]; int q = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) a[i] = (!c.include_roll && i == 3) ? 0.f : act[q++];
+    open_close = a[5];
+    float st = 2.0f / (2.0f * c.max_translation), sr = 2.0f / (2.0f * c.max_rotation);
+    float t0 = a[0] / st, t1 = a[1] / st, t2 = a[2] / st, r0 = a[3] / sr, r1 = a[4] / sr;
+    float len = sqrtf(t0 * t0 + t1 * t1 + t2 * t2);
+    if (len > c.max_translation) { float f = c.max_translation / len; t0 *= f; t1 *= f; t2 *= f; }
+    r0 = fminf(fmaxf(r0, -c.max_rotation), c.max_rotation); r1 = fminf(fmaxf(r1, -c.max_rotation), c.max_rotation);
+    float roll, pitch, yaw;
+    euler_from_matrix(k.Re, roll, pitch, yaw);
+    M3 Rold = euler_matrix(roll, pitch, yaw), Rrel = euler_matrix(r0, 0.f, r1);
+    M3 Rnew = mulm(Rold, Rrel);
+    V3 pos = k.pe + mulv(Rold, v3(t0, t1, t2));
+    float o0, o1, o2; euler_from_matrix(Rnew, o0, o1, o2);
+    const float PI4 = 0.78539816339744830962f;
+    if (!c.include_roll) o0 = 0.f; else o0 = fminf(fmaxf(o0, -PI4), PI4);
+    o1 = 0.f;
+    pos.z = fminf(fmaxf(pos.z, 0.1f), 0.5f);
+    V3 ep = pos - k.pe, eo = v3(o0 - roll, o1 - pitch, o2 - yaw);
+    target[0] = qpos[0] + ep.x; target[1] = qpos[1] + ep.y; target[2] = qpos[2] + ep.z;
+    target[3] = qpos[3] + eo.x; target[4] = qpos[4] + dot(k.a4, eo);
+}
+
+// reward.py:18-41
+DEVI float agent_reward(V3 o0, V3 o1, const DevConfig &c, int gripper_open, float c5, float c6, int grasped, float &line_distance) {
+    float p0 = project_dir(o0.x, o0.y, c), p1 = project_dir(o1.x, o1.y, c);
+    float dx = p1 * c.dir_x - o1.x, dy = p1 * c.dir_y - o1.y;
+    float lat = sqrtf(dx * dx + dy * dy), travel = p1 - p0, r = 0.f;
+    bool ok = travel > 0.f && travel < 0.1f && lat < 0.1f;
+    line_distance = ok ? travel : 0.f;
+    if (ok) {
+        r = travel;
+        if (!gripper_open && (c5 != 0.f && c6 != 0.f) && grasped == 3) { r *= 2.f; if (o1.z > 0.f) r *= 1.5f; }
+    }
+    return r * 30.f;
+}
+
+enum { PH_MOVE = 0, PH_RETURN, PH_OPEN, PH_CLOSE, PH_FINAL, PH_DONE };
+
+// ------------------------------------------------------------------------------------------------
+// kernels (one wave per workgroup; LDS_BYTES of dynamic LDS)
+// ------------------------------------------------------------------------------------------------
+extern __shared__ float lds_dyn[];
+
+__global__ void __launch_bounds__(WAVE) k_reset(const DevModel *mp, DevConfig cfg, StatePtrs st, const uint8_t *mask, StepOutDev out, float *reset_info) {
+    const DevModel &m = *mp;
+    float *lds = lds_dyn; const int lane = threadIdx.x;
+    int e = blockIdx.x * WAVE + lane;
+    bool valid = e < st.n;
+    if (!valid) e = st.n - 1;
+    bool doit = valid && (mask == nullptr || mask[e] != 0);
+    LaneState s; reset_lane(m, s);
+    Kin k; int ncon = 0, fault = 0;
+    forward_pos(m, s, lds, lane, k, ncon, fault);
+    int grasp = check_grasp(lds, lane, ncon), pher = pheromone_level(k.pe, cfg);
+    if (blockIdx.x == 0 && lane == 0 && reset_info) { reset_info[0] = (float)grasp; reset_info[1] = (float)pher; reset_info[2] = k.po.x; reset_info[3] = k.po.y; }
+    if (!doit) return;
+    st_state(st, e, s);
+    st.episode_step[e] = 0; st.status[e] = 0; st.gripper_open[e] = 1;
+    st.pad_grasp[e] = grasp; st.pad_pher[e] = pher;
+    if (out.achieved_goal) { out.achieved_goal[2 * e] = k.po.x; out.achieved_goal[2 * e + 1] = k.po.y; }
+    if (out.desired_goal) { out.desired_goal[2 * e] = cfg.dir_x; out.desired_goal[2 * e + 1] = cfg.dir_y; }
+    if (out.object_position) { out.object_position[3 * e] = k.po.x; out.object_position[3 * e + 1] = k.po.y; out.object_position[3 * e + 2] = k.po.z; }
+    if (out.gripper_position) { out.gripper_position[3 * e] = k.pe.x; out.gripper_position[3 * e + 1] = k.pe.y; out.gripper_position[3 * e + 2] = k.pe.z; }
+    if (out.status) out.status[e] = 0;
+    if (out.episode_step) out.episode_step[e] = 0;
+    if (out.gripper_open) out.gripper_open[e] = 1;
+    if (out.fault) out.fault[e] = fault;
+}
+
+// RobotEnv.step for 64 envs per wave (robot_env.py:77-241)
+__global__ void __launch_bounds__(WAVE) k_macro_step(const DevModel *mp, DevConfig cfg, StatePtrs st, const float *actions, StepOutDev out,
+                                                      const float *reset_info, float xfrc_z) {
+    const DevModel &m = *mp;
+    float *lds = lds_dyn; const int lane = threadIdx.x;
+    int e = blockIdx.x * WAVE + lane;
+    const bool valid = e < st.n;
+    if (!valid) e = st.n - 1;
+    LaneState s; ld_state(st, e, s);
+    int episode_step = st.episode_step[e], status = st.status[e], gripper_open = st.gripper_open[e];
+    const int adim = cfg.include_roll ? 6 : 5;
+    float act[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) act[i] = i < adim ? actions[(size_t)e * adim + i] : 0.f;
+
+    Kin k; int ncon = 0, fault = 0;
+    float target[5], init_q[5], open_close = 0.f, delta_pre = 0.f, tq = 0.f;
+    V3 init_obj = v3(0, 0, 0);
+    int phase = valid ? PH_MOVE : PH_DONE, cnt = 0, nsub = 0, grasped = 0;
+    bool reached_target = false, reached_initial = false, first = true;
+
+    while (__any(phase != PH_DONE)) {
+        if (phase != PH_DONE) {
+            forward_pos(m, s, lds, lane, k, ncon, fault);          // state of "now": contacts as check_grasp sees them
+            if (first) {
+                first = false;
+                init_obj = k.po;
+#pragma unroll
+                for (int i = 0; i < 5; i++) init_q[i] = s.qpos[i];
+                target_pose(cfg, act, s.qpos, k, target, open_close);
+            }
+            if (phase == PH_FINAL) {
+                // ---- robot_env.py:170-241 on the final state
+                V3 fo = k.po, fe = k.pe;
+                float dxy = sqrtf((fo.x - fe.x) * (fo.x - fe.x) + (fo.y - fe.y) * (fo.y - fe.y));
+                if (dxy > 1.f) status = 1;
+                float p1 = project_dir(fo.x, fo.y, cfg);
+                float dgx = p1 * cfg.dir_x, dgy = p1 * cfg.dir_y;
+                float line;
+                float reward = agent_reward(init_obj, fo, cfg, gripper_open, s.ctrl[5], s.ctrl[6], grasped, line);
+                if (cfg.her_buffer) { float gx = dgx - fo.x, gy = dgy - fo.y; reward += 1.0f / expf(sqrtf(gx * gx + gy * gy)); }
+                int done;
+                if (status != 0) done = 1;
+                else if (episode_step == cfg.time_horizon - 1) { done = 1; status = 2; }
+                else done = 0;
+                episode_step += 1;
+                int pg = check_grasp(lds, lane, ncon), ph = pheromone_level(fe, cfg);
+                if (out.reward) out.reward[e] = reward;
+                if (out.done) out.done[e] = (uint8_t)done;
+                if (out.status) out.status[e] = status;
+                if (out.episode_step) out.episode_step[e] = episode_step;
+                if (out.gripper_open) out.gripper_open[e] = gripper_open;
+                if (out.object_grasped) out.object_grasped[e] = grasped;
+                if (out.position_reached) out.position_reached[e] = (reached_target ? 1 : 0) | (reached_initial ? 2 : 0) | ((!reached_target && !reached_initial) ? 4 : 0);
+                if (out.total_distance) out.total_distance[e] = sqrtf((fo.x - init_obj.x) * (fo.x - init_obj.x) + (fo.y - init_obj.y) * (fo.y - init_obj.y));
+                if (out.line_distance) out.line_distance[e] = line;
+                if (out.gripper_position) { out.gripper_position[3 * e] = fe.x; out.gripper_position[3 * e + 1] = fe.y; out.gripper_position[3 * e + 2] = fe.z; }
+                if (out.object_position) { out.object_position[3 * e] = fo.x; out.object_position[3 * e + 1] = fo.y; out.object_position[3 * e + 2] = fo.z; }
+                if (out.init_obj_pos) { out.init_obj_pos[3 * e] = init_obj.x; out.init_obj_pos[3 * e + 1] = init_obj.y; out.init_obj_pos[3 * e + 2] = init_obj.z; }
+                if (out.n_substeps) out.n_substeps[e] = nsub;
+                if (out.fault) out.fault[e] = fault;
+                float agx = fo.x, agy = fo.y;
+                if (done && cfg.auto_reset) {
+                    reset_lane(m, s); episode_step = 0; status = 0; gripper_open = 1;
+                    pg = (int)reset_info[0]; ph = (int)reset_info[1]; agx = reset_info[2]; agy = reset_info[3]; dgx = cfg.dir_x; dgy = cfg.dir_y;
+                }
+                if (out.achieved_goal) { out.achieved_goal[2 * e] = agx; out.achieved_goal[2 * e + 1] = agy; }
+                if (out.desired_goal) { out.desired_goal[2 * e] = dgx; out.desired_goal[2 * e + 1] = dgy; }
+                st.pad_grasp[e] = pg; st.pad_pher[e] = ph;
+                st_state(st, e, s);
+                st.episode_step[e] = episode_step; st.status[e] = status; st.gripper_open[e] = gripper_open;
+                phase = PH_DONE;
+            } else {
+                // ---- pre-step hooks
+                if (phase == PH_MOVE || phase == PH_RETURN) {
+                    // Actuator.scale_control (actuator.py:46-48): MinMaxScaler.transform, no clipping
+                    float st_ = 2.0f / (2.0f * cfg.max_translation), sr_ = 2.0f / (2.0f * cfg.max_rotation);
+#pragma unroll
+                    for (int i = 0; i < 3; i++) s.ctrl[i] = (target[i] - s.qpos[i]) * st_;
+#pragma unroll
+                    for (int i = 3; i < 5; i++) s.ctrl[i] = (target[i] - s.qpos[i]) * sr_;
+                } else {
+                    delta_pre = fmaxf(fabsf(tq - s.qpos[5]), fabsf(tq - s.qpos[6]));
+                    if (phase == PH_CLOSE) grasped = check_grasp(lds, lane, ncon);     // robot_env.py:155, before the step
+                }
+                physics_advance(m, s, xfrc_z, lds, lane, k, ncon, fault);
+                nsub++; cnt++;
+                // ---- post-step transitions
+                bool to_gripper = false, to_final = false;
+                if (phase == PH_MOVE || phase == PH_RETURN) {
+                    float dmax = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 5; i++) dmax = fmaxf(dmax, fabsf(s.qpos[i] - target[i]));
+                    bool reached = dmax < cfg.pos_tolerance;            // post-step qpos (quirk Q4)
+                    if (reached) {
+#pragma unroll
+                        for (int i = 0; i < 5; i++) s.ctrl[i] = 0.f;
+                    }
+                    if (phase == PH_MOVE) {
+                        if (reached) reached_target = true;
+                        if (cnt == cfg.max_steps) {                     // step_limit == 0 (:112), also when reached on the last try (Q5)
+                            phase = PH_RETURN; cnt = 0;
+#pragma unroll
+                            for (int i = 0; i < 5; i++) target[i] = init_q[i];
+                        } else if (reached) to_gripper = true;
+                    } else {
+                        if (reached) reached_initial = true;
+                        if (reached || cnt == cfg.max_steps) { if (reached_target) to_gripper = true; else to_final = true; }
+                    }
+                } else if (phase == PH_OPEN) {
+                    bool stop = delta_pre < cfg.grasp_tolerance || (s.qpos[5] > tq && s.qpos[6] > tq);
+                    if (stop) gripper_open = 1;
+                    if (stop || cnt == cfg.max_steps) { s.ctrl[5] = 0.f; s.ctrl[6] = 0.f; to_final = true; }
+                } else {   // PH_CLOSE
+                    bool stop = delta_pre < cfg.grasp_tolerance || grasped == 3;
+                    if (stop) gripper_open = 0;
+                    if (stop || cnt == cfg.max_steps) { s.ctrl[5] = 0.f; s.ctrl[6] = 0.f; to_final = true; }
+                }
+                if (to_gripper) {
+                    if (!reached_target && !reached_initial) status = 1;
+                    if (open_close > 0.f && !gripper_open) { phase = PH_OPEN; cnt = 0; tq = 0.4f; s.ctrl[5] = 0.5f; s.ctrl[6] = 0.5f; }
+                    else if (open_close < 0.f && gripper_open) { phase = PH_CLOSE; cnt = 0; tq = -0.4f; s.ctrl[5] = -1.f; s.ctrl[6] = -1.f; }
+                    else to_final = true;
+                }
+                if (to_final) {
+                    if (!reached_target && !reached_initial) status = 1;       // robot_env.py:130-132
+                    phase = PH_FINAL;
+                }
+            }
+        }
+    }
+}
+
+// k calls of physics.step() with the stored ctrl (test hook / micro-benchmark)
+__global__ void __launch_bounds__(WAVE) k_substep(const DevModel *mp, StatePtrs st, int nsteps, float xfrc_z, int *fault_out) {
+    const DevModel &m = *mp;
+    float *lds = lds_dyn; const int lane = threadIdx.x;
+    int e = blockIdx.x * WAVE + lane;
+    const bool valid = e < st.n;
+    if (!valid) e = st.n - 1;
+    LaneState s; ld_state(st, e, s);
+    Kin k; int ncon = 0, fault = 0;
+    for (int i = 0; i < nsteps; i++) {
+        forward_pos(m, s, lds, lane, k, ncon, fault);
+        physics_advance(m, s, xfrc_z, lds, lane, k, ncon, fault);
+    }
+    if (valid) { st_state(st, e, s); if (fault_out) fault_out[e] = fault; }
+}
+
+__global__ void __launch_bounds__(WAVE) k_debug_forward(const DevModel *mp, StatePtrs st, float xfrc_z, int *ncon_out, float *con_out, float *xpos_out,
+                                                         float *qacc_out, float *qs_out, float *M_out, float *bias_out) {
+    const DevModel &m = *mp;
+    float *lds = lds_dyn; const int lane = threadIdx.x;
+    int e = blockIdx.x * WAVE + lane;
+    const bool valid = e < st.n;
+    if (!valid) e = st.n - 1;
+    LaneState s; ld_state(st, e, s);
+    Kin k; int ncon = 0, fault = 0, iters = 0;
+    forward_pos(m, s, lds, lane, k, ncon, fault);
+    float Mp[91], qfs[13], qacc[13], jtf[13], qs[13], bias[13];
+    forward_acc(m, s, xfrc_z, lds, lane, k, ncon, fault, Mp, qfs, qacc, jtf, iters, qs, bias);
+    if (!valid) return;
+    ncon_out[e] = ncon;
+    for (int c = 0; c < G_MAXC; c++) {
+        float *o = con_out + ((size_t)e * G_MAXC + c) * 10;
+        int sidx = CB_BASE + c * C_STRIDE;
+        bool live = c < ncon;
+        int meta = live ? __float_as_int(LD(sidx + C_META)) : 0;
+        for (int q = 0; q < 7; q++) o[q] = live ? LD(sidx + q) : 0.f;
+        o[7] = (float)(meta & 255); o[8] = (float)((meta >> 8) & 255); o[9] = (float)iters;
+    }
+    float *xp = xpos_out + (size_t)e * 24;
+    xp[0] = xp[1] = xp[2] = 0.f;
+    xp[3] = k.pe.x; xp[4] = k.pe.y; xp[5] = k.pe.z;
+    for (int g = 1; g <= 6; g++) { V3 p; M3 R; load_frame(lds, lane, g, p, R); xp[3 * (g + 1)] = p.x; xp[3 * (g + 1) + 1] = p.y; xp[3 * (g + 1) + 2] = p.z; }
+    for (int i = 0; i < 13; i++) { qacc_out[(size_t)e * 13 + i] = qacc[i]; qs_out[(size_t)e * 13 + i] = qs[i]; bias_out[(size_t)e * 13 + i] = bias[i]; }
+    for (int i = 0; i < 13; i++) for (int j = 0; j < 13; j++) M_out[(size_t)e * 169 + i * 13 + j] = Mp[pidx(i, j)];
+}
+
+__global__ void __launch_bounds__(WAVE) k_target_pose(const DevModel *mp, DevConfig cfg, StatePtrs st, const float *actions, float *target_out) {
+    const DevModel &m = *mp;
+    float *lds = lds_dyn; const int lane = threadIdx.x;
+    int e = blockIdx.x * WAVE + lane;
+    const bool valid = e < st.n;
+    if (!valid) e = st.n - 1;
+    LaneState s; ld_state(st, e, s);
+    Kin k; kinematics(m, s.qpos, k, lds, lane);
+    const int adim = cfg.include_roll ? 6 : 5;
+    float act[6], target[5], oc;
+    for (int i = 0; i < 6; i++) act[i] = i < adim ? actions[(size_t)e * adim + i] : 0.f;
+    target_pose(cfg, act, s.qpos, k, target, oc);
+    if (valid) for (int i = 0; i < 5; i++) target_out[(size_t)e * 5 + i] = target[i];
+}
+
+// [rows][cols] -> [cols][rows]; used by the env-major <-> SoA state hooks
+__global__ void k_transpose(const float *src, float *dst, int rows, int cols) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    int r = i / cols, c = i % cols;
+    dst[(size_t)c * rows + r] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host API
+// ------------------------------------------------------------------------------------------------
+static StatePtrs state_ptrs(GripBatch *b) {
+    StatePtrs p; p.qpos = b->qpos; p.qvel = b->qvel; p.ctrl = b->ctrl; p.warm = b->warm; p.episode_step = b->episode_step;
+    p.status = b->status; p.gripper_open = b->gripper_open; p.pad_grasp = b->pad_grasp; p.pad_pher = b->pad_pher; p.n = b->n;
+    return p;
+}
+static StepOutDev to_dev(const GripStepOut *o) {
+    StepOutDev d; memset(&d, 0, sizeof d);
+    if (!o) return d;
+    d.reward = o->reward; d.done = o->done; d.achieved_goal = o->achieved_goal; d.desired_goal = o->desired_goal; d.status = o->status;
+    d.episode_step = o->episode_step; d.gripper_open = o->gripper_open; d.object_grasped = o->object_grasped;
+    d.position_reached = o->position_reached; d.total_distance = o->total_distance; d.line_distance = o->line_distance;
+    d.gripper_position = o->gripper_position; d.object_position = o->object_position; d.init_obj_pos = o->init_obj_pos;
+    d.n_substeps = o->n_substeps; d.fault = o->fault;
+    return d;
+}
+static int grid_of(const GripBatch *b) { return (b->n + WAVE - 1) / WAVE; }
+
+static int ensure_lds_attr() {
+    static bool done = false;
+    if (done) return 0;
+    HIPCHK(hipFuncSetAttribute((const void *)k_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void *)k_macro_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void *)k_substep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void *)k_debug_forward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void *)k_target_pose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    done = true;
+    return 0;
+}
+
+extern "C" int grip_batch_create(const GripModel *m, int n_envs, int device_id, GripBatch **out) {
+    if (!m || n_envs <= 0 || !out) return fail("grip_batch_create: bad arguments");
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail("grip_batch_create: no HIP device (this library has no CPU fallback)");
+    HIPCHK(hipSetDevice(device_id));
+    if (ensure_lds_attr()) return -1;
+    GripBatch *b = new GripBatch(); b->n = n_envs; b->device = device_id;
+    size_t N = (size_t)n_envs;
+    HIPCHK(hipMalloc(&b->d_verts, m->verts4.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(b->d_verts, m->verts4.data(), m->verts4.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&b->d_nadr, m->nadr.size() * sizeof(int)));
+    HIPCHK(hipMemcpy(b->d_nadr, m->nadr.data(), m->nadr.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&b->d_nbr, m->nbr.size() * sizeof(int)));
+    HIPCHK(hipMemcpy(b->d_nbr, m->nbr.data(), m->nbr.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&b->d_planes, m->planes.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(b->d_planes, m->planes.data(), m->planes.size() * sizeof(float), hipMemcpyHostToDevice));
+    DevModel hm_ = m->host; hm_.hull_verts = b->d_verts; hm_.hull_nadr = b->d_nadr; hm_.hull_nbr = b->d_nbr; hm_.hull_planes = b->d_planes;
+    HIPCHK(hipMalloc(&b->d_model, sizeof(DevModel)));
+    HIPCHK(hipMemcpy(b->d_model, &hm_, sizeof(DevModel), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&b->qpos, 14 * N * sizeof(float))); HIPCHK(hipMalloc(&b->qvel, 13 * N * sizeof(float)));
+    HIPCHK(hipMalloc(&b->ctrl, 7 * N * sizeof(float))); HIPCHK(hipMalloc(&b->warm, 13 * N * sizeof(float)));
+    HIPCHK(hipMalloc(&b->episode_step, N * sizeof(int))); HIPCHK(hipMalloc(&b->status, N * sizeof(int)));
+    HIPCHK(hipMalloc(&b->gripper_open, N * sizeof(int))); HIPCHK(hipMalloc(&b->pad_grasp, N * sizeof(int)));
+    HIPCHK(hipMalloc(&b->pad_pher, N * sizeof(int))); HIPCHK(hipMalloc(&b->reset_info, 4 * sizeof(float)));
+    b->scratch_bytes = 169 * N * sizeof(float) + 1024;
+    HIPCHK(hipMalloc(&b->scratch, b->scratch_bytes));
+    // config defaults (config/base_config.py:12-54)
+    b->cfg.max_steps = 400; b->cfg.time_horizon = 400; b->cfg.include_roll = 1; b->cfg.full_observation = 1; b->cfg.her_buffer = 0;
+    b->cfg.auto_reset = 0; b->cfg.max_translation = 0.05f; b->cfg.max_rotation = 0.15f; b->cfg.pos_tolerance = 0.002f;
+    b->cfg.grasp_tolerance = 0.03f; b->cfg.dir_x = 1.f; b->cfg.dir_y = 0.f;
+    b->xfrc_z = -(0.438f * m->host.gravity_z);      // robot_env.py:64-65, constant verbatim
+    b->ev0.resize(EV_RING); b->ev1.resize(EV_RING);
+    for (int i = 0; i < EV_RING; i++) { HIPCHK(hipEventCreate(&b->ev0[i])); HIPCHK(hipEventCreate(&b->ev1[i])); }
+    *out = b;
+    return grip_batch_reset(b, nullptr, nullptr, nullptr);
+}
+
+extern "C" void grip_batch_destroy(GripBatch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    (void)hipDeviceSynchronize();
+    void *ptrs[] = {b->d_model, b->d_verts, b->d_nadr, b->d_nbr, b->d_planes, b->qpos, b->qvel, b->ctrl, b->warm, b->episode_step, b->status,
+                    b->gripper_open, b->pad_grasp, b->pad_pher, b->reset_info, b->scratch};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &e : b->ev0) (void)hipEventDestroy(e);
+    for (auto &e : b->ev1) (void)hipEventDestroy(e);
+    delete b;
+}
+
+extern "C" int grip_batch_num_envs(const GripBatch *b) { return b ? b->n : -1; }
+
+extern "C" int grip_batch_set_config(GripBatch *b, const GripEnvConfig *c) {
+    if (!b || !c) return fail("grip_batch_set_config: bad arguments");
+    if (c->max_steps <= 0 || c->time_horizon <= 0) return fail("grip_batch_set_config: max_steps and time_horizon must be positive");
+    b->cfg.max_steps = c->max_steps; b->cfg.time_horizon = c->time_horizon; b->cfg.include_roll = c->include_roll;
+    b->cfg.full_observation = c->full_observation; b->cfg.her_buffer = c->her_buffer; b->cfg.auto_reset = c->auto_reset;
+    b->cfg.max_translation = c->max_translation; b->cfg.max_rotation = c->max_rotation; b->cfg.pos_tolerance = c->pos_tolerance;
+    b->cfg.grasp_tolerance = c->grasp_tolerance; b->cfg.dir_x = c->target_dir[0]; b->cfg.dir_y = c->target_dir[1];
+    // the reset-state pad scalars depend on the target direction: refresh them (no lane is reset: mask of zeros)
+    HIPCHK(hipSetDevice(b->device));
+    uint8_t *zero_mask = (uint8_t *)b->scratch;
+    HIPCHK(hipMemsetAsync(zero_mask, 0, (size_t)b->n, nullptr));
+    StepOutDev none; memset(&none, 0, sizeof none);
+    hipLaunchKernelGGL(k_reset, dim3(1), dim3(WAVE), LDS_BYTES, nullptr, b->d_model, b->cfg, state_ptrs(b), zero_mask, none, b->reset_info);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return 0;
+}
+
+extern "C" int grip_batch_reset(GripBatch *b, const uint8_t *mask_dev, const GripStepOut *out, void *stream) {
+    if (!b) return fail("grip_batch_reset: null batch");
+    HIPCHK(hipSetDevice(b->device));
+    hipLaunchKernelGGL(k_reset, dim3(grid_of(b)), dim3(WAVE), LDS_BYTES, (hipStream_t)stream, b->d_model, b->cfg, state_ptrs(b), mask_dev,
+                       to_dev(out), b->reset_info);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int grip_batch_step(GripBatch *b, const float *actions_dev, const GripStepOut *out, void *stream) {
+    if (!b || !actions_dev) return fail("grip_batch_step: null argument");
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t s = (hipStream_t)stream;
+    int slot = b->ev_used % EV_RING;
+    HIPCHK(hipEventRecord(b->ev0[slot], s));
+    hipLaunchKernelGGL(k_macro_step, dim3(grid_of(b)), dim3(WAVE), LDS_BYTES, s, b->d_model, b->cfg, state_ptrs(b), actions_dev, to_dev(out),
+                       b->reset_info, b->xfrc_z);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(b->ev1[slot], s));
+    b->ev_used++;
+    return 0;
+}
+
+extern "C" int grip_batch_kernel_time(GripBatch *b, int reset, float *ms_avg, int *launches) {
+    if (!b) return fail("grip_batch_kernel_time: null batch");
+    HIPCHK(hipSetDevice(b->device));
+    int n = b->ev_used < EV_RING ? b->ev_used : EV_RING;
+    double tot = 0;
+    for (int i = 0; i < n; i++) {
+        HIPCHK(hipEventSynchronize(b->ev1[i]));
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, b->ev0[i], b->ev1[i])); tot += ms;
+    }
+    if (ms_avg) *ms_avg = n ? (float)(tot / n) : 0.f;
+    if (launches) *launches = n;
+    if (reset) b->ev_used = 0;
+    return 0;
+}
+
+extern "C" int grip_batch_substep(GripBatch *b, int k, void *stream) {
+    if (!b || k < 0) return fail("grip_batch_substep: bad arguments");
+    HIPCHK(hipSetDevice(b->device));
+    hipLaunchKernelGGL(k_substep, dim3(grid_of(b)), dim3(WAVE), LDS_BYTES, (hipStream_t)stream, b->d_model, state_ptrs(b), k, b->xfrc_z, (int *)nullptr);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int xfer_field(GripBatch *b, float *soa, float *user, int width, bool to_user, int host_or_dev, hipStream_t s) {
+    if (!user) return 0;
+    size_t cnt = (size_t)width * b->n;
+    int threads = 256, blocks = (int)((cnt + threads - 1) / threads);
+    if (cnt * sizeof(float) > b->scratch_bytes) return fail("state scratch too small");
+    if (to_user) {
+        float *dst = host_or_dev ? user : b->scratch;
+        hipLaunchKernelGGL(k_transpose, dim3(blocks), dim3(threads), 0, s, soa, dst, width, b->n);       // [width][N] -> [N][width]
+        HIPCHK(hipGetLastError());
+        if (!host_or_dev) { HIPCHK(hipMemcpyAsync(user, b->scratch, cnt * sizeof(float), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); }
+    } else {
+        const float *src = user;
+        if (!host_or_dev) { HIPCHK(hipMemcpyAsync(b->scratch, user, cnt * sizeof(float), hipMemcpyHostToDevice, s)); src = b->scratch; }
+        hipLaunchKernelGGL(k_transpose, dim3(blocks), dim3(threads), 0, s, src, soa, b->n, width);        // [N][width] -> [width][N]
+        HIPCHK(hipGetLastError());
+        if (!host_or_dev) HIPCHK(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+extern "C" int grip_batch_get_state(GripBatch *b, float *qpos, float *qvel, float *ctrl, float *warm, int host_or_dev, void *stream) {
+    if (!b) return fail("grip_batch_get_state: null batch");
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (xfer_field(b, b->qpos, qpos, 14, true, host_or_dev, s) || xfer_field(b, b->qvel, qvel, 13, true, host_or_dev, s) ||
+        xfer_field(b, b->ctrl, ctrl, 7, true, host_or_dev, s) || xfer_field(b, b->warm, warm, 13, true, host_or_dev, s)) return -1;
+    return 0;
+}
+extern "C" int grip_batch_set_state(GripBatch *b, const float *qpos, const float *qvel, const float *ctrl, const float *warm, int host_or_dev, void *stream) {
+    if (!b) return fail("grip_batch_set_state: null batch");
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (xfer_field(b, b->qpos, (float *)qpos, 14, false, host_or_dev, s) || xfer_field(b, b->qvel, (float *)qvel, 13, false, host_or_dev, s) ||
+        xfer_field(b, b->ctrl, (float *)ctrl, 7, false, host_or_dev, s) || xfer_field(b, b->warm, (float *)warm, 13, false, host_or_dev, s)) return -1;
+    return 0;
+}
+extern "C" int grip_batch_get_flags(GripBatch *b, int32_t *episode_step, int32_t *status, int32_t *gripper_open, void *stream) {
+    if (!b) return fail("grip_batch_get_flags: null batch");
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t s = (hipStream_t)stream; size_t nb = (size_t)b->n * sizeof(int);
+    if (episode_step) HIPCHK(hipMemcpyAsync(episode_step, b->episode_step, nb, hipMemcpyDeviceToHost, s));
+    if (status) HIPCHK(hipMemcpyAsync(status, b->status, nb, hipMemcpyDeviceToHost, s));
+    if (gripper_open) HIPCHK(hipMemcpyAsync(gripper_open, b->gripper_open, nb, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+extern "C" int grip_batch_set_flags(GripBatch *b, const int32_t *episode_step, const int32_t *status, const int32_t *gripper_open, void *stream) {
+    if (!b) return fail("grip_batch_set_flags: null batch");
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t s = (hipStream_t)stream; size_t nb = (size_t)b->n * sizeof(int);
+    if (episode_step) HIPCHK(hipMemcpyAsync(b->episode_step, episode_step, nb, hipMemcpyHostToDevice, s));
+    if (status) HIPCHK(hipMemcpyAsync(b->status, status, nb, hipMemcpyHostToDevice, s));
+    if (gripper_open) HIPCHK(hipMemcpyAsync(b->gripper_open, gripper_open, nb, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int grip_batch_debug_forward(GripBatch *b, int32_t *ncon, float *con, float *xpos, float *qacc, float *qacc_smooth, float *M, float *bias, void *stream) {
+    if (!b || !ncon || !con || !xpos || !qacc || !qacc_smooth || !M || !bias) return fail("grip_batch_debug_forward: null argument");
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t s = (hipStream_t)stream; size_t N = (size_t)b->n;
+    int *d_ncon; float *d_con, *d_xpos, *d_qacc, *d_qs, *d_M, *d_bias;
+    HIPCHK(hipMalloc(&d_ncon, N * sizeof(int))); HIPCHK(hipMalloc(&d_con, N * G_MAXC * 10 * sizeof(float))); HIPCHK(hipMalloc(&d_xpos, N * 24 * sizeof(float)));
+    HIPCHK(hipMalloc(&d_qacc, N * 13 * sizeof(float))); HIPCHK(hipMalloc(&d_qs, N * 13 * sizeof(float))); HIPCHK(hipMalloc(&d_M, N * 169 * sizeof(float)));
+    HIPCHK(hipMalloc(&d_bias, N * 13 * sizeof(float)));
+    hipLaunchKernelGGL(k_debug_forward, dim3(grid_of(b)), dim3(WAVE), LDS_BYTES, s, b->d_model, state_ptrs(b), b->xfrc_z, d_ncon, d_con, d_xpos, d_qacc, d_qs, d_M, d_bias);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(ncon, d_ncon, N * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(con, d_con, N * G_MAXC * 10 * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(xpos, d_xpos, N * 24 * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(qacc, d_qacc, N * 13 * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(qacc_smooth, d_qs, N * 13 * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(M, d_M, N * 169 * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(bias, d_bias, N * 13 * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    (void)hipFree(d_ncon); (void)hipFree(d_con); (void)hipFree(d_xpos); (void)hipFree(d_qacc); (void)hipFree(d_qs); (void)hipFree(d_M); (void)hipFree(d_bias);
+    return 0;
+}
+
+extern "C" int grip_batch_target_pose(GripBatch *b, const float *actions_dev, float *target_qpos_host, void *stream) {
+    if (!b || !actions_dev || !target_qpos_host) return fail("grip_batch_target_pose: null argument");
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t s = (hipStream_t)stream; size_t N = (size_t)b->n;
+    float *d_t; HIPCHK(hipMalloc(&d_t, N * 5 * sizeof(float)));
+    hipLaunchKernelGGL(k_target_pose, dim3(grid_of(b)), dim3(WAVE), LDS_BYTES, s, b->d_model, b->cfg, state_ptrs(b), actions_dev, d_t);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(target_qpos_host, d_t, N * 5 * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    (void)hipFree(d_t);
+    return 0;
+}
+
+// observation kernels live in grip_render.hip
+extern "C" int grip_render_launch(const DevModel *d_model, DevConfig cfg, const float *qpos, const int *pad_grasp, const int *pad_pher, int n,
+                                  uint8_t *obs, hipStream_t s);
+extern "C" int grip_batch_observe(GripBatch *b, uint8_t *obs_dev, void *stream) {
+    if (!b || !obs_dev) return fail("grip_batch_observe: null argument");
+    HIPCHK(hipSetDevice(b->device));
+    if (grip_render_launch(b->d_model, b->cfg, b->qpos, b->pad_grasp, b->pad_pher, b->n, obs_dev, (hipStream_t)stream)) return fail("render launch failed");
+    return 0;
+}

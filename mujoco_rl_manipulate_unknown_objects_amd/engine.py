@@ -1,0 +1,264 @@
+"""ctypes binding of ``libgrip_sim.so`` (include/grip_sim.h) + torch-tensor plumbing.
+
+The shared library is the product: hand-written HIP kernels for gfx950 behind a
+plain C ABI. This module only moves pointers: device memory, streams and
+``torch.distributed`` come from PyTorch-ROCm, nothing is computed here and there is
+NO CPU fallback -- if the library or a GPU is missing every call raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libgrip_sim.so")
+ASSETS = os.path.join(_HERE, "assets")
+OBJECTS = ("acorn", "sand_ball", "sugar_cube", "bread_crumb")
+MAXCON = 16
+
+
+class GripError(RuntimeError):
+    pass
+
+
+def build_library(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 of csrc/*.hip into csrc/libgrip_sim.so (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "grip_sim.h"))
+    if (not force and os.path.exists(LIB_PATH)
+            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs)):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH,
+           os.path.join(CSRC, "grip_sim.hip"), os.path.join(CSRC, "grip_render.hip")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout, r.stderr)
+    if r.returncode:
+        raise GripError("hipcc failed:\n" + r.stderr[-4000:])
+    return LIB_PATH
+
+
+class EnvConfigC(C.Structure):
+    _fields_ = [("max_steps", C.c_int32), ("time_horizon", C.c_int32), ("include_roll", C.c_int32),
+                ("full_observation", C.c_int32), ("her_buffer", C.c_int32), ("auto_reset", C.c_int32),
+                ("max_translation", C.c_float), ("max_rotation", C.c_float), ("pos_tolerance", C.c_float),
+                ("grasp_tolerance", C.c_float), ("target_dir", C.c_float * 2)]
+
+
+_OUT_FIELDS = [("reward", "float32", ()), ("done", "uint8", ()), ("achieved_goal", "float32", (2,)),
+               ("desired_goal", "float32", (2,)), ("status", "int32", ()), ("episode_step", "int32", ()),
+               ("gripper_open", "int32", ()), ("object_grasped", "int32", ()), ("position_reached", "int32", ()),
+               ("total_distance", "float32", ()), ("line_distance", "float32", ()), ("gripper_position", "float32", (3,)),
+               ("object_position", "float32", (3,)), ("init_obj_pos", "float32", (3,)), ("n_substeps", "int32", ()),
+               ("fault", "int32", ())]
+
+
+class StepOutC(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n, _, _ in _OUT_FIELDS]
+
+
+_lib = None
+EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_nvert", "grip_batch_create",
+           "grip_batch_destroy", "grip_batch_set_config", "grip_batch_num_envs", "grip_batch_reset", "grip_batch_step",
+           "grip_batch_observe", "grip_batch_get_state", "grip_batch_set_state", "grip_batch_get_flags",
+           "grip_batch_set_flags", "grip_batch_substep", "grip_batch_debug_forward", "grip_batch_target_pose",
+           "grip_batch_kernel_time"]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GripError(f"{LIB_PATH} is not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
+                        "There is no CPU fallback for the product path.")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.grip_last_error.restype = C.c_char_p
+    L.grip_model_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.grip_model_free.argtypes = [vp]
+    L.grip_model_nvert.argtypes = [vp]
+    L.grip_batch_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.grip_batch_destroy.argtypes = [vp]
+    L.grip_batch_set_config.argtypes = [vp, C.POINTER(EnvConfigC)]
+    L.grip_batch_num_envs.argtypes = [vp]
+    L.grip_batch_reset.argtypes = [vp, vp, C.POINTER(StepOutC), vp]
+    L.grip_batch_step.argtypes = [vp, vp, C.POINTER(StepOutC), vp]
+    L.grip_batch_observe.argtypes = [vp, vp, vp]
+    L.grip_batch_get_state.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
+    L.grip_batch_set_state.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp]
+    L.grip_batch_get_flags.argtypes = [vp, vp, vp, vp, vp]
+    L.grip_batch_set_flags.argtypes = [vp, vp, vp, vp, vp]
+    L.grip_batch_substep.argtypes = [vp, C.c_int, vp]
+    L.grip_batch_debug_forward.argtypes = [vp] + [vp] * 7 + [vp]
+    L.grip_batch_target_pose.argtypes = [vp, vp, vp, vp]
+    L.grip_batch_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    _lib = L
+    return L
+
+
+def _chk(rc):
+    if rc != 0:
+        raise GripError(lib().grip_last_error().decode())
+
+
+def asset_path(obj):
+    obj = os.path.basename(obj).replace("_env.xml", "").replace("_env.grpm", "")
+    p = os.path.join(ASSETS, f"{obj}_env.grpm")
+    if not os.path.exists(p):
+        raise GripError(f"no compiled model for '{obj}' under {ASSETS}")
+    return p
+
+
+class Model:
+    def __init__(self, obj_or_path):
+        path = obj_or_path if os.path.isfile(obj_or_path) else asset_path(obj_or_path)
+        self.ptr = C.c_void_p()
+        _chk(lib().grip_model_load(path.encode(), C.byref(self.ptr)))
+        self.path = path
+
+    def __del__(self):
+        if getattr(self, "ptr", None) and _lib is not None:
+            _lib.grip_model_free(self.ptr)
+            self.ptr = None
+
+
+def _np(a, dt):
+    a = np.ascontiguousarray(a, dtype=dt)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+class Batch:
+    """N environments of one model on one GPU (GripBatch). All tensors are torch CUDA tensors."""
+
+    def __init__(self, model, n_envs, device_index=0, **cfg):
+        import torch
+        if not torch.cuda.is_available():
+            raise GripError("no GPU visible: the rollout engine has no CPU path")
+        self.torch = torch
+        self.model = model if isinstance(model, Model) else Model(model)
+        self.n = int(n_envs)
+        self.device = torch.device("cuda", device_index)
+        self.ptr = C.c_void_p()
+        _chk(lib().grip_batch_create(self.model.ptr, self.n, device_index, C.byref(self.ptr)))
+        self.cfg = EnvConfigC(400, 400, 1, 1, 0, 0, 0.05, 0.15, 0.002, 0.03, (C.c_float * 2)(1.0, 0.0))
+        self.out = {}
+        for name, dt, shp in _OUT_FIELDS:
+            self.out[name] = torch.zeros((self.n,) + shp, dtype=getattr(torch, dt), device=self.device)
+        self._outc = StepOutC(**{n: self.out[n].data_ptr() for n, _, _ in _OUT_FIELDS})
+        if cfg:
+            self.set_config(**cfg)
+
+    # -- config ---------------------------------------------------------------------------------
+    def set_config(self, **kw):
+        for k, v in kw.items():
+            if k == "target_dir":
+                self.cfg.target_dir[0], self.cfg.target_dir[1] = float(v[0]), float(v[1])
+            elif hasattr(self.cfg, k):
+                setattr(self.cfg, k, v)
+            else:
+                raise GripError(f"unknown config field {k}")
+        _chk(lib().grip_batch_set_config(self.ptr, C.byref(self.cfg)))
+
+    @property
+    def action_dim(self):
+        return 6 if self.cfg.include_roll else 5
+
+    @property
+    def obs_channels(self):
+        return 5 if self.cfg.full_observation else 4
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- env surface ----------------------------------------------------------------------------
+    def reset(self, mask=None):
+        mp = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=self.torch.uint8).contiguous()
+            mp = C.c_void_p(mask.data_ptr())
+        _chk(lib().grip_batch_reset(self.ptr, mp, C.byref(self._outc), self._stream()))
+        return self.out
+
+    def step(self, actions):
+        a = actions.to(device=self.device, dtype=self.torch.float32).contiguous()
+        if a.shape != (self.n, self.action_dim):
+            raise GripError(f"actions must be [{self.n},{self.action_dim}], got {tuple(a.shape)}")
+        _chk(lib().grip_batch_step(self.ptr, C.c_void_p(a.data_ptr()), C.byref(self._outc), self._stream()))
+        return self.out
+
+    def observe(self, obs=None):
+        if obs is None:
+            obs = self.torch.empty((self.n, self.obs_channels, 64, 64), dtype=self.torch.uint8, device=self.device)
+        _chk(lib().grip_batch_observe(self.ptr, C.c_void_p(obs.data_ptr()), self._stream()))
+        return obs
+
+    # -- low-level hooks ------------------------------------------------------------------------
+    def get_state(self):
+        qpos = np.zeros((self.n, 14), np.float32); qvel = np.zeros((self.n, 13), np.float32)
+        ctrl = np.zeros((self.n, 7), np.float32); warm = np.zeros((self.n, 13), np.float32)
+        _chk(lib().grip_batch_get_state(self.ptr, qpos.ctypes.data, qvel.ctypes.data, ctrl.ctypes.data, warm.ctypes.data, 0, self._stream()))
+        return qpos, qvel, ctrl, warm
+
+    def set_state(self, qpos=None, qvel=None, ctrl=None, warm=None):
+        keep = []
+        ptrs = []
+        for a, w in ((qpos, 14), (qvel, 13), (ctrl, 7), (warm, 13)):
+            if a is None:
+                ptrs.append(None)
+            else:
+                arr, p = _np(a, np.float32)
+                assert arr.shape == (self.n, w), (arr.shape, w)
+                keep.append(arr); ptrs.append(p)
+        _chk(lib().grip_batch_set_state(self.ptr, *ptrs, 0, self._stream()))
+
+    def get_flags(self):
+        es = np.zeros(self.n, np.int32); st = np.zeros(self.n, np.int32); go = np.zeros(self.n, np.int32)
+        _chk(lib().grip_batch_get_flags(self.ptr, es.ctypes.data, st.ctypes.data, go.ctypes.data, self._stream()))
+        return es, st, go
+
+    def set_flags(self, episode_step=None, status=None, gripper_open=None):
+        keep, ptrs = [], []
+        for a in (episode_step, status, gripper_open):
+            if a is None:
+                ptrs.append(None)
+            else:
+                arr, p = _np(a, np.int32); keep.append(arr); ptrs.append(p)
+        _chk(lib().grip_batch_set_flags(self.ptr, *ptrs, self._stream()))
+
+    def substep(self, k=1):
+        _chk(lib().grip_batch_substep(self.ptr, int(k), self._stream()))
+
+    def debug_forward(self):
+        n = self.n
+        ncon = np.zeros(n, np.int32); con = np.zeros((n, MAXCON, 10), np.float32); xpos = np.zeros((n, 8, 3), np.float32)
+        qacc = np.zeros((n, 13), np.float32); qs = np.zeros((n, 13), np.float32); M = np.zeros((n, 13, 13), np.float32)
+        bias = np.zeros((n, 13), np.float32)
+        _chk(lib().grip_batch_debug_forward(self.ptr, ncon.ctypes.data, con.ctypes.data, xpos.ctypes.data, qacc.ctypes.data,
+                                            qs.ctypes.data, M.ctypes.data, bias.ctypes.data, self._stream()))
+        return dict(ncon=ncon, con=con, xpos=xpos, qacc=qacc, qacc_smooth=qs, M=M, bias=bias)
+
+    def target_pose(self, actions):
+        a = actions.to(device=self.device, dtype=self.torch.float32).contiguous()
+        t = np.zeros((self.n, 5), np.float32)
+        _chk(lib().grip_batch_target_pose(self.ptr, C.c_void_p(a.data_ptr()), t.ctypes.data, self._stream()))
+        return t
+
+    def kernel_time(self, reset=True):
+        ms = C.c_float(); n = C.c_int()
+        _chk(lib().grip_batch_kernel_time(self.ptr, int(reset), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if getattr(self, "ptr", None) and _lib is not None:
+            _lib.grip_batch_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,33 @@
+"""AugmentedNatureCNN (reference models/feature_extractor.py:7-49), same module names so that a
+state_dict of the reference loads unchanged: ``cnn.{0,2,4}`` convolutions, ``linear.0``.
+
+NatureCNN over the image channels (all but the last) -> 512 features, concatenated with the two
+scalars the environment writes into the sensor-pad channel (robot_env.py:281-283): 514 features,
+602 784 parameters for the default 5 x 64 x 64 observation. Runs on PyTorch-ROCm (MIOpen /
+hipBLASLt); ``channels_last`` + bf16 autocast are applied by the PPO policy, not here.
+"""
+import torch as th
+from torch import nn
+
+from ..sb3.torch_layers import BaseFeaturesExtractor
+
+
+class AugmentedNatureCNN(BaseFeaturesExtractor):
+    def __init__(self, observation_space, features_dim: int = 514):
+        super().__init__(observation_space, features_dim)
+        shape = observation_space["observation"].shape
+        n_input_channels = shape[0] - 1
+        self.cnn = nn.Sequential(
+            nn.Conv2d(n_input_channels, 32, kernel_size=8, stride=4, padding=0), nn.ReLU(),
+            nn.Conv2d(32, 64, kernel_size=4, stride=2, padding=0), nn.ReLU(),
+            nn.Conv2d(64, 64, kernel_size=3, stride=1, padding=0), nn.ReLU(),
+            nn.Flatten())
+        with th.no_grad():
+            n_flatten = self.cnn(th.zeros(1, n_input_channels, shape[1], shape[2])).shape[1]
+        self.linear = nn.Sequential(nn.Linear(n_flatten, features_dim - 2), nn.ReLU())
+
+    def forward(self, observations, num_direct_features: int = 2) -> th.Tensor:
+        obs = observations["observation"]
+        other = obs[:, -1, 0, :num_direct_features]        # grasp code, pheromone level (already / 255)
+        img = self.linear(self.cnn(obs[:, :-1]))
+        return th.cat((img, other.to(img.dtype)), dim=1)

@@ -1,0 +1,229 @@
+"""PPO with Stable-Baselines3's surface (``PPO(policy, env, policy_kwargs=...)``, ``learn``,
+``predict``, ``save`` / ``load``), built for one-process-per-GPU data parallelism.
+
+The reference trains SAC (train_agent.py:82); PPO is what BASELINE.json's north star asks for and has
+no reference hyper-parameters: SB3's PPO defaults are used (gamma 0.99, GAE lambda 0.95,
+clip 0.2, vf_coef 0.5, max_grad_norm 0.5, Adam 3e-4 eps 1e-5, advantage normalisation per minibatch),
+with n_steps / batch_size / n_epochs sized for thousands of envs per GPU.
+
+MI355X layout: the rollout buffer lives in HBM (uint8 observations: n_steps x N x 20 480 B), GAE is
+a reversed scan on device, minibatches are index-gathers of the buffer, and with world_size > 1 the
+gradients of one minibatch are flattened into a single bucket and summed with ONE all-reduce over
+RCCL/xGMI (about 4 MB: latency-bound, so one collective per optimiser step). No physics
+state ever crosses GPUs.
+"""
+import io
+import os
+import time
+import zipfile
+
+import numpy as np
+import torch as th
+import torch.distributed as dist
+
+from .policies import ActorCriticPolicy
+from .callbacks import BaseCallback, CallbackList
+
+
+def _to_t(x, device):
+    if isinstance(x, th.Tensor):
+        return x.to(device)
+    return th.as_tensor(np.asarray(x), device=device)
+
+
+class RolloutBuffer:
+    def __init__(self, n_steps, n_envs, obs_shape, action_dim, device):
+        self.n_steps, self.n_envs, self.device = n_steps, n_envs, device
+        self.obs = th.zeros((n_steps, n_envs) + tuple(obs_shape), dtype=th.uint8, device=device)
+        self.actions = th.zeros((n_steps, n_envs, action_dim), device=device)
+        z = lambda: th.zeros((n_steps, n_envs), device=device)
+        self.rewards, self.values, self.log_probs, self.dones, self.advantages, self.returns = z(), z(), z(), z(), z(), z()
+        self.pos = 0
+
+    def add(self, obs, actions, rewards, dones_before, values, log_probs):
+        t = self.pos
+        self.obs[t].copy_(obs); self.actions[t].copy_(actions); self.rewards[t].copy_(rewards)
+        self.dones[t].copy_(dones_before); self.values[t].copy_(values); self.log_probs[t].copy_(log_probs)
+        self.pos += 1
+
+    def compute_returns(self, last_values, last_dones, gamma, lam):
+        adv = th.zeros(self.n_envs, device=self.device)
+        for t in reversed(range(self.n_steps)):
+            if t == self.n_steps - 1:
+                nonterm, nextv = 1.0 - last_dones, last_values
+            else:
+                nonterm, nextv = 1.0 - self.dones[t + 1], self.values[t + 1]
+            delta = self.rewards[t] + gamma * nextv * nonterm - self.values[t]
+            adv = delta + gamma * lam * nonterm * adv
+            self.advantages[t] = adv
+        self.returns = self.advantages + self.values
+        self.pos = 0
+
+
+class PPO:
+    def __init__(self, policy, env, learning_rate=3e-4, n_steps=16, batch_size=4096, n_epochs=4, gamma=0.99, gae_lambda=0.95,
+                 clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, policy_kwargs=None, verbose=0, tensorboard_log=None,
+                 device=None, seed=None, autocast_dtype=None):
+        self.env = env
+        self.n_envs = getattr(env, "num_envs", 1)
+        self.device = th.device(device) if device is not None else getattr(env, "device", th.device("cuda" if th.cuda.is_available() else "cpu"))
+        self.n_steps, self.batch_size, self.n_epochs = n_steps, batch_size, n_epochs
+        self.gamma, self.gae_lambda, self.clip_range = gamma, gae_lambda, clip_range
+        self.ent_coef, self.vf_coef, self.max_grad_norm = ent_coef, vf_coef, max_grad_norm
+        self.verbose, self.tensorboard_log = verbose, tensorboard_log
+        self.policy_kwargs = dict(policy_kwargs or {})
+        self.autocast_dtype = autocast_dtype
+        if seed is not None:
+            th.manual_seed(seed)
+        policy_class = ActorCriticPolicy if isinstance(policy, str) else policy
+        self.policy = policy_class(env.observation_space, env.action_space, **self.policy_kwargs).to(self.device)
+        if self.device.type == "cuda":
+            self.policy = self.policy.to(memory_format=th.channels_last)
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if self.distributed:                      # identical initial parameters on every rank
+            for p in self.policy.parameters():
+                dist.broadcast(p.data, src=0)
+        self.optimizer = th.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5)
+        obs_shape = env.observation_space["observation"].shape
+        self.rollout_buffer = RolloutBuffer(n_steps, self.n_envs, obs_shape, self.policy.action_dim, self.device)
+        self.num_timesteps = 0
+        self._last_obs = None
+        self._last_dones = None
+        self._flat_grad = None
+        self.logger = {}
+
+    # ------------------------------------------------------------------ rollouts
+    def _obs_t(self, obs):
+        return {"observation": _to_t(obs["observation"], self.device)}
+
+    def _ac(self):
+        if self.autocast_dtype is not None and self.device.type == "cuda":
+            return th.autocast("cuda", dtype=self.autocast_dtype)
+        return th.autocast("cpu", enabled=False)
+
+    def collect_rollouts(self, callback=None):
+        buf = self.rollout_buffer
+        if self._last_obs is None:
+            self._last_obs = self._obs_t(self.env.reset())
+            self._last_dones = th.zeros(self.n_envs, device=self.device)
+        low = th.as_tensor(self.env.action_space.low, device=self.device); high = th.as_tensor(self.env.action_space.high, device=self.device)
+        for _ in range(self.n_steps):
+            with th.no_grad(), self._ac():
+                actions, values, log_probs = self.policy(self._last_obs)
+            clipped = th.max(th.min(actions, high), low)
+            env_actions = clipped if isinstance(self._last_obs["observation"], th.Tensor) and hasattr(self.env, "device") else clipped.cpu().numpy()
+            new_obs, rewards, dones, infos = self.env.step(env_actions)
+            buf.add(self._last_obs["observation"], actions, _to_t(rewards, self.device).float(), self._last_dones, values, log_probs)
+            self._last_obs = self._obs_t(new_obs)
+            self._last_dones = _to_t(dones, self.device).float()
+            self.num_timesteps += self.n_envs
+            if callback is not None and not callback.on_step():
+                return False
+        with th.no_grad(), self._ac():
+            last_values = self.policy.predict_values(self._last_obs)
+        buf.compute_returns(last_values, self._last_dones, self.gamma, self.gae_lambda)
+        return True
+
+    # ------------------------------------------------------------------ update
+    def _allreduce_grads(self):
+        params = [p for p in self.policy.parameters() if p.grad is not None]
+        flat = th.cat([p.grad.reshape(-1) for p in params])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= dist.get_world_size()
+        off = 0
+        for p in params:
+            n = p.numel(); p.grad.copy_(flat[off:off + n].view_as(p.grad)); off += n
+
+    def train(self):
+        buf = self.rollout_buffer
+        total = self.n_steps * self.n_envs
+        obs = buf.obs.view((total,) + buf.obs.shape[2:]); actions = buf.actions.view(total, -1)
+        old_values, old_logp = buf.values.view(-1), buf.log_probs.view(-1)
+        adv_all, ret_all = buf.advantages.view(-1), buf.returns.view(-1)
+        bs = min(self.batch_size, total)
+        stats = {}
+        for _ in range(self.n_epochs):
+            perm = th.randperm(total, device=self.device)
+            for s in range(0, total - bs + 1, bs):
+                idx = perm[s:s + bs]
+                mb_obs = {"observation": obs[idx]}
+                adv = adv_all[idx]
+                adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+                with self._ac():
+                    values, logp, entropy = self.policy.evaluate_actions(mb_obs, actions[idx])
+                ratio = th.exp(logp - old_logp[idx])
+                pl = -th.min(adv * ratio, adv * th.clamp(ratio, 1 - self.clip_range, 1 + self.clip_range)).mean()
+                vl = th.nn.functional.mse_loss(ret_all[idx], values)
+                el = -entropy.mean()
+                loss = pl + self.ent_coef * el + self.vf_coef * vl
+                self.optimizer.zero_grad(set_to_none=False)
+                loss.backward()
+                if self.distributed:
+                    self._allreduce_grads()
+                th.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
+                self.optimizer.step()
+                stats = {"policy_loss": pl.detach(), "value_loss": vl.detach(), "loss": loss.detach()}
+        self.logger = stats
+        return stats
+
+    # ------------------------------------------------------------------ SB3 surface
+    def learn(self, total_timesteps, callback=None, reset_num_timesteps=True, log_interval=1):
+        if isinstance(callback, (list, tuple)):
+            callback = CallbackList(list(callback))
+        if callback is not None:
+            callback.init_callback(self)
+            callback.on_training_start(locals(), globals())
+        if reset_num_timesteps:
+            self.num_timesteps = 0
+        it, t0 = 0, time.time()
+        while self.num_timesteps < total_timesteps:
+            if not self.collect_rollouts(callback):
+                break
+            self.train()
+            it += 1
+            if self.verbose and it % log_interval == 0:
+                fps = self.num_timesteps / max(1e-9, time.time() - t0)
+                print(f"[ppo] iter {it} timesteps {self.num_timesteps} fps {fps:.0f} loss {float(self.logger.get('loss', 0)):.4f}")
+        if callback is not None:
+            callback.on_training_end()
+        return self
+
+    def predict(self, observation, state=None, episode_start=None, deterministic=False):
+        obs = observation["observation"]
+        single = (obs.ndim == 3)
+        o = _to_t(obs, self.device)
+        if single:
+            o = o.unsqueeze(0)
+        with th.no_grad(), self._ac():
+            actions, _, _ = self.policy({"observation": o}, deterministic=deterministic)
+        low = th.as_tensor(self.env.action_space.low, device=self.device); high = th.as_tensor(self.env.action_space.high, device=self.device)
+        a = th.max(th.min(actions, high), low).cpu().numpy()
+        return (a[0] if single else a), state
+
+    def save(self, path):
+        if not path.endswith(".zip"):
+            path = path + ".zip"
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        with zipfile.ZipFile(path, "w") as z:
+            for name, obj in (("policy.pth", self.policy.state_dict()), ("policy.optimizer.pth", self.optimizer.state_dict())):
+                b = io.BytesIO(); th.save(obj, b); z.writestr(name, b.getvalue())
+            meta = dict(num_timesteps=self.num_timesteps, n_steps=self.n_steps, batch_size=self.batch_size, n_epochs=self.n_epochs,
+                        gamma=self.gamma, gae_lambda=self.gae_lambda, clip_range=self.clip_range)
+            b = io.BytesIO(); th.save(meta, b); z.writestr("data.pth", b.getvalue())
+
+    @classmethod
+    def load(cls, path, env=None, custom_objects=None, device=None, **kwargs):
+        if not path.endswith(".zip"):
+            path = path + ".zip"
+        kw = dict(kwargs)
+        if custom_objects and "policy_kwargs" in custom_objects:
+            kw["policy_kwargs"] = custom_objects["policy_kwargs"]
+        with zipfile.ZipFile(path) as z:
+            meta = th.load(io.BytesIO(z.read("data.pth")), weights_only=False)
+            for k in ("n_steps", "batch_size", "n_epochs", "gamma", "gae_lambda", "clip_range"):
+                kw.setdefault(k, meta[k])
+            model = cls("MultiInputPolicy", env, device=device, **kw)
+            model.policy.load_state_dict(th.load(io.BytesIO(z.read("policy.pth")), map_location=model.device))
+            model.optimizer.load_state_dict(th.load(io.BytesIO(z.read("policy.optimizer.pth")), map_location=model.device))
+            model.num_timesteps = meta["num_timesteps"]
+        return model

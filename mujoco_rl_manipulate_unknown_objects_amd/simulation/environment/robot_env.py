@@ -1,0 +1,169 @@
+"""Gym-shaped environment surfaces over the HIP rollout engine.
+
+``BatchedRobotEnv``  N reference environments on one GPU; tensors in, tensors out.
+``RobotEnv(config)`` the reference's class (simulation/environment/robot_env.py:16), one env,
+                     numpy in / numpy out, same reset / step / compute_reward / render / seed /
+                     close members, same ``info`` keys (robot_env.py:226-241) -- a drop-in for
+                     train_agent.py:17 and eval_agent.py:32.
+Every number comes from ``libgrip_sim.so`` (csrc/); nothing here falls back to the CPU.
+"""
+import os
+from enum import Enum
+from types import SimpleNamespace
+
+import numpy as np
+
+from ... import engine
+from ..controller.actuator import Actuator
+from ..controller.sensor import RGBDSensor
+from .reward import Reward, IntrinsicReward  # noqa: F401
+
+
+def default_config(**overrides):
+    """config/base_config.py defaults as a Namespace (handy for tests and bench)."""
+    from ...config.base_config import _FLAGS
+    ns = SimpleNamespace(**{name: default for name, _, default, _ in _FLAGS})
+    for k, v in overrides.items():
+        setattr(ns, k, v)
+    return ns
+
+
+def _object_name(sim_env):
+    return os.path.basename(sim_env).replace("_env.xml", "")
+
+
+class Status(Enum):
+    RUNNING = 0
+    FAIL = 1
+    TIME_LIMIT = 2
+
+
+class BatchedRobotEnv:
+    metadata = {'render.modes': ['rgb_array', 'depth_array']}
+    Status = Status
+
+    def __init__(self, config, n_envs=1, device_index=0, auto_reset=False):
+        self.config = config
+        self.n_envs = int(n_envs)
+        if getattr(config, "im_reward", False):
+            raise NotImplementedError("--im_reward (IntrinsicReward) is not built yet: SURVEY.md §8(f) n2")
+        if config.width_capture != 64 or config.height_capture != 64:
+            raise ValueError("the observation kernel renders 64x64 (config/base_config.py:18-19 defaults)")
+        if config.direction == 0:                      # robot_env.py:30-33
+            self.target_direction = np.array([1, 0])
+        elif config.direction == 45:
+            self.target_direction = np.array([1, 1])
+        else:
+            raise ValueError("direction must be 0 or 45 (robot_env.py:30-33)")
+        self.batch = engine.Batch(_object_name(config.sim_env), self.n_envs, device_index,
+                                  max_steps=config.max_steps, time_horizon=config.time_horizon,
+                                  include_roll=int(bool(config.include_roll)), full_observation=int(bool(config.full_observation)),
+                                  her_buffer=int(bool(config.her_buffer)), auto_reset=int(bool(auto_reset)),
+                                  max_translation=config.max_translation, max_rotation=config.max_rotation,
+                                  pos_tolerance=config.pos_tolerance, grasp_tolerance=config.grasp_tolerance,
+                                  target_dir=self.target_direction)
+        self.device = self.batch.device
+        self._sensor = RGBDSensor(config=config)
+        self._actuator = Actuator(config=config)
+        self._reward_fn = Reward(config=config)
+        self.setup_spaces()
+        self._obs = self.batch.torch.empty((self.n_envs, self.batch.obs_channels, 64, 64), dtype=self.batch.torch.uint8, device=self.device)
+
+    def setup_spaces(self):
+        self.action_space = self._actuator.setup_action_space()
+        self.observation_space = self._sensor.setup_observation_space()
+
+    def _obs_dict(self, out):
+        self.batch.observe(self._obs)
+        return {"observation": self._obs, "achieved_goal": out["achieved_goal"], "desired_goal": out["desired_goal"]}
+
+    def reset(self, mask=None):
+        """robot_env.py:56-75 for every env (or the masked ones)."""
+        return self._obs_dict(self.batch.reset(mask))
+
+    def step(self, actions):
+        """robot_env.py:77-241 for every env. Returns (obs, reward[N], done[N] bool, info dict of tensors)."""
+        out = self.batch.step(actions)
+        obs = self._obs_dict(out)
+        return obs, out["reward"], out["done"].bool(), out
+
+    def compute_reward(self, achieved_goal, desired_goal, info):
+        """robot_env.py:243-273 on host arrays (HER-style relabelling); the step kernel already returned this."""
+        if isinstance(info, np.ndarray):
+            info = info[0]
+        r = self._reward_fn(info.get("old_obs"), info.get("new_obs"), info["init_obj_pos"], info["final_obj_pos"], info["target_dir"],
+                            info["gripper_open"], info["controls"], info["object_grasped"])
+        if self.config.her_buffer:
+            dist = np.linalg.norm(np.asarray(desired_goal) - np.asarray(achieved_goal), axis=-1)
+            r = r + 1 / np.exp(dist)
+        return r
+
+    def render(self, mode='rgb_array', env_index=0):
+        """Gripper-camera image of one env (robot_env.py:302-340 renders three cameras at a zoomed size;
+        only the observation camera exists here: SURVEY.md §8(f) n4)."""
+        o = self.batch.observe(self._obs)[env_index].cpu().numpy()
+        if mode == 'depth_array':
+            return o[3]
+        return o[:3].transpose(1, 2, 0)
+
+    def seed(self, seed=None):
+        self.np_random = np.random.default_rng(seed)
+        return self.np_random
+
+    def close(self):
+        self.batch.close()
+
+
+class RobotEnv(BatchedRobotEnv):
+    """One environment with the reference's numpy surface (robot_env.py:16)."""
+
+    def __init__(self, config):
+        super().__init__(config, n_envs=1, auto_reset=False)
+        self.obs = dict()
+        self.episode_rewards = np.zeros(config.time_horizon)
+        self.status = Status.RUNNING
+        self.episode_step = 0
+        self.gripper_open = True
+
+    def _np_obs(self, obs):
+        self.obs["observation"] = obs["observation"][0].cpu().numpy()
+        self.obs["achieved_goal"] = obs["achieved_goal"][0].cpu().numpy()
+        self.obs["desired_goal"] = obs["desired_goal"][0].cpu().numpy()
+        return self.obs
+
+    def reset(self):
+        obs = super().reset()
+        self.episode_step = 0
+        self.episode_rewards = np.zeros(self.config.time_horizon)
+        self.status = Status.RUNNING
+        self.gripper_open = True
+        return self._np_obs(obs)
+
+    def step(self, action):
+        torch = self.batch.torch
+        old_obs = self.obs.get("observation")
+        old_obs = None if old_obs is None else old_obs.copy()
+        a = torch.as_tensor(np.asarray(action, dtype=np.float32)).reshape(1, -1)
+        obs, reward, done, out = super().step(a)
+        o = {k: v[0].cpu().numpy() for k, v in out.items()}
+        self._np_obs(obs)
+        reward = float(o["reward"]); done = bool(o["done"])
+        self.status = Status(int(o["status"])); self.gripper_open = bool(o["gripper_open"])
+        step_idx = int(o["episode_step"]) - 1
+        if 0 <= step_idx < len(self.episode_rewards):
+            self.episode_rewards[step_idx] = reward
+        self.episode_step = int(o["episode_step"])
+        pr = int(o["position_reached"])
+        info = {"old_obs": old_obs, "new_obs": self.obs["observation"],
+                "init_obj_pos": o["init_obj_pos"].astype(np.float64), "final_obj_pos": o["object_position"].astype(np.float64),
+                "target_dir": self.target_direction, "gripper_open": self.gripper_open,
+                "controls": np.zeros(2), "object_grasped": int(o["object_grasped"]),
+                "episode_step": self.episode_step, "episode_rewards": self.episode_rewards, "status": self.status,
+                "gripper_position": o["gripper_position"].astype(np.float64), "object_position": o["object_position"].astype(np.float64),
+                "position_reached": {"target": bool(pr & 1), "initial": bool(pr & 2), "fail": bool(pr & 4)},
+                "total_distance": float(o["total_distance"]), "line_distance": float(o["line_distance"]),
+                "n_substeps": int(o["n_substeps"])}
+        return self.obs, reward, done, info
+
+    def get_observation(self):
+        return self.batch.observe(self._obs)[0].cpu().numpy()

@@ -5,9 +5,9 @@
 
 int orc_num_threads(void) { return omp_get_max_threads(); }
 
-/* steps n envs once each; actions [n][6]; returns total mj substeps */
+/* steps n envs once each; actions [n][6]; obs (may be NULL) [n][5*64*64]; returns total mj substeps */
 long orc_batch_env_step(const OrcModel *m, const OrcEnvConfig *c, OrcEnv *envs, int n, const double *actions,
-                        OrcStepOut *outs, int auto_reset, int threads) {
+                        OrcStepOut *outs, int auto_reset, int threads, unsigned char *obs) {
     long total = 0;
     if (threads > 0) omp_set_num_threads(threads);
 #pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
@@ -15,6 +15,7 @@ long orc_batch_env_step(const OrcModel *m, const OrcEnvConfig *c, OrcEnv *envs, 
         orc_env_step(m, c, envs + i, actions + 6 * i, outs + i);
         total += outs[i].n_substeps;
         if (auto_reset && outs[i].done) { OrcStepOut tmp; orc_env_reset(m, c, envs + i, &tmp); }
+        if (obs) orc_observation(m, c, &envs[i].d, obs + (size_t)i * 5 * 64 * 64);
     }
     return total;
 }

@@ -118,7 +118,7 @@ void orc_target_pose(const OrcModel *m, const OrcEnvConfig *c, const OrcData *d,
 }
 
 /* actuator.py:46-48: MinMaxScaler.transform => delta * scale_ (+ min_ = 0), first five entries */
-static void scale_control(const OrcEnvConfig *c, const double dq[5], double ctrl[5]) {
+void orc_scale_control(const OrcEnvConfig *c, const double dq[5], double ctrl[5]) {
     double st = 2.0 / (2 * c->max_translation), sr = 2.0 / (2 * c->max_rotation);
     double mt = -1.0 + c->max_translation * st, mr = -1.0 + c->max_rotation * sr;
     for (int i = 0; i < 3; i++) ctrl[i] = dq[i] * st + mt;
@@ -207,7 +207,7 @@ void orc_env_step(const OrcModel *m, const OrcEnvConfig *c, OrcEnv *e, const dou
     int step_limit = c->max_steps;
     for (int i = 0; i < c->max_steps; i++) {                      /* :97-110 */
         for (int k = 0; k < 5; k++) dq[k] = target[k] - d->qpos[k];
-        scale_control(c, dq, ctrl5); memcpy(d->ctrl, ctrl5, sizeof ctrl5);
+        orc_scale_control(c, dq, ctrl5); memcpy(d->ctrl, ctrl5, sizeof ctrl5);
         orc_step(m, d); nsub++;
         step_limit--;
         if (max_abs_diff(d->qpos, target, 5) < c->pos_tolerance) {   /* post-step qpos (view, quirk Q4) */
@@ -218,7 +218,7 @@ void orc_env_step(const OrcModel *m, const OrcEnvConfig *c, OrcEnv *e, const dou
         memcpy(target, init_qpos, sizeof target);
         for (int i = 0; i < c->max_steps; i++) {
             for (int k = 0; k < 5; k++) dq[k] = target[k] - d->qpos[k];
-            scale_control(c, dq, ctrl5); memcpy(d->ctrl, ctrl5, sizeof ctrl5);
+            orc_scale_control(c, dq, ctrl5); memcpy(d->ctrl, ctrl5, sizeof ctrl5);
             orc_step(m, d); nsub++;
             if (max_abs_diff(d->qpos, target, 5) < c->pos_tolerance) {
                 reached_initial = 1; for (int k = 0; k < 5; k++) d->ctrl[k] = 0; break;

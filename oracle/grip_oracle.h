@@ -130,6 +130,7 @@ int orc_plane_hull(const OrcModel *m, const OrcData *d, int g, OrcContact *out);
 void orc_env_config_default(OrcEnvConfig *c);
 void orc_env_reset(const OrcModel *m, const OrcEnvConfig *c, OrcEnv *e, OrcStepOut *o);
 void orc_env_step(const OrcModel *m, const OrcEnvConfig *c, OrcEnv *e, const double action[6], OrcStepOut *o);
+void orc_scale_control(const OrcEnvConfig *c, const double dq[5], double ctrl[5]);
 int orc_check_grasp(const OrcData *d);
 int orc_pheromone_level(const OrcData *d, const double dir[2]);
 void orc_target_pose(const OrcModel *m, const OrcEnvConfig *c, const OrcData *d, const double action[6],

@@ -93,6 +93,7 @@ def lib():
     L.orc_env_config_default.argtypes = [C.POINTER(EnvConfig)]
     L.orc_env_reset.argtypes = [vp, C.POINTER(EnvConfig), C.POINTER(Env), C.POINTER(StepOut)]
     L.orc_env_step.argtypes = [vp, C.POINTER(EnvConfig), C.POINTER(Env), dp, C.POINTER(StepOut)]
+    L.orc_scale_control.argtypes = [C.POINTER(EnvConfig), dp, dp]
     L.orc_check_grasp.argtypes = [C.POINTER(Data)]; L.orc_check_grasp.restype = C.c_int
     L.orc_pheromone_level.argtypes = [C.POINTER(Data), dp]; L.orc_pheromone_level.restype = C.c_int
     L.orc_target_pose.argtypes = [vp, C.POINTER(EnvConfig), C.POINTER(Data), dp, dp]
@@ -103,7 +104,7 @@ def lib():
     L.orc_sizeof_data.restype = C.c_ulong; L.orc_sizeof_env.restype = C.c_ulong
     L.orc_num_threads.restype = C.c_int
     L.orc_batch_env_step.restype = C.c_long
-    L.orc_batch_env_step.argtypes = [vp, C.POINTER(EnvConfig), C.POINTER(Env), C.c_int, dp, C.POINTER(StepOut), C.c_int, C.c_int]
+    L.orc_batch_env_step.argtypes = [vp, C.POINTER(EnvConfig), C.POINTER(Env), C.c_int, dp, C.POINTER(StepOut), C.c_int, C.c_int, C.POINTER(C.c_ubyte)]
     assert L.orc_sizeof_data() == C.sizeof(Data), (L.orc_sizeof_data(), C.sizeof(Data))
     assert L.orc_sizeof_env() == C.sizeof(Env)
     _lib = L
@@ -129,8 +130,8 @@ class Model:
         return lib().orc_model_scalar(self.ptr, name.encode(), idx)
 
     def __del__(self):
-        if getattr(self, "ptr", None):
-            lib().orc_model_free(self.ptr); self.ptr = None
+        if getattr(self, "ptr", None) and _lib is not None:
+            _lib.orc_model_free(self.ptr); self.ptr = None
 
 
 class Sim:
@@ -203,3 +204,25 @@ class EnvOracle:
     @property
     def d(self):
         return self.e.d
+
+
+class BatchOracle:
+    """n independent oracle envs stepped with OpenMP (cpu_baseline / property tests)."""
+
+    def __init__(self, model, n, **cfg):
+        self.m, self.n = model, n
+        self.cfg = EnvConfig(); lib().orc_env_config_default(C.byref(self.cfg))
+        for k, v in cfg.items():
+            if k == "target_dir":
+                self.cfg.target_dir[0], self.cfg.target_dir[1] = v
+            else:
+                setattr(self.cfg, k, v)
+        self.envs = (Env * n)(); self.outs = (StepOut * n)()
+        tmp = StepOut()
+        for i in range(n):
+            lib().orc_env_reset(model.ptr, C.byref(self.cfg), C.byref(self.envs[i]), C.byref(tmp))
+
+    def step(self, actions, auto_reset=True, threads=0, obs=None):
+        a = np.ascontiguousarray(actions, dtype=np.float64)
+        op = obs.ctypes.data_as(C.POINTER(C.c_ubyte)) if obs is not None else None
+        return lib().orc_batch_env_step(self.m.ptr, C.byref(self.cfg), self.envs, self.n, _dp(a), self.outs, int(auto_reset), threads, op)

@@ -1,0 +1,48 @@
+"""-m gpu: the Gym / SB3-shaped surfaces (RobotEnv, GpuVecEnv, PPO) on the real engine."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    if not t.cuda.is_available():
+        pytest.skip("no GPU")
+    return t
+
+
+def test_robot_env_surface(torch):
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import RobotEnv, default_config, Status
+    env = RobotEnv(default_config(sim_env="/xmls/sand_ball_env.xml"))
+    assert env.action_space.shape == (6,) and env.observation_space["observation"].shape == (5, 64, 64)
+    obs = env.reset()
+    assert obs["observation"].shape == (5, 64, 64) and obs["observation"].dtype == np.uint8
+    assert obs["achieved_goal"].dtype == np.float32 and np.allclose(obs["desired_goal"], [1, 0])
+    obs, reward, done, info = env.step(env.action_space.sample())
+    keys = {"old_obs", "new_obs", "init_obj_pos", "final_obj_pos", "target_dir", "gripper_open", "controls", "object_grasped",
+            "episode_step", "episode_rewards", "status", "gripper_position", "object_position", "position_reached",
+            "total_distance", "line_distance"}
+    assert keys <= set(info)                                     # robot_env.py:226-241
+    assert isinstance(reward, float) and isinstance(done, bool) and info["status"] == Status.RUNNING and info["episode_step"] == 1
+    r2 = env.compute_reward(obs["achieved_goal"], obs["desired_goal"], info)
+    assert float(r2) == pytest.approx(reward, abs=1e-4)
+    assert env.render(mode="rgb_array").shape == (64, 64, 3)
+    env.close()
+
+
+def test_ppo_learns_on_gpu_vec_env(torch):
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import BatchedRobotEnv, default_config
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3 import PPO, GpuVecEnv
+    from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
+    env = GpuVecEnv(BatchedRobotEnv(default_config(sim_env="/xmls/sand_ball_env.xml"), n_envs=128, auto_reset=True))
+    model = PPO("MultiInputPolicy", env, n_steps=4, batch_size=128, n_epochs=2,
+                policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]))
+    before = [p.detach().clone() for p in model.policy.parameters()]
+    model.learn(total_timesteps=128 * 4 * 2)
+    assert model.num_timesteps == 1024 and np.isfinite(float(model.logger["loss"]))
+    assert any(not torch.equal(a, b) for a, b in zip(before, model.policy.parameters()))
+    a, _ = model.predict({"observation": env.env._obs[0].cpu().numpy()}, deterministic=True)
+    assert a.shape == (6,) and np.abs(a).max() <= 1
+    env.close()

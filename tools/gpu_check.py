@@ -1,0 +1,102 @@
+"""Quick GPU-vs-oracle comparison used while developing (the real tests live in tests/)."""
+import sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np
+import torch
+from mujoco_rl_manipulate_unknown_objects_amd import engine
+from oracle import orc
+
+obj = sys.argv[1] if len(sys.argv) > 1 else "sand_ball"
+N = 64
+m = orc.Model(obj)
+b = engine.Batch(obj, N)
+rng = np.random.default_rng(0)
+
+# ---- build a set of interesting states with the oracle
+states = []
+e = orc.EnvOracle(m)
+e.reset()
+states.append((np.array(e.d.qpos), np.array(e.d.qvel), np.array(e.d.ctrl), np.array(e.d.qacc_warmstart)))
+for i in range(N - 1):
+    a = rng.uniform(-1, 1, 6).astype(np.float32)
+    a[0] = abs(a[0])
+    o = e.step(a)
+    if o.done:
+        e.reset()
+    # perturb mid-flight: a few raw substeps with random ctrl so velocities are non-zero
+    e.d.ctrl[:] = list(rng.uniform(-1, 1, 7))
+    for _ in range(int(rng.integers(1, 20))):
+        orc.lib().orc_step(m.ptr, e.d)
+    states.append((np.array(e.d.qpos), np.array(e.d.qvel), np.array(e.d.ctrl), np.array(e.d.qacc_warmstart)))
+    e.d.ctrl[:] = [0] * 7
+qpos = np.array([s[0] for s in states]); qvel = np.array([s[1] for s in states])
+ctrl = np.array([s[2] for s in states]); warm = np.array([s[3] for s in states])
+b.set_state(qpos, qvel, ctrl, warm)
+dbg = b.debug_forward()
+torch.cuda.synchronize()
+
+# ---- oracle forward on the same (float32-rounded) states
+errs = dict(M=0, bias=0, qs=0, qacc=0, xpos=0)
+ncon_mismatch = 0
+for i in range(N):
+    s = orc.Sim(m)
+    s.qpos[:] = qpos[i].astype(np.float32); s.qvel[:] = qvel[i].astype(np.float32)
+    s.ctrl[:] = ctrl[i].astype(np.float32); s.qacc_warmstart[:] = warm[i].astype(np.float32)
+    s.d.xfrc[1][2] = 0.438 * 9.81
+    s.forward()
+    errs["M"] = max(errs["M"], np.abs(s.M - dbg["M"][i]).max())
+    errs["bias"] = max(errs["bias"], np.abs(s.qfrc_bias - dbg["bias"][i]).max())
+    errs["qs"] = max(errs["qs"], np.abs(s.qacc_smooth - dbg["qacc_smooth"][i]).max() / (1 + np.abs(s.qacc_smooth).max()))
+    eq = np.abs(s.qacc - dbg["qacc"][i]).max() / (1 + np.abs(s.qacc).max())
+    errs["qacc"] = max(errs["qacc"], eq)
+    errs["xpos"] = max(errs["xpos"], np.abs(s.xpos - dbg["xpos"][i]).max())
+    if s.d.ncon != dbg["ncon"][i]:
+        ncon_mismatch += 1
+        print("ncon mismatch env", i, s.d.ncon, dbg["ncon"][i])
+    if eq > 1e-3:
+        print("env", i, "qacc rel err", eq, "ncon", s.d.ncon, "iters", s.d.solver_iter, "gpu iters", dbg["con"][i, 0, 9])
+        print("  orc", np.round(s.qacc, 3)); print("  gpu", np.round(dbg["qacc"][i], 3))
+        for c in range(s.d.ncon):
+            oc = s.d.con[c]
+            print("   orc con", oc.g1, oc.g2, "%.6f" % oc.dist, np.round(list(oc.pos), 4), np.round(list(oc.frame)[:3], 4))
+            print("   gpu con", dbg["con"][i, c, 7:9], "%.6f" % dbg["con"][i, c, 6], np.round(dbg["con"][i, c, :3], 4), np.round(dbg["con"][i, c, 3:6], 4))
+print("forward errors", errs, "ncon mismatches", ncon_mismatch)
+
+# ---- substep parity: 50 raw steps
+K = 50
+b.set_state(qpos, qvel, ctrl, warm)
+b.substep(K); torch.cuda.synchronize()
+gq, gv, gc, gw = b.get_state()
+eqp = 0; eqv = 0
+for i in range(N):
+    s = orc.Sim(m)
+    s.qpos[:] = qpos[i].astype(np.float32); s.qvel[:] = qvel[i].astype(np.float32)
+    s.ctrl[:] = ctrl[i].astype(np.float32); s.qacc_warmstart[:] = warm[i].astype(np.float32)
+    s.d.xfrc[1][2] = 0.438 * 9.81
+    s.fwd_position()
+    s.step(K)
+    dq = np.abs(s.qpos - gq[i]).max(); dv = np.abs(s.qvel - gv[i]).max()
+    if dq > 1e-3:
+        print("substep env", i, "dq", dq, "dv", dv)
+    eqp = max(eqp, dq); eqv = max(eqv, dv)
+print(f"after {K} substeps: max |dqpos| {eqp:.3e} max |dqvel| {eqv:.3e}")
+
+# ---- macro-step parity from reset with common actions
+b.reset(); torch.cuda.synchronize()
+envs = [orc.EnvOracle(m) for _ in range(N)]
+for en in envs: en.reset()
+for t in range(6):
+    acts = rng.uniform(-1, 1, (N, 6)).astype(np.float32)
+    acts[:, 0] = np.abs(acts[:, 0])
+    t0 = time.time()
+    out = b.step(torch.from_numpy(acts).cuda()); torch.cuda.synchronize()
+    dt = time.time() - t0
+    rw = out["reward"].cpu().numpy(); ns = out["n_substeps"].cpu().numpy(); op = out["object_position"].cpu().numpy()
+    gp = out["gripper_position"].cpu().numpy(); flt = out["fault"].cpu().numpy()
+    dn = 0; dr = 0; dp = 0
+    for i, en in enumerate(envs):
+        o = en.step(acts[i])
+        dn = max(dn, abs(o.n_substeps - ns[i])); dr = max(dr, abs(o.reward - rw[i]))
+        dp = max(dp, np.abs(np.array(o.gripper_pos) - gp[i]).max(), np.abs(np.array(o.final_obj_pos) - op[i]).max())
+    print(f"macro step {t}: gpu {dt*1e3:.1f} ms, substeps mean {ns.mean():.1f} max {ns.max()}, |dnsub| {dn}, |dreward| {dr:.2e}, |dpos| {dp:.2e}, faults {np.unique(flt)}")
+print("kernel time", b.kernel_time())
