@@ -27,7 +27,7 @@ extern "C" {
 #define GRIP_OBS_C 5
 #define GRIP_OBS_H 64
 #define GRIP_OBS_W 64
-#define GRIP_MAXCON 16
+#define GRIP_MAXCON 14
 
 typedef struct GripModel GripModel;
 typedef struct GripBatch GripBatch;

@@ -12,7 +12,7 @@
 #define GN_GEOM 7          // 0 floor, 1 base, 2 lk, 3 lf, 4 rk, 5 rf, 6 object
 #define GN_HULL 6
 #define GN_PAIR_MAX 16
-#define G_MAXC 16          // contact slots per env (GRIP_MAXCON)
+#define G_MAXC 14          // contact slots per env (GRIP_MAXCON)
 #define WAVE 64
 
 enum { GRP_G = 0, GRP_L = 1, GRP_R = 2, GRP_O = 3, GRP_WORLD = 4 };
@@ -45,9 +45,10 @@ struct DevModel {
     int hull_vadr[GN_HULL], hull_vnum[GN_HULL];
     int npair;
     int pairs[GN_PAIR_MAX][2];
-    const float *hull_verts;                    // [nvert][4] xyz + pad, body frame
-    const int *hull_nadr;                       // CSR over all hull vertices
-    const int *hull_nbr;
+    // hull tables as one word blob (staged into LDS by every launch): [nvert][4] f32 vertices in the body
+    // frame | u16 CSR offsets over all hull vertices | u16 neighbour ids (local) | u16 cube-map start vertices
+    const unsigned *hull_blob;
+    int hull_words, hull_off_nadr, hull_off_nbr, hull_off_lut;
     // camera / rendering
     float cam_pos[3], cam_R[9], cam_fovy;
     float znear, zfar;

@@ -5,12 +5,17 @@
 // for the lane-per-env execution model:
 //   * four rigid groups instead of seven bodies (grip_device.h);
 //   * the constraint Jacobian is never materialised: J x and J^T f are evaluated from group
-//     twists / wrenches at each contact point, only the rows needed for the Newton Hessian are
-//     expanded, into registers;
+//     twists / wrenches at each contact point; for the Newton Hessian one row at a time is
+//     expanded into registers and folded in as weighted rank-1 updates;
 //   * per-lane variable-length data (geom frames, contact list, per-row solver scratch) sits in
-//     LDS as [slot][lane] so that a wave's access to one slot is one conflict-free 256-byte row;
-//   * hull vertices are read with wave-uniform indices (scalar loads), every lane scanning the
-//     same vertex against its own direction.
+//     LDS as [slot][lane], so a wave's access to one slot is one conflict-free 256-byte row;
+//   * the convex hulls (vertices, edge graph, a cube-map table of start vertices) are staged once
+//     per launch into LDS; support queries hill-climb the edge graph from the table entry
+//     (about 9 neighbour tests per query instead of 70-573 vertex tests);
+//   * every heavy routine has ONE call site inside a loop (MPR is a per-lane state machine around a
+//     single support evaluation, the Newton solver a staged loop around a single constraint pass),
+//     which keeps the kernel inside the instruction cache and lets lanes in different phases share
+//     the same instructions.
 #pragma once
 #include "grip_device.h"
 
@@ -29,11 +34,14 @@
 #define C_JV 19
 #define C_STRIDE 23
 #define LDS_FLOATS_PER_LANE (CB_BASE + G_MAXC * C_STRIDE)
+#define LDS_LANE_WORDS (LDS_FLOATS_PER_LANE * WAVE)
 
-#define NEWTON_MAXIT 24
-#define LS_MAXIT 14
+#define NEWTON_MAXIT 20
+#define LS_MAXIT 16
 #define MPR_TOL_F 1e-6f
 #define MPR_MAXIT 50
+#define LUT_RES 8
+#define LUT_CELLS (6 * LUT_RES * LUT_RES)
 
 #define LD(slot) lds[(slot) * WAVE + lane]
 
@@ -45,7 +53,28 @@ struct Kin {
     float Ic[4][6];
 };
 
+// hull tables staged in LDS behind the per-lane region (word offsets from DevModel)
+struct Hulls {
+    const float *v;                 // [nvert][4]
+    const unsigned short *nadr;     // CSR over all hull vertices
+    const unsigned short *nbr;      // neighbour ids, local to the hull
+    const unsigned short *lut;      // [6][LUT_CELLS] start vertices
+};
+
 constexpr DEVI int pidx(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+DEVI Hulls stage_hulls(const DevModel &m, float *lds, int lane) {
+    unsigned *dst = reinterpret_cast<unsigned *>(lds + LDS_LANE_WORDS);
+    const unsigned *src = m.hull_blob;
+    for (int i = lane; i < m.hull_words; i += WAVE) dst[i] = src[i];
+    __syncthreads();
+    Hulls h;
+    h.v = reinterpret_cast<const float *>(dst);
+    h.nadr = reinterpret_cast<const unsigned short *>(dst + m.hull_off_nadr);
+    h.nbr = reinterpret_cast<const unsigned short *>(dst + m.hull_off_nbr);
+    h.lut = reinterpret_cast<const unsigned short *>(dst + m.hull_off_lut);
+    return h;
+}
 
 // ---------------------------------------------------------------- kinematics
 DEVI void store_frame(float *lds, int lane, int g, V3 p, const M3 &R) {
@@ -67,8 +96,7 @@ DEVI void kinematics(const DevModel &m, float (&qpos)[14], Kin &k, float *lds, i
     if (qn < 1e-15f) { qpos[10] = 1.f; qpos[11] = qpos[12] = qpos[13] = 0.f; }
     else { float iq = 1.0f / qn; qpos[10] *= iq; qpos[11] *= iq; qpos[12] *= iq; qpos[13] *= iq; }
     k.pe = v3(m.ee_pos0[0] + qpos[0], m.ee_pos0[1] + qpos[1], m.ee_pos0[2] + qpos[2]);
-    float sr, cr, sy, cy;
-    sr = sinf(qpos[3]); cr = cosf(qpos[3]); sy = sinf(qpos[4]); cy = cosf(qpos[4]);
+    float sr = sinf(qpos[3]), cr = cosf(qpos[3]), sy = sinf(qpos[4]), cy = cosf(qpos[4]);
     // Re = Rx(roll) * Rz(yaw)
     k.Re.m[0] = cy;      k.Re.m[1] = -sy;     k.Re.m[2] = 0.f;
     k.Re.m[3] = cr * sy; k.Re.m[4] = cr * cy; k.Re.m[5] = -sr;
@@ -101,9 +129,9 @@ DEVI void kinematics(const DevModel &m, float (&qpos)[14], Kin &k, float *lds, i
     rot_sym(k.Ro, m.grp_inertia[3], k.Ic[3]);
 }
 
-// ---------------------------------------------------------------- mass matrix (packed lower 13x13; cross block stays 0)
-template <int NC>
-DEVI void add_body(float (&Mp)[91], const int (&dofs)[NC], const V3 (&jp)[NC], const V3 (&jr)[NC], float mass, const float *Ic) {
+// ---------------------------------------------------------------- mass matrix: gripper 7x7 (Mg) and object 6x6 (Mo), packed lower
+template <int NC, int NM>
+DEVI void add_body(float (&Mp)[NM], const int (&dofs)[NC], const V3 (&jp)[NC], const V3 (&jr)[NC], float mass, const float *Ic) {
 #pragma unroll
     for (int a = 0; a < NC; a++) {
         V3 Ia = symv(Ic, jr[a]);
@@ -112,40 +140,54 @@ DEVI void add_body(float (&Mp)[91], const int (&dofs)[NC], const V3 (&jp)[NC], c
     }
 }
 
-DEVI void mass_matrix(const DevModel &m, const Kin &k, float (&Mp)[91]) {
+DEVI void mass_matrix(const DevModel &m, const Kin &k, float (&Mg)[28], float (&Mo)[21]) {
 #pragma unroll
-    for (int i = 0; i < 91; i++) Mp[i] = 0.f;
+    for (int i = 0; i < 28; i++) Mg[i] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 13; i++) Mp[pidx(i, i)] = m.armature[i];
+    for (int i = 0; i < 21; i++) Mo[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 7; i++) Mg[pidx(i, i)] = m.armature[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) Mo[pidx(i, i)] = m.armature[7 + i];
     const V3 ex = v3(1, 0, 0), ey = v3(0, 1, 0), ez = v3(0, 0, 1), z0 = v3(0, 0, 0);
-    {   // G
-        const int dofs[5] = {0, 1, 2, 3, 4};
+    {   const int dofs[5] = {0, 1, 2, 3, 4};
         V3 r = k.c[0] - k.pe;
         const V3 jp[5] = {ex, ey, ez, cross(ex, r), cross(k.a4, r)};
         const V3 jr[5] = {z0, z0, z0, ex, k.a4};
-        add_body<5>(Mp, dofs, jp, jr, m.grp_mass[0], k.Ic[0]);
-    }
-    {   // L
-        const int dofs[6] = {0, 1, 2, 3, 4, 5};
+        add_body<5, 28>(Mg, dofs, jp, jr, m.grp_mass[0], k.Ic[0]); }
+    {   const int dofs[6] = {0, 1, 2, 3, 4, 5};
         V3 r = k.c[1] - k.pe, rk = k.c[1] - k.pk[0];
         const V3 jp[6] = {ex, ey, ez, cross(ex, r), cross(k.a4, r), cross(k.ak[0], rk)};
         const V3 jr[6] = {z0, z0, z0, ex, k.a4, k.ak[0]};
-        add_body<6>(Mp, dofs, jp, jr, m.grp_mass[1], k.Ic[1]);
-    }
-    {   // R
-        const int dofs[6] = {0, 1, 2, 3, 4, 6};
+        add_body<6, 28>(Mg, dofs, jp, jr, m.grp_mass[1], k.Ic[1]); }
+    {   const int dofs[6] = {0, 1, 2, 3, 4, 6};
         V3 r = k.c[2] - k.pe, rk = k.c[2] - k.pk[1];
         const V3 jp[6] = {ex, ey, ez, cross(ex, r), cross(k.a4, r), cross(k.ak[1], rk)};
         const V3 jr[6] = {z0, z0, z0, ex, k.a4, k.ak[1]};
-        add_body<6>(Mp, dofs, jp, jr, m.grp_mass[2], k.Ic[2]);
-    }
-    {   // O
-        const int dofs[6] = {7, 8, 9, 10, 11, 12};
+        add_body<6, 28>(Mg, dofs, jp, jr, m.grp_mass[2], k.Ic[2]); }
+    {   const int dofs[6] = {0, 1, 2, 3, 4, 5};
         V3 r = k.c[3] - k.po;
         V3 c0 = col(k.Ro, 0), c1 = col(k.Ro, 1), c2 = col(k.Ro, 2);
         const V3 jp[6] = {ex, ey, ez, cross(c0, r), cross(c1, r), cross(c2, r)};
         const V3 jr[6] = {z0, z0, z0, c0, c1, c2};
-        add_body<6>(Mp, dofs, jp, jr, m.grp_mass[3], k.Ic[3]);
+        add_body<6, 21>(Mo, dofs, jp, jr, m.grp_mass[3], k.Ic[3]); }
+}
+
+// y = M x with the block-diagonal mass matrix
+DEVI void mass_mulv(const float (&Mg)[28], const float (&Mo)[21], const float (&x)[13], float (&y)[13]) {
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 7; j++) s = fmaf(Mg[pidx(i, j)], x[j], s);
+        y[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; j++) s = fmaf(Mo[pidx(i, j)], x[7 + j], s);
+        y[7 + i] = s;
     }
 }
 
@@ -161,9 +203,6 @@ DEVI void twists(const Kin &k, const float (&x)[13], Twist &t) {
     t.wO = mulv(k.Ro, v3(x[10], x[11], x[12]));
 }
 
-DEVI void group_ref(const Kin &k, int g, V3 &ref) {
-    ref = g == GRP_G ? k.pe : g == GRP_L ? k.pk[0] : g == GRP_R ? k.pk[1] : g == GRP_O ? k.po : v3(0, 0, 0);
-}
 DEVI void group_motion(const Kin &k, const Twist &t, int g, V3 p, V3 &v, V3 &w) {
     V3 ref, v0;
     if (g == GRP_G) { ref = k.pe; v0 = t.vG; w = t.wG; }
@@ -213,7 +252,6 @@ DEVI void row_add(const Kin &k, float (&j)[13], int g, V3 p, V3 e, float sgn, bo
 // ---------------------------------------------------------------- bias forces (gravity + Coriolis/centrifugal)
 DEVI void bias_forces(const DevModel &m, const Kin &k, const float (&qvel)[13], float (&bias)[13]) {
     Twist t; twists(k, qvel, t);
-    // angular bias accelerations (qacc = 0)
     V3 alG = cross(v3(qvel[3], 0, 0), k.a4 * qvel[4]);
     V3 sL = k.pk[0] - k.pe, sR = k.pk[1] - k.pe;
     V3 aL = cross(alG, sL) + cross(t.wG, cross(t.wG, sL));
@@ -250,8 +288,8 @@ DEVI void chol_packed(float *A) {
 #pragma unroll
         for (int q = 0; q < j; q++) s -= A[pidx(j, q)] * A[pidx(j, q)];
         s = fmaxf(s, 1e-30f);
-        float d = sqrtf(s), inv = 1.0f / d;
-        A[pidx(j, j)] = d;
+        float inv = rsqrtf(s);
+        A[pidx(j, j)] = inv;                       // the diagonal holds 1 / L_jj
 #pragma unroll
         for (int i = j + 1; i < N; i++) {
             float t = A[pidx(i, j)];
@@ -268,23 +306,14 @@ DEVI void chol_solve_packed(const float *L, float *x) {
         float s = x[i];
 #pragma unroll
         for (int q = 0; q < i; q++) s -= L[pidx(i, q)] * x[q];
-        x[i] = s / L[pidx(i, i)];
+        x[i] = s * L[pidx(i, i)];
     }
 #pragma unroll
     for (int i = N - 1; i >= 0; i--) {
         float s = x[i];
 #pragma unroll
         for (int q = i + 1; q < N; q++) s -= L[pidx(q, i)] * x[q];
-        x[i] = s / L[pidx(i, i)];
-    }
-}
-DEVI void sym_mulv13(const float (&Mp)[91], const float (&x)[13], float (&y)[13]) {
-#pragma unroll
-    for (int i = 0; i < 13; i++) {
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 13; j++) s = fmaf(Mp[pidx(i, j)], x[j], s);
-        y[i] = s;
+        x[i] = s * L[pidx(i, i)];
     }
 }
 
@@ -295,18 +324,39 @@ DEVI void make_tangents(V3 n, V3 &t1, V3 &t2) {
     t2 = cross(n, t1);
 }
 
-// support point of hull g (1..6) in world direction `dir`, every lane scanning the same vertex
-DEVI V3 hull_support(const DevModel &m, int g, V3 p, const M3 &R, V3 dir, float inflate) {
-    V3 dl = multv(R, dir);
-    const float *v = m.hull_verts + 4 * m.hull_vadr[g - 1];
-    int n = m.hull_vnum[g - 1];
-    float best = -3.0e38f; V3 bv = v3(0, 0, 0);
-    for (int i = 0; i < n; i++) {
-        float x = v[4 * i], y = v[4 * i + 1], z = v[4 * i + 2];
-        float s = fmaf(x, dl.x, fmaf(y, dl.y, z * dl.z));
-        if (s > best) { best = s; bv = v3(x, y, z); }
+// Support vertex of hull `h` (0..5) for the LOCAL direction dl: start at the cube-map table entry and
+// hill-climb the edge graph to the best neighbour until no neighbour improves. Lanes walk different
+// vertices; the loop is flattened to one neighbour test per iteration so lanes stay busy.
+DEVI int support_vertex(const DevModel &m, const Hulls &H, int h, V3 dl, V3 &vout) {
+    float ax = fabsf(dl.x), ay = fabsf(dl.y), az = fabsf(dl.z);
+    int axis = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+    float mj = axis == 0 ? dl.x : axis == 1 ? dl.y : dl.z;
+    float u = axis == 0 ? dl.y : dl.x, v = axis == 2 ? dl.y : dl.z;
+    float im = 1.0f / fmaxf(fabsf(mj), 1e-30f);
+    int iu = min(LUT_RES - 1, max(0, (int)((u * im + 1.f) * (0.5f * LUT_RES))));
+    int iv = min(LUT_RES - 1, max(0, (int)((v * im + 1.f) * (0.5f * LUT_RES))));
+    int cell = (2 * axis + (mj < 0.f ? 1 : 0)) * (LUT_RES * LUT_RES) + iu * LUT_RES + iv;
+    const int base = m.hull_vadr[h];
+    const float *vb = H.v + 4 * base;
+    int cur = H.lut[h * LUT_CELLS + cell];
+    float bx = vb[4 * cur], by = vb[4 * cur + 1], bz = vb[4 * cur + 2];
+    float bv = fmaf(bx, dl.x, fmaf(by, dl.y, bz * dl.z));
+    int e = H.nadr[base + cur], eend = H.nadr[base + cur + 1];
+    int cand = cur; float cv = bv, cx = bx, cy = by, cz = bz;
+    for (int guard = 0; guard < 4096; guard++) {
+        if (e < eend) {
+            int j = H.nbr[e]; e++;
+            float x = vb[4 * j], y = vb[4 * j + 1], z = vb[4 * j + 2];
+            float s = fmaf(x, dl.x, fmaf(y, dl.y, z * dl.z));
+            if (s > cv) { cv = s; cand = j; cx = x; cy = y; cz = z; }
+        } else {
+            if (cand == cur) break;
+            cur = cand; bx = cx; by = cy; bz = cz;
+            e = H.nadr[base + cur]; eend = H.nadr[base + cur + 1];
+        }
     }
-    return p + mulv(R, bv) + dir * inflate;
+    vout = v3(bx, by, bz);
+    return cur;
 }
 
 DEVI void push_contact(float *lds, int lane, int &ncon, int &fault, V3 pos, V3 n, float dist, int g1, int g2, const DevModel &m) {
@@ -321,42 +371,8 @@ DEVI void push_contact(float *lds, int lane, int &ncon, int &fault, V3 pos, V3 n
     ncon++;
 }
 
-// floor vs hull g: deepest vertex + up to 3 graph neighbours inside the margin
-DEVI void plane_hull(const DevModel &m, int g, float *lds, int lane, int &ncon, int &fault) {
-    V3 p; M3 R; load_frame(lds, lane, g, p, R);
-    V3 cw = p + mulv(R, ldv(m.geom_center[g]));
-    bool active = cw.z <= m.geom_rbound[g] + m.margin;
-    if (!active) return;
-    const float *v = m.hull_verts + 4 * m.hull_vadr[g - 1];
-    int n = m.hull_vnum[g - 1];
-    float hmin = 3.0e38f; int best = 0;
-    for (int i = 0; i < n; i++) {
-        float h = p.z + R.m[6] * v[4 * i] + R.m[7] * v[4 * i + 1] + R.m[8] * v[4 * i + 2];
-        if (h < hmin) { hmin = h; best = i; }
-    }
-    if (hmin > m.margin) return;
-    int cand[4]; int nc = 1; cand[0] = best;
-    int base = m.hull_vadr[g - 1];
-    int e0 = m.hull_nadr[base + best], e1 = m.hull_nadr[base + best + 1];
-    for (int e = e0; e < e1 && nc < 4; e++) {
-        int j = m.hull_nbr[e];
-        float h = p.z + R.m[6] * v[4 * j] + R.m[7] * v[4 * j + 1] + R.m[8] * v[4 * j + 2];
-        if (h <= m.margin) { cand[nc] = j; nc++; }
-    }
-    for (int q = 0; q < nc; q++) {
-        int j = cand[q];
-        V3 w = p + mulv(R, v3(v[4 * j], v[4 * j + 1], v[4 * j + 2]));
-        push_contact(lds, lane, ncon, fault, v3(w.x, w.y, 0.5f * w.z), v3(0, 0, 1), w.z, 0, g, m);
-    }
-}
-
 struct Sup { V3 v, v1, v2; };
 
-DEVI void mpr_support(const DevModel &m, int g1, V3 p1, const M3 &R1, int g2, V3 p2, const M3 &R2, V3 dir, float infl, Sup &s) {
-    s.v1 = hull_support(m, g1, p1, R1, dir, infl);
-    s.v2 = hull_support(m, g2, p2, R2, -dir, infl);
-    s.v = s.v1 - s.v2;
-}
 DEVI V3 portal_dir(const Sup &a, const Sup &b, const Sup &c) { return normalized(cross(b.v - a.v, c.v - a.v)); }
 DEVI void expand_portal(const Sup &p0, Sup &p1, Sup &p2, Sup &p3, const Sup &p4) {
     V3 v4v0 = cross(p4.v, p0.v);
@@ -399,77 +415,123 @@ DEVI V3 find_pos(const Sup &p0, const Sup &p1, const Sup &p2, const Sup &p3) {
     return ((p0.v1 + p0.v2) * b0 + (p1.v1 + p1.v2) * b1 + (p2.v1 + p2.v2) * b2 + (p3.v1 + p3.v2) * b3) * inv;
 }
 
-// Minkowski portal refinement on the margin-inflated hulls. Returns true with depth/dir/pos.
-DEVI bool mpr(const DevModel &m, int g1, V3 p1, const M3 &R1, int g2, V3 p2, const M3 &R2, float infl, float &depth, V3 &dirout, V3 &pos) {
-    const float EPS2 = 1e-12f, EPSD = 1e-10f;
-    Sup s0, s1, s2, s3, s4;
-    s0.v1 = p1 + mulv(R1, ldv(m.geom_center[g1])); s0.v2 = p2 + mulv(R2, ldv(m.geom_center[g2])); s0.v = s0.v1 - s0.v2;
-    if (dot(s0.v, s0.v) < EPS2) s0.v.x += 1e-5f;
-    V3 dir = normalized(-s0.v);
-    mpr_support(m, g1, p1, R1, g2, p2, R2, dir, infl, s1);
-    if (dot(s1.v, dir) <= 0.f) return false;
-    dir = cross(s0.v, s1.v);
-    if (dot(dir, dir) < EPS2 * 1e-2f) {
-        if (dot(s1.v, s1.v) < EPS2) { depth = 0.f; dirout = v3(0, 0, 0); }
-        else { depth = norm(s1.v); dirout = normalized(s1.v); }
-        pos = (s1.v1 + s1.v2) * 0.5f;
-        return true;
-    }
-    dir = normalized(dir);
-    mpr_support(m, g1, p1, R1, g2, p2, R2, dir, infl, s2);
-    if (dot(s2.v, dir) <= 0.f) return false;
-    dir = normalized(cross(s1.v - s0.v, s2.v - s0.v));
-    if (dot(dir, s0.v) > 0.f) { Sup t = s1; s1 = s2; s2 = t; dir = -dir; }
-    for (int it = 0;; it++) {
-        if (it > 4 * MPR_MAXIT) return false;
-        mpr_support(m, g1, p1, R1, g2, p2, R2, dir, infl, s3);
-        if (dot(s3.v, dir) <= 0.f) return false;
-        bool cont = false;
-        if (dot(cross(s1.v, s3.v), s0.v) < -EPSD) { s2 = s3; cont = true; }
-        if (!cont && dot(cross(s3.v, s2.v), s0.v) < -EPSD) { s1 = s3; cont = true; }
-        if (!cont) break;
-        dir = normalized(cross(s1.v - s0.v, s2.v - s0.v));
-    }
-    for (int it = 0;; it++) {
-        dir = portal_dir(s1, s2, s3);
-        if (dot(dir, s1.v) >= -EPSD) break;
-        mpr_support(m, g1, p1, R1, g2, p2, R2, dir, infl, s4);
-        if (dot(s4.v, dir) < 0.f || reach_tol(s1, s2, s3, s4, dir) || it > MPR_MAXIT) return false;
-        expand_portal(s0, s1, s2, s3, s4);
-    }
-    for (int it = 0;; it++) {
-        dir = portal_dir(s1, s2, s3);
-        mpr_support(m, g1, p1, R1, g2, p2, R2, dir, infl, s4);
-        if (reach_tol(s1, s2, s3, s4, dir) || it > MPR_MAXIT) {
-            V3 w; float d2 = origin_tri_dist2(s1.v, s2.v, s3.v, w);
-            depth = sqrtf(d2);
-            dirout = depth < 1e-9f ? v3(0, 0, 0) : normalized(w);
-            pos = find_pos(s0, s1, s2, s3);
-            return true;
-        }
-        expand_portal(s0, s1, s2, s3, s4);
-    }
-}
-
-DEVI void hull_hull(const DevModel &m, int g1, int g2, float *lds, int lane, int &ncon, int &fault) {
-    V3 p1, p2; M3 R1, R2;
-    load_frame(lds, lane, g1, p1, R1); load_frame(lds, lane, g2, p2, R2);
-    V3 c1 = p1 + mulv(R1, ldv(m.geom_center[g1])), c2 = p2 + mulv(R2, ldv(m.geom_center[g2]));
-    V3 dc = c2 - c1;
-    float bound = m.geom_rbound[g1] + m.geom_rbound[g2] + m.margin;
-    if (dot(dc, dc) > bound * bound) return;
-    float depth; V3 dir, pos;
-    if (!mpr(m, g1, p1, R1, g2, p2, R2, 0.5f * m.margin, depth, dir, pos)) return;
-    float dist = m.margin - depth;
-    if (dist >= m.margin) return;
-    if (dot(dir, dir) < 0.5f) dir = normalized(dc);
-    push_contact(lds, lane, ncon, fault, pos, dir, dist, g1, g2, m);
-}
-
-DEVI void collide(const DevModel &m, float *lds, int lane, int &ncon, int &fault) {
+// All narrow-phase work of one state: floor-hull and hull-hull tests run through ONE loop whose body holds
+// the single support evaluation. Item q < 6: floor vs hull geom q + 1 (support along -z, then graph
+// neighbours inside the margin). Item q >= 6: hull pair q - 6, Minkowski portal refinement (XenoCollide) on the
+// margin-inflated hulls as a per-lane phase machine: 0/1 seed the portal, 2 discover, 3 refine, 4 penetrate.
+DEVI void collide(const DevModel &m, const Hulls &H, float *lds, int lane, int &ncon, int &fault) {
     ncon = 0;
-    for (int g = 1; g < GN_GEOM; g++) plane_hull(m, g, lds, lane, ncon, fault);
-    for (int q = 0; q < m.npair; q++) hull_hull(m, m.pairs[q][0], m.pairs[q][1], lds, lane, ncon, fault);
+    const float EPS2 = 1e-12f, EPSD = 1e-10f;
+    const float infl = 0.5f * m.margin;
+    const int nitem = 6 + m.npair;
+    for (int q = 0; q < nitem; q++) {
+        const bool plane = q < 6;
+        const int g1 = plane ? 0 : m.pairs[q - 6][0], g2 = plane ? q + 1 : m.pairs[q - 6][1];
+        V3 p1 = v3(0, 0, 0), p2; M3 R1, R2;
+#pragma unroll
+        for (int i = 0; i < 9; i++) R1.m[i] = (i % 4 == 0) ? 1.f : 0.f;
+        if (!plane) load_frame(lds, lane, g1, p1, R1);
+        load_frame(lds, lane, g2, p2, R2);
+        V3 c2 = p2 + mulv(R2, ldv(m.geom_center[g2]));
+        Sup s0, s1, s2, s3;
+        V3 dir;
+        int phase;                 // -1 = finished
+        if (plane) {
+            phase = (c2.z <= m.geom_rbound[g2] + m.margin) ? 5 : -1;
+            dir = v3(0, 0, -1);
+        } else {
+            V3 c1 = p1 + mulv(R1, ldv(m.geom_center[g1]));
+            V3 dc = c2 - c1;
+            float bound = m.geom_rbound[g1] + m.geom_rbound[g2] + m.margin;
+            phase = dot(dc, dc) > bound * bound ? -1 : 0;
+            s0.v1 = c1; s0.v2 = c2; s0.v = c1 - c2;
+            if (dot(s0.v, s0.v) < EPS2) s0.v.x += 1e-5f;
+            dir = normalized(-s0.v);
+        }
+        int cnt = 0;
+        while (__any(phase >= 0)) {
+            if (phase >= 0) {
+                // ---- the one support evaluation: hull g2 along -dir (and hull g1 along +dir for pairs)
+                Sup s;
+                V3 vl; int vi2 = support_vertex(m, H, g2 - 1, multv(R2, plane ? dir : -dir), vl);
+                s.v2 = p2 + mulv(R2, vl);
+                if (plane) {
+                    // deepest vertex and up to three graph neighbours inside the margin (mjc_PlaneConvex)
+                    if (s.v2.z <= m.margin) {
+                        push_contact(lds, lane, ncon, fault, v3(s.v2.x, s.v2.y, 0.5f * s.v2.z), v3(0, 0, 1), s.v2.z, 0, g2, m);
+                        const int base = m.hull_vadr[g2 - 1];
+                        int e0 = H.nadr[base + vi2], e1 = H.nadr[base + vi2 + 1], extra = 0;
+                        for (int e = e0; e < e1 && extra < 3; e++) {
+                            int j = H.nbr[e];
+                            const float *vp = H.v + 4 * (base + j);
+                            V3 w = p2 + mulv(R2, v3(vp[0], vp[1], vp[2]));
+                            if (w.z <= m.margin) { push_contact(lds, lane, ncon, fault, v3(w.x, w.y, 0.5f * w.z), v3(0, 0, 1), w.z, 0, g2, m); extra++; }
+                        }
+                    }
+                    phase = -1;
+                } else {
+                    s.v2 = s.v2 - dir * infl;
+                    V3 vl1; support_vertex(m, H, g1 - 1, multv(R1, dir), vl1);
+                    s.v1 = p1 + mulv(R1, vl1) + dir * infl;
+                    s.v = s.v1 - s.v2;
+                    cnt++;
+                    bool hit = false; float depth = 0.f; V3 nrm = v3(0, 0, 0), pos = v3(0, 0, 0);
+                    if (phase == 0) {
+                        s1 = s;
+                        if (dot(s1.v, dir) <= 0.f) phase = -1;
+                        else {
+                            V3 d = cross(s0.v, s1.v);
+                            if (dot(d, d) < EPS2 * 1e-2f) {      // origin on the ray v0 -> v1
+                                hit = true; depth = norm(s1.v); nrm = depth < 1e-6f ? v3(0, 0, 0) : normalized(s1.v);
+                                pos = (s1.v1 + s1.v2) * 0.5f;
+                            } else { dir = normalized(d); phase = 1; }
+                        }
+                    } else if (phase == 1) {
+                        s2 = s;
+                        if (dot(s2.v, dir) <= 0.f) phase = -1;
+                        else {
+                            dir = normalized(cross(s1.v - s0.v, s2.v - s0.v));
+                            if (dot(dir, s0.v) > 0.f) { Sup t = s1; s1 = s2; s2 = t; dir = -dir; }
+                            phase = 2; cnt = 0;
+                        }
+                    } else if (phase == 2) {
+                        s3 = s;
+                        if (dot(s3.v, dir) <= 0.f || cnt > 4 * MPR_MAXIT) phase = -1;
+                        else if (dot(cross(s1.v, s3.v), s0.v) < -EPSD) { s2 = s3; dir = normalized(cross(s1.v - s0.v, s2.v - s0.v)); }
+                        else if (dot(cross(s3.v, s2.v), s0.v) < -EPSD) { s1 = s3; dir = normalized(cross(s1.v - s0.v, s2.v - s0.v)); }
+                        else {
+                            dir = portal_dir(s1, s2, s3);
+                            phase = dot(dir, s1.v) >= -EPSD ? 4 : 3; cnt = 0;
+                        }
+                    } else if (phase == 3) {
+                        if (dot(s.v, dir) < 0.f || reach_tol(s1, s2, s3, s, dir) || cnt > MPR_MAXIT) phase = -1;
+                        else {
+                            expand_portal(s0, s1, s2, s3, s);
+                            dir = portal_dir(s1, s2, s3);
+                            if (dot(dir, s1.v) >= -EPSD) { phase = 4; cnt = 0; }
+                        }
+                    } else {   // phase 4
+                        if (reach_tol(s1, s2, s3, s, dir) || cnt > MPR_MAXIT) {
+                            V3 w; float d2 = origin_tri_dist2(s1.v, s2.v, s3.v, w);
+                            depth = sqrtf(d2); nrm = depth < 1e-9f ? v3(0, 0, 0) : normalized(w);
+                            pos = find_pos(s0, s1, s2, s3); hit = true;
+                        } else {
+                            expand_portal(s0, s1, s2, s3, s);
+                            dir = portal_dir(s1, s2, s3);
+                        }
+                    }
+                    if (hit) {
+                        float dist = m.margin - depth;
+                        if (dist < m.margin) {
+                            if (dot(nrm, nrm) < 0.5f) nrm = normalized(s0.v2 - s0.v1);
+                            push_contact(lds, lane, ncon, fault, pos, nrm, dist, g1, g2, m);
+                        }
+                        phase = -1;
+                    }
+                }
+            }
+        }
+    }
 }
 
 // actuator.py:134-184 on the device contact list
@@ -499,44 +561,42 @@ DEVI float impedance(const float *si, float pos, float margin) {
 
 struct Limits { float sgn[7], D[7], aref[7]; };
 
-// elliptic condim-4 contact: cost, gradient and (optionally) the 4x4 Hessian in jar space
-//   s(jar) = (D0 / 2 mu^2) dist^2(U, K), U = diag(mu, fs, fs, ft) jar, K = {U0 >= mu |U_t|}
-DEVI float cone_eval(const float (&jar)[4], float D0, float impratio, float fs, float ft, float (&grad)[4], float *H /*10 packed or null*/) {
+// Elliptic condim-4 contact in jar space:  s(jar) = (D0 / 2 mu^2) dist^2(U, K), U = diag(mu, fs, fs, ft) jar,
+// K = {U0 >= mu |U_t|}. Returns the cost and gradient, plus the Hessian in rank-structured form
+//   H = diag(w) + ka a a^T - kb b b^T      (top zone: all zero; bottom zone: w = D, ka = kb = 0)
+struct Cone { float cost, grad[4], w[4], a[4], b[4], ka, kb; };
+DEVI void cone_eval(const float (&jar)[4], float D0, float impratio, float fs, float ft, Cone &c) {
     float mu = fs * rsqrtf(impratio);
     float D1 = D0 * impratio, D3 = D1 * ft * ft / fmaxf(1e-30f, fs * fs);
-    float S[4] = {mu, fs, fs, ft};
-    float U[4];
+    float S[4] = {mu, fs, fs, ft}, U[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) { U[i] = S[i] * jar[i]; grad[i] = 0.f; }
-    if (H) {
-#pragma unroll
-        for (int i = 0; i < 10; i++) H[i] = 0.f;
-    }
+    for (int i = 0; i < 4; i++) { U[i] = S[i] * jar[i]; c.grad[i] = 0.f; c.w[i] = 0.f; c.a[i] = 0.f; c.b[i] = 0.f; }
+    c.cost = 0.f; c.ka = 0.f; c.kb = 0.f;
     float N = U[0], T = sqrtf(U[1] * U[1] + U[2] * U[2] + U[3] * U[3]);
-    if (N >= mu * T || (T <= 0.f && N >= 0.f)) return 0.f;
+    if (N >= mu * T || (T <= 0.f && N >= 0.f)) return;
     if (mu * N + T <= 0.f || (T <= 0.f && N < 0.f)) {
-        float D[4] = {D0, D1, D1, D3}; float c = 0.f;
+        float D[4] = {D0, D1, D1, D3};
 #pragma unroll
-        for (int i = 0; i < 4; i++) { c += 0.5f * D[i] * jar[i] * jar[i]; grad[i] = D[i] * jar[i]; if (H) H[pidx(i, i)] = D[i]; }
-        return c;
+        for (int i = 0; i < 4; i++) { c.cost += 0.5f * D[i] * jar[i] * jar[i]; c.grad[i] = D[i] * jar[i]; c.w[i] = D[i]; }
+        return;
     }
     float kap = D0 / fmaxf(1e-30f, mu * mu), s1 = rsqrtf(1.f + mu * mu);
     float dist = (mu * T - N) * s1, invT = 1.0f / T;
-    float nU[4] = {-s1, mu * s1 * U[1] * invT, mu * s1 * U[2] * invT, mu * s1 * U[3] * invT};
+    float c2 = dist * mu * s1 * invT;
+    c.a[0] = -s1 * S[0];
 #pragma unroll
-    for (int i = 0; i < 4; i++) grad[i] = kap * S[i] * dist * nU[i];
-    if (H) {
-        float c2 = dist * mu * s1 * invT;
+    for (int i = 1; i < 4; i++) { float t = U[i] * invT; c.a[i] = mu * s1 * t * S[i]; c.b[i] = t * S[i]; c.w[i] = kap * c2 * S[i] * S[i]; }
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+    for (int i = 0; i < 4; i++) c.grad[i] = kap * dist * c.a[i];
+    c.ka = kap; c.kb = kap * c2;
+    c.cost = 0.5f * kap * dist * dist;
+}
+// jv^T H jv for the structured Hessian
+DEVI float cone_quad(const Cone &c, const float (&jv)[4]) {
+    float q = 0.f, da = 0.f, db = 0.f;
 #pragma unroll
-            for (int j = 0; j <= i; j++) {
-                float h = nU[i] * nU[j];
-                if (i > 0 && j > 0) h += c2 * ((i == j ? 1.f : 0.f) - (U[i] * invT) * (U[j] * invT));
-                H[pidx(i, j)] = kap * S[i] * S[j] * h;
-            }
-    }
-    return 0.5f * kap * dist * dist;
+    for (int i = 0; i < 4; i++) { q = fmaf(c.w[i] * jv[i], jv[i], q); da = fmaf(c.a[i], jv[i], da); db = fmaf(c.b[i], jv[i], db); }
+    return q + c.ka * da * da - c.kb * db * db;
 }
 
 struct ContactGeo { V3 p, n, t1, t2; int gA, gB; float fs, ft, D0; };
@@ -588,67 +648,81 @@ DEVI void make_constraints(const DevModel &m, const Kin &k, const float (&qpos)[
     }
 }
 
-// One pass over all constraints at acceleration `qacc`: stores jar in LDS, returns the constraint
-// cost, accumulates J^T force into `jtf` and (if Hp) adds J^T s'' J to the packed Hessian.
-DEVI float constraint_pass(const DevModel &m, const Kin &k, const Limits &lim, const float (&qacc)[13],
-                           float *lds, int lane, int ncon, float (&jtf)[13], float *Hp) {
+// H (13x13 packed lower) += w * u u^T, full or object-block only
+DEVI void rank1_full(float (&Hp)[91], const float (&u)[13], float w) {
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        float wi = w * u[i];
+#pragma unroll
+        for (int j = 0; j <= i; j++) Hp[pidx(i, j)] = fmaf(wi, u[j], Hp[pidx(i, j)]);
+    }
+}
+DEVI void rank1_obj(float (&Hp)[91], const float (&u)[13], float w) {
+#pragma unroll
+    for (int i = 7; i < 13; i++) {
+        float wi = w * u[i];
+#pragma unroll
+        for (int j = 7; j <= i; j++) Hp[pidx(i, j)] = fmaf(wi, u[j], Hp[pidx(i, j)]);
+    }
+}
+
+// One pass over all constraints at acceleration x: stores jar in LDS, returns the constraint cost,
+// accumulates J^T force into `jtf` and, if wantH, adds J^T s'' J to the packed Hessian.
+DEVI float constraint_pass(const DevModel &m, const Kin &k, const Limits &lim, const float (&x)[13],
+                           float *lds, int lane, int ncon, float (&jtf)[13], float (&Hp)[91], bool wantH) {
     float cost = 0.f;
     Wrench w; wrench_zero(w);
     float flim[7];
 #pragma unroll
     for (int j = 0; j < 7; j++) {
-        float jar = lim.sgn[j] * qacc[j] - lim.aref[j];
+        float jar = lim.sgn[j] * x[j] - lim.aref[j];
         bool act = lim.sgn[j] != 0.f && jar < 0.f;
         flim[j] = act ? -lim.D[j] * jar * lim.sgn[j] : 0.f;
         cost += act ? 0.5f * lim.D[j] * jar * jar : 0.f;
-        if (Hp) Hp[pidx(j, j)] += act ? lim.D[j] : 0.f;
+        if (wantH) Hp[pidx(j, j)] += act ? lim.D[j] : 0.f;
     }
-    Twist t; twists(k, qacc, t);
+    Twist t; twists(k, x, t);
     for (int c = 0; c < ncon; c++) {
         int s = CB_BASE + c * C_STRIDE;
         ContactGeo g; load_contact(m, lds, lane, c, g);
         float jar[4]; contact_rows(k, t, g, jar);
 #pragma unroll
         for (int r = 0; r < 4; r++) { jar[r] -= LD(s + C_AREF + r); LD(s + C_JAR + r) = jar[r]; }
-        float grad[4], H[10];
-        cost += cone_eval(jar, g.D0, m.impratio, g.fs, g.ft, grad, Hp ? H : nullptr);
-        // force = -grad
-        V3 F = g.n * (-grad[0]) + g.t1 * (-grad[1]) + g.t2 * (-grad[2]);
-        V3 Tq = g.n * (-grad[3]);
+        Cone cn; cone_eval(jar, g.D0, m.impratio, g.fs, g.ft, cn);
+        cost += cn.cost;
+        V3 F = g.n * (-cn.grad[0]) + g.t1 * (-cn.grad[1]) + g.t2 * (-cn.grad[2]);
+        V3 Tq = g.n * (-cn.grad[3]);
         wrench_add(k, w, g.gB, g.p, F, Tq, 1.f);
         wrench_add(k, w, g.gA, g.p, F, Tq, -1.f);
-        if (Hp) {
-            bool any = false;
+        bool any = cn.w[0] != 0.f || cn.w[1] != 0.f || cn.ka != 0.f;
+        if (wantH && any) {
+            const bool objonly = g.gA == GRP_WORLD && g.gB == GRP_O;     // floor-object rows touch dofs 7..12 only
+            float ua[13], ub[13];
 #pragma unroll
-            for (int i = 0; i < 10; i++) any |= H[i] != 0.f;
-            if (any) {
-                float J[4][13];
+            for (int i = 0; i < 13; i++) { ua[i] = 0.f; ub[i] = 0.f; }
+#pragma unroll 1
+            for (int r = 0; r < 4; r++) {
+                float j[13];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
+                for (int i = 0; i < 13; i++) j[i] = 0.f;
+                V3 e = r == 1 ? g.t1 : r == 2 ? g.t2 : g.n;
+                row_add(k, j, g.gB, g.p, e, 1.f, r == 3);
+                row_add(k, j, g.gA, g.p, e, -1.f, r == 3);
+                float ar = r == 0 ? cn.a[0] : r == 1 ? cn.a[1] : r == 2 ? cn.a[2] : cn.a[3];
+                float br = r == 0 ? cn.b[0] : r == 1 ? cn.b[1] : r == 2 ? cn.b[2] : cn.b[3];
+                float wr = r == 0 ? cn.w[0] : r == 1 ? cn.w[1] : r == 2 ? cn.w[2] : cn.w[3];
 #pragma unroll
-                    for (int i = 0; i < 13; i++) J[r][i] = 0.f;
-                    V3 e = r == 0 ? g.n : r == 1 ? g.t1 : r == 2 ? g.t2 : g.n;
-                    row_add(k, J[r], g.gB, g.p, e, 1.f, r == 3);
-                    row_add(k, J[r], g.gA, g.p, e, -1.f, r == 3);
-                }
-                // W = H J ; Hp += J^T W (lower)
+                for (int i = 0; i < 13; i++) { ua[i] = fmaf(ar, j[i], ua[i]); ub[i] = fmaf(br, j[i], ub[i]); }
+                if (objonly) rank1_obj(Hp, j, wr); else rank1_full(Hp, j, wr);
+            }
+            if (cn.ka != 0.f) {
+#pragma unroll 1
+                for (int q = 0; q < 2; q++) {
+                    float u[13];
 #pragma unroll
-                for (int i = 0; i < 13; i++) {
-                    float wcol[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        float a = 0.f;
-#pragma unroll
-                        for (int q = 0; q < 4; q++) a = fmaf(H[pidx(r, q)], J[q][i], a);
-                        wcol[r] = a;
-                    }
-#pragma unroll
-                    for (int j = i; j < 13; j++) {
-                        float a = 0.f;
-#pragma unroll
-                        for (int r = 0; r < 4; r++) a = fmaf(J[r][j], wcol[r], a);
-                        Hp[pidx(j, i)] += a;
-                    }
+                    for (int i = 0; i < 13; i++) u[i] = q == 0 ? ua[i] : ub[i];
+                    float wq = q == 0 ? cn.ka : -cn.kb;
+                    if (objonly) rank1_obj(Hp, u, wq); else rank1_full(Hp, u, wq);
                 }
             }
         }
@@ -672,91 +746,124 @@ DEVI void line_eval(const DevModel &m, const Limits &lim, const float (&qacc)[13
     }
     for (int c = 0; c < ncon; c++) {
         int s = CB_BASE + c * C_STRIDE;
-        float ja[4], jv[4], grad[4], H[10];
+        float ja[4], jv[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) { jv[r] = LD(s + C_JV + r); ja[r] = LD(s + C_JAR + r) + alpha * jv[r]; }
-        cone_eval(ja, LD(s + C_D0), m.impratio, LD(s + C_FS), LD(s + C_FT), grad, H);
+        Cone cn; cone_eval(ja, LD(s + C_D0), m.impratio, LD(s + C_FS), LD(s + C_FT), cn);
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            dp = fmaf(grad[r], jv[r], dp);
-#pragma unroll
-            for (int q = 0; q < 4; q++) hp = fmaf(jv[r] * H[pidx(r, q)], jv[q], hp);
-        }
+        for (int r = 0; r < 4; r++) dp = fmaf(cn.grad[r], jv[r], dp);
+        hp += cone_quad(cn, jv);
     }
     dphi = dp; ddphi = hp;
 }
 
-DEVI float gauss_cost(const float (&Mp)[91], const float (&qacc)[13], const float (&qs)[13], float (&Md)[13]) {
-    float dq[13];
-#pragma unroll
-    for (int i = 0; i < 13; i++) dq[i] = qacc[i] - qs[i];
-    sym_mulv13(Mp, dq, Md);
-    float g = 0.f;
-#pragma unroll
-    for (int i = 0; i < 13; i++) g = fmaf(0.5f * Md[i], dq[i], g);
-    return g;
-}
-
-// Primal Newton solve of  min 1/2 (a - a_s)^T M (a - a_s) + s(J a - aref)   (mj_solNewton's problem)
-DEVI void solve_newton(const DevModel &m, const Kin &k, const float (&Mp)[91], const Limits &lim,
-                       const float (&qacc_smooth)[13], const float (&warm)[13], float *lds, int lane, int ncon,
+// Primal Newton solve of  min 1/2 (a - a_s)^T M (a - a_s) + s(J a - aref)   (mj_solNewton's problem).
+// Staged loop with ONE constraint-pass site: stage 0 prices qacc_warmstart, stage 1 prices qacc_smooth (the
+// better one is the start, as MuJoCo does), stages >= 2 are Newton iterations with exact line search.
+DEVI void solve_newton(const DevModel &m, const Kin &k, const float (&Mg)[28], const float (&Mo)[21], const Limits &lim,
+                       const float (&qs)[13], const float (&warm)[13], float *lds, int lane, int ncon,
                        float (&qacc)[13], float (&jtf)[13], int &fault, int &iters) {
     const float scale = 1.0f / (m.meaninertia * 13.f);
     const float tol = fmaxf(m.tolerance, 1e-6f);
-    float Md[13], H[91], grad[13], p[13];
-    // warm start: the better of qacc_warmstart and qacc_smooth
-    float cw = gauss_cost(Mp, warm, qacc_smooth, Md) + constraint_pass(m, k, lim, warm, lds, lane, ncon, jtf, nullptr);
-    float cs = constraint_pass(m, k, lim, qacc_smooth, lds, lane, ncon, jtf, nullptr);
-    bool usew = cw < cs;
-#pragma unroll
-    for (int i = 0; i < 13; i++) qacc[i] = usew ? warm[i] : qacc_smooth[i];
-#pragma unroll
-    for (int i = 0; i < 91; i++) H[i] = Mp[i];
-    float cost = gauss_cost(Mp, qacc, qacc_smooth, Md) + constraint_pass(m, k, lim, qacc, lds, lane, ncon, jtf, H);
+    float H[91], Md[13], x[13];
+    float cost = 0.f, cw = 0.f;
+    int stage = 0; bool done = false;
     iters = 0;
-    for (int it = 0; it < NEWTON_MAXIT; it++) {
-        float gn = 0.f;
 #pragma unroll
-        for (int i = 0; i < 13; i++) { grad[i] = Md[i] - jtf[i]; gn = fmaf(grad[i], grad[i], gn); }
-        if (scale * sqrtf(gn) < tol) break;
-        chol_packed<13>(H);
+    for (int i = 0; i < 13; i++) { qacc[i] = qs[i]; x[i] = warm[i]; }
+    while (__any(!done)) {
+        if (!done) {
+            const bool wantH = stage >= 2;
+            if (wantH) {
 #pragma unroll
-        for (int i = 0; i < 13; i++) p[i] = -grad[i];
-        chol_solve_packed<13>(H, p);
-        float Mpv[13]; sym_mulv13(Mp, p, Mpv);
-        float g0 = 0.f, g1 = 0.f;
+                for (int i = 0; i < 91; i++) H[i] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 13; i++) { g0 = fmaf(Mpv[i], qacc[i] - qacc_smooth[i], g0); g1 = fmaf(Mpv[i], p[i], g1); }
-        {   Twist tp; twists(k, p, tp);
-            for (int c = 0; c < ncon; c++) {
-                ContactGeo g; load_contact(m, lds, lane, c, g);
-                float jv[4]; contact_rows(k, tp, g, jv);
+                for (int i = 0; i < 7; i++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) LD(CB_BASE + c * C_STRIDE + C_JV + r) = jv[r];
-            } }
-        float lo = 0.f, hi = -1.f, alpha = 0.f, dp, hp;
-        line_eval(m, lim, qacc, p, lds, lane, ncon, 0.f, g0, g1, dp, hp);
-        if (dp >= 0.f) break;
-        float gtol = 1e-5f * fabsf(dp) + 1e-30f;
-        for (int ls = 0; ls < LS_MAXIT; ls++) {
-            float an = alpha - dp / fmaxf(hp, 1e-30f);
-            if (hi > 0.f && (an <= lo || an >= hi)) an = 0.5f * (lo + hi);
-            alpha = an;
-            line_eval(m, lim, qacc, p, lds, lane, ncon, alpha, g0, g1, dp, hp);
-            if (fabsf(dp) < gtol) break;
-            if (dp < 0.f) lo = alpha; else hi = alpha;
-            if (hi > 0.f && (hi - lo) < 1e-6f * hi) break;
+                    for (int j = 0; j <= i; j++) H[pidx(i, j)] = Mg[pidx(i, j)];
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = 0; j <= i; j++) H[pidx(7 + i, 7 + j)] = Mo[pidx(i, j)];
+            }
+            float dq[13];
+#pragma unroll
+            for (int i = 0; i < 13; i++) dq[i] = x[i] - qs[i];
+            mass_mulv(Mg, Mo, dq, Md);
+            float newcost = 0.f;
+#pragma unroll
+            for (int i = 0; i < 13; i++) newcost = fmaf(0.5f * Md[i], dq[i], newcost);
+            newcost += constraint_pass(m, k, lim, x, lds, lane, ncon, jtf, H, wantH);
+            if (stage == 0) {
+                cw = newcost; stage = 1;
+#pragma unroll
+                for (int i = 0; i < 13; i++) x[i] = qs[i];
+            } else if (stage == 1) {
+                bool usew = cw < newcost;
+#pragma unroll
+                for (int i = 0; i < 13; i++) { qacc[i] = usew ? warm[i] : qs[i]; x[i] = qacc[i]; }
+                stage = 2;
+            } else {
+                bool stop = false;
+                if (stage > 2) { stop = scale * (cost - newcost) < tol; }
+                cost = newcost;
+                float grad[13], gn = 0.f;
+#pragma unroll
+                for (int i = 0; i < 13; i++) { grad[i] = Md[i] - jtf[i]; gn = fmaf(grad[i], grad[i], gn); }
+                if (scale * sqrtf(gn) < tol) stop = true;
+                if (!stop && iters >= NEWTON_MAXIT) { stop = true; fault |= 4; }
+                if (stop) done = true;
+                else {
+                    float p[13];
+                    chol_packed<13>(H);
+#pragma unroll
+                    for (int i = 0; i < 13; i++) p[i] = -grad[i];
+                    chol_solve_packed<13>(H, p);
+                    float Mpv[13]; mass_mulv(Mg, Mo, p, Mpv);
+                    float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 13; i++) { g0 = fmaf(Mpv[i], qacc[i] - qs[i], g0); g1 = fmaf(Mpv[i], p[i], g1); }
+                    {   Twist tp; twists(k, p, tp);
+                        for (int c = 0; c < ncon; c++) {
+                            ContactGeo g; load_contact(m, lds, lane, c, g);
+                            float jv[4]; contact_rows(k, tp, g, jv);
+#pragma unroll
+                            for (int r = 0; r < 4; r++) LD(CB_BASE + c * C_STRIDE + C_JV + r) = jv[r];
+                        } }
+                    // exact line search: safeguarded 1-D Newton on phi'(alpha); one evaluation site
+                    float lo = 0.f, hi = -1.f, alpha = 0.f, gtol = 0.f;
+                    bool lsdone = false, descent = true;
+                    for (int ls = 0; ls <= LS_MAXIT; ls++) {
+                        if (!__any(!lsdone)) break;
+                        if (!lsdone) {
+                            float dp, hp;
+                            line_eval(m, lim, qacc, p, lds, lane, ncon, alpha, g0, g1, dp, hp);
+                            if (ls == 0) {
+                                if (dp >= 0.f) { descent = false; lsdone = true; }
+                                gtol = 1e-5f * fabsf(dp) + 1e-30f;
+                            } else {
+                                if (fabsf(dp) < gtol) lsdone = true;
+                                else {
+                                    if (dp < 0.f) lo = alpha; else hi = alpha;
+                                    if (hi > 0.f && (hi - lo) < 1e-6f * hi) lsdone = true;
+                                }
+                            }
+                            if (!lsdone && ls < LS_MAXIT) {
+                                float an = alpha - dp / fmaxf(hp, 1e-30f);
+                                if (hi > 0.f && (an <= lo || an >= hi)) an = 0.5f * (lo + hi);
+                                alpha = an;
+                            }
+                        }
+                    }
+                    if (!descent) done = true;
+                    else {
+#pragma unroll
+                        for (int i = 0; i < 13; i++) { qacc[i] = fmaf(alpha, p[i], qacc[i]); x[i] = qacc[i]; }
+                        iters++; stage++;
+                    }
+                }
+            }
         }
-#pragma unroll
-        for (int i = 0; i < 13; i++) qacc[i] = fmaf(alpha, p[i], qacc[i]);
-#pragma unroll
-        for (int i = 0; i < 91; i++) H[i] = Mp[i];
-        float newcost = gauss_cost(Mp, qacc, qacc_smooth, Md) + constraint_pass(m, k, lim, qacc, lds, lane, ncon, jtf, H);
-        iters = it + 1;
-        float improvement = scale * (cost - newcost);
-        cost = newcost;
-        if (improvement < tol) break;
-        if (it == NEWTON_MAXIT - 1) fault |= 4;
     }
 }
 
@@ -764,15 +871,16 @@ DEVI void solve_newton(const DevModel &m, const Kin &k, const float (&Mp)[91], c
 struct LaneState { float qpos[14], qvel[13], ctrl[7], warm[13]; };
 
 // position stage (mj_step1's share): kinematics + collision of the current state; contacts stay in LDS.
-DEVI void forward_pos(const DevModel &m, LaneState &s, float *lds, int lane, Kin &k, int &ncon, int &fault) {
+DEVI void forward_pos(const DevModel &m, const Hulls &H, LaneState &s, float *lds, int lane, Kin &k, int &ncon, int &fault) {
     kinematics(m, s.qpos, k, lds, lane);
-    collide(m, lds, lane, ncon, fault);
+    collide(m, H, lds, lane, ncon, fault);
 }
 
 // dynamics stage (mj_step2's share up to qacc) on top of forward_pos
 DEVI void forward_acc(const DevModel &m, LaneState &s, float xfrc_z, float *lds, int lane, const Kin &k, int ncon, int &fault,
-                      float (&Mp)[91], float (&qfrc_smooth)[13], float (&qacc)[13], float (&jtf)[13], int &iters, float *dbg_qs, float *dbg_bias) {
-    mass_matrix(m, k, Mp);
+                      float (&Mg)[28], float (&Mo)[21], float (&qfrc_smooth)[13], float (&qacc)[13], float (&jtf)[13], int &iters,
+                      float *dbg_qs, float *dbg_bias) {
+    mass_matrix(m, k, Mg, Mo);
     float bias[13];
     bias_forces(m, k, s.qvel, bias);
     if (dbg_bias) {
@@ -789,13 +897,9 @@ DEVI void forward_acc(const DevModel &m, LaneState &s, float xfrc_z, float *lds,
     {   // block solves M qacc_smooth = qfrc_smooth  (gripper 7x7, object 6x6; the cross block is zero)
         float Lg[28], Lo[21], xg[7], xo[6];
 #pragma unroll
-        for (int i = 0; i < 7; i++)
+        for (int i = 0; i < 28; i++) Lg[i] = Mg[i];
 #pragma unroll
-            for (int j = 0; j <= i; j++) Lg[pidx(i, j)] = Mp[pidx(i, j)];
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-#pragma unroll
-            for (int j = 0; j <= i; j++) Lo[pidx(i, j)] = Mp[pidx(7 + i, 7 + j)];
+        for (int i = 0; i < 21; i++) Lo[i] = Mo[i];
         chol_packed<7>(Lg); chol_packed<6>(Lo);
 #pragma unroll
         for (int i = 0; i < 7; i++) xg[i] = qfrc_smooth[i];
@@ -817,30 +921,26 @@ DEVI void forward_acc(const DevModel &m, LaneState &s, float xfrc_z, float *lds,
 #pragma unroll
     for (int j = 0; j < 7; j++) anylim |= lim.sgn[j] != 0.f;
     iters = 0;
-    if (ncon == 0 && !anylim) {
+    const bool constrained = ncon > 0 || anylim;
 #pragma unroll
-        for (int i = 0; i < 13; i++) { qacc[i] = qs[i]; jtf[i] = 0.f; }
-    } else {
-        solve_newton(m, k, Mp, lim, qs, s.warm, lds, lane, ncon, qacc, jtf, fault, iters);
+    for (int i = 0; i < 13; i++) { qacc[i] = qs[i]; jtf[i] = 0.f; }
+    if (__any(constrained)) {
+        if (constrained) solve_newton(m, k, Mg, Mo, lim, qs, s.warm, lds, lane, ncon, qacc, jtf, fault, iters);
     }
 }
 
 // dynamics + integration of one physics.step(); forward_pos must have run on the current state
 DEVI void physics_advance(const DevModel &m, LaneState &s, float xfrc_z, float *lds, int lane, const Kin &k, int ncon, int &fault) {
-    float Mp[91], qfs[13], qacc[13], jtf[13]; int iters;
-    forward_acc(m, s, xfrc_z, lds, lane, k, ncon, fault, Mp, qfs, qacc, jtf, iters, nullptr, nullptr);
+    float Mg[28], Mo[21], qfs[13], qacc[13], jtf[13]; int iters;
+    forward_acc(m, s, xfrc_z, lds, lane, k, ncon, fault, Mg, Mo, qfs, qacc, jtf, iters, nullptr, nullptr);
     const float h = m.timestep;
     // semi-implicit Euler with implicit joint damping: (M + h D) a' = qfrc_smooth + J^T f.
     // Only the gripper block carries damping; for the object block a' = qacc.
-    float Lg[28], xg[7];
+    float xg[7];
 #pragma unroll
-    for (int i = 0; i < 7; i++)
-#pragma unroll
-        for (int j = 0; j <= i; j++) Lg[pidx(i, j)] = Mp[pidx(i, j)] + (i == j ? h * m.damping[i] : 0.f);
-    chol_packed<7>(Lg);
-#pragma unroll
-    for (int i = 0; i < 7; i++) xg[i] = qfs[i] + jtf[i];
-    chol_solve_packed<7>(Lg, xg);
+    for (int i = 0; i < 7; i++) { Mg[pidx(i, i)] += h * m.damping[i]; xg[i] = qfs[i] + jtf[i]; }
+    chol_packed<7>(Mg);
+    chol_solve_packed<7>(Mg, xg);
 #pragma unroll
     for (int i = 0; i < 13; i++) s.warm[i] = qacc[i];
 #pragma unroll

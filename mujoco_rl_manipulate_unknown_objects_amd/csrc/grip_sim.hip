@@ -62,8 +62,7 @@ struct Blob {
 
 struct GripModel {
     DevModel host;                       // pointer members are filled per device at batch creation
-    std::vector<float> verts4;           // [nvert][4]
-    std::vector<int> nadr, nbr;
+    std::vector<unsigned> hull_blob;     // vertices | nadr | nbr | lut (see DevModel)
     std::vector<float> planes;           // [nplane][4]
     int nvert = 0;
 };
@@ -116,7 +115,7 @@ extern "C" int grip_model_load(const char *blob_path, GripModel **out) {
     if (!b.load(blob_path)) return fail(std::string("cannot read model blob ") + blob_path);
     std::vector<double> opt, margin, solref, solimp, lsolref, lsolimp, bpos, bquat, bmass, bipos, biquat, binert, arm, damp, rng, gear,
         crange, qpos0, gfric, gcen, grb, grgba, hverts, hplanes, biw, diw, mi, campos, camquat, camfovy, visual, frgb, srgb, ldir;
-    std::vector<int> gbody, hvadr, hvnum, hpadr, hpnum, nadr, nbr, pairs;
+    std::vector<int> gbody, hvadr, hvnum, hpadr, hpnum, nadr, nbr, pairs, lut;
     bool ok = b.f64("opt", opt, 5) && b.f64("geom_margin", margin, 1) && b.f64("geom_solref", solref, 2) && b.f64("geom_solimp", solimp, 5) &&
               b.f64("lim_solref", lsolref, 2) && b.f64("lim_solimp", lsolimp, 5) && b.f64("body_pos", bpos, 24) && b.f64("body_quat", bquat, 32) &&
               b.f64("body_mass", bmass, 8) && b.f64("body_ipos", bipos, 24) && b.f64("body_iquat", biquat, 32) && b.f64("body_inertia", binert, 24) &&
@@ -127,7 +126,7 @@ extern "C" int grip_model_load(const char *blob_path, GripModel **out) {
               b.f64("cam_quat", camquat, 4) && b.f64("cam_fovy", camfovy, 1) && b.f64("visual", visual, 3) && b.f64("floor_rgb", frgb, 6) &&
               b.f64("sky_rgb", srgb, 6) && b.f64("light_dir", ldir, 6) && b.i32("geom_body", gbody, 7) && b.i32("hull_vadr", hvadr, 6) &&
               b.i32("hull_vnum", hvnum, 6) && b.i32("hull_padr", hpadr, 6) && b.i32("hull_pnum", hpnum, 6) && b.i32("hull_nadr", nadr) &&
-              b.i32("hull_nbr", nbr) && b.i32("hull_pairs", pairs);
+              b.i32("hull_nbr", nbr) && b.i32("hull_pairs", pairs) && b.i32("hull_lut", lut, 6 * 6 * 64);
     if (!ok) return fail(std::string("model blob ") + blob_path + " is missing fields or has the wrong version");
     GripModel *gm = new GripModel();
     DevModel &m = gm->host; memset(&m, 0, sizeof m);
@@ -189,9 +188,22 @@ extern "C" int grip_model_load(const char *blob_path, GripModel **out) {
     if (m.npair > GN_PAIR_MAX) { delete gm; return fail("too many collision pairs"); }
     for (int q = 0; q < m.npair; q++) { m.pairs[q][0] = pairs[2*q]; m.pairs[q][1] = pairs[2*q+1]; }
     gm->nvert = (int)hverts.size() / 3;
-    gm->verts4.resize(4 * (size_t)gm->nvert);
-    for (int i = 0; i < gm->nvert; i++) { for (int k = 0; k < 3; k++) gm->verts4[4*i+k] = (float)hverts[3*i+k]; gm->verts4[4*i+3] = 0.f; }
-    gm->nadr = nadr; gm->nbr = nbr;
+    {   // pack the hull tables into one word blob
+        auto pack16 = [](std::vector<unsigned> &dst, const std::vector<int> &src) {
+            size_t w0 = dst.size(); dst.resize(w0 + (src.size() + 1) / 2, 0u);
+            unsigned short *p = reinterpret_cast<unsigned short *>(dst.data() + w0);
+            for (size_t i = 0; i < src.size(); i++) p[i] = (unsigned short)src[i];
+        };
+        for (int v : nadr) if (v < 0 || v > 65535) { delete gm; return fail("hull graph too large for 16-bit offsets"); }
+        std::vector<unsigned> &hb = gm->hull_blob;
+        hb.resize(4 * (size_t)gm->nvert);
+        float *vf = reinterpret_cast<float *>(hb.data());
+        for (int i = 0; i < gm->nvert; i++) { for (int k = 0; k < 3; k++) vf[4*i+k] = (float)hverts[3*i+k]; vf[4*i+3] = 0.f; }
+        m.hull_off_nadr = (int)hb.size(); pack16(hb, nadr);
+        m.hull_off_nbr = (int)hb.size(); pack16(hb, nbr);
+        m.hull_off_lut = (int)hb.size(); pack16(hb, lut);
+        m.hull_words = (int)hb.size();
+    }
     gm->planes.resize(hplanes.size()); for (size_t i = 0; i < hplanes.size(); i++) gm->planes[i] = (float)hplanes[i];
     for (int k = 0; k < 3; k++) m.cam_pos[k] = (float)campos[k];
     {   double Rc[9]; hm::qmat(camquat.data(), Rc); for (int k = 0; k < 9; k++) m.cam_R[k] = (float)Rc[k]; }
@@ -214,7 +226,7 @@ struct StepOutDev {     // device copy of GripStepOut (kernel argument)
 
 struct GripBatch {
     int n = 0, device = 0;
-    DevModel *d_model = nullptr; float *d_verts = nullptr; int *d_nadr = nullptr, *d_nbr = nullptr; float *d_planes = nullptr;
+    DevModel *d_model = nullptr; unsigned *d_hull = nullptr; float *d_planes = nullptr; size_t lds_bytes = 0;
     DevConfig cfg;
     float *qpos = nullptr, *qvel = nullptr, *ctrl = nullptr, *warm = nullptr;     // SoA [field][N]
     int *episode_step = nullptr, *status = nullptr, *gripper_open = nullptr;
@@ -227,7 +239,8 @@ struct GripBatch {
 };
 
 static constexpr int EV_RING = 1024;
-static constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS_PER_LANE * WAVE * sizeof(float);
+static constexpr size_t LDS_LANE_BYTES = (size_t)LDS_LANE_WORDS * sizeof(float);
+static constexpr int LDS_MAX_BYTES = 160 * 1024;
 
 // ---- state load / store (coalesced SoA)
 struct StatePtrs { float *qpos, *qvel, *ctrl, *warm; int *episode_step, *status, *gripper_open, *pad_grasp, *pad_pher; int n; };
@@ -347,9 +360,10 @@ __global__ void __launch_bounds__(WAVE) k_reset(const DevModel *mp, DevConfig cf
     bool valid = e < st.n;
     if (!valid) e = st.n - 1;
     bool doit = valid && (mask == nullptr || mask[e] != 0);
+    const Hulls H = stage_hulls(m, lds, lane);
     LaneState s; reset_lane(m, s);
     Kin k; int ncon = 0, fault = 0;
-    forward_pos(m, s, lds, lane, k, ncon, fault);
+    forward_pos(m, H, s, lds, lane, k, ncon, fault);
     int grasp = check_grasp(lds, lane, ncon), pher = pheromone_level(k.pe, cfg);
     if (blockIdx.x == 0 && lane == 0 && reset_info) { reset_info[0] = (float)grasp; reset_info[1] = (float)pher; reset_info[2] = k.po.x; reset_info[3] = k.po.y; }
     if (!doit) return;
@@ -374,6 +388,7 @@ __global__ void __launch_bounds__(WAVE) k_macro_step(const DevModel *mp, DevConf
     int e = blockIdx.x * WAVE + lane;
     const bool valid = e < st.n;
     if (!valid) e = st.n - 1;
+    const Hulls H = stage_hulls(m, lds, lane);
     LaneState s; ld_state(st, e, s);
     int episode_step = st.episode_step[e], status = st.status[e], gripper_open = st.gripper_open[e];
     const int adim = cfg.include_roll ? 6 : 5;
@@ -389,7 +404,7 @@ __global__ void __launch_bounds__(WAVE) k_macro_step(const DevModel *mp, DevConf
 
     while (__any(phase != PH_DONE)) {
         if (phase != PH_DONE) {
-            forward_pos(m, s, lds, lane, k, ncon, fault);          // state of "now": contacts as check_grasp sees them
+            forward_pos(m, H, s, lds, lane, k, ncon, fault);       // state of "now": contacts as check_grasp sees them
             if (first) {
                 first = false;
                 init_obj = k.po;
@@ -506,10 +521,11 @@ __global__ void __launch_bounds__(WAVE) k_substep(const DevModel *mp, StatePtrs 
     int e = blockIdx.x * WAVE + lane;
     const bool valid = e < st.n;
     if (!valid) e = st.n - 1;
+    const Hulls H = stage_hulls(m, lds, lane);
     LaneState s; ld_state(st, e, s);
     Kin k; int ncon = 0, fault = 0;
     for (int i = 0; i < nsteps; i++) {
-        forward_pos(m, s, lds, lane, k, ncon, fault);
+        forward_pos(m, H, s, lds, lane, k, ncon, fault);
         physics_advance(m, s, xfrc_z, lds, lane, k, ncon, fault);
     }
     if (valid) { st_state(st, e, s); if (fault_out) fault_out[e] = fault; }
@@ -522,11 +538,12 @@ __global__ void __launch_bounds__(WAVE) k_debug_forward(const DevModel *mp, Stat
     int e = blockIdx.x * WAVE + lane;
     const bool valid = e < st.n;
     if (!valid) e = st.n - 1;
+    const Hulls H = stage_hulls(m, lds, lane);
     LaneState s; ld_state(st, e, s);
     Kin k; int ncon = 0, fault = 0, iters = 0;
-    forward_pos(m, s, lds, lane, k, ncon, fault);
-    float Mp[91], qfs[13], qacc[13], jtf[13], qs[13], bias[13];
-    forward_acc(m, s, xfrc_z, lds, lane, k, ncon, fault, Mp, qfs, qacc, jtf, iters, qs, bias);
+    forward_pos(m, H, s, lds, lane, k, ncon, fault);
+    float Mg[28], Mo[21], qfs[13], qacc[13], jtf[13], qs[13], bias[13];
+    forward_acc(m, s, xfrc_z, lds, lane, k, ncon, fault, Mg, Mo, qfs, qacc, jtf, iters, qs, bias);
     if (!valid) return;
     ncon_out[e] = ncon;
     for (int c = 0; c < G_MAXC; c++) {
@@ -542,7 +559,8 @@ __global__ void __launch_bounds__(WAVE) k_debug_forward(const DevModel *mp, Stat
     xp[3] = k.pe.x; xp[4] = k.pe.y; xp[5] = k.pe.z;
     for (int g = 1; g <= 6; g++) { V3 p; M3 R; load_frame(lds, lane, g, p, R); xp[3 * (g + 1)] = p.x; xp[3 * (g + 1) + 1] = p.y; xp[3 * (g + 1) + 2] = p.z; }
     for (int i = 0; i < 13; i++) { qacc_out[(size_t)e * 13 + i] = qacc[i]; qs_out[(size_t)e * 13 + i] = qs[i]; bias_out[(size_t)e * 13 + i] = bias[i]; }
-    for (int i = 0; i < 13; i++) for (int j = 0; j < 13; j++) M_out[(size_t)e * 169 + i * 13 + j] = Mp[pidx(i, j)];
+    for (int i = 0; i < 13; i++) for (int j = 0; j < 13; j++)
+        M_out[(size_t)e * 169 + i * 13 + j] = (i < 7 && j < 7) ? Mg[pidx(i, j)] : (i >= 7 && j >= 7) ? Mo[pidx(i - 7, j - 7)] : 0.f;
 }
 
 __global__ void __launch_bounds__(WAVE) k_target_pose(const DevModel *mp, DevConfig cfg, StatePtrs st, const float *actions, float *target_out) {
@@ -591,11 +609,11 @@ static int grid_of(const GripBatch *b) { return (b->n + WAVE - 1) / WAVE; }
 static int ensure_lds_attr() {
     static bool done = false;
     if (done) return 0;
-    HIPCHK(hipFuncSetAttribute((const void *)k_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void *)k_macro_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void *)k_substep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void *)k_debug_forward, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void *)k_target_pose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void *)k_reset, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void *)k_macro_step, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void *)k_substep, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void *)k_debug_forward, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void *)k_target_pose, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES));
     done = true;
     return 0;
 }
@@ -609,15 +627,13 @@ extern "C" int grip_batch_create(const GripModel *m, int n_envs, int device_id, 
     if (ensure_lds_attr()) return -1;
     GripBatch *b = new GripBatch(); b->n = n_envs; b->device = device_id;
     size_t N = (size_t)n_envs;
-    HIPCHK(hipMalloc(&b->d_verts, m->verts4.size() * sizeof(float)));
-    HIPCHK(hipMemcpy(b->d_verts, m->verts4.data(), m->verts4.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&b->d_nadr, m->nadr.size() * sizeof(int)));
-    HIPCHK(hipMemcpy(b->d_nadr, m->nadr.data(), m->nadr.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&b->d_nbr, m->nbr.size() * sizeof(int)));
-    HIPCHK(hipMemcpy(b->d_nbr, m->nbr.data(), m->nbr.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&b->d_hull, m->hull_blob.size() * sizeof(unsigned)));
+    HIPCHK(hipMemcpy(b->d_hull, m->hull_blob.data(), m->hull_blob.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    b->lds_bytes = LDS_LANE_BYTES + m->hull_blob.size() * sizeof(unsigned);
+    if (b->lds_bytes > 160 * 1024) return fail("model hull tables do not fit the 160 KiB LDS next to the per-lane contact storage");
     HIPCHK(hipMalloc(&b->d_planes, m->planes.size() * sizeof(float)));
     HIPCHK(hipMemcpy(b->d_planes, m->planes.data(), m->planes.size() * sizeof(float), hipMemcpyHostToDevice));
-    DevModel hm_ = m->host; hm_.hull_verts = b->d_verts; hm_.hull_nadr = b->d_nadr; hm_.hull_nbr = b->d_nbr; hm_.hull_planes = b->d_planes;
+    DevModel hm_ = m->host; hm_.hull_blob = b->d_hull; hm_.hull_planes = b->d_planes;
     HIPCHK(hipMalloc(&b->d_model, sizeof(DevModel)));
     HIPCHK(hipMemcpy(b->d_model, &hm_, sizeof(DevModel), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&b->qpos, 14 * N * sizeof(float))); HIPCHK(hipMalloc(&b->qvel, 13 * N * sizeof(float)));
@@ -642,7 +658,7 @@ extern "C" void grip_batch_destroy(GripBatch *b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {b->d_model, b->d_verts, b->d_nadr, b->d_nbr, b->d_planes, b->qpos, b->qvel, b->ctrl, b->warm, b->episode_step, b->status,
+    void *ptrs[] = {b->d_model, b->d_hull, b->d_planes, b->qpos, b->qvel, b->ctrl, b->warm, b->episode_step, b->status,
                     b->gripper_open, b->pad_grasp, b->pad_pher, b->reset_info, b->scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : b->ev0) (void)hipEventDestroy(e);
@@ -664,7 +680,7 @@ extern "C" int grip_batch_set_config(GripBatch *b, const GripEnvConfig *c) {
     uint8_t *zero_mask = (uint8_t *)b->scratch;
     HIPCHK(hipMemsetAsync(zero_mask, 0, (size_t)b->n, nullptr));
     StepOutDev none; memset(&none, 0, sizeof none);
-    hipLaunchKernelGGL(k_reset, dim3(1), dim3(WAVE), LDS_BYTES, nullptr, b->d_model, b->cfg, state_ptrs(b), zero_mask, none, b->reset_info);
+    hipLaunchKernelGGL(k_reset, dim3(1), dim3(WAVE), b->lds_bytes, nullptr, b->d_model, b->cfg, state_ptrs(b), zero_mask, none, b->reset_info);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(nullptr));
     return 0;
@@ -673,7 +689,7 @@ extern "C" int grip_batch_set_config(GripBatch *b, const GripEnvConfig *c) {
 extern "C" int grip_batch_reset(GripBatch *b, const uint8_t *mask_dev, const GripStepOut *out, void *stream) {
     if (!b) return fail("grip_batch_reset: null batch");
     HIPCHK(hipSetDevice(b->device));
-    hipLaunchKernelGGL(k_reset, dim3(grid_of(b)), dim3(WAVE), LDS_BYTES, (hipStream_t)stream, b->d_model, b->cfg, state_ptrs(b), mask_dev,
+    hipLaunchKernelGGL(k_reset, dim3(grid_of(b)), dim3(WAVE), b->lds_bytes, (hipStream_t)stream, b->d_model, b->cfg, state_ptrs(b), mask_dev,
                        to_dev(out), b->reset_info);
     HIPCHK(hipGetLastError());
     return 0;
@@ -685,7 +701,7 @@ extern "C" int grip_batch_step(GripBatch *b, const float *actions_dev, const Gri
     hipStream_t s = (hipStream_t)stream;
     int slot = b->ev_used % EV_RING;
     HIPCHK(hipEventRecord(b->ev0[slot], s));
-    hipLaunchKernelGGL(k_macro_step, dim3(grid_of(b)), dim3(WAVE), LDS_BYTES, s, b->d_model, b->cfg, state_ptrs(b), actions_dev, to_dev(out),
+    hipLaunchKernelGGL(k_macro_step, dim3(grid_of(b)), dim3(WAVE), b->lds_bytes, s, b->d_model, b->cfg, state_ptrs(b), actions_dev, to_dev(out),
                        b->reset_info, b->xfrc_z);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev1[slot], s));
@@ -711,7 +727,7 @@ extern "C" int grip_batch_kernel_time(GripBatch *b, int reset, float *ms_avg, in
 extern "C" int grip_batch_substep(GripBatch *b, int k, void *stream) {
     if (!b || k < 0) return fail("grip_batch_substep: bad arguments");
     HIPCHK(hipSetDevice(b->device));
-    hipLaunchKernelGGL(k_substep, dim3(grid_of(b)), dim3(WAVE), LDS_BYTES, (hipStream_t)stream, b->d_model, state_ptrs(b), k, b->xfrc_z, (int *)nullptr);
+    hipLaunchKernelGGL(k_substep, dim3(grid_of(b)), dim3(WAVE), b->lds_bytes, (hipStream_t)stream, b->d_model, state_ptrs(b), k, b->xfrc_z, (int *)nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -781,7 +797,7 @@ extern "C" int grip_batch_debug_forward(GripBatch *b, int32_t *ncon, float *con,
     HIPCHK(hipMalloc(&d_ncon, N * sizeof(int))); HIPCHK(hipMalloc(&d_con, N * G_MAXC * 10 * sizeof(float))); HIPCHK(hipMalloc(&d_xpos, N * 24 * sizeof(float)));
     HIPCHK(hipMalloc(&d_qacc, N * 13 * sizeof(float))); HIPCHK(hipMalloc(&d_qs, N * 13 * sizeof(float))); HIPCHK(hipMalloc(&d_M, N * 169 * sizeof(float)));
     HIPCHK(hipMalloc(&d_bias, N * 13 * sizeof(float)));
-    hipLaunchKernelGGL(k_debug_forward, dim3(grid_of(b)), dim3(WAVE), LDS_BYTES, s, b->d_model, state_ptrs(b), b->xfrc_z, d_ncon, d_con, d_xpos, d_qacc, d_qs, d_M, d_bias);
+    hipLaunchKernelGGL(k_debug_forward, dim3(grid_of(b)), dim3(WAVE), b->lds_bytes, s, b->d_model, state_ptrs(b), b->xfrc_z, d_ncon, d_con, d_xpos, d_qacc, d_qs, d_M, d_bias);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(ncon, d_ncon, N * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(con, d_con, N * G_MAXC * 10 * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -800,7 +816,7 @@ extern "C" int grip_batch_target_pose(GripBatch *b, const float *actions_dev, fl
     HIPCHK(hipSetDevice(b->device));
     hipStream_t s = (hipStream_t)stream; size_t N = (size_t)b->n;
     float *d_t; HIPCHK(hipMalloc(&d_t, N * 5 * sizeof(float)));
-    hipLaunchKernelGGL(k_target_pose, dim3(grid_of(b)), dim3(WAVE), LDS_BYTES, s, b->d_model, b->cfg, state_ptrs(b), actions_dev, d_t);
+    hipLaunchKernelGGL(k_target_pose, dim3(grid_of(b)), dim3(WAVE), b->lds_bytes, s, b->d_model, b->cfg, state_ptrs(b), actions_dev, d_t);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(target_qpos_host, d_t, N * 5 * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -16,7 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libgrip_sim.so")
 ASSETS = os.path.join(_HERE, "assets")
 OBJECTS = ("acorn", "sand_ball", "sugar_cube", "bread_crumb")
-MAXCON = 16
+MAXCON = 14
 
 
 class GripError(RuntimeError):

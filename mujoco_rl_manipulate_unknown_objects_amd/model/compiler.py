@@ -210,6 +210,32 @@ def build_hull(points):
     return verts, nadr, np.array(flat, dtype=np.int32), planes
 
 
+LUT_RES = 8
+
+
+def lut_cell_dirs(res=LUT_RES):
+    """Centre directions of a 6 x res x res cube map; cell id = face * res^2 + iu * res + iv.
+    face = 2 * major_axis + (0 if the major component is positive else 1); (u, v) are the two other
+    components divided by |major|, in axis order, mapped from [-1, 1] to [0, res)."""
+    dirs = np.zeros((6 * res * res, 3))
+    for face in range(6):
+        ax, neg = face // 2, face % 2
+        o = [a for a in range(3) if a != ax]
+        for iu in range(res):
+            for iv in range(res):
+                d = np.zeros(3)
+                d[ax] = -1.0 if neg else 1.0
+                d[o[0]] = (iu + 0.5) / res * 2 - 1
+                d[o[1]] = (iv + 0.5) / res * 2 - 1
+                dirs[face * res * res + iu * res + iv] = d
+    return dirs
+
+
+def support_lut(verts):
+    """Start vertex for hill-climbing support queries: exhaustive argmax at every cube-map cell centre."""
+    return np.argmax(lut_cell_dirs() @ verts.T, axis=1).astype(np.int32)
+
+
 # --------------------------------------------------------------------------
 # MJCF subset
 # --------------------------------------------------------------------------
@@ -401,6 +427,7 @@ def compile_model(xml_path, mesh_dir, standin_acorn=False):
     hv, hvadr, hvnum = [], [0], []
     hn_adr, hn = [np.zeros(1, dtype=np.int32)], []
     hp, hpadr, hpnum = [], [0], []
+    hlut = []
     standin = 0
     for gi, bn in enumerate(BODY_NAMES[2:], start=1):
         bi = BODY_NAMES.index(bn)
@@ -438,6 +465,7 @@ def compile_model(xml_path, mesh_dir, standin_acorn=False):
         hn_adr.append(nadr[1:] + sum(len(a) for a in hn))
         hn.append(nbr)
         hp.append(planes); hpnum.append(len(planes)); hpadr.append(hpadr[-1] + len(planes))
+        hlut.append(support_lut(verts))
     # ee keeps its explicit <inertial> (no geoms on it)
     ine = B["ee"]["inertial"]
     body_mass[1] = float(ine["mass"]); body_ipos[1] = _floats(ine["pos"]); body_inertia[1] = _floats(ine["diaginertia"])
@@ -452,6 +480,7 @@ def compile_model(xml_path, mesh_dir, standin_acorn=False):
     mdl["hull_nbr"] = np.concatenate(hn).astype(np.int32)
     mdl["hull_padr"] = np.array(hpadr[:-1], dtype=np.int32); mdl["hull_pnum"] = np.array(hpnum, dtype=np.int32)
     mdl["hull_planes"] = np.vstack(hp)
+    mdl["hull_lut"] = np.concatenate(hlut).astype(np.int32)          # [6 hulls][6 * LUT_RES^2]
     # --- qpos0
     qpos0 = np.zeros(NQ); qpos0[7:10] = body_pos[7]; qpos0[10:14] = body_quat[7]
     mdl["qpos0"] = qpos0

@@ -1,0 +1,20 @@
+"""Micro-benchmark of the physics.step() kernel: settle, then time k_substep launches."""
+import sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np, torch
+from mujoco_rl_manipulate_unknown_objects_amd import engine
+obj = sys.argv[1] if len(sys.argv) > 1 else "acorn"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+k = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+mode = sys.argv[4] if len(sys.argv) > 4 else "rest"
+b = engine.Batch(obj, n)
+b.reset(); b.substep(300); torch.cuda.synchronize()      # object settles on the floor
+if mode == "push":                                       # gripper tip touching the object: hull-hull contacts active
+    q, v, c, w = b.get_state()
+    q[:, 0] = 0.235 + 0.01 * np.random.default_rng(0).random(n); q[:, 2] = 0.05
+    b.set_state(qpos=q); b.substep(20); torch.cuda.synchronize()
+for rep in range(3):
+    t0 = time.perf_counter(); b.substep(k); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"{obj} n={n} mode={mode}: {k} substeps in {dt*1e3:.2f} ms -> {dt/k*1e6:.1f} us/substep/launch, {n*k/dt:.3e} env-substeps/s")
+d = b.debug_forward()
+print("ncon hist", np.bincount(d["ncon"]), "newton iters hist", np.bincount(d["con"][:, 0, 9].astype(int)))
