@@ -648,55 +648,62 @@ DEVI void make_constraints(const DevModel &m, const Kin &k, const float (&qpos)[
     }
 }
 
-// H (13x13 packed lower) += w * u u^T, full or object-block only
-DEVI void rank1_full(float (&Hp)[91], const float (&u)[13], float w) {
+// Hessian storage: the full problem keeps 13x13 packed lower (91); the object-only problem (no constraint touches
+// the gripper: the usual case, object resting on the floor while the gripper moves freely) keeps the 6x6 object block (21).
+template <bool OBJ> struct HessT { static constexpr int N = OBJ ? 21 : 91; };
+template <bool OBJ> constexpr DEVI int hidx(int i, int j) { return OBJ ? pidx(i - 7, j - 7) : pidx(i, j); }
+
+// H += w * u u^T restricted to dofs [lo, 13)
+template <bool OBJ, int LO>
+DEVI void rank1(float *Hp, const float (&u)[13], float w) {
 #pragma unroll
-    for (int i = 0; i < 13; i++) {
+    for (int i = LO; i < 13; i++) {
         float wi = w * u[i];
 #pragma unroll
-        for (int j = 0; j <= i; j++) Hp[pidx(i, j)] = fmaf(wi, u[j], Hp[pidx(i, j)]);
-    }
-}
-DEVI void rank1_obj(float (&Hp)[91], const float (&u)[13], float w) {
-#pragma unroll
-    for (int i = 7; i < 13; i++) {
-        float wi = w * u[i];
-#pragma unroll
-        for (int j = 7; j <= i; j++) Hp[pidx(i, j)] = fmaf(wi, u[j], Hp[pidx(i, j)]);
+        for (int j = LO; j <= i; j++) Hp[hidx<OBJ>(i, j)] = fmaf(wi, u[j], Hp[hidx<OBJ>(i, j)]);
     }
 }
 
 // One pass over all constraints at acceleration x: stores jar in LDS, returns the constraint cost,
 // accumulates J^T force into `jtf` and, if wantH, adds J^T s'' J to the packed Hessian.
+template <bool OBJ>
 DEVI float constraint_pass(const DevModel &m, const Kin &k, const Limits &lim, const float (&x)[13],
-                           float *lds, int lane, int ncon, float (&jtf)[13], float (&Hp)[91], bool wantH) {
+                           float *lds, int lane, int ncon, float (&jtf)[13], float *Hp, bool wantH) {
     float cost = 0.f;
     Wrench w; wrench_zero(w);
     float flim[7];
 #pragma unroll
-    for (int j = 0; j < 7; j++) {
-        float jar = lim.sgn[j] * x[j] - lim.aref[j];
-        bool act = lim.sgn[j] != 0.f && jar < 0.f;
-        flim[j] = act ? -lim.D[j] * jar * lim.sgn[j] : 0.f;
-        cost += act ? 0.5f * lim.D[j] * jar * jar : 0.f;
-        if (wantH) Hp[pidx(j, j)] += act ? lim.D[j] : 0.f;
+    for (int j = 0; j < 7; j++) flim[j] = 0.f;
+    if (!OBJ) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            float jar = lim.sgn[j] * x[j] - lim.aref[j];
+            bool act = lim.sgn[j] != 0.f && jar < 0.f;
+            flim[j] = act ? -lim.D[j] * jar * lim.sgn[j] : 0.f;
+            cost += act ? 0.5f * lim.D[j] * jar * jar : 0.f;
+            if (wantH) Hp[hidx<OBJ>(OBJ ? 7 : j, OBJ ? 7 : j)] += act ? lim.D[j] : 0.f;
+        }
     }
     Twist t; twists(k, x, t);
     for (int c = 0; c < ncon; c++) {
         int s = CB_BASE + c * C_STRIDE;
         ContactGeo g; load_contact(m, lds, lane, c, g);
-        float jar[4]; contact_rows(k, t, g, jar);
+        float jar[4];
+        if (OBJ) {          // floor-object contact: only the object moves
+            V3 dv = t.vO + cross(t.wO, g.p - k.po);
+            jar[0] = dot(g.n, dv); jar[1] = dot(g.t1, dv); jar[2] = dot(g.t2, dv); jar[3] = dot(g.n, t.wO);
+        } else contact_rows(k, t, g, jar);
 #pragma unroll
         for (int r = 0; r < 4; r++) { jar[r] -= LD(s + C_AREF + r); LD(s + C_JAR + r) = jar[r]; }
         Cone cn; cone_eval(jar, g.D0, m.impratio, g.fs, g.ft, cn);
         cost += cn.cost;
         V3 F = g.n * (-cn.grad[0]) + g.t1 * (-cn.grad[1]) + g.t2 * (-cn.grad[2]);
         V3 Tq = g.n * (-cn.grad[3]);
-        wrench_add(k, w, g.gB, g.p, F, Tq, 1.f);
-        wrench_add(k, w, g.gA, g.p, F, Tq, -1.f);
+        if (OBJ) { w.FO = w.FO + F; w.TO = w.TO + Tq + cross(g.p - k.po, F); }
+        else { wrench_add(k, w, g.gB, g.p, F, Tq, 1.f); wrench_add(k, w, g.gA, g.p, F, Tq, -1.f); }
         bool any = cn.w[0] != 0.f || cn.w[1] != 0.f || cn.ka != 0.f;
         if (wantH && any) {
-            const bool objonly = g.gA == GRP_WORLD && g.gB == GRP_O;     // floor-object rows touch dofs 7..12 only
+            const bool objonly = OBJ || (g.gA == GRP_WORLD && g.gB == GRP_O);     // rows touch dofs 7..12 only
             float ua[13], ub[13];
 #pragma unroll
             for (int i = 0; i < 13; i++) { ua[i] = 0.f; ub[i] = 0.f; }
@@ -706,14 +713,14 @@ DEVI float constraint_pass(const DevModel &m, const Kin &k, const Limits &lim, c
 #pragma unroll
                 for (int i = 0; i < 13; i++) j[i] = 0.f;
                 V3 e = r == 1 ? g.t1 : r == 2 ? g.t2 : g.n;
-                row_add(k, j, g.gB, g.p, e, 1.f, r == 3);
-                row_add(k, j, g.gA, g.p, e, -1.f, r == 3);
+                if (OBJ) row_add(k, j, GRP_O, g.p, e, 1.f, r == 3);
+                else { row_add(k, j, g.gB, g.p, e, 1.f, r == 3); row_add(k, j, g.gA, g.p, e, -1.f, r == 3); }
                 float ar = r == 0 ? cn.a[0] : r == 1 ? cn.a[1] : r == 2 ? cn.a[2] : cn.a[3];
                 float br = r == 0 ? cn.b[0] : r == 1 ? cn.b[1] : r == 2 ? cn.b[2] : cn.b[3];
                 float wr = r == 0 ? cn.w[0] : r == 1 ? cn.w[1] : r == 2 ? cn.w[2] : cn.w[3];
 #pragma unroll
-                for (int i = 0; i < 13; i++) { ua[i] = fmaf(ar, j[i], ua[i]); ub[i] = fmaf(br, j[i], ub[i]); }
-                if (objonly) rank1_obj(Hp, j, wr); else rank1_full(Hp, j, wr);
+                for (int i = OBJ ? 7 : 0; i < 13; i++) { ua[i] = fmaf(ar, j[i], ua[i]); ub[i] = fmaf(br, j[i], ub[i]); }
+                if (objonly) rank1<OBJ, 7>(Hp, j, wr); else rank1<OBJ, OBJ ? 7 : 0>(Hp, j, wr);
             }
             if (cn.ka != 0.f) {
 #pragma unroll 1
@@ -722,27 +729,38 @@ DEVI float constraint_pass(const DevModel &m, const Kin &k, const Limits &lim, c
 #pragma unroll
                     for (int i = 0; i < 13; i++) u[i] = q == 0 ? ua[i] : ub[i];
                     float wq = q == 0 ? cn.ka : -cn.kb;
-                    if (objonly) rank1_obj(Hp, u, wq); else rank1_full(Hp, u, wq);
+                    if (objonly) rank1<OBJ, 7>(Hp, u, wq); else rank1<OBJ, OBJ ? 7 : 0>(Hp, u, wq);
                 }
             }
         }
     }
-    wrench_project(k, w, jtf);
+    if (OBJ) {
 #pragma unroll
-    for (int j = 0; j < 7; j++) jtf[j] += flim[j];
+        for (int i = 0; i < 7; i++) jtf[i] = 0.f;
+        jtf[7] = w.FO.x; jtf[8] = w.FO.y; jtf[9] = w.FO.z;
+        V3 tl = multv(k.Ro, w.TO);
+        jtf[10] = tl.x; jtf[11] = tl.y; jtf[12] = tl.z;
+    } else {
+        wrench_project(k, w, jtf);
+#pragma unroll
+        for (int j = 0; j < 7; j++) jtf[j] += flim[j];
+    }
     return cost;
 }
 
 // phi'(alpha), phi''(alpha) of the total cost along the search direction (jar, jv cached in LDS)
+template <bool OBJ>
 DEVI void line_eval(const DevModel &m, const Limits &lim, const float (&qacc)[13], const float (&p)[13],
                     const float *lds, int lane, int ncon, float alpha, float g0, float g1, float &dphi, float &ddphi) {
     float dp = g0 + alpha * g1, hp = g1;
+    if (!OBJ) {
 #pragma unroll
-    for (int j = 0; j < 7; j++) {
-        float jv = lim.sgn[j] * p[j];
-        float x = lim.sgn[j] * qacc[j] - lim.aref[j] + alpha * jv;
-        bool act = lim.sgn[j] != 0.f && x < 0.f;
-        dp += act ? lim.D[j] * x * jv : 0.f; hp += act ? lim.D[j] * jv * jv : 0.f;
+        for (int j = 0; j < 7; j++) {
+            float jv = lim.sgn[j] * p[j];
+            float x = lim.sgn[j] * qacc[j] - lim.aref[j] + alpha * jv;
+            bool act = lim.sgn[j] != 0.f && x < 0.f;
+            dp += act ? lim.D[j] * x * jv : 0.f; hp += act ? lim.D[j] * jv * jv : 0.f;
+        }
     }
     for (int c = 0; c < ncon; c++) {
         int s = CB_BASE + c * C_STRIDE;
@@ -758,33 +776,40 @@ DEVI void line_eval(const DevModel &m, const Limits &lim, const float (&qacc)[13
 }
 
 // Primal Newton solve of  min 1/2 (a - a_s)^T M (a - a_s) + s(J a - aref)   (mj_solNewton's problem).
-// Staged loop with ONE constraint-pass site: stage 0 prices qacc_warmstart, stage 1 prices qacc_smooth (the
-// better one is the start, as MuJoCo does), stages >= 2 are Newton iterations with exact line search.
+// Staged loop with ONE constraint-pass site: stage 0 prices qacc_smooth, stage 1 prices qacc_warmstart (the better
+// one is the start, as MuJoCo does) and stops right there when the start already satisfies the gradient
+// tolerance -- the common case of a persisting contact, which then never builds a Hessian; stages >= 2 are
+// Newton iterations (Hessian, Cholesky, exact line search). OBJ = only the 6 object dofs are constrained.
+template <bool OBJ>
 DEVI void solve_newton(const DevModel &m, const Kin &k, const float (&Mg)[28], const float (&Mo)[21], const Limits &lim,
                        const float (&qs)[13], const float (&warm)[13], float *lds, int lane, int ncon,
                        float (&qacc)[13], float (&jtf)[13], int &fault, int &iters) {
+    constexpr int LO = OBJ ? 7 : 0;
+    constexpr int NH = HessT<OBJ>::N;
     const float scale = 1.0f / (m.meaninertia * 13.f);
-    const float tol = fmaxf(m.tolerance, 1e-6f);
-    float H[91], Md[13], x[13];
-    float cost = 0.f, cw = 0.f;
+    const float tol = fmaxf(m.tolerance, 1e-5f);            // fp32 noise floor of the scaled gradient is ~1e-6
+    float H[NH], Md[13], x[13];
+    float cost = 0.f, cs = 0.f;
     int stage = 0; bool done = false;
     iters = 0;
 #pragma unroll
-    for (int i = 0; i < 13; i++) { qacc[i] = qs[i]; x[i] = warm[i]; }
+    for (int i = 0; i < 13; i++) { qacc[i] = qs[i]; x[i] = qs[i]; Md[i] = 0.f; }
     while (__any(!done)) {
         if (!done) {
             const bool wantH = stage >= 2;
             if (wantH) {
 #pragma unroll
-                for (int i = 0; i < 91; i++) H[i] = 0.f;
+                for (int i = 0; i < NH; i++) H[i] = 0.f;
+                if (!OBJ) {
 #pragma unroll
-                for (int i = 0; i < 7; i++)
+                    for (int i = 0; i < 7; i++)
 #pragma unroll
-                    for (int j = 0; j <= i; j++) H[pidx(i, j)] = Mg[pidx(i, j)];
+                        for (int j = 0; j <= i; j++) H[hidx<OBJ>(OBJ ? 7 : i, OBJ ? 7 : j)] = Mg[pidx(i, j)];
+                }
 #pragma unroll
                 for (int i = 0; i < 6; i++)
 #pragma unroll
-                    for (int j = 0; j <= i; j++) H[pidx(7 + i, 7 + j)] = Mo[pidx(i, j)];
+                    for (int j = 0; j <= i; j++) H[hidx<OBJ>(7 + i, 7 + j)] = Mo[pidx(i, j)];
             }
             float dq[13];
 #pragma unroll
@@ -792,41 +817,56 @@ DEVI void solve_newton(const DevModel &m, const Kin &k, const float (&Mg)[28], c
             mass_mulv(Mg, Mo, dq, Md);
             float newcost = 0.f;
 #pragma unroll
-            for (int i = 0; i < 13; i++) newcost = fmaf(0.5f * Md[i], dq[i], newcost);
-            newcost += constraint_pass(m, k, lim, x, lds, lane, ncon, jtf, H, wantH);
+            for (int i = LO; i < 13; i++) newcost = fmaf(0.5f * Md[i], dq[i], newcost);
+            newcost += constraint_pass<OBJ>(m, k, lim, x, lds, lane, ncon, jtf, H, wantH);
+            float gn = 0.f;
+#pragma unroll
+            for (int i = LO; i < 13; i++) { float g = Md[i] - jtf[i]; gn = fmaf(g, g, gn); }
+            const bool gconv = scale * sqrtf(gn) < tol;
             if (stage == 0) {
-                cw = newcost; stage = 1;
+                cs = newcost; stage = 1;
 #pragma unroll
-                for (int i = 0; i < 13; i++) x[i] = qs[i];
+                for (int i = LO; i < 13; i++) x[i] = warm[i];
+                if (gconv) done = true;                     // qacc_smooth already optimal (constraints inactive)
             } else if (stage == 1) {
-                bool usew = cw < newcost;
+                if (newcost < cs) {
 #pragma unroll
-                for (int i = 0; i < 13; i++) { qacc[i] = usew ? warm[i] : qs[i]; x[i] = qacc[i]; }
+                    for (int i = LO; i < 13; i++) qacc[i] = warm[i];
+                    if (gconv) done = true;
+                } else {
+#pragma unroll
+                    for (int i = LO; i < 13; i++) x[i] = qs[i];
+                }
                 stage = 2;
             } else {
-                bool stop = false;
-                if (stage > 2) { stop = scale * (cost - newcost) < tol; }
+                bool stop = gconv;
+                if (stage > 2 && scale * (cost - newcost) < tol) stop = true;
                 cost = newcost;
-                float grad[13], gn = 0.f;
-#pragma unroll
-                for (int i = 0; i < 13; i++) { grad[i] = Md[i] - jtf[i]; gn = fmaf(grad[i], grad[i], gn); }
-                if (scale * sqrtf(gn) < tol) stop = true;
                 if (!stop && iters >= NEWTON_MAXIT) { stop = true; fault |= 4; }
                 if (stop) done = true;
                 else {
                     float p[13];
-                    chol_packed<13>(H);
 #pragma unroll
-                    for (int i = 0; i < 13; i++) p[i] = -grad[i];
-                    chol_solve_packed<13>(H, p);
+                    for (int i = 0; i < 13; i++) p[i] = 0.f;
+                    chol_packed<13 - LO>(H);
+                    {   float pr[13 - LO];
+#pragma unroll
+                        for (int i = LO; i < 13; i++) pr[i - LO] = -(Md[i] - jtf[i]);
+                        chol_solve_packed<13 - LO>(H, pr);
+#pragma unroll
+                        for (int i = LO; i < 13; i++) p[i] = pr[i - LO]; }
                     float Mpv[13]; mass_mulv(Mg, Mo, p, Mpv);
                     float g0 = 0.f, g1 = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 13; i++) { g0 = fmaf(Mpv[i], qacc[i] - qs[i], g0); g1 = fmaf(Mpv[i], p[i], g1); }
+                    for (int i = LO; i < 13; i++) { g0 = fmaf(Mpv[i], qacc[i] - qs[i], g0); g1 = fmaf(Mpv[i], p[i], g1); }
                     {   Twist tp; twists(k, p, tp);
                         for (int c = 0; c < ncon; c++) {
                             ContactGeo g; load_contact(m, lds, lane, c, g);
-                            float jv[4]; contact_rows(k, tp, g, jv);
+                            float jv[4];
+                            if (OBJ) {
+                                V3 dv = tp.vO + cross(tp.wO, g.p - k.po);
+                                jv[0] = dot(g.n, dv); jv[1] = dot(g.t1, dv); jv[2] = dot(g.t2, dv); jv[3] = dot(g.n, tp.wO);
+                            } else contact_rows(k, tp, g, jv);
 #pragma unroll
                             for (int r = 0; r < 4; r++) LD(CB_BASE + c * C_STRIDE + C_JV + r) = jv[r];
                         } }
@@ -837,10 +877,10 @@ DEVI void solve_newton(const DevModel &m, const Kin &k, const float (&Mg)[28], c
                         if (!__any(!lsdone)) break;
                         if (!lsdone) {
                             float dp, hp;
-                            line_eval(m, lim, qacc, p, lds, lane, ncon, alpha, g0, g1, dp, hp);
+                            line_eval<OBJ>(m, lim, qacc, p, lds, lane, ncon, alpha, g0, g1, dp, hp);
                             if (ls == 0) {
                                 if (dp >= 0.f) { descent = false; lsdone = true; }
-                                gtol = 1e-5f * fabsf(dp) + 1e-30f;
+                                gtol = 1e-4f * fabsf(dp) + 1e-30f;
                             } else {
                                 if (fabsf(dp) < gtol) lsdone = true;
                                 else {
@@ -858,7 +898,7 @@ DEVI void solve_newton(const DevModel &m, const Kin &k, const float (&Mg)[28], c
                     if (!descent) done = true;
                     else {
 #pragma unroll
-                        for (int i = 0; i < 13; i++) { qacc[i] = fmaf(alpha, p[i], qacc[i]); x[i] = qacc[i]; }
+                        for (int i = LO; i < 13; i++) { qacc[i] = fmaf(alpha, p[i], qacc[i]); x[i] = qacc[i]; }
                         iters++; stage++;
                     }
                 }
@@ -921,11 +961,20 @@ DEVI void forward_acc(const DevModel &m, LaneState &s, float xfrc_z, float *lds,
 #pragma unroll
     for (int j = 0; j < 7; j++) anylim |= lim.sgn[j] != 0.f;
     iters = 0;
+    // does any constraint touch the gripper? (joint limit, or a contact whose geoms are not floor + object)
+    bool grip = anylim;
+    for (int c = 0; c < ncon; c++) {
+        int meta = __float_as_int(LD(CB_BASE + c * C_STRIDE + C_META));
+        grip |= !((meta & 255) == 0 && ((meta >> 8) & 255) == 6);
+    }
     const bool constrained = ncon > 0 || anylim;
 #pragma unroll
     for (int i = 0; i < 13; i++) { qacc[i] = qs[i]; jtf[i] = 0.f; }
-    if (__any(constrained)) {
-        if (constrained) solve_newton(m, k, Mg, Mo, lim, qs, s.warm, lds, lane, ncon, qacc, jtf, fault, iters);
+    if (__any(constrained && !grip)) {
+        if (constrained && !grip) solve_newton<true>(m, k, Mg, Mo, lim, qs, s.warm, lds, lane, ncon, qacc, jtf, fault, iters);
+    }
+    if (__any(constrained && grip)) {
+        if (constrained && grip) solve_newton<false>(m, k, Mg, Mo, lim, qs, s.warm, lds, lane, ncon, qacc, jtf, fault, iters);
     }
 }
 
