@@ -45,6 +45,7 @@ struct DevModel {
     int hull_vadr[GN_HULL], hull_vnum[GN_HULL];
     int npair;
     int pairs[GN_PAIR_MAX][2];
+    int coop_items[16][2];                      // narrow-phase item of each of an env's 16 lanes, per round (-1 = none)
     // hull tables as one word blob (staged into LDS by every launch): [nvert][4] f32 vertices in the body
     // frame | u16 CSR offsets over all hull vertices | u16 neighbour ids (local) | u16 cube-map start vertices
     const unsigned *hull_blob;
@@ -80,11 +81,15 @@ DEVI V3 operator*(float s, V3 a) { return v3(a.x * s, a.y * s, a.z * s); }
 DEVI float dot(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
 DEVI V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 DEVI float norm(V3 a) { return sqrtf(dot(a, a)); }
+// Hides a value's provenance from the optimiser at zero run-time cost. Used at the top of loop bodies so that LLVM's
+// (register-pressure-blind) loop-invariant code motion does not hoist whole Jacobian rows out of the solver loops
+// and keep them live across everything else.
+DEVI void opaque(float &x) { asm volatile("" : "+v"(x)); }
+DEVI float rcp(float x) { return __builtin_amdgcn_rcpf(x); }          // v_rcp_f32, 1 ulp
 DEVI V3 normalized(V3 a) {
-    float n = norm(a);
-    if (n < 1e-20f) return v3(1.f, 0.f, 0.f);
-    float inv = 1.0f / n;
-    return a * inv;
+    float d = dot(a, a);
+    if (d < 1e-38f) return v3(1.f, 0.f, 0.f);
+    return a * rsqrtf(d);
 }
 DEVI V3 ldv(const float *p) { return v3(p[0], p[1], p[2]); }
 DEVI V3 mulv(const M3 &R, V3 v) {

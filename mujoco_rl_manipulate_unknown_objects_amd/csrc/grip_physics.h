@@ -1,40 +1,40 @@
-// grip_physics.h -- fp32 device physics for one environment per wavefront lane (gfx950).
+// grip_physics.h -- fp32 device physics: SIXTEEN LANES COOPERATE ON ONE ENVIRONMENT (gfx950).
 //
-// What one `physics.step()` of the reference computes (robot_env.py:100,119,142,157 ->
-// dm_control Physics.step -> mj_step2 + mj_step1), restructured
-// for the lane-per-env execution model:
-//   * four rigid groups instead of seven bodies (grip_device.h);
-//   * the constraint Jacobian is never materialised: J x and J^T f are evaluated from group
-//     twists / wrenches at each contact point; for the Newton Hessian one row at a time is
-//     expanded into registers and folded in as weighted rank-1 updates;
-//   * per-lane variable-length data (geom frames, contact list, per-row solver scratch) sits in
-//     LDS as [slot][lane], so a wave's access to one slot is one conflict-free 256-byte row;
-//   * the convex hulls (vertices, edge graph, a cube-map table of start vertices) are staged once
-//     per launch into LDS; support queries hill-climb the edge graph from the table entry
-//     (about 9 neighbour tests per query instead of 70-573 vertex tests);
-//   * every heavy routine has ONE call site inside a loop (MPR is a per-lane state machine around a
-//     single support evaluation, the Newton solver a staged loop around a single constraint pass),
-//     which keeps the kernel inside the instruction cache and lets lanes in different phases share
-//     the same instructions.
+// What one `physics.step()` of the reference computes (robot_env.py:100,119,142,157 -> dm_control
+// Physics.step -> mj_step2 + mj_step1), laid out for CDNA4:
+//
+//   * a wavefront holds 4 environments x 16 lanes, a 256-thread workgroup 16 environments. 4096 envs
+//     are 1024 waves -- one per SIMD of the chip -- instead of the 64 waves a lane-per-env mapping gives,
+//     and a wave waits for the slowest of 4 macro steps, not of 64;
+//   * the small dense per-env algebra (kinematics of four rigid groups, 7x7 + 6x6 mass matrix, bias forces,
+//     Cholesky solves, integration) is computed redundantly by the 16 lanes, bit-identically, so no
+//     broadcast is ever needed for it;
+//   * everything with per-contact or per-geom-pair parallelism is spread over the lanes: the 17 narrow-phase
+//     items (6 floor-hull, 11 hull-hull) run one per lane, each lane driving its own Minkowski-portal
+//     state machine around the single support evaluation; a contact lives in the registers of ONE lane
+//     (<= 14 contacts <= 16 lanes), which evaluates its rows, cone, force, its six rank-1 Hessian terms and
+//     its share of every line-search derivative;
+//   * lanes combine with DPP row rotations (row_ror 8/4/2/1 = a 16-lane all-reduce in four VALU ops,
+//     commutative so every lane gets the bit-identical sum), never through memory;
+//   * LDS holds what is shared: the convex hulls (vertices, edge graph, cube-map table of start vertices
+//     for the hill-climbing support search) once per workgroup, and per env the six geom frames and a
+//     14-slot contact staging area used to compact the contacts found by different lanes.
 #pragma once
 #include "grip_device.h"
 
-// ---------------------------------------------------------------- LDS layout (floats per lane)
-#define GF_BASE 0                       // 6 geom frames x 12 (pos3, R9)
-#define CB_BASE (GF_BASE + 72)
-#define C_POS 0
-#define C_N 3
-#define C_DIST 6
-#define C_META 7                        // g1 | g2 << 8
-#define C_FS 8
-#define C_FT 9
-#define C_D0 10
-#define C_AREF 11
-#define C_JAR 15
-#define C_JV 19
-#define C_STRIDE 23
-#define LDS_FLOATS_PER_LANE (CB_BASE + G_MAXC * C_STRIDE)
-#define LDS_LANE_WORDS (LDS_FLOATS_PER_LANE * WAVE)
+#define KL 16                           // lanes per environment
+#define EPW (WAVE / KL)                 // environments per wave
+#define WG_THREADS 256
+#define EPB (WG_THREADS / KL)           // environments per workgroup
+
+// per-env LDS region (floats)
+#define EF_FRAMES 0                     // 6 geom frames x 12 (pos3, R9)
+#define EF_STAGE 72                     // G_MAXC staged contacts x ST_STRIDE
+#define ST_STRIDE 11                    // pos3, n3, dist, meta, fs, ft, tran
+#define ENV_FLOATS (EF_STAGE + G_MAXC * ST_STRIDE)
+// per-workgroup geom table (floats per geom): centre3, rbound, fs, ft, invweight, group, hull_vadr
+#define GT_STRIDE 9
+#define GT_FLOATS (GN_GEOM * GT_STRIDE)
 
 #define NEWTON_MAXIT 20
 #define LS_MAXIT 16
@@ -43,7 +43,31 @@
 #define LUT_RES 8
 #define LUT_CELLS (6 * LUT_RES * LUT_RES)
 
-#define LD(slot) lds[(slot) * WAVE + lane]
+// diagnostic build only (-DGRIP_STAMPS): per-phase cycle accounting with s_memtime, never in the shipped library
+#ifdef GRIP_STAMPS
+#define NSTAMP 8
+__device__ unsigned long long g_stamp_acc[NSTAMP];
+struct Stamps { unsigned long long t; unsigned long long acc[NSTAMP]; };
+DEVI unsigned long long stamp_now() { __builtin_amdgcn_sched_barrier(0); unsigned long long t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); return t; }
+#define STAMP(st, i) do { unsigned long long n_ = stamp_now(); (st).acc[i] += n_ - (st).t; (st).t = n_; } while (0)
+#else
+struct Stamps { int dummy; };
+#define STAMP(st, i) do { } while (0)
+#endif
+
+// ---------------------------------------------------------------- cross-lane primitives (16-lane rows)
+template <int CTRL> DEVI float dpp_f(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false)); }
+#define DPP_ROW_ROR(n) (0x120 + (n))
+// all-reduce sum over the 16 lanes of a row: every lane adds the same pairs, fp add is commutative -> identical bits
+DEVI float sum16(float x) {
+    x += dpp_f<DPP_ROW_ROR(8)>(x); x += dpp_f<DPP_ROW_ROR(4)>(x);
+    x += dpp_f<DPP_ROW_ROR(2)>(x); x += dpp_f<DPP_ROW_ROR(1)>(x);
+    return x;
+}
+// ordering point for wave-private LDS traffic (LDS ops of one wave execute in order; this only pins the compiler)
+DEVI void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+// 16-bit group of a 64-bit ballot that belongs to this lane's environment
+DEVI unsigned group_bits(unsigned long long b, int lane) { return (unsigned)(b >> (lane & 48)) & 0xFFFFu; }
 
 struct Kin {
     V3 pe; M3 Re; V3 a4;
@@ -53,76 +77,101 @@ struct Kin {
     float Ic[4][6];
 };
 
-// hull tables staged in LDS behind the per-lane region (word offsets from DevModel)
-struct Hulls {
-    const float *v;                 // [nvert][4]
+// tables staged in LDS, shared by the workgroup
+struct Tables {
+    const float *v;                 // hull vertices [nvert][4]
     const unsigned short *nadr;     // CSR over all hull vertices
     const unsigned short *nbr;      // neighbour ids, local to the hull
     const unsigned short *lut;      // [6][LUT_CELLS] start vertices
+    const float *gt;                // geom table [GN_GEOM][GT_STRIDE]
+};
+
+struct Ctx {
+    int lane, sub;                  // lane in wave, lane in env
+    float *envl;                    // this env's LDS region
+    Tables T;
 };
 
 constexpr DEVI int pidx(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
-DEVI Hulls stage_hulls(const DevModel &m, float *lds, int lane) {
-    unsigned *dst = reinterpret_cast<unsigned *>(lds + LDS_LANE_WORDS);
+// workgroup prologue: hulls + geom table into LDS; returns the context of the calling lane
+DEVI Ctx stage_tables(const DevModel &m, float *lds) {
+    unsigned *dst = reinterpret_cast<unsigned *>(lds);
     const unsigned *src = m.hull_blob;
-    for (int i = lane; i < m.hull_words; i += WAVE) dst[i] = src[i];
+    for (int i = threadIdx.x; i < m.hull_words; i += blockDim.x) dst[i] = src[i];
+    float *gt = lds + m.hull_words;
+    for (int i = threadIdx.x; i < GT_FLOATS; i += blockDim.x) {
+        int g = i / GT_STRIDE, f = i % GT_STRIDE;
+        float v;
+        if (f < 3) v = m.geom_center[g][f];
+        else if (f == 3) v = m.geom_rbound[g];
+        else if (f == 4) v = m.geom_friction[g][0];
+        else if (f == 5) v = m.geom_friction[g][1];
+        else if (f == 6) v = m.geom_invweight[g];
+        else if (f == 7) v = __int_as_float(m.geom_group[g]);
+        else v = __int_as_float(g >= 1 ? m.hull_vadr[g - 1] : 0);
+        gt[i] = v;
+    }
     __syncthreads();
-    Hulls h;
-    h.v = reinterpret_cast<const float *>(dst);
-    h.nadr = reinterpret_cast<const unsigned short *>(dst + m.hull_off_nadr);
-    h.nbr = reinterpret_cast<const unsigned short *>(dst + m.hull_off_nbr);
-    h.lut = reinterpret_cast<const unsigned short *>(dst + m.hull_off_lut);
-    return h;
+    Ctx c;
+    c.lane = threadIdx.x & (WAVE - 1); c.sub = threadIdx.x & (KL - 1);
+    c.T.v = reinterpret_cast<const float *>(dst);
+    c.T.nadr = reinterpret_cast<const unsigned short *>(dst + m.hull_off_nadr);
+    c.T.nbr = reinterpret_cast<const unsigned short *>(dst + m.hull_off_nbr);
+    c.T.lut = reinterpret_cast<const unsigned short *>(dst + m.hull_off_lut);
+    c.T.gt = gt;
+    c.envl = lds + m.hull_words + GT_FLOATS + (threadIdx.x / KL) * ENV_FLOATS;
+    return c;
 }
 
-// ---------------------------------------------------------------- kinematics
-DEVI void store_frame(float *lds, int lane, int g, V3 p, const M3 &R) {
-    int s = GF_BASE + (g - 1) * 12;
-    LD(s) = p.x; LD(s + 1) = p.y; LD(s + 2) = p.z;
+// ---------------------------------------------------------------- kinematics (redundant in the 16 lanes)
+DEVI void store_frame(float *envl, int g, V3 p, const M3 &R) {
+    float *f = envl + EF_FRAMES + (g - 1) * 12;
+    f[0] = p.x; f[1] = p.y; f[2] = p.z;
 #pragma unroll
-    for (int i = 0; i < 9; i++) LD(s + 3 + i) = R.m[i];
+    for (int i = 0; i < 9; i++) f[3 + i] = R.m[i];
 }
-DEVI void load_frame(const float *lds, int lane, int g, V3 &p, M3 &R) {
-    int s = GF_BASE + (g - 1) * 12;
-    p = v3(LD(s), LD(s + 1), LD(s + 2));
+DEVI void load_frame(const float *envl, int g, V3 &p, M3 &R) {
+    const float *f = envl + EF_FRAMES + (g - 1) * 12;
+    p = v3(f[0], f[1], f[2]);
 #pragma unroll
-    for (int i = 0; i < 9; i++) R.m[i] = LD(s + 3 + i);
+    for (int i = 0; i < 9; i++) R.m[i] = f[3 + i];
 }
 
-DEVI void kinematics(const DevModel &m, float (&qpos)[14], Kin &k, float *lds, int lane) {
+DEVI void kinematics(const DevModel &m, float (&qpos)[14], Kin &k, const Ctx &cx, bool store) {
     // free-joint quaternion normalised in place (mj_kinematics does the same)
     float qn = sqrtf(qpos[10] * qpos[10] + qpos[11] * qpos[11] + qpos[12] * qpos[12] + qpos[13] * qpos[13]);
     if (qn < 1e-15f) { qpos[10] = 1.f; qpos[11] = qpos[12] = qpos[13] = 0.f; }
     else { float iq = 1.0f / qn; qpos[10] *= iq; qpos[11] *= iq; qpos[12] *= iq; qpos[13] *= iq; }
     k.pe = v3(m.ee_pos0[0] + qpos[0], m.ee_pos0[1] + qpos[1], m.ee_pos0[2] + qpos[2]);
-    float sr = sinf(qpos[3]), cr = cosf(qpos[3]), sy = sinf(qpos[4]), cy = cosf(qpos[4]);
+    float sr, cr, sy, cy;
+    sincosf(qpos[3], &sr, &cr); sincosf(qpos[4], &sy, &cy);
     // Re = Rx(roll) * Rz(yaw)
     k.Re.m[0] = cy;      k.Re.m[1] = -sy;     k.Re.m[2] = 0.f;
     k.Re.m[3] = cr * sy; k.Re.m[4] = cr * cy; k.Re.m[5] = -sr;
     k.Re.m[6] = sr * sy; k.Re.m[7] = sr * cy; k.Re.m[8] = cr;
     k.a4 = v3(0.f, -sr, cr);
+    const bool wr = store && cx.sub == 0;           // one lane of the env publishes the geom frames
     V3 pb = k.pe + mulv(k.Re, ldv(m.base_pos));
     M3 Rb = mulm(k.Re, ldm(m.base_R));
-    store_frame(lds, lane, 1, pb, Rb);
+    if (wr) store_frame(cx.envl, 1, pb, Rb);
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         V3 pk = pb + mulv(Rb, ldv(m.kn_pos[s]));
         M3 Rk0 = mulm(Rb, ldm(m.kn_R[s]));
         k.pk[s] = pk; k.ak[s] = col(Rk0, 1);
-        float sq = sinf(qpos[5 + s]), cq = cosf(qpos[5 + s]);
+        float sq, cq; sincosf(qpos[5 + s], &sq, &cq);
         M3 Ry; Ry.m[0] = cq; Ry.m[1] = 0; Ry.m[2] = sq; Ry.m[3] = 0; Ry.m[4] = 1; Ry.m[5] = 0; Ry.m[6] = -sq; Ry.m[7] = 0; Ry.m[8] = cq;
         M3 Rk = mulm(Rk0, Ry);
-        store_frame(lds, lane, 2 + 2 * s, pk, Rk);
         V3 pf = pk + mulv(Rk, ldv(m.fin_pos[s]));
         M3 Rf = mulm(Rk, ldm(m.fin_R[s]));
-        store_frame(lds, lane, 3 + 2 * s, pf, Rf);
+        if (wr) { store_frame(cx.envl, 2 + 2 * s, pk, Rk); store_frame(cx.envl, 3 + 2 * s, pf, Rf); }
         k.c[1 + s] = pk + mulv(Rk, ldv(m.grp_com[1 + s]));
         rot_sym(Rk, m.grp_inertia[1 + s], k.Ic[1 + s]);
     }
     k.po = v3(qpos[7], qpos[8], qpos[9]);
     k.Ro = quat_mat(qpos[10], qpos[11], qpos[12], qpos[13]);
-    store_frame(lds, lane, 6, k.po, k.Ro);
+    if (wr) store_frame(cx.envl, 6, k.po, k.Ro);
     k.c[0] = k.pe + mulv(k.Re, ldv(m.grp_com[0]));
     rot_sym(k.Re, m.grp_inertia[0], k.Ic[0]);
     k.c[3] = k.po + mulv(k.Ro, ldv(m.grp_com[3]));
@@ -324,51 +373,45 @@ DEVI void make_tangents(V3 n, V3 &t1, V3 &t2) {
     t2 = cross(n, t1);
 }
 
-// Support vertex of hull `h` (0..5) for the LOCAL direction dl: start at the cube-map table entry and
-// hill-climb the edge graph to the best neighbour until no neighbour improves. Lanes walk different
-// vertices; the loop is flattened to one neighbour test per iteration so lanes stay busy.
-DEVI int support_vertex(const DevModel &m, const Hulls &H, int h, V3 dl, V3 &vout) {
+// Support vertex of the hull starting at vertex offset `base` (cube-map table `h`) for the LOCAL direction dl:
+// start at the table entry and hill-climb the edge graph to the best neighbour until none improves. Four
+// neighbour tests per iteration so that their dependent index -> vertex LDS hops overlap.
+DEVI int support_vertex(const Tables &T, int h, int base, V3 dl, V3 &vout) {
     float ax = fabsf(dl.x), ay = fabsf(dl.y), az = fabsf(dl.z);
     int axis = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
     float mj = axis == 0 ? dl.x : axis == 1 ? dl.y : dl.z;
     float u = axis == 0 ? dl.y : dl.x, v = axis == 2 ? dl.y : dl.z;
-    float im = 1.0f / fmaxf(fabsf(mj), 1e-30f);
+    float im = rcp(fmaxf(fabsf(mj), 1e-30f));
     int iu = min(LUT_RES - 1, max(0, (int)((u * im + 1.f) * (0.5f * LUT_RES))));
     int iv = min(LUT_RES - 1, max(0, (int)((v * im + 1.f) * (0.5f * LUT_RES))));
     int cell = (2 * axis + (mj < 0.f ? 1 : 0)) * (LUT_RES * LUT_RES) + iu * LUT_RES + iv;
-    const int base = m.hull_vadr[h];
-    const float *vb = H.v + 4 * base;
-    int cur = H.lut[h * LUT_CELLS + cell];
+    const float *vb = T.v + 4 * base;
+    int cur = T.lut[h * LUT_CELLS + cell];
     float bx = vb[4 * cur], by = vb[4 * cur + 1], bz = vb[4 * cur + 2];
     float bv = fmaf(bx, dl.x, fmaf(by, dl.y, bz * dl.z));
-    int e = H.nadr[base + cur], eend = H.nadr[base + cur + 1];
+    int e = T.nadr[base + cur], eend = T.nadr[base + cur + 1];
     int cand = cur; float cv = bv, cx = bx, cy = by, cz = bz;
-    for (int guard = 0; guard < 4096; guard++) {
+    for (int guard = 0; guard < 2048; guard++) {
         if (e < eend) {
-            int j = H.nbr[e]; e++;
-            float x = vb[4 * j], y = vb[4 * j + 1], z = vb[4 * j + 2];
-            float s = fmaf(x, dl.x, fmaf(y, dl.y, z * dl.z));
-            if (s > cv) { cv = s; cand = j; cx = x; cy = y; cz = z; }
+            int j[4]; float x[4], y[4], z[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) j[q] = T.nbr[min(e + q, eend - 1)];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { x[q] = vb[4 * j[q]]; y[q] = vb[4 * j[q] + 1]; z[q] = vb[4 * j[q] + 2]; }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float s = fmaf(x[q], dl.x, fmaf(y[q], dl.y, z[q] * dl.z));
+                if (s > cv) { cv = s; cand = j[q]; cx = x[q]; cy = y[q]; cz = z[q]; }
+            }
+            e += 4;
         } else {
             if (cand == cur) break;
             cur = cand; bx = cx; by = cy; bz = cz;
-            e = H.nadr[base + cur]; eend = H.nadr[base + cur + 1];
+            e = T.nadr[base + cur]; eend = T.nadr[base + cur + 1];
         }
     }
     vout = v3(bx, by, bz);
     return cur;
-}
-
-DEVI void push_contact(float *lds, int lane, int &ncon, int &fault, V3 pos, V3 n, float dist, int g1, int g2, const DevModel &m) {
-    if (ncon >= G_MAXC) { fault |= 2; return; }
-    int s = CB_BASE + ncon * C_STRIDE;
-    LD(s + C_POS) = pos.x; LD(s + C_POS + 1) = pos.y; LD(s + C_POS + 2) = pos.z;
-    LD(s + C_N) = n.x; LD(s + C_N + 1) = n.y; LD(s + C_N + 2) = n.z;
-    LD(s + C_DIST) = dist;
-    LD(s + C_META) = __int_as_float(g1 | (g2 << 8));
-    LD(s + C_FS) = fmaxf(m.geom_friction[g1][0], m.geom_friction[g2][0]);
-    LD(s + C_FT) = fmaxf(m.geom_friction[g1][1], m.geom_friction[g2][1]);
-    ncon++;
 }
 
 struct Sup { V3 v, v1, v2; };
@@ -415,63 +458,78 @@ DEVI V3 find_pos(const Sup &p0, const Sup &p1, const Sup &p2, const Sup &p3) {
     return ((p0.v1 + p0.v2) * b0 + (p1.v1 + p1.v2) * b1 + (p2.v1 + p2.v2) * b2 + (p3.v1 + p3.v2) * b3) * inv;
 }
 
-// All narrow-phase work of one state: floor-hull and hull-hull tests run through ONE loop whose body holds
-// the single support evaluation. Item q < 6: floor vs hull geom q + 1 (support along -z, then graph
-// neighbours inside the margin). Item q >= 6: hull pair q - 6, Minkowski portal refinement (XenoCollide) on the
-// margin-inflated hulls as a per-lane phase machine: 0/1 seed the portal, 2 discover, 3 refine, 4 penetrate.
-DEVI void collide(const DevModel &m, const Hulls &H, float *lds, int lane, int &ncon, int &fault) {
-    ncon = 0;
+// a contact owned by one lane
+struct Contact {
+    V3 p, n; float dist; int g1, g2, gA, gB; float fs, ft, tran, D0;
+    float aref[4], jar[4], jv[4];
+};
+
+// Narrow phase of one state, one item per lane and round. Items 0..5: floor vs hull geom item + 1 (support along -z,
+// then graph neighbours inside the margin; mjc_PlaneConvex). Items >= 6: hull pair item - 6, Minkowski portal
+// refinement (XenoCollide) on the margin-inflated hulls as a per-lane phase machine (0/1 seed the portal, 2 discover,
+// 3 refine, 4 penetrate) around the ONE support evaluation. The contacts found by the 16 lanes are compacted through
+// the env's LDS staging area (deterministic order: round, then lane); lane c then owns contact c.
+DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault) {
     const float EPS2 = 1e-12f, EPSD = 1e-10f;
     const float infl = 0.5f * m.margin;
-    const int nitem = 6 + m.npair;
-    for (int q = 0; q < nitem; q++) {
-        const bool plane = q < 6;
-        const int g1 = plane ? 0 : m.pairs[q - 6][0], g2 = plane ? q + 1 : m.pairs[q - 6][1];
+    const Tables &T = cx.T;
+    int total = 0;
+#pragma unroll 1
+    for (int round = 0; round < 2; round++) {
+        const int item = m.coop_items[cx.sub][round];
+        const bool has = item >= 0;
+        const bool plane = item < 6;
+        const int g1 = plane ? 0 : m.pairs[max(item - 6, 0)][0], g2 = !has ? 1 : plane ? item + 1 : m.pairs[max(item - 6, 0)][1];
+        const float *t1 = T.gt + g1 * GT_STRIDE, *t2 = T.gt + g2 * GT_STRIDE;
         V3 p1 = v3(0, 0, 0), p2; M3 R1, R2;
 #pragma unroll
         for (int i = 0; i < 9; i++) R1.m[i] = (i % 4 == 0) ? 1.f : 0.f;
-        if (!plane) load_frame(lds, lane, g1, p1, R1);
-        load_frame(lds, lane, g2, p2, R2);
-        V3 c2 = p2 + mulv(R2, ldv(m.geom_center[g2]));
+        if (has && !plane) load_frame(cx.envl, g1, p1, R1);
+        load_frame(cx.envl, g2, p2, R2);
+        const int base2 = __float_as_int(t2[8]), base1 = __float_as_int(t1[8]);
+        V3 c2 = p2 + mulv(R2, v3(t2[0], t2[1], t2[2]));
         Sup s0, s1, s2, s3;
-        V3 dir;
-        int phase;                 // -1 = finished
-        if (plane) {
-            phase = (c2.z <= m.geom_rbound[g2] + m.margin) ? 5 : -1;
-            dir = v3(0, 0, -1);
-        } else {
-            V3 c1 = p1 + mulv(R1, ldv(m.geom_center[g1]));
+        V3 dir = v3(0, 0, -1);
+        int phase = -1;
+        if (has && plane) {
+            phase = (c2.z <= t2[3] + m.margin) ? 5 : -1;
+        } else if (has) {
+            V3 c1 = p1 + mulv(R1, v3(t1[0], t1[1], t1[2]));
             V3 dc = c2 - c1;
-            float bound = m.geom_rbound[g1] + m.geom_rbound[g2] + m.margin;
+            float bound = t1[3] + t2[3] + m.margin;
             phase = dot(dc, dc) > bound * bound ? -1 : 0;
             s0.v1 = c1; s0.v2 = c2; s0.v = c1 - c2;
             if (dot(s0.v, s0.v) < EPS2) s0.v.x += 1e-5f;
             dir = normalized(-s0.v);
         }
+        // results of this lane's item: up to 4 contacts
+        V3 rp0 = v3(0, 0, 0), rp1 = rp0, rp2 = rp0, rp3 = rp0; float rd0 = 0.f, rd1 = 0.f, rd2 = 0.f, rd3 = 0.f;
+        V3 rn = v3(0, 0, 1); int rc = 0;
         int cnt = 0;
         while (__any(phase >= 0)) {
             if (phase >= 0) {
-                // ---- the one support evaluation: hull g2 along -dir (and hull g1 along +dir for pairs)
                 Sup s;
-                V3 vl; int vi2 = support_vertex(m, H, g2 - 1, multv(R2, plane ? dir : -dir), vl);
+                V3 vl; int vi2 = support_vertex(T, g2 - 1, base2, multv(R2, plane ? dir : -dir), vl);
                 s.v2 = p2 + mulv(R2, vl);
                 if (plane) {
-                    // deepest vertex and up to three graph neighbours inside the margin (mjc_PlaneConvex)
                     if (s.v2.z <= m.margin) {
-                        push_contact(lds, lane, ncon, fault, v3(s.v2.x, s.v2.y, 0.5f * s.v2.z), v3(0, 0, 1), s.v2.z, 0, g2, m);
-                        const int base = m.hull_vadr[g2 - 1];
-                        int e0 = H.nadr[base + vi2], e1 = H.nadr[base + vi2 + 1], extra = 0;
-                        for (int e = e0; e < e1 && extra < 3; e++) {
-                            int j = H.nbr[e];
-                            const float *vp = H.v + 4 * (base + j);
+                        rp0 = v3(s.v2.x, s.v2.y, 0.5f * s.v2.z); rd0 = s.v2.z; rc = 1;
+                        int e0 = T.nadr[base2 + vi2], e1 = T.nadr[base2 + vi2 + 1];
+                        for (int e = e0; e < e1 && rc < 4; e++) {
+                            int j = T.nbr[e];
+                            const float *vp = T.v + 4 * (base2 + j);
                             V3 w = p2 + mulv(R2, v3(vp[0], vp[1], vp[2]));
-                            if (w.z <= m.margin) { push_contact(lds, lane, ncon, fault, v3(w.x, w.y, 0.5f * w.z), v3(0, 0, 1), w.z, 0, g2, m); extra++; }
+                            if (w.z <= m.margin) {
+                                V3 pw = v3(w.x, w.y, 0.5f * w.z);
+                                if (rc == 1) { rp1 = pw; rd1 = w.z; } else if (rc == 2) { rp2 = pw; rd2 = w.z; } else { rp3 = pw; rd3 = w.z; }
+                                rc++;
+                            }
                         }
                     }
                     phase = -1;
                 } else {
                     s.v2 = s.v2 - dir * infl;
-                    V3 vl1; support_vertex(m, H, g1 - 1, multv(R1, dir), vl1);
+                    V3 vl1; support_vertex(T, g1 - 1, base1, multv(R1, dir), vl1);
                     s.v1 = p1 + mulv(R1, vl1) + dir * infl;
                     s.v = s.v1 - s.v2;
                     cnt++;
@@ -524,32 +582,60 @@ DEVI void collide(const DevModel &m, const Hulls &H, float *lds, int lane, int &
                         float dist = m.margin - depth;
                         if (dist < m.margin) {
                             if (dot(nrm, nrm) < 0.5f) nrm = normalized(s0.v2 - s0.v1);
-                            push_contact(lds, lane, ncon, fault, pos, nrm, dist, g1, g2, m);
+                            rp0 = pos; rd0 = dist; rn = nrm; rc = 1;
                         }
                         phase = -1;
                     }
                 }
             }
         }
+        // ---- compaction: exclusive prefix of rc over the env's 16 lanes (rc <= 4: three ballots)
+        unsigned b0 = group_bits(__ballot(rc & 1), cx.lane), b1 = group_bits(__ballot(rc & 2), cx.lane), b2 = group_bits(__ballot(rc & 4), cx.lane);
+        unsigned below = (1u << cx.sub) - 1u;
+        int off = total + __popc(b0 & below) + 2 * __popc(b1 & below) + 4 * __popc(b2 & below);
+        total += __popc(b0) + 2 * __popc(b1) + 4 * __popc(b2);
+        const float fs = fmaxf(t1[4], t2[4]), ft = fmaxf(t1[5], t2[5]), tran = t1[6] + t2[6];
+        const int meta = g1 | (g2 << 8) | (__float_as_int(t1[7]) << 16) | (__float_as_int(t2[7]) << 24);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (q < rc) {
+                int slot = off + q;
+                if (slot < G_MAXC) {
+                    float *st = cx.envl + EF_STAGE + slot * ST_STRIDE;
+                    V3 pp = q == 0 ? rp0 : q == 1 ? rp1 : q == 2 ? rp2 : rp3;
+                    float dd = q == 0 ? rd0 : q == 1 ? rd1 : q == 2 ? rd2 : rd3;
+                    st[0] = pp.x; st[1] = pp.y; st[2] = pp.z; st[3] = rn.x; st[4] = rn.y; st[5] = rn.z;
+                    st[6] = dd; st[7] = __int_as_float(meta); st[8] = fs; st[9] = ft; st[10] = tran;
+                }
+            }
+        }
     }
+    if (total > G_MAXC) { fault |= 2; total = G_MAXC; }
+    wave_sync();
+    // lane c takes contact c
+    {   const float *st = cx.envl + EF_STAGE + min(cx.sub, G_MAXC - 1) * ST_STRIDE;
+        con.p = v3(st[0], st[1], st[2]); con.n = v3(st[3], st[4], st[5]); con.dist = st[6];
+        int meta = __float_as_int(st[7]);
+        con.g1 = meta & 255; con.g2 = (meta >> 8) & 255; con.gA = (meta >> 16) & 255; con.gB = (meta >> 24) & 255;
+        con.fs = st[8]; con.ft = st[9]; con.tran = st[10]; con.D0 = 0.f;
+    }
+    if (cx.sub >= total) { con.p = v3(0, 0, 0); con.n = v3(0, 0, 1); con.dist = 1.f; con.g1 = con.g2 = 0; con.gA = con.gB = GRP_WORLD; con.fs = con.ft = 1.f; con.tran = 1.f; }
+    wave_sync();
+    return total;
 }
 
-// actuator.py:134-184 on the device contact list
-DEVI int check_grasp(const float *lds, int lane, int ncon) {
-    int t1 = 0, t2 = 0;
-    for (int c = 0; c < ncon; c++) {
-        int meta = __float_as_int(LD(CB_BASE + c * C_STRIDE + C_META));
-        int g1 = meta & 255, g2 = (meta >> 8) & 255, other;
-        if (g1 == 6) other = g2; else if (g2 == 6) other = g1; else continue;
-        if (other == 2 || other == 3) t1 = 1;
-        if (other == 4 || other == 5) t2 = 1;
-    }
-    return t1 + 2 * t2;
+// actuator.py:134-184: does this env's contact list hold object-left-finger / object-right-finger contacts?
+DEVI int check_grasp(const Ctx &cx, const Contact &con, int ncon) {
+    bool mine = cx.sub < ncon && (con.g1 == 6 || con.g2 == 6);
+    int other = con.g1 == 6 ? con.g2 : con.g1;
+    unsigned t1 = group_bits(__ballot(mine && (other == 2 || other == 3)), cx.lane);
+    unsigned t2 = group_bits(__ballot(mine && (other == 4 || other == 5)), cx.lane);
+    return (t1 ? 1 : 0) + (t2 ? 2 : 0);
 }
 
 // ---------------------------------------------------------------- soft constraints
 DEVI float impedance(const float *si, float pos, float margin) {
-    float x = fabsf(pos - margin) / fmaxf(1e-15f, si[2]);
+    float x = fabsf(pos - margin) * rcp(fmaxf(1e-15f, si[2]));
     if (x >= 1.f) return si[1];
     if (x <= 0.f) return si[0];
     float mid = si[3], power = si[4], y;
@@ -581,7 +667,7 @@ DEVI void cone_eval(const float (&jar)[4], float D0, float impratio, float fs, f
         return;
     }
     float kap = D0 / fmaxf(1e-30f, mu * mu), s1 = rsqrtf(1.f + mu * mu);
-    float dist = (mu * T - N) * s1, invT = 1.0f / T;
+    float dist = (mu * T - N) * s1, invT = rcp(T);
     float c2 = dist * mu * s1 * invT;
     c.a[0] = -s1 * S[0];
 #pragma unroll
@@ -599,27 +685,22 @@ DEVI float cone_quad(const Cone &c, const float (&jv)[4]) {
     return q + c.ka * da * da - c.kb * db * db;
 }
 
-struct ContactGeo { V3 p, n, t1, t2; int gA, gB; float fs, ft, D0; };
-DEVI void load_contact(const DevModel &m, const float *lds, int lane, int c, ContactGeo &g) {
-    int s = CB_BASE + c * C_STRIDE;
-    g.p = v3(LD(s + C_POS), LD(s + C_POS + 1), LD(s + C_POS + 2));
-    g.n = v3(LD(s + C_N), LD(s + C_N + 1), LD(s + C_N + 2));
-    make_tangents(g.n, g.t1, g.t2);
-    int meta = __float_as_int(LD(s + C_META));
-    g.gA = m.geom_group[meta & 255]; g.gB = m.geom_group[(meta >> 8) & 255];
-    g.fs = LD(s + C_FS); g.ft = LD(s + C_FT); g.D0 = LD(s + C_D0);
-}
-// relative motion rows of contact g for group twists t: (n.v, t1.v, t2.v, n.w)
-DEVI void contact_rows(const Kin &k, const Twist &t, const ContactGeo &g, float (&r)[4]) {
-    V3 vA, wA, vB, wB;
-    group_motion(k, t, g.gA, g.p, vA, wA); group_motion(k, t, g.gB, g.p, vB, wB);
-    V3 dv = vB - vA, dw = wB - wA;
-    r[0] = dot(g.n, dv); r[1] = dot(g.t1, dv); r[2] = dot(g.t2, dv); r[3] = dot(g.n, dw);
+// relative motion rows of this lane's contact for group twists t: (n.v, t1.v, t2.v, n.w)
+template <bool OBJ>
+DEVI void contact_rows(const Kin &k, const Twist &t, const Contact &c, V3 t1, V3 t2, float (&r)[4]) {
+    V3 dv, dw;
+    if (OBJ) { dv = t.vO + cross(t.wO, c.p - k.po); dw = t.wO; }
+    else {
+        V3 vA, wA, vB, wB;
+        group_motion(k, t, c.gA, c.p, vA, wA); group_motion(k, t, c.gB, c.p, vB, wB);
+        dv = vB - vA; dw = wB - wA;
+    }
+    r[0] = dot(c.n, dv); r[1] = dot(t1, dv); r[2] = dot(t2, dv); r[3] = dot(c.n, dw);
 }
 
-// reference accelerations and regularisation for limits and contacts (mj_makeConstraint / mj_makeImpedance)
+// reference accelerations and regularisation (mj_makeConstraint / mj_makeImpedance): limits redundantly, this lane's contact
 DEVI void make_constraints(const DevModel &m, const Kin &k, const float (&qpos)[14], const float (&qvel)[13],
-                           Limits &lim, float *lds, int lane, int ncon) {
+                           Limits &lim, Contact &c, bool live) {
 #pragma unroll
     for (int j = 0; j < 7; j++) {
         float lo = qpos[j] - m.range[j][0], hi = m.range[j][1] - qpos[j];
@@ -630,21 +711,17 @@ DEVI void make_constraints(const DevModel &m, const Kin &k, const float (&qpos)[
         lim.sgn[j] = sgn; lim.D[j] = 1.0f / R;
         lim.aref[j] = -m.b_lim * (sgn * qvel[j]) - m.k_lim * imp * dist;
     }
-    Twist tv; twists(k, qvel, tv);
-    for (int c = 0; c < ncon; c++) {
-        int s = CB_BASE + c * C_STRIDE;
-        ContactGeo g; load_contact(m, lds, lane, c, g);
-        float dist = LD(s + C_DIST);
-        int meta = __float_as_int(LD(s + C_META));
-        float imp = impedance(m.solimp, dist, m.margin);
-        float tran = m.geom_invweight[meta & 255] + m.geom_invweight[(meta >> 8) & 255];
-        float R0 = fmaxf(1e-15f, (1.f - imp) * tran / imp);
-        LD(s + C_D0) = 1.0f / R0;
-        float vel[4]; contact_rows(k, tv, g, vel);
-        LD(s + C_AREF) = -m.b_con * vel[0] - m.k_con * imp * (dist - m.margin);
-        LD(s + C_AREF + 1) = -m.b_con * vel[1];
-        LD(s + C_AREF + 2) = -m.b_con * vel[2];
-        LD(s + C_AREF + 3) = -m.b_con * vel[3];
+#pragma unroll
+    for (int r = 0; r < 4; r++) { c.aref[r] = 0.f; c.jar[r] = 0.f; c.jv[r] = 0.f; }
+    if (live) {
+        Twist tv; twists(k, qvel, tv);
+        V3 t1, t2; make_tangents(c.n, t1, t2);
+        float imp = impedance(m.solimp, c.dist, m.margin);
+        float R0 = fmaxf(1e-15f, (1.f - imp) * c.tran / imp);
+        c.D0 = 1.0f / R0;
+        float vel[4]; contact_rows<false>(k, tv, c, t1, t2, vel);
+        c.aref[0] = -m.b_con * vel[0] - m.k_con * imp * (c.dist - m.margin);
+        c.aref[1] = -m.b_con * vel[1]; c.aref[2] = -m.b_con * vel[2]; c.aref[3] = -m.b_con * vel[3];
     }
 }
 
@@ -653,7 +730,7 @@ DEVI void make_constraints(const DevModel &m, const Kin &k, const float (&qpos)[
 template <bool OBJ> struct HessT { static constexpr int N = OBJ ? 21 : 91; };
 template <bool OBJ> constexpr DEVI int hidx(int i, int j) { return OBJ ? pidx(i - 7, j - 7) : pidx(i, j); }
 
-// H += w * u u^T restricted to dofs [lo, 13)
+// H += w * u u^T restricted to dofs [LO, 13)
 template <bool OBJ, int LO>
 DEVI void rank1(float *Hp, const float (&u)[13], float w) {
 #pragma unroll
@@ -664,46 +741,53 @@ DEVI void rank1(float *Hp, const float (&u)[13], float w) {
     }
 }
 
-// One pass over all constraints at acceleration x: stores jar in LDS, returns the constraint cost,
-// accumulates J^T force into `jtf` and, if wantH, adds J^T s'' J to the packed Hessian.
+// One cooperative pass over all constraints at acceleration x (identical in the 16 lanes): each lane prices ITS contact
+// (jar kept in its registers), the 16 lanes all-reduce the cost and J^T force; if wantH each lane folds its contact's
+// six weighted rank-1 terms into a private matrix and the matrices are all-reduced entry by entry.
 template <bool OBJ>
 DEVI float constraint_pass(const DevModel &m, const Kin &k, const Limits &lim, const float (&x)[13],
-                           float *lds, int lane, int ncon, float (&jtf)[13], float *Hp, bool wantH) {
+                           Contact &c, bool live, float (&jtf)[13], float *Hp, bool wantH) {
     float cost = 0.f;
-    Wrench w; wrench_zero(w);
-    float flim[7];
+    float jl[13];
 #pragma unroll
-    for (int j = 0; j < 7; j++) flim[j] = 0.f;
-    if (!OBJ) {
+    for (int i = 0; i < 13; i++) jl[i] = 0.f;
+    Cone cn;
 #pragma unroll
-        for (int j = 0; j < 7; j++) {
-            float jar = lim.sgn[j] * x[j] - lim.aref[j];
-            bool act = lim.sgn[j] != 0.f && jar < 0.f;
-            flim[j] = act ? -lim.D[j] * jar * lim.sgn[j] : 0.f;
-            cost += act ? 0.5f * lim.D[j] * jar * jar : 0.f;
-            if (wantH) Hp[hidx<OBJ>(OBJ ? 7 : j, OBJ ? 7 : j)] += act ? lim.D[j] : 0.f;
-        }
+    for (int i = 0; i < 4; i++) { cn.grad[i] = 0.f; cn.w[i] = 0.f; cn.a[i] = 0.f; cn.b[i] = 0.f; }
+    cn.cost = 0.f; cn.ka = 0.f; cn.kb = 0.f;
+    opaque(c.p.x); opaque(c.n.x);          // keep the per-contact geometry work inside the solver loop (see opaque())
+    V3 t1, t2; make_tangents(c.n, t1, t2);
+    if (live) {
+        Twist t; twists(k, x, t);
+        float jar[4]; contact_rows<OBJ>(k, t, c, t1, t2, jar);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { jar[r] -= c.aref[r]; c.jar[r] = jar[r]; }
+        cone_eval(jar, c.D0, m.impratio, c.fs, c.ft, cn);
+        cost = cn.cost;
+        V3 F = c.n * (-cn.grad[0]) + t1 * (-cn.grad[1]) + t2 * (-cn.grad[2]);
+        V3 Tq = c.n * (-cn.grad[3]);
+        Wrench w; wrench_zero(w);
+        if (OBJ) { w.FO = F; w.TO = Tq + cross(c.p - k.po, F); }
+        else { wrench_add(k, w, c.gB, c.p, F, Tq, 1.f); wrench_add(k, w, c.gA, c.p, F, Tq, -1.f); }
+        if (OBJ) {
+            jl[7] = w.FO.x; jl[8] = w.FO.y; jl[9] = w.FO.z;
+            V3 tl = multv(k.Ro, w.TO); jl[10] = tl.x; jl[11] = tl.y; jl[12] = tl.z;
+        } else wrench_project(k, w, jl);
     }
-    Twist t; twists(k, x, t);
-    for (int c = 0; c < ncon; c++) {
-        int s = CB_BASE + c * C_STRIDE;
-        ContactGeo g; load_contact(m, lds, lane, c, g);
-        float jar[4];
-        if (OBJ) {          // floor-object contact: only the object moves
-            V3 dv = t.vO + cross(t.wO, g.p - k.po);
-            jar[0] = dot(g.n, dv); jar[1] = dot(g.t1, dv); jar[2] = dot(g.t2, dv); jar[3] = dot(g.n, t.wO);
-        } else contact_rows(k, t, g, jar);
+    cost = sum16(cost);
 #pragma unroll
-        for (int r = 0; r < 4; r++) { jar[r] -= LD(s + C_AREF + r); LD(s + C_JAR + r) = jar[r]; }
-        Cone cn; cone_eval(jar, g.D0, m.impratio, g.fs, g.ft, cn);
-        cost += cn.cost;
-        V3 F = g.n * (-cn.grad[0]) + g.t1 * (-cn.grad[1]) + g.t2 * (-cn.grad[2]);
-        V3 Tq = g.n * (-cn.grad[3]);
-        if (OBJ) { w.FO = w.FO + F; w.TO = w.TO + Tq + cross(g.p - k.po, F); }
-        else { wrench_add(k, w, g.gB, g.p, F, Tq, 1.f); wrench_add(k, w, g.gA, g.p, F, Tq, -1.f); }
-        bool any = cn.w[0] != 0.f || cn.w[1] != 0.f || cn.ka != 0.f;
-        if (wantH && any) {
-            const bool objonly = OBJ || (g.gA == GRP_WORLD && g.gB == GRP_O);     // rows touch dofs 7..12 only
+    for (int i = OBJ ? 7 : 0; i < 13; i++) jtf[i] = sum16(jl[i]);
+    if (OBJ) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) jtf[i] = 0.f;
+    }
+    if (wantH) {
+        // this lane's contact folds its six weighted rank-1 terms into Hp (zero on entry), then the 16 lanes all-reduce
+        // Hp entry by entry in place; the caller adds the mass matrix afterwards
+        constexpr int NH = HessT<OBJ>::N;
+        const bool any = live && (cn.w[0] != 0.f || cn.w[1] != 0.f || cn.ka != 0.f);
+        if (any) {
+            const bool objonly = OBJ || (c.gA == GRP_WORLD && c.gB == GRP_O);     // rows touch dofs 7..12 only
             float ua[13], ub[13];
 #pragma unroll
             for (int i = 0; i < 13; i++) { ua[i] = 0.f; ub[i] = 0.f; }
@@ -712,9 +796,9 @@ DEVI float constraint_pass(const DevModel &m, const Kin &k, const Limits &lim, c
                 float j[13];
 #pragma unroll
                 for (int i = 0; i < 13; i++) j[i] = 0.f;
-                V3 e = r == 1 ? g.t1 : r == 2 ? g.t2 : g.n;
-                if (OBJ) row_add(k, j, GRP_O, g.p, e, 1.f, r == 3);
-                else { row_add(k, j, g.gB, g.p, e, 1.f, r == 3); row_add(k, j, g.gA, g.p, e, -1.f, r == 3); }
+                V3 e = r == 1 ? t1 : r == 2 ? t2 : c.n;
+                if (OBJ) row_add(k, j, GRP_O, c.p, e, 1.f, r == 3);
+                else { row_add(k, j, c.gB, c.p, e, 1.f, r == 3); row_add(k, j, c.gA, c.p, e, -1.f, r == 3); }
                 float ar = r == 0 ? cn.a[0] : r == 1 ? cn.a[1] : r == 2 ? cn.a[2] : cn.a[3];
                 float br = r == 0 ? cn.b[0] : r == 1 ? cn.b[1] : r == 2 ? cn.b[2] : cn.b[3];
                 float wr = r == 0 ? cn.w[0] : r == 1 ? cn.w[1] : r == 2 ? cn.w[2] : cn.w[3];
@@ -733,26 +817,37 @@ DEVI float constraint_pass(const DevModel &m, const Kin &k, const Limits &lim, c
                 }
             }
         }
+#pragma unroll
+        for (int i = 0; i < NH; i++) Hp[i] = sum16(Hp[i]);
     }
-    if (OBJ) {
+    if (!OBJ) {                 // joint limits: identical in every lane, added after the all-reduce
 #pragma unroll
-        for (int i = 0; i < 7; i++) jtf[i] = 0.f;
-        jtf[7] = w.FO.x; jtf[8] = w.FO.y; jtf[9] = w.FO.z;
-        V3 tl = multv(k.Ro, w.TO);
-        jtf[10] = tl.x; jtf[11] = tl.y; jtf[12] = tl.z;
-    } else {
-        wrench_project(k, w, jtf);
-#pragma unroll
-        for (int j = 0; j < 7; j++) jtf[j] += flim[j];
+        for (int j = 0; j < 7; j++) {
+            float jar = lim.sgn[j] * x[j] - lim.aref[j];
+            bool act = lim.sgn[j] != 0.f && jar < 0.f;
+            jtf[j] += act ? -lim.D[j] * jar * lim.sgn[j] : 0.f;
+            cost += act ? 0.5f * lim.D[j] * jar * jar : 0.f;
+            if (wantH) Hp[hidx<OBJ>(OBJ ? 7 : j, OBJ ? 7 : j)] += act ? lim.D[j] : 0.f;
+        }
     }
     return cost;
 }
 
-// phi'(alpha), phi''(alpha) of the total cost along the search direction (jar, jv cached in LDS)
+// phi'(alpha), phi''(alpha) of the total cost along the search direction: this lane's contact, then all-reduce
 template <bool OBJ>
 DEVI void line_eval(const DevModel &m, const Limits &lim, const float (&qacc)[13], const float (&p)[13],
-                    const float *lds, int lane, int ncon, float alpha, float g0, float g1, float &dphi, float &ddphi) {
-    float dp = g0 + alpha * g1, hp = g1;
+                    const Contact &c, bool live, float alpha, float g0, float g1, float &dphi, float &ddphi) {
+    float dp = 0.f, hp = 0.f;
+    if (live) {
+        float ja[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) ja[r] = c.jar[r] + alpha * c.jv[r];
+        Cone cn; cone_eval(ja, c.D0, m.impratio, c.fs, c.ft, cn);
+#pragma unroll
+        for (int r = 0; r < 4; r++) dp = fmaf(cn.grad[r], c.jv[r], dp);
+        hp = cone_quad(cn, c.jv);
+    }
+    dp = sum16(dp) + g0 + alpha * g1; hp = sum16(hp) + g1;
     if (!OBJ) {
 #pragma unroll
         for (int j = 0; j < 7; j++) {
@@ -762,27 +857,17 @@ DEVI void line_eval(const DevModel &m, const Limits &lim, const float (&qacc)[13
             dp += act ? lim.D[j] * x * jv : 0.f; hp += act ? lim.D[j] * jv * jv : 0.f;
         }
     }
-    for (int c = 0; c < ncon; c++) {
-        int s = CB_BASE + c * C_STRIDE;
-        float ja[4], jv[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) { jv[r] = LD(s + C_JV + r); ja[r] = LD(s + C_JAR + r) + alpha * jv[r]; }
-        Cone cn; cone_eval(ja, LD(s + C_D0), m.impratio, LD(s + C_FS), LD(s + C_FT), cn);
-#pragma unroll
-        for (int r = 0; r < 4; r++) dp = fmaf(cn.grad[r], jv[r], dp);
-        hp += cone_quad(cn, jv);
-    }
     dphi = dp; ddphi = hp;
 }
 
-// Primal Newton solve of  min 1/2 (a - a_s)^T M (a - a_s) + s(J a - aref)   (mj_solNewton's problem).
+// Primal Newton solve of  min 1/2 (a - a_s)^T M (a - a_s) + s(J a - aref)   (mj_solNewton's problem), cooperatively.
 // Staged loop with ONE constraint-pass site: stage 0 prices qacc_smooth, stage 1 prices qacc_warmstart (the better
-// one is the start, as MuJoCo does) and stops right there when the start already satisfies the gradient
-// tolerance -- the common case of a persisting contact, which then never builds a Hessian; stages >= 2 are
-// Newton iterations (Hessian, Cholesky, exact line search). OBJ = only the 6 object dofs are constrained.
+// one is the start, as MuJoCo does) and stops right there when the start already satisfies the gradient tolerance;
+// stages >= 2 are Newton iterations (Hessian, Cholesky, exact line search). All control flow depends only on
+// all-reduced values, so the 16 lanes of an env always agree. OBJ = only the 6 object dofs are constrained.
 template <bool OBJ>
 DEVI void solve_newton(const DevModel &m, const Kin &k, const float (&Mg)[28], const float (&Mo)[21], const Limits &lim,
-                       const float (&qs)[13], const float (&warm)[13], float *lds, int lane, int ncon,
+                       const float (&qs)[13], const float (&warm)[13], Contact &c, bool live,
                        float (&qacc)[13], float (&jtf)[13], int &fault, int &iters) {
     constexpr int LO = OBJ ? 7 : 0;
     constexpr int NH = HessT<OBJ>::N;
@@ -800,16 +885,6 @@ DEVI void solve_newton(const DevModel &m, const Kin &k, const float (&Mg)[28], c
             if (wantH) {
 #pragma unroll
                 for (int i = 0; i < NH; i++) H[i] = 0.f;
-                if (!OBJ) {
-#pragma unroll
-                    for (int i = 0; i < 7; i++)
-#pragma unroll
-                        for (int j = 0; j <= i; j++) H[hidx<OBJ>(OBJ ? 7 : i, OBJ ? 7 : j)] = Mg[pidx(i, j)];
-                }
-#pragma unroll
-                for (int i = 0; i < 6; i++)
-#pragma unroll
-                    for (int j = 0; j <= i; j++) H[hidx<OBJ>(7 + i, 7 + j)] = Mo[pidx(i, j)];
             }
             float dq[13];
 #pragma unroll
@@ -818,7 +893,19 @@ DEVI void solve_newton(const DevModel &m, const Kin &k, const float (&Mg)[28], c
             float newcost = 0.f;
 #pragma unroll
             for (int i = LO; i < 13; i++) newcost = fmaf(0.5f * Md[i], dq[i], newcost);
-            newcost += constraint_pass<OBJ>(m, k, lim, x, lds, lane, ncon, jtf, H, wantH);
+            newcost += constraint_pass<OBJ>(m, k, lim, x, c, live, jtf, H, wantH);
+            if (wantH) {                                   // H = M + J^T s'' J
+                if (!OBJ) {
+#pragma unroll
+                    for (int i = 0; i < 7; i++)
+#pragma unroll
+                        for (int j = 0; j <= i; j++) H[hidx<OBJ>(OBJ ? 7 : i, OBJ ? 7 : j)] += Mg[pidx(i, j)];
+                }
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int j = 0; j <= i; j++) H[hidx<OBJ>(7 + i, 7 + j)] += Mo[pidx(i, j)];
+            }
             float gn = 0.f;
 #pragma unroll
             for (int i = LO; i < 13; i++) { float g = Md[i] - jtf[i]; gn = fmaf(g, g, gn); }
@@ -859,17 +946,11 @@ DEVI void solve_newton(const DevModel &m, const Kin &k, const float (&Mg)[28], c
                     float g0 = 0.f, g1 = 0.f;
 #pragma unroll
                     for (int i = LO; i < 13; i++) { g0 = fmaf(Mpv[i], qacc[i] - qs[i], g0); g1 = fmaf(Mpv[i], p[i], g1); }
-                    {   Twist tp; twists(k, p, tp);
-                        for (int c = 0; c < ncon; c++) {
-                            ContactGeo g; load_contact(m, lds, lane, c, g);
-                            float jv[4];
-                            if (OBJ) {
-                                V3 dv = tp.vO + cross(tp.wO, g.p - k.po);
-                                jv[0] = dot(g.n, dv); jv[1] = dot(g.t1, dv); jv[2] = dot(g.t2, dv); jv[3] = dot(g.n, tp.wO);
-                            } else contact_rows(k, tp, g, jv);
-#pragma unroll
-                            for (int r = 0; r < 4; r++) LD(CB_BASE + c * C_STRIDE + C_JV + r) = jv[r];
-                        } }
+                    if (live) {
+                        Twist tp; twists(k, p, tp);
+                        V3 t1, t2; make_tangents(c.n, t1, t2);
+                        contact_rows<OBJ>(k, tp, c, t1, t2, c.jv);
+                    }
                     // exact line search: safeguarded 1-D Newton on phi'(alpha); one evaluation site
                     float lo = 0.f, hi = -1.f, alpha = 0.f, gtol = 0.f;
                     bool lsdone = false, descent = true;
@@ -877,7 +958,7 @@ DEVI void solve_newton(const DevModel &m, const Kin &k, const float (&Mg)[28], c
                         if (!__any(!lsdone)) break;
                         if (!lsdone) {
                             float dp, hp;
-                            line_eval<OBJ>(m, lim, qacc, p, lds, lane, ncon, alpha, g0, g1, dp, hp);
+                            line_eval<OBJ>(m, lim, qacc, p, c, live, alpha, g0, g1, dp, hp);
                             if (ls == 0) {
                                 if (dp >= 0.f) { descent = false; lsdone = true; }
                                 gtol = 1e-4f * fabsf(dp) + 1e-30f;
@@ -889,7 +970,7 @@ DEVI void solve_newton(const DevModel &m, const Kin &k, const float (&Mg)[28], c
                                 }
                             }
                             if (!lsdone && ls < LS_MAXIT) {
-                                float an = alpha - dp / fmaxf(hp, 1e-30f);
+                                float an = alpha - dp * rcp(fmaxf(hp, 1e-30f));
                                 if (hi > 0.f && (an <= lo || an >= hi)) an = 0.5f * (lo + hi);
                                 alpha = an;
                             }
@@ -910,16 +991,19 @@ DEVI void solve_newton(const DevModel &m, const Kin &k, const float (&Mg)[28], c
 // ---------------------------------------------------------------- one physics.step()
 struct LaneState { float qpos[14], qvel[13], ctrl[7], warm[13]; };
 
-// position stage (mj_step1's share): kinematics + collision of the current state; contacts stay in LDS.
-DEVI void forward_pos(const DevModel &m, const Hulls &H, LaneState &s, float *lds, int lane, Kin &k, int &ncon, int &fault) {
-    kinematics(m, s.qpos, k, lds, lane);
-    collide(m, H, lds, lane, ncon, fault);
+// position stage (mj_step1's share): kinematics + collision of the current state; lane c then owns contact c.
+DEVI void forward_pos(const DevModel &m, const Ctx &cx, LaneState &s, Kin &k, Contact &con, int &ncon, int &fault, Stamps &st) {
+    kinematics(m, s.qpos, k, cx, true);
+    wave_sync();
+    STAMP(st, 0);
+    ncon = collide(m, cx, con, fault);
+    STAMP(st, 1);
 }
 
 // dynamics stage (mj_step2's share up to qacc) on top of forward_pos
-DEVI void forward_acc(const DevModel &m, LaneState &s, float xfrc_z, float *lds, int lane, const Kin &k, int ncon, int &fault,
+DEVI void forward_acc(const DevModel &m, const Ctx &cx, LaneState &s, float xfrc_z, const Kin &k, Contact &con, int ncon, int &fault,
                       float (&Mg)[28], float (&Mo)[21], float (&qfrc_smooth)[13], float (&qacc)[13], float (&jtf)[13], int &iters,
-                      float *dbg_qs, float *dbg_bias) {
+                      float *dbg_qs, float *dbg_bias, Stamps &st) {
     mass_matrix(m, k, Mg, Mo);
     float bias[13];
     bias_forces(m, k, s.qvel, bias);
@@ -955,33 +1039,33 @@ DEVI void forward_acc(const DevModel &m, LaneState &s, float xfrc_z, float *lds,
 #pragma unroll
         for (int i = 0; i < 13; i++) dbg_qs[i] = qs[i];
     }
+    STAMP(st, 2);
     Limits lim;
-    make_constraints(m, k, s.qpos, s.qvel, lim, lds, lane, ncon);
+    const bool live = cx.sub < ncon;
+    make_constraints(m, k, s.qpos, s.qvel, lim, con, live);
+    STAMP(st, 3);
     bool anylim = false;
 #pragma unroll
     for (int j = 0; j < 7; j++) anylim |= lim.sgn[j] != 0.f;
     iters = 0;
     // does any constraint touch the gripper? (joint limit, or a contact whose geoms are not floor + object)
-    bool grip = anylim;
-    for (int c = 0; c < ncon; c++) {
-        int meta = __float_as_int(LD(CB_BASE + c * C_STRIDE + C_META));
-        grip |= !((meta & 255) == 0 && ((meta >> 8) & 255) == 6);
-    }
+    const bool grip = anylim || group_bits(__ballot(live && !(con.g1 == 0 && con.g2 == 6)), cx.lane) != 0u;
     const bool constrained = ncon > 0 || anylim;
 #pragma unroll
     for (int i = 0; i < 13; i++) { qacc[i] = qs[i]; jtf[i] = 0.f; }
     if (__any(constrained && !grip)) {
-        if (constrained && !grip) solve_newton<true>(m, k, Mg, Mo, lim, qs, s.warm, lds, lane, ncon, qacc, jtf, fault, iters);
+        if (constrained && !grip) solve_newton<true>(m, k, Mg, Mo, lim, qs, s.warm, con, live, qacc, jtf, fault, iters);
     }
     if (__any(constrained && grip)) {
-        if (constrained && grip) solve_newton<false>(m, k, Mg, Mo, lim, qs, s.warm, lds, lane, ncon, qacc, jtf, fault, iters);
+        if (constrained && grip) solve_newton<false>(m, k, Mg, Mo, lim, qs, s.warm, con, live, qacc, jtf, fault, iters);
     }
+    STAMP(st, 4);
 }
 
 // dynamics + integration of one physics.step(); forward_pos must have run on the current state
-DEVI void physics_advance(const DevModel &m, LaneState &s, float xfrc_z, float *lds, int lane, const Kin &k, int ncon, int &fault) {
+DEVI void physics_advance(const DevModel &m, const Ctx &cx, LaneState &s, float xfrc_z, const Kin &k, Contact &con, int ncon, int &fault, Stamps &st) {
     float Mg[28], Mo[21], qfs[13], qacc[13], jtf[13]; int iters;
-    forward_acc(m, s, xfrc_z, lds, lane, k, ncon, fault, Mg, Mo, qfs, qacc, jtf, iters, nullptr, nullptr);
+    forward_acc(m, cx, s, xfrc_z, k, con, ncon, fault, Mg, Mo, qfs, qacc, jtf, iters, nullptr, nullptr, st);
     const float h = m.timestep;
     // semi-implicit Euler with implicit joint damping: (M + h D) a' = qfrc_smooth + J^T f.
     // Only the gripper block carries damping; for the object block a' = qacc.
@@ -1002,7 +1086,7 @@ DEVI void physics_advance(const DevModel &m, LaneState &s, float xfrc_z, float *
     float ang = norm(w) * h;
     if (ang > 0.f) {
         V3 ax = normalized(w);
-        float sh = sinf(0.5f * ang), ch = cosf(0.5f * ang);
+        float sh, ch; sincosf(0.5f * ang, &sh, &ch);
         float bw = ch, bx = ax.x * sh, by = ax.y * sh, bz = ax.z * sh;
         float aw = s.qpos[10], axx = s.qpos[11], ay = s.qpos[12], az = s.qpos[13];
         float rw = aw * bw - axx * bx - ay * by - az * bz;
@@ -1018,4 +1102,5 @@ DEVI void physics_advance(const DevModel &m, LaneState &s, float xfrc_z, float *
 #pragma unroll
     for (int i = 0; i < 13; i++) bad |= !(fabsf(s.qvel[i]) < 1e6f);
     if (bad) fault |= 1;
+    STAMP(st, 5);
 }

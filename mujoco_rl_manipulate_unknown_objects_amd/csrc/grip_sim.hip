@@ -187,6 +187,13 @@ extern "C" int grip_model_load(const char *blob_path, GripModel **out) {
     m.npair = (int)pairs.size() / 2;
     if (m.npair > GN_PAIR_MAX) { delete gm; return fail("too many collision pairs"); }
     for (int q = 0; q < m.npair; q++) { m.pairs[q][0] = pairs[2*q]; m.pairs[q][1] = pairs[2*q+1]; }
+    // narrow-phase items over an env's 16 lanes: lanes 0..10 the hull pairs, lanes 11..15 the floor tests of geoms 2..6,
+    // lane 11 also takes the (almost always sphere-culled) floor test of the base in a second round
+    if (m.npair > 11) { delete gm; return fail("the 16-lane item map holds at most 11 hull pairs"); }
+    for (int l = 0; l < 16; l++) { m.coop_items[l][0] = -1; m.coop_items[l][1] = -1; }
+    for (int q = 0; q < m.npair; q++) m.coop_items[q][0] = 6 + q;
+    for (int g = 2; g <= 6; g++) m.coop_items[11 + (g - 2)][0] = g - 1;
+    m.coop_items[11][1] = 0;
     gm->nvert = (int)hverts.size() / 3;
     {   // pack the hull tables into one word blob
         auto pack16 = [](std::vector<unsigned> &dst, const std::vector<int> &src) {
@@ -226,7 +233,7 @@ struct StepOutDev {     // device copy of GripStepOut (kernel argument)
 
 struct GripBatch {
     int n = 0, device = 0;
-    DevModel *d_model = nullptr; unsigned *d_hull = nullptr; float *d_planes = nullptr; size_t lds_bytes = 0;
+    DevModel hmodel; DevModel *d_model = nullptr; unsigned *d_hull = nullptr; float *d_planes = nullptr; size_t lds_bytes = 0;
     DevConfig cfg;
     float *qpos = nullptr, *qvel = nullptr, *ctrl = nullptr, *warm = nullptr;     // SoA [field][N]
     int *episode_step = nullptr, *status = nullptr, *gripper_open = nullptr;
@@ -239,10 +246,9 @@ struct GripBatch {
 };
 
 static constexpr int EV_RING = 1024;
-static constexpr size_t LDS_LANE_BYTES = (size_t)LDS_LANE_WORDS * sizeof(float);
 static constexpr int LDS_MAX_BYTES = 160 * 1024;
 
-// ---- state load / store (coalesced SoA)
+// ---- state load / store (SoA; the 16 lanes of an env read the same words)
 struct StatePtrs { float *qpos, *qvel, *ctrl, *warm; int *episode_step, *status, *gripper_open, *pad_grasp, *pad_pher; int n; };
 
 DEVI void ld_state(const StatePtrs &p, int e, LaneState &s) {
@@ -349,24 +355,30 @@ DEVI float agent_reward(V3 o0, V3 o1, const DevConfig &c, int gripper_open, floa
 enum { PH_MOVE = 0, PH_RETURN, PH_OPEN, PH_CLOSE, PH_FINAL, PH_DONE };
 
 // ------------------------------------------------------------------------------------------------
-// kernels (one wave per workgroup; LDS_BYTES of dynamic LDS)
+// kernels: 256-thread workgroups = 16 environments x 16 cooperating lanes (grip_physics.h)
 // ------------------------------------------------------------------------------------------------
 extern __shared__ float lds_dyn[];
 
-__global__ void __launch_bounds__(WAVE) k_reset(const DevModel *mp, DevConfig cfg, StatePtrs st, const uint8_t *mask, StepOutDev out, float *reset_info) {
-    const DevModel &m = *mp;
-    float *lds = lds_dyn; const int lane = threadIdx.x;
-    int e = blockIdx.x * WAVE + lane;
+#define STAMPS_DECL Stamps stm; STAMPS_INIT
+#ifdef GRIP_STAMPS
+#define STAMPS_INIT for (int i_ = 0; i_ < NSTAMP; i_++) stm.acc[i_] = 0; stm.t = stamp_now();
+#else
+#define STAMPS_INIT
+#endif
+
+__global__ void __launch_bounds__(WG_THREADS, 1) k_reset(const DevModel m, DevConfig cfg, StatePtrs st, const uint8_t *mask, StepOutDev out, float *reset_info) {
+    const Ctx cx = stage_tables(m, lds_dyn);
+    STAMPS_DECL
+    int e = blockIdx.x * EPB + threadIdx.x / KL;
     bool valid = e < st.n;
     if (!valid) e = st.n - 1;
     bool doit = valid && (mask == nullptr || mask[e] != 0);
-    const Hulls H = stage_hulls(m, lds, lane);
     LaneState s; reset_lane(m, s);
-    Kin k; int ncon = 0, fault = 0;
-    forward_pos(m, H, s, lds, lane, k, ncon, fault);
-    int grasp = check_grasp(lds, lane, ncon), pher = pheromone_level(k.pe, cfg);
-    if (blockIdx.x == 0 && lane == 0 && reset_info) { reset_info[0] = (float)grasp; reset_info[1] = (float)pher; reset_info[2] = k.po.x; reset_info[3] = k.po.y; }
-    if (!doit) return;
+    Kin k; Contact con; int ncon = 0, fault = 0;
+    forward_pos(m, cx, s, k, con, ncon, fault, stm);
+    int grasp = check_grasp(cx, con, ncon), pher = pheromone_level(k.pe, cfg);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && reset_info) { reset_info[0] = (float)grasp; reset_info[1] = (float)pher; reset_info[2] = k.po.x; reset_info[3] = k.po.y; }
+    if (!doit || cx.sub != 0) return;
     st_state(st, e, s);
     st.episode_step[e] = 0; st.status[e] = 0; st.gripper_open[e] = 1;
     st.pad_grasp[e] = grasp; st.pad_pher[e] = pher;
@@ -380,15 +392,15 @@ __global__ void __launch_bounds__(WAVE) k_reset(const DevModel *mp, DevConfig cf
     if (out.fault) out.fault[e] = fault;
 }
 
-// RobotEnv.step for 64 envs per wave (robot_env.py:77-241)
-__global__ void __launch_bounds__(WAVE) k_macro_step(const DevModel *mp, DevConfig cfg, StatePtrs st, const float *actions, StepOutDev out,
-                                                      const float *reset_info, float xfrc_z) {
-    const DevModel &m = *mp;
-    float *lds = lds_dyn; const int lane = threadIdx.x;
-    int e = blockIdx.x * WAVE + lane;
+// RobotEnv.step (robot_env.py:77-241): 4 envs per wave, 16 lanes per env
+__global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, DevConfig cfg, StatePtrs st, const float *actions, StepOutDev out,
+                                                              const float *reset_info, float xfrc_z) {
+    const Ctx cx = stage_tables(m, lds_dyn);
+    STAMPS_DECL
+    int e = blockIdx.x * EPB + threadIdx.x / KL;
     const bool valid = e < st.n;
     if (!valid) e = st.n - 1;
-    const Hulls H = stage_hulls(m, lds, lane);
+    const bool writer = valid && cx.sub == 0;
     LaneState s; ld_state(st, e, s);
     int episode_step = st.episode_step[e], status = st.status[e], gripper_open = st.gripper_open[e];
     const int adim = cfg.include_roll ? 6 : 5;
@@ -396,7 +408,7 @@ __global__ void __launch_bounds__(WAVE) k_macro_step(const DevModel *mp, DevConf
 #pragma unroll
     for (int i = 0; i < 6; i++) act[i] = i < adim ? actions[(size_t)e * adim + i] : 0.f;
 
-    Kin k; int ncon = 0, fault = 0;
+    Kin k; Contact con; int ncon = 0, fault = 0;
     float target[5], init_q[5], open_close = 0.f, delta_pre = 0.f, tq = 0.f;
     V3 init_obj = v3(0, 0, 0);
     int phase = valid ? PH_MOVE : PH_DONE, cnt = 0, nsub = 0, grasped = 0;
@@ -404,7 +416,7 @@ __global__ void __launch_bounds__(WAVE) k_macro_step(const DevModel *mp, DevConf
 
     while (__any(phase != PH_DONE)) {
         if (phase != PH_DONE) {
-            forward_pos(m, H, s, lds, lane, k, ncon, fault);       // state of "now": contacts as check_grasp sees them
+            forward_pos(m, cx, s, k, con, ncon, fault, stm);       // state of "now": contacts as check_grasp sees them
             if (first) {
                 first = false;
                 init_obj = k.po;
@@ -427,31 +439,35 @@ __global__ void __launch_bounds__(WAVE) k_macro_step(const DevModel *mp, DevConf
                 else if (episode_step == cfg.time_horizon - 1) { done = 1; status = 2; }
                 else done = 0;
                 episode_step += 1;
-                int pg = check_grasp(lds, lane, ncon), ph = pheromone_level(fe, cfg);
-                if (out.reward) out.reward[e] = reward;
-                if (out.done) out.done[e] = (uint8_t)done;
-                if (out.status) out.status[e] = status;
-                if (out.episode_step) out.episode_step[e] = episode_step;
-                if (out.gripper_open) out.gripper_open[e] = gripper_open;
-                if (out.object_grasped) out.object_grasped[e] = grasped;
-                if (out.position_reached) out.position_reached[e] = (reached_target ? 1 : 0) | (reached_initial ? 2 : 0) | ((!reached_target && !reached_initial) ? 4 : 0);
-                if (out.total_distance) out.total_distance[e] = sqrtf((fo.x - init_obj.x) * (fo.x - init_obj.x) + (fo.y - init_obj.y) * (fo.y - init_obj.y));
-                if (out.line_distance) out.line_distance[e] = line;
-                if (out.gripper_position) { out.gripper_position[3 * e] = fe.x; out.gripper_position[3 * e + 1] = fe.y; out.gripper_position[3 * e + 2] = fe.z; }
-                if (out.object_position) { out.object_position[3 * e] = fo.x; out.object_position[3 * e + 1] = fo.y; out.object_position[3 * e + 2] = fo.z; }
-                if (out.init_obj_pos) { out.init_obj_pos[3 * e] = init_obj.x; out.init_obj_pos[3 * e + 1] = init_obj.y; out.init_obj_pos[3 * e + 2] = init_obj.z; }
-                if (out.n_substeps) out.n_substeps[e] = nsub;
-                if (out.fault) out.fault[e] = fault;
+                int pg = check_grasp(cx, con, ncon), ph = pheromone_level(fe, cfg);
+                if (writer) {
+                    if (out.reward) out.reward[e] = reward;
+                    if (out.done) out.done[e] = (uint8_t)done;
+                    if (out.status) out.status[e] = status;
+                    if (out.episode_step) out.episode_step[e] = episode_step;
+                    if (out.gripper_open) out.gripper_open[e] = gripper_open;
+                    if (out.object_grasped) out.object_grasped[e] = grasped;
+                    if (out.position_reached) out.position_reached[e] = (reached_target ? 1 : 0) | (reached_initial ? 2 : 0) | ((!reached_target && !reached_initial) ? 4 : 0);
+                    if (out.total_distance) out.total_distance[e] = sqrtf((fo.x - init_obj.x) * (fo.x - init_obj.x) + (fo.y - init_obj.y) * (fo.y - init_obj.y));
+                    if (out.line_distance) out.line_distance[e] = line;
+                    if (out.gripper_position) { out.gripper_position[3 * e] = fe.x; out.gripper_position[3 * e + 1] = fe.y; out.gripper_position[3 * e + 2] = fe.z; }
+                    if (out.object_position) { out.object_position[3 * e] = fo.x; out.object_position[3 * e + 1] = fo.y; out.object_position[3 * e + 2] = fo.z; }
+                    if (out.init_obj_pos) { out.init_obj_pos[3 * e] = init_obj.x; out.init_obj_pos[3 * e + 1] = init_obj.y; out.init_obj_pos[3 * e + 2] = init_obj.z; }
+                    if (out.n_substeps) out.n_substeps[e] = nsub;
+                    if (out.fault) out.fault[e] = fault;
+                }
                 float agx = fo.x, agy = fo.y;
                 if (done && cfg.auto_reset) {
                     reset_lane(m, s); episode_step = 0; status = 0; gripper_open = 1;
                     pg = (int)reset_info[0]; ph = (int)reset_info[1]; agx = reset_info[2]; agy = reset_info[3]; dgx = cfg.dir_x; dgy = cfg.dir_y;
                 }
-                if (out.achieved_goal) { out.achieved_goal[2 * e] = agx; out.achieved_goal[2 * e + 1] = agy; }
-                if (out.desired_goal) { out.desired_goal[2 * e] = dgx; out.desired_goal[2 * e + 1] = dgy; }
-                st.pad_grasp[e] = pg; st.pad_pher[e] = ph;
-                st_state(st, e, s);
-                st.episode_step[e] = episode_step; st.status[e] = status; st.gripper_open[e] = gripper_open;
+                if (writer) {
+                    if (out.achieved_goal) { out.achieved_goal[2 * e] = agx; out.achieved_goal[2 * e + 1] = agy; }
+                    if (out.desired_goal) { out.desired_goal[2 * e] = dgx; out.desired_goal[2 * e + 1] = dgy; }
+                    st.pad_grasp[e] = pg; st.pad_pher[e] = ph;
+                    st_state(st, e, s);
+                    st.episode_step[e] = episode_step; st.status[e] = status; st.gripper_open[e] = gripper_open;
+                }
                 phase = PH_DONE;
             } else {
                 // ---- pre-step hooks
@@ -464,9 +480,9 @@ __global__ void __launch_bounds__(WAVE) k_macro_step(const DevModel *mp, DevConf
                     for (int i = 3; i < 5; i++) s.ctrl[i] = (target[i] - s.qpos[i]) * sr_;
                 } else {
                     delta_pre = fmaxf(fabsf(tq - s.qpos[5]), fabsf(tq - s.qpos[6]));
-                    if (phase == PH_CLOSE) grasped = check_grasp(lds, lane, ncon);     // robot_env.py:155, before the step
+                    if (phase == PH_CLOSE) grasped = check_grasp(cx, con, ncon);       // robot_env.py:155, before the step
                 }
-                physics_advance(m, s, xfrc_z, lds, lane, k, ncon, fault);
+                physics_advance(m, cx, s, xfrc_z, k, con, ncon, fault, stm);
                 nsub++; cnt++;
                 // ---- post-step transitions
                 bool to_gripper = false, to_final = false;
@@ -500,7 +516,6 @@ __global__ void __launch_bounds__(WAVE) k_macro_step(const DevModel *mp, DevConf
                     if (stop || cnt == cfg.max_steps) { s.ctrl[5] = 0.f; s.ctrl[6] = 0.f; to_final = true; }
                 }
                 if (to_gripper) {
-                    if (!reached_target && !reached_initial) status = 1;
                     if (open_close > 0.f && !gripper_open) { phase = PH_OPEN; cnt = 0; tq = 0.4f; s.ctrl[5] = 0.5f; s.ctrl[6] = 0.5f; }
                     else if (open_close < 0.f && gripper_open) { phase = PH_CLOSE; cnt = 0; tq = -0.4f; s.ctrl[5] = -1.f; s.ctrl[6] = -1.f; }
                     else to_final = true;
@@ -515,67 +530,67 @@ __global__ void __launch_bounds__(WAVE) k_macro_step(const DevModel *mp, DevConf
 }
 
 // k calls of physics.step() with the stored ctrl (test hook / micro-benchmark)
-__global__ void __launch_bounds__(WAVE) k_substep(const DevModel *mp, StatePtrs st, int nsteps, float xfrc_z, int *fault_out) {
-    const DevModel &m = *mp;
-    float *lds = lds_dyn; const int lane = threadIdx.x;
-    int e = blockIdx.x * WAVE + lane;
+__global__ void __launch_bounds__(WG_THREADS, 1) k_substep(const DevModel m, StatePtrs st, int nsteps, float xfrc_z, int *fault_out) {
+    const Ctx cx = stage_tables(m, lds_dyn);
+    STAMPS_DECL
+    int e = blockIdx.x * EPB + threadIdx.x / KL;
     const bool valid = e < st.n;
     if (!valid) e = st.n - 1;
-    const Hulls H = stage_hulls(m, lds, lane);
     LaneState s; ld_state(st, e, s);
-    Kin k; int ncon = 0, fault = 0;
+    Kin k; Contact con; int ncon = 0, fault = 0;
     for (int i = 0; i < nsteps; i++) {
-        forward_pos(m, H, s, lds, lane, k, ncon, fault);
-        physics_advance(m, s, xfrc_z, lds, lane, k, ncon, fault);
+        forward_pos(m, cx, s, k, con, ncon, fault, stm);
+        physics_advance(m, cx, s, xfrc_z, k, con, ncon, fault, stm);
     }
-    if (valid) { st_state(st, e, s); if (fault_out) fault_out[e] = fault; }
+    if (valid && cx.sub == 0) { st_state(st, e, s); if (fault_out) fault_out[e] = fault; }
+#ifdef GRIP_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) for (int i = 0; i < NSTAMP; i++) g_stamp_acc[i] = stm.acc[i];
+#endif
 }
 
-__global__ void __launch_bounds__(WAVE) k_debug_forward(const DevModel *mp, StatePtrs st, float xfrc_z, int *ncon_out, float *con_out, float *xpos_out,
-                                                         float *qacc_out, float *qs_out, float *M_out, float *bias_out) {
-    const DevModel &m = *mp;
-    float *lds = lds_dyn; const int lane = threadIdx.x;
-    int e = blockIdx.x * WAVE + lane;
+__global__ void __launch_bounds__(WG_THREADS, 1) k_debug_forward(const DevModel m, StatePtrs st, float xfrc_z, int *ncon_out, float *con_out, float *xpos_out,
+                                                                 float *qacc_out, float *qs_out, float *M_out, float *bias_out) {
+    const Ctx cx = stage_tables(m, lds_dyn);
+    STAMPS_DECL
+    int e = blockIdx.x * EPB + threadIdx.x / KL;
     const bool valid = e < st.n;
     if (!valid) e = st.n - 1;
-    const Hulls H = stage_hulls(m, lds, lane);
     LaneState s; ld_state(st, e, s);
-    Kin k; int ncon = 0, fault = 0, iters = 0;
-    forward_pos(m, H, s, lds, lane, k, ncon, fault);
+    Kin k; Contact con; int ncon = 0, fault = 0, iters = 0;
+    forward_pos(m, cx, s, k, con, ncon, fault, stm);
     float Mg[28], Mo[21], qfs[13], qacc[13], jtf[13], qs[13], bias[13];
-    forward_acc(m, s, xfrc_z, lds, lane, k, ncon, fault, Mg, Mo, qfs, qacc, jtf, iters, qs, bias);
+    forward_acc(m, cx, s, xfrc_z, k, con, ncon, fault, Mg, Mo, qfs, qacc, jtf, iters, qs, bias, stm);
     if (!valid) return;
-    ncon_out[e] = ncon;
-    for (int c = 0; c < G_MAXC; c++) {
-        float *o = con_out + ((size_t)e * G_MAXC + c) * 10;
-        int sidx = CB_BASE + c * C_STRIDE;
-        bool live = c < ncon;
-        int meta = live ? __float_as_int(LD(sidx + C_META)) : 0;
-        for (int q = 0; q < 7; q++) o[q] = live ? LD(sidx + q) : 0.f;
-        o[7] = (float)(meta & 255); o[8] = (float)((meta >> 8) & 255); o[9] = (float)iters;
+    if (cx.sub < G_MAXC) {                      // lane c reports contact c
+        float *o = con_out + ((size_t)e * G_MAXC + cx.sub) * 10;
+        bool live = cx.sub < ncon;
+        o[0] = live ? con.p.x : 0.f; o[1] = live ? con.p.y : 0.f; o[2] = live ? con.p.z : 0.f;
+        o[3] = live ? con.n.x : 0.f; o[4] = live ? con.n.y : 0.f; o[5] = live ? con.n.z : 0.f;
+        o[6] = live ? con.dist : 0.f; o[7] = live ? (float)con.g1 : 0.f; o[8] = live ? (float)con.g2 : 0.f; o[9] = (float)iters;
     }
+    if (cx.sub != 0) return;
+    ncon_out[e] = ncon;
     float *xp = xpos_out + (size_t)e * 24;
     xp[0] = xp[1] = xp[2] = 0.f;
     xp[3] = k.pe.x; xp[4] = k.pe.y; xp[5] = k.pe.z;
-    for (int g = 1; g <= 6; g++) { V3 p; M3 R; load_frame(lds, lane, g, p, R); xp[3 * (g + 1)] = p.x; xp[3 * (g + 1) + 1] = p.y; xp[3 * (g + 1) + 2] = p.z; }
+    for (int g = 1; g <= 6; g++) { V3 p; M3 R; load_frame(cx.envl, g, p, R); xp[3 * (g + 1)] = p.x; xp[3 * (g + 1) + 1] = p.y; xp[3 * (g + 1) + 2] = p.z; }
     for (int i = 0; i < 13; i++) { qacc_out[(size_t)e * 13 + i] = qacc[i]; qs_out[(size_t)e * 13 + i] = qs[i]; bias_out[(size_t)e * 13 + i] = bias[i]; }
     for (int i = 0; i < 13; i++) for (int j = 0; j < 13; j++)
         M_out[(size_t)e * 169 + i * 13 + j] = (i < 7 && j < 7) ? Mg[pidx(i, j)] : (i >= 7 && j >= 7) ? Mo[pidx(i - 7, j - 7)] : 0.f;
 }
 
-__global__ void __launch_bounds__(WAVE) k_target_pose(const DevModel *mp, DevConfig cfg, StatePtrs st, const float *actions, float *target_out) {
-    const DevModel &m = *mp;
-    float *lds = lds_dyn; const int lane = threadIdx.x;
-    int e = blockIdx.x * WAVE + lane;
+__global__ void __launch_bounds__(WG_THREADS, 1) k_target_pose(const DevModel m, DevConfig cfg, StatePtrs st, const float *actions, float *target_out) {
+    const Ctx cx = stage_tables(m, lds_dyn);
+    int e = blockIdx.x * EPB + threadIdx.x / KL;
     const bool valid = e < st.n;
     if (!valid) e = st.n - 1;
     LaneState s; ld_state(st, e, s);
-    Kin k; kinematics(m, s.qpos, k, lds, lane);
+    Kin k; kinematics(m, s.qpos, k, cx, false);
     const int adim = cfg.include_roll ? 6 : 5;
     float act[6], target[5], oc;
     for (int i = 0; i < 6; i++) act[i] = i < adim ? actions[(size_t)e * adim + i] : 0.f;
     target_pose(cfg, act, s.qpos, k, target, oc);
-    if (valid) for (int i = 0; i < 5; i++) target_out[(size_t)e * 5 + i] = target[i];
+    if (valid && cx.sub == 0) for (int i = 0; i < 5; i++) target_out[(size_t)e * 5 + i] = target[i];
 }
 
 // [rows][cols] -> [cols][rows]; used by the env-major <-> SoA state hooks
@@ -604,7 +619,7 @@ static StepOutDev to_dev(const GripStepOut *o) {
     d.n_substeps = o->n_substeps; d.fault = o->fault;
     return d;
 }
-static int grid_of(const GripBatch *b) { return (b->n + WAVE - 1) / WAVE; }
+static int grid_of(const GripBatch *b) { return (b->n + EPB - 1) / EPB; }
 
 static int ensure_lds_attr() {
     static bool done = false;
@@ -629,11 +644,12 @@ extern "C" int grip_batch_create(const GripModel *m, int n_envs, int device_id, 
     size_t N = (size_t)n_envs;
     HIPCHK(hipMalloc(&b->d_hull, m->hull_blob.size() * sizeof(unsigned)));
     HIPCHK(hipMemcpy(b->d_hull, m->hull_blob.data(), m->hull_blob.size() * sizeof(unsigned), hipMemcpyHostToDevice));
-    b->lds_bytes = LDS_LANE_BYTES + m->hull_blob.size() * sizeof(unsigned);
+    b->lds_bytes = (m->hull_blob.size() + GT_FLOATS + (size_t)EPB * ENV_FLOATS) * sizeof(float);
     if (b->lds_bytes > 160 * 1024) return fail("model hull tables do not fit the 160 KiB LDS next to the per-lane contact storage");
     HIPCHK(hipMalloc(&b->d_planes, m->planes.size() * sizeof(float)));
     HIPCHK(hipMemcpy(b->d_planes, m->planes.data(), m->planes.size() * sizeof(float), hipMemcpyHostToDevice));
     DevModel hm_ = m->host; hm_.hull_blob = b->d_hull; hm_.hull_planes = b->d_planes;
+    b->hmodel = hm_;
     HIPCHK(hipMalloc(&b->d_model, sizeof(DevModel)));
     HIPCHK(hipMemcpy(b->d_model, &hm_, sizeof(DevModel), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&b->qpos, 14 * N * sizeof(float))); HIPCHK(hipMalloc(&b->qvel, 13 * N * sizeof(float)));
@@ -680,7 +696,7 @@ extern "C" int grip_batch_set_config(GripBatch *b, const GripEnvConfig *c) {
     uint8_t *zero_mask = (uint8_t *)b->scratch;
     HIPCHK(hipMemsetAsync(zero_mask, 0, (size_t)b->n, nullptr));
     StepOutDev none; memset(&none, 0, sizeof none);
-    hipLaunchKernelGGL(k_reset, dim3(1), dim3(WAVE), b->lds_bytes, nullptr, b->d_model, b->cfg, state_ptrs(b), zero_mask, none, b->reset_info);
+    hipLaunchKernelGGL(k_reset, dim3(1), dim3(WG_THREADS), b->lds_bytes, nullptr, b->hmodel, b->cfg, state_ptrs(b), zero_mask, none, b->reset_info);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(nullptr));
     return 0;
@@ -689,7 +705,7 @@ extern "C" int grip_batch_set_config(GripBatch *b, const GripEnvConfig *c) {
 extern "C" int grip_batch_reset(GripBatch *b, const uint8_t *mask_dev, const GripStepOut *out, void *stream) {
     if (!b) return fail("grip_batch_reset: null batch");
     HIPCHK(hipSetDevice(b->device));
-    hipLaunchKernelGGL(k_reset, dim3(grid_of(b)), dim3(WAVE), b->lds_bytes, (hipStream_t)stream, b->d_model, b->cfg, state_ptrs(b), mask_dev,
+    hipLaunchKernelGGL(k_reset, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, (hipStream_t)stream, b->hmodel, b->cfg, state_ptrs(b), mask_dev,
                        to_dev(out), b->reset_info);
     HIPCHK(hipGetLastError());
     return 0;
@@ -701,7 +717,7 @@ extern "C" int grip_batch_step(GripBatch *b, const float *actions_dev, const Gri
     hipStream_t s = (hipStream_t)stream;
     int slot = b->ev_used % EV_RING;
     HIPCHK(hipEventRecord(b->ev0[slot], s));
-    hipLaunchKernelGGL(k_macro_step, dim3(grid_of(b)), dim3(WAVE), b->lds_bytes, s, b->d_model, b->cfg, state_ptrs(b), actions_dev, to_dev(out),
+    hipLaunchKernelGGL(k_macro_step, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, s, b->hmodel, b->cfg, state_ptrs(b), actions_dev, to_dev(out),
                        b->reset_info, b->xfrc_z);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev1[slot], s));
@@ -727,7 +743,7 @@ extern "C" int grip_batch_kernel_time(GripBatch *b, int reset, float *ms_avg, in
 extern "C" int grip_batch_substep(GripBatch *b, int k, void *stream) {
     if (!b || k < 0) return fail("grip_batch_substep: bad arguments");
     HIPCHK(hipSetDevice(b->device));
-    hipLaunchKernelGGL(k_substep, dim3(grid_of(b)), dim3(WAVE), b->lds_bytes, (hipStream_t)stream, b->d_model, state_ptrs(b), k, b->xfrc_z, (int *)nullptr);
+    hipLaunchKernelGGL(k_substep, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, (hipStream_t)stream, b->hmodel, state_ptrs(b), k, b->xfrc_z, (int *)nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -797,7 +813,7 @@ extern "C" int grip_batch_debug_forward(GripBatch *b, int32_t *ncon, float *con,
     HIPCHK(hipMalloc(&d_ncon, N * sizeof(int))); HIPCHK(hipMalloc(&d_con, N * G_MAXC * 10 * sizeof(float))); HIPCHK(hipMalloc(&d_xpos, N * 24 * sizeof(float)));
     HIPCHK(hipMalloc(&d_qacc, N * 13 * sizeof(float))); HIPCHK(hipMalloc(&d_qs, N * 13 * sizeof(float))); HIPCHK(hipMalloc(&d_M, N * 169 * sizeof(float)));
     HIPCHK(hipMalloc(&d_bias, N * 13 * sizeof(float)));
-    hipLaunchKernelGGL(k_debug_forward, dim3(grid_of(b)), dim3(WAVE), b->lds_bytes, s, b->d_model, state_ptrs(b), b->xfrc_z, d_ncon, d_con, d_xpos, d_qacc, d_qs, d_M, d_bias);
+    hipLaunchKernelGGL(k_debug_forward, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, s, b->hmodel, state_ptrs(b), b->xfrc_z, d_ncon, d_con, d_xpos, d_qacc, d_qs, d_M, d_bias);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(ncon, d_ncon, N * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(con, d_con, N * G_MAXC * 10 * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -816,7 +832,7 @@ extern "C" int grip_batch_target_pose(GripBatch *b, const float *actions_dev, fl
     HIPCHK(hipSetDevice(b->device));
     hipStream_t s = (hipStream_t)stream; size_t N = (size_t)b->n;
     float *d_t; HIPCHK(hipMalloc(&d_t, N * 5 * sizeof(float)));
-    hipLaunchKernelGGL(k_target_pose, dim3(grid_of(b)), dim3(WAVE), b->lds_bytes, s, b->d_model, b->cfg, state_ptrs(b), actions_dev, d_t);
+    hipLaunchKernelGGL(k_target_pose, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, s, b->hmodel, b->cfg, state_ptrs(b), actions_dev, d_t);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(target_qpos_host, d_t, N * 5 * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -833,3 +849,9 @@ extern "C" int grip_batch_observe(GripBatch *b, uint8_t *obs_dev, void *stream) 
     if (grip_render_launch(b->d_model, b->cfg, b->qpos, b->pad_grasp, b->pad_pher, b->n, obs_dev, (hipStream_t)stream)) return fail("render launch failed");
     return 0;
 }
+
+#ifdef GRIP_STAMPS
+extern "C" int grip_debug_stamps(unsigned long long *out8) {
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp_acc), sizeof(unsigned long long) * NSTAMP) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -29,5 +29,9 @@ class AugmentedNatureCNN(BaseFeaturesExtractor):
     def forward(self, observations, num_direct_features: int = 2) -> th.Tensor:
         obs = observations["observation"]
         other = obs[:, -1, 0, :num_direct_features]        # grasp code, pheromone level (already / 255)
-        img = self.linear(self.cnn(obs[:, :-1]))
+        # the channel slice is a strided view: MIOpen only has a naive kernel for non-packed inputs (157 ms vs 2 ms
+        # per 4096-sample fwd+bwd on MI355X), so pack it first
+        x = obs[:, :-1]
+        x = x.contiguous(memory_format=th.channels_last) if x.is_cuda else x.contiguous()
+        img = self.linear(self.cnn(x))
         return th.cat((img, other.to(img.dtype)), dim=1)
