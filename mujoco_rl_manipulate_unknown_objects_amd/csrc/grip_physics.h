@@ -31,7 +31,10 @@
 #define EF_FRAMES 0                     // 6 geom frames x 12 (pos3, R9)
 #define EF_STAGE 72                     // G_MAXC staged contacts x ST_STRIDE
 #define ST_STRIDE 11                    // pos3, n3, dist, meta, fs, ft, tran
-#define ENV_FLOATS (EF_STAGE + G_MAXC * ST_STRIDE)
+#define EF_M (EF_STAGE + G_MAXC * ST_STRIDE)   // 13 x 13 mass matrix, row-major
+#define EF_U (EF_M + 169)               // per-contact Hessian vectors: G_MAXC x 6 slots x U_STRIDE (13 entries + weight)
+#define U_STRIDE 14
+#define ENV_FLOATS (EF_U + G_MAXC * 6 * U_STRIDE)
 // per-workgroup geom table (floats per geom): centre3, rbound, fs, ft, invweight, group, hull_vadr
 #define GT_STRIDE 9
 #define GT_FLOATS (GN_GEOM * GT_STRIDE)
@@ -58,11 +61,31 @@ struct Stamps { int dummy; };
 // ---------------------------------------------------------------- cross-lane primitives (16-lane rows)
 template <int CTRL> DEVI float dpp_f(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false)); }
 #define DPP_ROW_ROR(n) (0x120 + (n))
-// all-reduce sum over the 16 lanes of a row: every lane adds the same pairs, fp add is commutative -> identical bits
+// All-reduce sum over the 16 lanes of a row. Every lane adds the same pairs and fp add is commutative, so all lanes get
+// the bit-identical sum -- PROVIDED the adds stay adds: if the compiler contracts the caller's multiply into the first
+// add, lane i computes fma(a_i, b_i, round(a_j b_j)) and lane j fma(a_j, b_j, round(a_i b_i)), which differ in the last
+// bit, and the env's lanes then take different branches (line search, convergence tests). Hence contract(off) + opaque.
 DEVI float sum16(float x) {
-    x += dpp_f<DPP_ROW_ROR(8)>(x); x += dpp_f<DPP_ROW_ROR(4)>(x);
-    x += dpp_f<DPP_ROW_ROR(2)>(x); x += dpp_f<DPP_ROW_ROR(1)>(x);
+#pragma clang fp contract(off)
+    opaque(x);
+    x = x + dpp_f<DPP_ROW_ROR(8)>(x); x = x + dpp_f<DPP_ROW_ROR(4)>(x);
+    x = x + dpp_f<DPP_ROW_ROR(2)>(x); x = x + dpp_f<DPP_ROW_ROR(1)>(x);
     return x;
+}
+// broadcast from lane J of each 16-lane row (ds_swizzle bit-mask mode: lane' = (lane & 0x10) | J inside each 32)
+template <int J> DEVI float bcast16(float x) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), (J << 5) | 0x10)); }
+// component `sub` of a vector that every lane holds (static select chain: no dynamic register indexing)
+DEVI float pick13(const float (&v)[13], int sub) {
+    float r = 0.f;
+#pragma unroll
+    for (int j = 0; j < 13; j++) r = sub == j ? v[j] : r;
+    return r;
+}
+// every lane gets the whole vector whose component i lives in lane i
+DEVI void gather13(float xi, float (&v)[13]) {
+    v[0] = bcast16<0>(xi); v[1] = bcast16<1>(xi); v[2] = bcast16<2>(xi); v[3] = bcast16<3>(xi); v[4] = bcast16<4>(xi);
+    v[5] = bcast16<5>(xi); v[6] = bcast16<6>(xi); v[7] = bcast16<7>(xi); v[8] = bcast16<8>(xi); v[9] = bcast16<9>(xi);
+    v[10] = bcast16<10>(xi); v[11] = bcast16<11>(xi); v[12] = bcast16<12>(xi);
 }
 // ordering point for wave-private LDS traffic (LDS ops of one wave execute in order; this only pins the compiler)
 DEVI void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
@@ -328,42 +351,55 @@ DEVI void bias_forces(const DevModel &m, const Kin &k, const float (&qvel)[13], 
     wrench_project(k, w, bias);
 }
 
-// ---------------------------------------------------------------- dense helpers (packed lower, static indices)
-template <int N>
-DEVI void chol_packed(float *A) {
+// ---------------------------------------------------------------- dense algebra, one matrix row per lane
+// Lane i (i < 13) of an env holds row i of a symmetric positive definite 13 x 13 matrix. Cholesky in place: on exit
+// row[q < i] = L[i][q] and row[i] = 1 / L[i][i]. Row j is handed to the other lanes with ds_swizzle broadcasts.
+template <int J>
+DEVI void chol_col(float (&row)[13], int sub) {
+    float d = row[J], t = row[J];
 #pragma unroll
-    for (int j = 0; j < N; j++) {
-        float s = A[pidx(j, j)];
-#pragma unroll
-        for (int q = 0; q < j; q++) s -= A[pidx(j, q)] * A[pidx(j, q)];
-        s = fmaxf(s, 1e-30f);
-        float inv = rsqrtf(s);
-        A[pidx(j, j)] = inv;                       // the diagonal holds 1 / L_jj
-#pragma unroll
-        for (int i = j + 1; i < N; i++) {
-            float t = A[pidx(i, j)];
-#pragma unroll
-            for (int q = 0; q < j; q++) t -= A[pidx(i, q)] * A[pidx(j, q)];
-            A[pidx(i, j)] = t * inv;
-        }
-    }
+    for (int q = 0; q < J; q++) { d = fmaf(-row[q], row[q], d); t = fmaf(-row[q], bcast16<J>(row[q]), t); }
+    float inv = bcast16<J>(rsqrtf(fmaxf(d, 1e-30f)));          // lane J's diagonal
+    row[J] = sub == J ? inv : t * inv;                         // lanes below J: junk in the unused upper triangle
 }
-template <int N>
-DEVI void chol_solve_packed(const float *L, float *x) {
+DEVI void chol_rows(float (&row)[13], int sub) {
+    chol_col<0>(row, sub); chol_col<1>(row, sub); chol_col<2>(row, sub); chol_col<3>(row, sub); chol_col<4>(row, sub);
+    chol_col<5>(row, sub); chol_col<6>(row, sub); chol_col<7>(row, sub); chol_col<8>(row, sub); chol_col<9>(row, sub);
+    chol_col<10>(row, sub); chol_col<11>(row, sub); chol_col<12>(row, sub);
+}
+// solves L L^T x = b with b_i in lane i; returns x_i in lane i (0 in lanes 13..15)
+template <int J> DEVI void fwd_step(const float (&row)[13], int sub, float &acc, float &y) {
+    float yj = bcast16<J>(acc * row[J]);
+    y = sub == J ? yj : y;
+    acc = sub > J ? fmaf(-row[J], yj, acc) : acc;
+}
+template <int I> DEVI void bwd_step(const float (&row)[13], int sub, float y, float &x) {
+    float s = sum16(sub > I && sub < 13 ? row[I] * x : 0.f);   // sum over q > I of L[q][I] x_q
+    x = sub == I ? (y - s) * row[I] : x;
+}
+DEVI float chol_solve_rows(const float (&row)[13], float b, int sub) {
+    float acc = b, y = 0.f, x = 0.f;
+    fwd_step<0>(row, sub, acc, y); fwd_step<1>(row, sub, acc, y); fwd_step<2>(row, sub, acc, y); fwd_step<3>(row, sub, acc, y);
+    fwd_step<4>(row, sub, acc, y); fwd_step<5>(row, sub, acc, y); fwd_step<6>(row, sub, acc, y); fwd_step<7>(row, sub, acc, y);
+    fwd_step<8>(row, sub, acc, y); fwd_step<9>(row, sub, acc, y); fwd_step<10>(row, sub, acc, y); fwd_step<11>(row, sub, acc, y);
+    fwd_step<12>(row, sub, acc, y);
+    bwd_step<12>(row, sub, y, x); bwd_step<11>(row, sub, y, x); bwd_step<10>(row, sub, y, x); bwd_step<9>(row, sub, y, x);
+    bwd_step<8>(row, sub, y, x); bwd_step<7>(row, sub, y, x); bwd_step<6>(row, sub, y, x); bwd_step<5>(row, sub, y, x);
+    bwd_step<4>(row, sub, y, x); bwd_step<3>(row, sub, y, x); bwd_step<2>(row, sub, y, x); bwd_step<1>(row, sub, y, x);
+    bwd_step<0>(row, sub, y, x);
+    return x;
+}
+// this lane's row of the env's mass matrix (zero in lanes 13..15)
+DEVI void load_mrow(const Ctx &cx, float (&mrow)[13]) {
+    const float *M = cx.envl + EF_M + min(cx.sub, 12) * 13;
 #pragma unroll
-    for (int i = 0; i < N; i++) {
-        float s = x[i];
+    for (int j = 0; j < 13; j++) mrow[j] = cx.sub < 13 ? M[j] : 0.f;
+}
+DEVI float row_dot(const float (&row)[13], const float (&v)[13]) {
+    float s = 0.f;
 #pragma unroll
-        for (int q = 0; q < i; q++) s -= L[pidx(i, q)] * x[q];
-        x[i] = s * L[pidx(i, i)];
-    }
-#pragma unroll
-    for (int i = N - 1; i >= 0; i--) {
-        float s = x[i];
-#pragma unroll
-        for (int q = i + 1; q < N; q++) s -= L[pidx(q, i)] * x[q];
-        x[i] = s * L[pidx(i, i)];
-    }
+    for (int j = 0; j < 13; j++) s = fmaf(row[j], v[j], s);
+    return s;
 }
 
 // ---------------------------------------------------------------- collision
@@ -645,7 +681,7 @@ DEVI float impedance(const float *si, float pos, float margin) {
     return si[0] + y * (si[1] - si[0]);
 }
 
-struct Limits { float sgn[7], D[7], aref[7]; };
+struct Limits { float sgn_pad[13], D_pad[13], aref_pad[13]; };      // entries 0..6 used (one joint limit per dof), rest 0
 
 // Elliptic condim-4 contact in jar space:  s(jar) = (D0 / 2 mu^2) dist^2(U, K), U = diag(mu, fs, fs, ft) jar,
 // K = {U0 >= mu |U_t|}. Returns the cost and gradient, plus the Hessian in rank-structured form
@@ -708,9 +744,11 @@ DEVI void make_constraints(const DevModel &m, const Kin &k, const float (&qpos)[
         if (lo < 0.f) { sgn = 1.f; dist = lo; } else if (hi < 0.f) { sgn = -1.f; dist = hi; }
         float imp = impedance(m.lim_solimp, dist, 0.f);
         float R = fmaxf(1e-15f, (1.f - imp) * m.dof_invweight0[j] / imp);
-        lim.sgn[j] = sgn; lim.D[j] = 1.0f / R;
-        lim.aref[j] = -m.b_lim * (sgn * qvel[j]) - m.k_lim * imp * dist;
+        lim.sgn_pad[j] = sgn; lim.D_pad[j] = 1.0f / R;
+        lim.aref_pad[j] = -m.b_lim * (sgn * qvel[j]) - m.k_lim * imp * dist;
     }
+#pragma unroll
+    for (int j = 7; j < 13; j++) { lim.sgn_pad[j] = 0.f; lim.D_pad[j] = 0.f; lim.aref_pad[j] = 0.f; }
 #pragma unroll
     for (int r = 0; r < 4; r++) { c.aref[r] = 0.f; c.jar[r] = 0.f; c.jv[r] = 0.f; }
     if (live) {
@@ -725,28 +763,12 @@ DEVI void make_constraints(const DevModel &m, const Kin &k, const float (&qpos)[
     }
 }
 
-// Hessian storage: the full problem keeps 13x13 packed lower (91); the object-only problem (no constraint touches
-// the gripper: the usual case, object resting on the floor while the gripper moves freely) keeps the 6x6 object block (21).
-template <bool OBJ> struct HessT { static constexpr int N = OBJ ? 21 : 91; };
-template <bool OBJ> constexpr DEVI int hidx(int i, int j) { return OBJ ? pidx(i - 7, j - 7) : pidx(i, j); }
-
-// H += w * u u^T restricted to dofs [LO, 13)
-template <bool OBJ, int LO>
-DEVI void rank1(float *Hp, const float (&u)[13], float w) {
-#pragma unroll
-    for (int i = LO; i < 13; i++) {
-        float wi = w * u[i];
-#pragma unroll
-        for (int j = LO; j <= i; j++) Hp[hidx<OBJ>(i, j)] = fmaf(wi, u[j], Hp[hidx<OBJ>(i, j)]);
-    }
-}
-
 // One cooperative pass over all constraints at acceleration x (identical in the 16 lanes): each lane prices ITS contact
-// (jar kept in its registers), the 16 lanes all-reduce the cost and J^T force; if wantH each lane folds its contact's
-// six weighted rank-1 terms into a private matrix and the matrices are all-reduced entry by entry.
-template <bool OBJ>
-DEVI float constraint_pass(const DevModel &m, const Kin &k, const Limits &lim, const float (&x)[13],
-                           Contact &c, bool live, float (&jtf)[13], float *Hp, bool wantH) {
+// (jar kept in its registers) and, for j < 7, ITS joint limit; the 16 lanes all-reduce the cost and J^T force. If wantH
+// the contact's six weighted Hessian vectors (rows n, t1, t2, torsion and the two cone combinations) go to the env's
+// LDS slots, from where every lane assembles its own row of H (assemble_rows).
+DEVI float constraint_pass(const DevModel &m, const Kin &k, const Ctx &cx, float lsgn, float lD, float laref, float xi,
+                           const float (&x)[13], Contact &c, bool live, float (&jtf)[13], bool wantH, float &hdiag) {
     float cost = 0.f;
     float jl[13];
 #pragma unroll
@@ -759,7 +781,7 @@ DEVI float constraint_pass(const DevModel &m, const Kin &k, const Limits &lim, c
     V3 t1, t2; make_tangents(c.n, t1, t2);
     if (live) {
         Twist t; twists(k, x, t);
-        float jar[4]; contact_rows<OBJ>(k, t, c, t1, t2, jar);
+        float jar[4]; contact_rows<false>(k, t, c, t1, t2, jar);
 #pragma unroll
         for (int r = 0; r < 4; r++) { jar[r] -= c.aref[r]; c.jar[r] = jar[r]; }
         cone_eval(jar, c.D0, m.impratio, c.fs, c.ft, cn);
@@ -767,75 +789,69 @@ DEVI float constraint_pass(const DevModel &m, const Kin &k, const Limits &lim, c
         V3 F = c.n * (-cn.grad[0]) + t1 * (-cn.grad[1]) + t2 * (-cn.grad[2]);
         V3 Tq = c.n * (-cn.grad[3]);
         Wrench w; wrench_zero(w);
-        if (OBJ) { w.FO = F; w.TO = Tq + cross(c.p - k.po, F); }
-        else { wrench_add(k, w, c.gB, c.p, F, Tq, 1.f); wrench_add(k, w, c.gA, c.p, F, Tq, -1.f); }
-        if (OBJ) {
-            jl[7] = w.FO.x; jl[8] = w.FO.y; jl[9] = w.FO.z;
-            V3 tl = multv(k.Ro, w.TO); jl[10] = tl.x; jl[11] = tl.y; jl[12] = tl.z;
-        } else wrench_project(k, w, jl);
+        wrench_add(k, w, c.gB, c.p, F, Tq, 1.f); wrench_add(k, w, c.gA, c.p, F, Tq, -1.f);
+        wrench_project(k, w, jl);
     }
+    // joint limit owned by this lane (lanes 0..6): J = sgn at dof `sub`
+    float ljar = lsgn * xi - laref;
+    bool lact = lsgn != 0.f && ljar < 0.f;
+    float lforce = lact ? -lD * ljar * lsgn : 0.f;
+    cost += lact ? 0.5f * lD * ljar * ljar : 0.f;
+    hdiag = lact ? lD : 0.f;
     cost = sum16(cost);
 #pragma unroll
-    for (int i = OBJ ? 7 : 0; i < 13; i++) jtf[i] = sum16(jl[i]);
-    if (OBJ) {
+    for (int i = 0; i < 13; i++) jtf[i] = sum16(jl[i] + (cx.sub == i ? lforce : 0.f));
+    if (wantH && live) {
+        float *U = cx.envl + EF_U + cx.sub * 6 * U_STRIDE;
+        float ua[13], ub[13];
 #pragma unroll
-        for (int i = 0; i < 7; i++) jtf[i] = 0.f;
-    }
-    if (wantH) {
-        // this lane's contact folds its six weighted rank-1 terms into Hp (zero on entry), then the 16 lanes all-reduce
-        // Hp entry by entry in place; the caller adds the mass matrix afterwards
-        constexpr int NH = HessT<OBJ>::N;
-        const bool any = live && (cn.w[0] != 0.f || cn.w[1] != 0.f || cn.ka != 0.f);
-        if (any) {
-            const bool objonly = OBJ || (c.gA == GRP_WORLD && c.gB == GRP_O);     // rows touch dofs 7..12 only
-            float ua[13], ub[13];
-#pragma unroll
-            for (int i = 0; i < 13; i++) { ua[i] = 0.f; ub[i] = 0.f; }
+        for (int i = 0; i < 13; i++) { ua[i] = 0.f; ub[i] = 0.f; }
 #pragma unroll 1
-            for (int r = 0; r < 4; r++) {
-                float j[13];
+        for (int r = 0; r < 4; r++) {
+            float j[13];
 #pragma unroll
-                for (int i = 0; i < 13; i++) j[i] = 0.f;
-                V3 e = r == 1 ? t1 : r == 2 ? t2 : c.n;
-                if (OBJ) row_add(k, j, GRP_O, c.p, e, 1.f, r == 3);
-                else { row_add(k, j, c.gB, c.p, e, 1.f, r == 3); row_add(k, j, c.gA, c.p, e, -1.f, r == 3); }
-                float ar = r == 0 ? cn.a[0] : r == 1 ? cn.a[1] : r == 2 ? cn.a[2] : cn.a[3];
-                float br = r == 0 ? cn.b[0] : r == 1 ? cn.b[1] : r == 2 ? cn.b[2] : cn.b[3];
-                float wr = r == 0 ? cn.w[0] : r == 1 ? cn.w[1] : r == 2 ? cn.w[2] : cn.w[3];
+            for (int i = 0; i < 13; i++) j[i] = 0.f;
+            V3 e = r == 1 ? t1 : r == 2 ? t2 : c.n;
+            row_add(k, j, c.gB, c.p, e, 1.f, r == 3); row_add(k, j, c.gA, c.p, e, -1.f, r == 3);
+            float ar = r == 0 ? cn.a[0] : r == 1 ? cn.a[1] : r == 2 ? cn.a[2] : cn.a[3];
+            float br = r == 0 ? cn.b[0] : r == 1 ? cn.b[1] : r == 2 ? cn.b[2] : cn.b[3];
+            float wr = r == 0 ? cn.w[0] : r == 1 ? cn.w[1] : r == 2 ? cn.w[2] : cn.w[3];
 #pragma unroll
-                for (int i = OBJ ? 7 : 0; i < 13; i++) { ua[i] = fmaf(ar, j[i], ua[i]); ub[i] = fmaf(br, j[i], ub[i]); }
-                if (objonly) rank1<OBJ, 7>(Hp, j, wr); else rank1<OBJ, OBJ ? 7 : 0>(Hp, j, wr);
-            }
-            if (cn.ka != 0.f) {
-#pragma unroll 1
-                for (int q = 0; q < 2; q++) {
-                    float u[13];
-#pragma unroll
-                    for (int i = 0; i < 13; i++) u[i] = q == 0 ? ua[i] : ub[i];
-                    float wq = q == 0 ? cn.ka : -cn.kb;
-                    if (objonly) rank1<OBJ, 7>(Hp, u, wq); else rank1<OBJ, OBJ ? 7 : 0>(Hp, u, wq);
-                }
-            }
+            for (int i = 0; i < 13; i++) { ua[i] = fmaf(ar, j[i], ua[i]); ub[i] = fmaf(br, j[i], ub[i]); U[r * U_STRIDE + i] = j[i]; }
+            U[r * U_STRIDE + 13] = wr;
         }
 #pragma unroll
-        for (int i = 0; i < NH; i++) Hp[i] = sum16(Hp[i]);
-    }
-    if (!OBJ) {                 // joint limits: identical in every lane, added after the all-reduce
-#pragma unroll
-        for (int j = 0; j < 7; j++) {
-            float jar = lim.sgn[j] * x[j] - lim.aref[j];
-            bool act = lim.sgn[j] != 0.f && jar < 0.f;
-            jtf[j] += act ? -lim.D[j] * jar * lim.sgn[j] : 0.f;
-            cost += act ? 0.5f * lim.D[j] * jar * jar : 0.f;
-            if (wantH) Hp[hidx<OBJ>(OBJ ? 7 : j, OBJ ? 7 : j)] += act ? lim.D[j] : 0.f;
-        }
+        for (int i = 0; i < 13; i++) { U[4 * U_STRIDE + i] = ua[i]; U[5 * U_STRIDE + i] = ub[i]; }
+        U[4 * U_STRIDE + 13] = cn.ka; U[5 * U_STRIDE + 13] = -cn.kb;
     }
     return cost;
 }
 
-// phi'(alpha), phi''(alpha) of the total cost along the search direction: this lane's contact, then all-reduce
-template <bool OBJ>
-DEVI void line_eval(const DevModel &m, const Limits &lim, const float (&qacc)[13], const float (&p)[13],
+// row `sub` of  H = M + sum over the env's contact slots of  w u u^T  (+ this lane's joint-limit term on the diagonal)
+DEVI void assemble_rows(const Ctx &cx, int ncon, const float (&mrow)[13], float hdiag, float (&row)[13]) {
+#pragma unroll
+    for (int j = 0; j < 13; j++) row[j] = mrow[j];
+    const int isub = min(cx.sub, 12);
+    const float *U = cx.envl + EF_U;
+    for (int s = 0; s < 6 * ncon; s++) {
+        const float *u = U + s * U_STRIDE;
+        float w = u[13];
+        if (w != 0.f) {
+            float wi = w * u[isub];
+#pragma unroll
+            for (int j = 0; j < 13; j++) row[j] = fmaf(wi, u[j], row[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 13; j++) row[j] += cx.sub == j ? hdiag : 0.f;
+    if (cx.sub >= 13) {                                    // lanes 13..15 carry identity rows
+#pragma unroll
+        for (int j = 0; j < 13; j++) row[j] = 0.f;
+    }
+}
+
+// phi'(alpha), phi''(alpha) of the total cost along the search direction: this lane's contact and limit, then all-reduce
+DEVI void line_eval(const DevModel &m, float lsgn, float lD, float laref, float qi, float pi,
                     const Contact &c, bool live, float alpha, float g0, float g1, float &dphi, float &ddphi) {
     float dp = 0.f, hp = 0.f;
     if (live) {
@@ -847,82 +863,60 @@ DEVI void line_eval(const DevModel &m, const Limits &lim, const float (&qacc)[13
         for (int r = 0; r < 4; r++) dp = fmaf(cn.grad[r], c.jv[r], dp);
         hp = cone_quad(cn, c.jv);
     }
-    dp = sum16(dp) + g0 + alpha * g1; hp = sum16(hp) + g1;
-    if (!OBJ) {
-#pragma unroll
-        for (int j = 0; j < 7; j++) {
-            float jv = lim.sgn[j] * p[j];
-            float x = lim.sgn[j] * qacc[j] - lim.aref[j] + alpha * jv;
-            bool act = lim.sgn[j] != 0.f && x < 0.f;
-            dp += act ? lim.D[j] * x * jv : 0.f; hp += act ? lim.D[j] * jv * jv : 0.f;
-        }
-    }
-    dphi = dp; ddphi = hp;
+    {   float jv = lsgn * pi;
+        float xx = lsgn * qi - laref + alpha * jv;
+        bool act = lsgn != 0.f && xx < 0.f;
+        dp += act ? lD * xx * jv : 0.f; hp += act ? lD * jv * jv : 0.f; }
+    dphi = sum16(dp) + g0 + alpha * g1; ddphi = sum16(hp) + g1;
 }
 
 // Primal Newton solve of  min 1/2 (a - a_s)^T M (a - a_s) + s(J a - aref)   (mj_solNewton's problem), cooperatively.
 // Staged loop with ONE constraint-pass site: stage 0 prices qacc_smooth, stage 1 prices qacc_warmstart (the better
 // one is the start, as MuJoCo does) and stops right there when the start already satisfies the gradient tolerance;
-// stages >= 2 are Newton iterations (Hessian, Cholesky, exact line search). All control flow depends only on
-// all-reduced values, so the 16 lanes of an env always agree. OBJ = only the 6 object dofs are constrained.
-template <bool OBJ>
-DEVI void solve_newton(const DevModel &m, const Kin &k, const float (&Mg)[28], const float (&Mo)[21], const Limits &lim,
-                       const float (&qs)[13], const float (&warm)[13], Contact &c, bool live,
-                       float (&qacc)[13], float (&jtf)[13], int &fault, int &iters) {
-    constexpr int LO = OBJ ? 7 : 0;
-    constexpr int NH = HessT<OBJ>::N;
+// stages >= 2 are Newton iterations: every lane assembles and factorises its own row of the Hessian, the direction comes
+// from the lane-distributed triangular solves, the exact line search all-reduces two scalars per evaluation. All control
+// flow depends only on all-reduced values, so the 16 lanes of an env always agree.
+DEVI void solve_newton(const DevModel &m, const Kin &k, const Ctx &cx, float lsgn, float lD, float laref,
+                       const float (&qs)[13], float qsi, const float (&warm)[13], Contact &c, bool live, int ncon,
+                       float (&qacc)[13], float (&jtf)[13], int &fault, int &iters, float *dbgH = nullptr, float *dbgA = nullptr, float *dbgB = nullptr) {
     const float scale = 1.0f / (m.meaninertia * 13.f);
     const float tol = fmaxf(m.tolerance, 1e-5f);            // fp32 noise floor of the scaled gradient is ~1e-6
-    float H[NH], Md[13], x[13];
+    float mrow[13]; load_mrow(cx, mrow);
+    const float warmi = pick13(warm, cx.sub);
+    float x[13], xi = qsi, qi = qsi;                        // x: evaluation point (all lanes); xi / qi: own component of x / qacc
     float cost = 0.f, cs = 0.f;
     int stage = 0; bool done = false;
     iters = 0;
 #pragma unroll
-    for (int i = 0; i < 13; i++) { qacc[i] = qs[i]; x[i] = qs[i]; Md[i] = 0.f; }
+    for (int i = 0; i < 13; i++) { qacc[i] = qs[i]; x[i] = qs[i]; }
     while (__any(!done)) {
         if (!done) {
             const bool wantH = stage >= 2;
-            if (wantH) {
-#pragma unroll
-                for (int i = 0; i < NH; i++) H[i] = 0.f;
-            }
             float dq[13];
 #pragma unroll
             for (int i = 0; i < 13; i++) dq[i] = x[i] - qs[i];
-            mass_mulv(Mg, Mo, dq, Md);
-            float newcost = 0.f;
-#pragma unroll
-            for (int i = LO; i < 13; i++) newcost = fmaf(0.5f * Md[i], dq[i], newcost);
-            newcost += constraint_pass<OBJ>(m, k, lim, x, c, live, jtf, H, wantH);
-            if (wantH) {                                   // H = M + J^T s'' J
-                if (!OBJ) {
-#pragma unroll
-                    for (int i = 0; i < 7; i++)
-#pragma unroll
-                        for (int j = 0; j <= i; j++) H[hidx<OBJ>(OBJ ? 7 : i, OBJ ? 7 : j)] += Mg[pidx(i, j)];
-                }
-#pragma unroll
-                for (int i = 0; i < 6; i++)
-#pragma unroll
-                    for (int j = 0; j <= i; j++) H[hidx<OBJ>(7 + i, 7 + j)] += Mo[pidx(i, j)];
-            }
-            float gn = 0.f;
-#pragma unroll
-            for (int i = LO; i < 13; i++) { float g = Md[i] - jtf[i]; gn = fmaf(g, g, gn); }
-            const bool gconv = scale * sqrtf(gn) < tol;
+            float Mdi = row_dot(mrow, dq);                                  // (M (x - qs))_sub
+            float hdiag;
+            float newcost = sum16(0.5f * Mdi * (xi - qsi));
+            newcost += constraint_pass(m, k, cx, lsgn, lD, laref, xi, x, c, live, jtf, wantH, hdiag);
+            float gi = Mdi - pick13(jtf, cx.sub);                           // gradient component of this lane
+            const bool gconv = scale * sqrtf(sum16(gi * gi)) < tol;
             if (stage == 0) {
                 cs = newcost; stage = 1;
 #pragma unroll
-                for (int i = LO; i < 13; i++) x[i] = warm[i];
+                for (int i = 0; i < 13; i++) x[i] = warm[i];
+                xi = warmi;
                 if (gconv) done = true;                     // qacc_smooth already optimal (constraints inactive)
             } else if (stage == 1) {
                 if (newcost < cs) {
 #pragma unroll
-                    for (int i = LO; i < 13; i++) qacc[i] = warm[i];
+                    for (int i = 0; i < 13; i++) qacc[i] = warm[i];
+                    qi = warmi;
                     if (gconv) done = true;
                 } else {
 #pragma unroll
-                    for (int i = LO; i < 13; i++) x[i] = qs[i];
+                    for (int i = 0; i < 13; i++) x[i] = qs[i];
+                    xi = qsi;
                 }
                 stage = 2;
             } else {
@@ -932,24 +926,23 @@ DEVI void solve_newton(const DevModel &m, const Kin &k, const float (&Mg)[28], c
                 if (!stop && iters >= NEWTON_MAXIT) { stop = true; fault |= 4; }
                 if (stop) done = true;
                 else {
-                    float p[13];
+                    wave_sync();                            // the contact lanes' Hessian vectors are in LDS
+                    float row[13];
+                    assemble_rows(cx, ncon, mrow, hdiag, row);
+                    if (dbgH && iters == 0 && cx.sub < 13) {
 #pragma unroll
-                    for (int i = 0; i < 13; i++) p[i] = 0.f;
-                    chol_packed<13 - LO>(H);
-                    {   float pr[13 - LO];
-#pragma unroll
-                        for (int i = LO; i < 13; i++) pr[i - LO] = -(Md[i] - jtf[i]);
-                        chol_solve_packed<13 - LO>(H, pr);
-#pragma unroll
-                        for (int i = LO; i < 13; i++) p[i] = pr[i - LO]; }
-                    float Mpv[13]; mass_mulv(Mg, Mo, p, Mpv);
-                    float g0 = 0.f, g1 = 0.f;
-#pragma unroll
-                    for (int i = LO; i < 13; i++) { g0 = fmaf(Mpv[i], qacc[i] - qs[i], g0); g1 = fmaf(Mpv[i], p[i], g1); }
+                        for (int j = 0; j < 13; j++) dbgH[cx.sub * 13 + j] = row[j];
+                    }
+                    if (cx.sub >= 13) row[12] = 1.f;        // harmless: those lanes never take part (sub > 12 masked everywhere)
+                    chol_rows(row, cx.sub);
+                    float pi = chol_solve_rows(row, -gi, cx.sub);
+                    float p[13]; gather13(pi, p);
+                    float Mpi = row_dot(mrow, p);
+                    float g0 = sum16(Mpi * (qi - qsi)), g1 = sum16(Mpi * pi);
                     if (live) {
                         Twist tp; twists(k, p, tp);
                         V3 t1, t2; make_tangents(c.n, t1, t2);
-                        contact_rows<OBJ>(k, tp, c, t1, t2, c.jv);
+                        contact_rows<false>(k, tp, c, t1, t2, c.jv);
                     }
                     // exact line search: safeguarded 1-D Newton on phi'(alpha); one evaluation site
                     float lo = 0.f, hi = -1.f, alpha = 0.f, gtol = 0.f;
@@ -958,7 +951,7 @@ DEVI void solve_newton(const DevModel &m, const Kin &k, const float (&Mg)[28], c
                         if (!__any(!lsdone)) break;
                         if (!lsdone) {
                             float dp, hp;
-                            line_eval<OBJ>(m, lim, qacc, p, c, live, alpha, g0, g1, dp, hp);
+                            line_eval(m, lsgn, lD, laref, qi, pi, c, live, alpha, g0, g1, dp, hp);
                             if (ls == 0) {
                                 if (dp >= 0.f) { descent = false; lsdone = true; }
                                 gtol = 1e-4f * fabsf(dp) + 1e-30f;
@@ -979,7 +972,8 @@ DEVI void solve_newton(const DevModel &m, const Kin &k, const float (&Mg)[28], c
                     if (!descent) done = true;
                     else {
 #pragma unroll
-                        for (int i = LO; i < 13; i++) { qacc[i] = fmaf(alpha, p[i], qacc[i]); x[i] = qacc[i]; }
+                        for (int i = 0; i < 13; i++) { qacc[i] = fmaf(alpha, p[i], qacc[i]); x[i] = qacc[i]; }
+                        qi = fmaf(alpha, pi, qi); xi = qi;
                         iters++; stage++;
                     }
                 }
@@ -1002,9 +996,19 @@ DEVI void forward_pos(const DevModel &m, const Ctx &cx, LaneState &s, Kin &k, Co
 
 // dynamics stage (mj_step2's share up to qacc) on top of forward_pos
 DEVI void forward_acc(const DevModel &m, const Ctx &cx, LaneState &s, float xfrc_z, const Kin &k, Contact &con, int ncon, int &fault,
-                      float (&Mg)[28], float (&Mo)[21], float (&qfrc_smooth)[13], float (&qacc)[13], float (&jtf)[13], int &iters,
-                      float *dbg_qs, float *dbg_bias, Stamps &st) {
-    mass_matrix(m, k, Mg, Mo);
+                      float (&qfrc_smooth)[13], float (&qacc)[13], float (&jtf)[13], int &iters,
+                      float *dbg_qs, float *dbg_bias, Stamps &st, float *dbgH = nullptr, float *dbgA = nullptr, float *dbgB = nullptr) {
+    {   float Mg[28], Mo[21];
+        mass_matrix(m, k, Mg, Mo);
+        if (cx.sub == 0) {                  // one lane publishes the env's mass matrix, every lane then owns a row of it
+            float *M = cx.envl + EF_M;
+#pragma unroll
+            for (int i = 0; i < 13; i++)
+#pragma unroll
+                for (int j = 0; j < 13; j++) M[i * 13 + j] = (i < 7 && j < 7) ? Mg[pidx(i, j)] : (i >= 7 && j >= 7) ? Mo[pidx(i - 7, j - 7)] : 0.f;
+        }
+    }
+    wave_sync();
     float bias[13];
     bias_forces(m, k, s.qvel, bias);
     if (dbg_bias) {
@@ -1017,23 +1021,13 @@ DEVI void forward_acc(const DevModel &m, const Ctx &cx, LaneState &s, float xfrc
     for (int u = 0; u < 7; u++) qfrc_smooth[u] += m.gear[u] * fminf(fmaxf(s.ctrl[u], m.ctrlrange[u][0]), m.ctrlrange[u][1]);
     // xfrc_applied on body ee (force along z at its COM = frame origin): only the z slide sees it
     qfrc_smooth[2] += xfrc_z;
-    float qs[13];
-    {   // block solves M qacc_smooth = qfrc_smooth  (gripper 7x7, object 6x6; the cross block is zero)
-        float Lg[28], Lo[21], xg[7], xo[6];
-#pragma unroll
-        for (int i = 0; i < 28; i++) Lg[i] = Mg[i];
-#pragma unroll
-        for (int i = 0; i < 21; i++) Lo[i] = Mo[i];
-        chol_packed<7>(Lg); chol_packed<6>(Lo);
-#pragma unroll
-        for (int i = 0; i < 7; i++) xg[i] = qfrc_smooth[i];
-#pragma unroll
-        for (int i = 0; i < 6; i++) xo[i] = qfrc_smooth[7 + i];
-        chol_solve_packed<7>(Lg, xg); chol_solve_packed<6>(Lo, xo);
-#pragma unroll
-        for (int i = 0; i < 7; i++) qs[i] = xg[i];
-#pragma unroll
-        for (int i = 0; i < 6; i++) qs[7 + i] = xo[i];
+    // qacc_smooth = M^-1 qfrc_smooth with the lane-distributed Cholesky
+    float qs[13], qsi;
+    {   float row[13]; load_mrow(cx, row);
+        if (cx.sub >= 13) row[12] = 1.f;
+        chol_rows(row, cx.sub);
+        qsi = chol_solve_rows(row, pick13(qfrc_smooth, cx.sub), cx.sub);
+        gather13(qsi, qs);
     }
     if (dbg_qs) {
 #pragma unroll
@@ -1043,43 +1037,52 @@ DEVI void forward_acc(const DevModel &m, const Ctx &cx, LaneState &s, float xfrc
     Limits lim;
     const bool live = cx.sub < ncon;
     make_constraints(m, k, s.qpos, s.qvel, lim, con, live);
+    // lane j < 7 owns joint limit j
+    const float lsgn = cx.sub < 7 ? pick13(reinterpret_cast<const float (&)[13]>(lim.sgn_pad), cx.sub) : 0.f;
+    const float lD = pick13(reinterpret_cast<const float (&)[13]>(lim.D_pad), cx.sub);
+    const float laref = pick13(reinterpret_cast<const float (&)[13]>(lim.aref_pad), cx.sub);
     STAMP(st, 3);
-    bool anylim = false;
-#pragma unroll
-    for (int j = 0; j < 7; j++) anylim |= lim.sgn[j] != 0.f;
+    const bool anylim = group_bits(__ballot(lsgn != 0.f), cx.lane) != 0u;
     iters = 0;
-    // does any constraint touch the gripper? (joint limit, or a contact whose geoms are not floor + object)
-    const bool grip = anylim || group_bits(__ballot(live && !(con.g1 == 0 && con.g2 == 6)), cx.lane) != 0u;
     const bool constrained = ncon > 0 || anylim;
+    // when no constraint touches the gripper (no joint limit, only floor-object contacts) its block of the problem is
+    // unconstrained and decoupled: start it at qacc_smooth, which is then already optimal for those 7 dofs
+    const bool grip = anylim || group_bits(__ballot(live && !(con.g1 == 0 && con.g2 == 6)), cx.lane) != 0u;
+    float warm[13];
 #pragma unroll
-    for (int i = 0; i < 13; i++) { qacc[i] = qs[i]; jtf[i] = 0.f; }
-    if (__any(constrained && !grip)) {
-        if (constrained && !grip) solve_newton<true>(m, k, Mg, Mo, lim, qs, s.warm, con, live, qacc, jtf, fault, iters);
-    }
-    if (__any(constrained && grip)) {
-        if (constrained && grip) solve_newton<false>(m, k, Mg, Mo, lim, qs, s.warm, con, live, qacc, jtf, fault, iters);
+    for (int i = 0; i < 13; i++) { qacc[i] = qs[i]; jtf[i] = 0.f; warm[i] = (i < 7 && !grip) ? qs[i] : s.warm[i]; }
+    if (__any(constrained)) {
+        if (constrained) solve_newton(m, k, cx, lsgn, lD, laref, qs, qsi, warm, con, live, ncon, qacc, jtf, fault, iters, dbgH, dbgA, dbgB);
     }
     STAMP(st, 4);
 }
 
 // dynamics + integration of one physics.step(); forward_pos must have run on the current state
 DEVI void physics_advance(const DevModel &m, const Ctx &cx, LaneState &s, float xfrc_z, const Kin &k, Contact &con, int ncon, int &fault, Stamps &st) {
-    float Mg[28], Mo[21], qfs[13], qacc[13], jtf[13]; int iters;
-    forward_acc(m, cx, s, xfrc_z, k, con, ncon, fault, Mg, Mo, qfs, qacc, jtf, iters, nullptr, nullptr, st);
+    float qfs[13], qacc[13], jtf[13]; int iters;
+    forward_acc(m, cx, s, xfrc_z, k, con, ncon, fault, qfs, qacc, jtf, iters, nullptr, nullptr, st);
     const float h = m.timestep;
-    // semi-implicit Euler with implicit joint damping: (M + h D) a' = qfrc_smooth + J^T f.
-    // Only the gripper block carries damping; for the object block a' = qacc.
-    float xg[7];
+    // semi-implicit Euler with implicit joint damping: (M + h D) a' = qfrc_smooth + J^T f   (mj_Euler). The object block has
+    // no damping, so a' = qacc there; the distributed solve covers all 13 dofs at once.
+    float acc[13];
+    {   float row[13]; load_mrow(cx, row);
+        float dmp[13];
 #pragma unroll
-    for (int i = 0; i < 7; i++) { Mg[pidx(i, i)] += h * m.damping[i]; xg[i] = qfs[i] + jtf[i]; }
-    chol_packed<7>(Mg);
-    chol_solve_packed<7>(Mg, xg);
+        for (int i = 0; i < 13; i++) dmp[i] = m.damping[i];
+#pragma unroll
+        for (int j = 0; j < 13; j++) row[j] += cx.sub == j ? h * dmp[j] : 0.f;
+        if (cx.sub >= 13) row[12] = 1.f;
+        chol_rows(row, cx.sub);
+        float rhs[13];
+#pragma unroll
+        for (int i = 0; i < 13; i++) rhs[i] = qfs[i] + jtf[i];
+        float ai = chol_solve_rows(row, pick13(rhs, cx.sub), cx.sub);
+        gather13(ai, acc);
+    }
 #pragma unroll
     for (int i = 0; i < 13; i++) s.warm[i] = qacc[i];
 #pragma unroll
-    for (int i = 0; i < 7; i++) s.qvel[i] = fmaf(h, xg[i], s.qvel[i]);
-#pragma unroll
-    for (int i = 7; i < 13; i++) s.qvel[i] = fmaf(h, qacc[i], s.qvel[i]);
+    for (int i = 0; i < 13; i++) s.qvel[i] = fmaf(h, acc[i], s.qvel[i]);
 #pragma unroll
     for (int i = 0; i < 10; i++) s.qpos[i] = fmaf(h, s.qvel[i], s.qpos[i]);
     V3 w = v3(s.qvel[10], s.qvel[11], s.qvel[12]);

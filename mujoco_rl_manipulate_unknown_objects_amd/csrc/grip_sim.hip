@@ -548,7 +548,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_substep(const DevModel m, Sta
 #endif
 }
 
-__global__ void __launch_bounds__(WG_THREADS, 1) k_debug_forward(const DevModel m, StatePtrs st, float xfrc_z, int *ncon_out, float *con_out, float *xpos_out,
+__global__ void __launch_bounds__(WG_THREADS, 1) k_debug_forward(const DevModel m, StatePtrs st, float xfrc_z, int getenv_dbgH, int *ncon_out, float *con_out, float *xpos_out,
                                                                  float *qacc_out, float *qs_out, float *M_out, float *bias_out) {
     const Ctx cx = stage_tables(m, lds_dyn);
     STAMPS_DECL
@@ -558,8 +558,8 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_debug_forward(const DevModel 
     LaneState s; ld_state(st, e, s);
     Kin k; Contact con; int ncon = 0, fault = 0, iters = 0;
     forward_pos(m, cx, s, k, con, ncon, fault, stm);
-    float Mg[28], Mo[21], qfs[13], qacc[13], jtf[13], qs[13], bias[13];
-    forward_acc(m, cx, s, xfrc_z, k, con, ncon, fault, Mg, Mo, qfs, qacc, jtf, iters, qs, bias, stm);
+    float qfs[13], qacc[13], jtf[13], qs[13], bias[13];
+    forward_acc(m, cx, s, xfrc_z, k, con, ncon, fault, qfs, qacc, jtf, iters, qs, bias, stm, getenv_dbgH ? M_out + (size_t)e * 169 : nullptr, getenv_dbgH ? bias_out + (size_t)e * 13 : nullptr, getenv_dbgH ? xpos_out + (size_t)e * 24 : nullptr);
     if (!valid) return;
     if (cx.sub < G_MAXC) {                      // lane c reports contact c
         float *o = con_out + ((size_t)e * G_MAXC + cx.sub) * 10;
@@ -570,13 +570,13 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_debug_forward(const DevModel 
     }
     if (cx.sub != 0) return;
     ncon_out[e] = ncon;
-    float *xp = xpos_out + (size_t)e * 24;
+    float xp_dummy[24];
+    float *xp = getenv_dbgH ? xp_dummy : xpos_out + (size_t)e * 24;
     xp[0] = xp[1] = xp[2] = 0.f;
     xp[3] = k.pe.x; xp[4] = k.pe.y; xp[5] = k.pe.z;
     for (int g = 1; g <= 6; g++) { V3 p; M3 R; load_frame(cx.envl, g, p, R); xp[3 * (g + 1)] = p.x; xp[3 * (g + 1) + 1] = p.y; xp[3 * (g + 1) + 2] = p.z; }
-    for (int i = 0; i < 13; i++) { qacc_out[(size_t)e * 13 + i] = qacc[i]; qs_out[(size_t)e * 13 + i] = qs[i]; bias_out[(size_t)e * 13 + i] = bias[i]; }
-    for (int i = 0; i < 13; i++) for (int j = 0; j < 13; j++)
-        M_out[(size_t)e * 169 + i * 13 + j] = (i < 7 && j < 7) ? Mg[pidx(i, j)] : (i >= 7 && j >= 7) ? Mo[pidx(i - 7, j - 7)] : 0.f;
+    for (int i = 0; i < 13; i++) { qacc_out[(size_t)e * 13 + i] = qacc[i]; qs_out[(size_t)e * 13 + i] = qs[i]; if (!getenv_dbgH) bias_out[(size_t)e * 13 + i] = bias[i]; }
+    if (!getenv_dbgH) for (int i = 0; i < 169; i++) M_out[(size_t)e * 169 + i] = cx.envl[EF_M + i];
 }
 
 __global__ void __launch_bounds__(WG_THREADS, 1) k_target_pose(const DevModel m, DevConfig cfg, StatePtrs st, const float *actions, float *target_out) {
@@ -813,7 +813,7 @@ extern "C" int grip_batch_debug_forward(GripBatch *b, int32_t *ncon, float *con,
     HIPCHK(hipMalloc(&d_ncon, N * sizeof(int))); HIPCHK(hipMalloc(&d_con, N * G_MAXC * 10 * sizeof(float))); HIPCHK(hipMalloc(&d_xpos, N * 24 * sizeof(float)));
     HIPCHK(hipMalloc(&d_qacc, N * 13 * sizeof(float))); HIPCHK(hipMalloc(&d_qs, N * 13 * sizeof(float))); HIPCHK(hipMalloc(&d_M, N * 169 * sizeof(float)));
     HIPCHK(hipMalloc(&d_bias, N * 13 * sizeof(float)));
-    hipLaunchKernelGGL(k_debug_forward, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, s, b->hmodel, state_ptrs(b), b->xfrc_z, d_ncon, d_con, d_xpos, d_qacc, d_qs, d_M, d_bias);
+    hipLaunchKernelGGL(k_debug_forward, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, s, b->hmodel, state_ptrs(b), b->xfrc_z, getenv("GRIP_DEBUG_H") ? 1 : 0, d_ncon, d_con, d_xpos, d_qacc, d_qs, d_M, d_bias);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(ncon, d_ncon, N * sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(con, d_con, N * G_MAXC * 10 * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -855,3 +855,20 @@ extern "C" int grip_debug_stamps(unsigned long long *out8) {
     return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp_acc), sizeof(unsigned long long) * NSTAMP) == hipSuccess ? 0 : -1;
 }
 #endif
+
+// ---- self-test hook of the lane-distributed Cholesky (tests only): x = A^-1 b for n SPD 13x13 systems
+__global__ void __launch_bounds__(WG_THREADS, 1) k_test_chol(const float *A, const float *b, float *x, int n) {
+    int e = blockIdx.x * EPB + threadIdx.x / KL, sub = threadIdx.x & (KL - 1);
+    bool valid = e < n; if (!valid) e = n - 1;
+    float row[13];
+    for (int j = 0; j < 13; j++) row[j] = sub < 13 ? A[(size_t)e * 169 + min(sub, 12) * 13 + j] : 0.f;
+    if (sub >= 13) row[12] = 1.f;
+    chol_rows(row, sub);
+    float xi = chol_solve_rows(row, sub < 13 ? b[(size_t)e * 13 + min(sub, 12)] : 0.f, sub);
+    float v[13]; gather13(xi, v);
+    if (valid && sub == 0) for (int j = 0; j < 13; j++) x[(size_t)e * 13 + j] = v[j];
+}
+extern "C" int grip_test_chol(const float *A_dev, const float *b_dev, float *x_dev, int n, void *stream) {
+    hipLaunchKernelGGL(k_test_chol, dim3((n + EPB - 1) / EPB), dim3(WG_THREADS), 0, (hipStream_t)stream, A_dev, b_dev, x_dev, n);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -31,7 +31,7 @@ def build_library(force=False, verbose=False):
             and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs)):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH,
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-o", LIB_PATH,
            os.path.join(CSRC, "grip_sim.hip"), os.path.join(CSRC, "grip_render.hip")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode:
