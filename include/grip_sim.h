@@ -116,6 +116,10 @@ int grip_batch_debug_forward(GripBatch *b, int32_t *ncon, float *con, float *xpo
 /* mjlib.mj_jacBody for body `ee` (actuator.py:86-95) + pinv IK: target_qpos float32 [N,5] to host. */
 int grip_batch_target_pose(GripBatch *b, const float *actions_dev, float *target_qpos_host, void *stream);
 
+/* self-test of the solver's lane-distributed 13x13 Cholesky (the factorisation mj_solNewton does per iteration):
+ * x = A^-1 b for n SPD systems, A float32 [n,13,13], b and x float32 [n,13], device pointers. */
+int grip_selftest_cholesky(const float *A_dev, const float *b_dev, float *x_dev, int n, void *stream);
+
 /* timing of the macro-step kernel on its own stream: average ms per launch since the last call with reset != 0 */
 int grip_batch_kernel_time(GripBatch *b, int reset, float *ms_avg, int *launches);
 

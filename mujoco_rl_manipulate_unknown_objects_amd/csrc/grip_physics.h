@@ -32,15 +32,21 @@
 #define EF_STAGE 72                     // G_MAXC staged contacts x ST_STRIDE
 #define ST_STRIDE 11                    // pos3, n3, dist, meta, fs, ft, tran
 #define EF_M (EF_STAGE + G_MAXC * ST_STRIDE)   // 13 x 13 mass matrix, row-major
-#define EF_U (EF_M + 169)               // per-contact Hessian vectors: G_MAXC x 6 slots x U_STRIDE (13 entries + weight)
-#define U_STRIDE 14
+#define EF_U ((EF_M + 169 + 3) & ~3)     // per-contact Hessian vectors (16-byte aligned): G_MAXC x 6 slots x U_STRIDE (13 entries + weight)
+#define U_STRIDE 16                    // 13 entries + weight, padded to 64 B so a slot is four ds_read_b128
 #define ENV_FLOATS (EF_U + G_MAXC * 6 * U_STRIDE)
 // per-workgroup geom table (floats per geom): centre3, rbound, fs, ft, invweight, group, hull_vadr
 #define GT_STRIDE 9
 #define GT_FLOATS (GN_GEOM * GT_STRIDE)
+#define LDS_ENV_BASE(hull_words) (((hull_words) + GT_FLOATS + 3) & ~3)      // float offset of the first env region (16-byte aligned)
 
 #define NEWTON_MAXIT 20
+#ifndef LS_MAXIT
 #define LS_MAXIT 16
+#endif
+#ifndef LS_GTOL
+#define LS_GTOL 1e-4f
+#endif
 #define MPR_TOL_F 1e-6f
 #define MPR_MAXIT 50
 #define LUT_RES 8
@@ -48,7 +54,7 @@
 
 // diagnostic build only (-DGRIP_STAMPS): per-phase cycle accounting with s_memtime, never in the shipped library
 #ifdef GRIP_STAMPS
-#define NSTAMP 8
+#define NSTAMP 12
 __device__ unsigned long long g_stamp_acc[NSTAMP];
 struct Stamps { unsigned long long t; unsigned long long acc[NSTAMP]; };
 DEVI unsigned long long stamp_now() { __builtin_amdgcn_sched_barrier(0); unsigned long long t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); return t; }
@@ -143,7 +149,7 @@ DEVI Ctx stage_tables(const DevModel &m, float *lds) {
     c.T.nbr = reinterpret_cast<const unsigned short *>(dst + m.hull_off_nbr);
     c.T.lut = reinterpret_cast<const unsigned short *>(dst + m.hull_off_lut);
     c.T.gt = gt;
-    c.envl = lds + m.hull_words + GT_FLOATS + (threadIdx.x / KL) * ENV_FLOATS;
+    c.envl = lds + LDS_ENV_BASE(m.hull_words) + (threadIdx.x / KL) * ENV_FLOATS;
     return c;
 }
 
@@ -351,15 +357,68 @@ DEVI void bias_forces(const DevModel &m, const Kin &k, const float (&qvel)[13], 
     wrench_project(k, w, bias);
 }
 
+// ---------------------------------------------------------------- small dense helpers in registers (packed lower, static indices)
+template <int N>
+DEVI void chol_packed(float *A) {
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        float s = A[pidx(j, j)];
+#pragma unroll
+        for (int q = 0; q < j; q++) s -= A[pidx(j, q)] * A[pidx(j, q)];
+        float inv = rsqrtf(fmaxf(s, 1e-30f));
+        A[pidx(j, j)] = inv;                       // the diagonal holds 1 / L_jj
+#pragma unroll
+        for (int i = j + 1; i < N; i++) {
+            float t = A[pidx(i, j)];
+#pragma unroll
+            for (int q = 0; q < j; q++) t -= A[pidx(i, q)] * A[pidx(j, q)];
+            A[pidx(i, j)] = t * inv;
+        }
+    }
+}
+template <int N>
+DEVI void chol_solve_packed(const float *L, float *x) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        float s = x[i];
+#pragma unroll
+        for (int q = 0; q < i; q++) s -= L[pidx(i, q)] * x[q];
+        x[i] = s * L[pidx(i, i)];
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) {
+        float s = x[i];
+#pragma unroll
+        for (int q = i + 1; q < N; q++) s -= L[pidx(q, i)] * x[q];
+        x[i] = s * L[pidx(i, i)];
+    }
+}
+// x <- blockdiag(Ag, Ao)^-1 x for the gripper 7x7 and object 6x6 blocks (Ag, Ao are destroyed)
+DEVI void block_solve(float (&Ag)[28], float (&Ao)[21], float (&x)[13]) {
+    chol_packed<7>(Ag); chol_packed<6>(Ao);
+    float xg[7], xo[6];
+#pragma unroll
+    for (int i = 0; i < 7; i++) xg[i] = x[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) xo[i] = x[7 + i];
+    chol_solve_packed<7>(Ag, xg); chol_solve_packed<6>(Ao, xo);
+#pragma unroll
+    for (int i = 0; i < 7; i++) x[i] = xg[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[7 + i] = xo[i];
+}
+
 // ---------------------------------------------------------------- dense algebra, one matrix row per lane
 // Lane i (i < 13) of an env holds row i of a symmetric positive definite 13 x 13 matrix. Cholesky in place: on exit
 // row[q < i] = L[i][q] and row[i] = 1 / L[i][i]. Row j is handed to the other lanes with ds_swizzle broadcasts.
 template <int J>
 DEVI void chol_col(float (&row)[13], int sub) {
-    float d = row[J], t = row[J];
+    // one ds_swizzle round trip per column: lane J's L[J][0..J-1] and A[J][J] go to everyone, every lane then forms both its
+    // own entry and the pivot 1 / L[J][J] (redundantly, bit-identically)
+    float d = bcast16<J>(row[J]), t = row[J];
 #pragma unroll
-    for (int q = 0; q < J; q++) { d = fmaf(-row[q], row[q], d); t = fmaf(-row[q], bcast16<J>(row[q]), t); }
-    float inv = bcast16<J>(rsqrtf(fmaxf(d, 1e-30f)));          // lane J's diagonal
+    for (int q = 0; q < J; q++) { float ljq = bcast16<J>(row[q]); d = fmaf(-ljq, ljq, d); t = fmaf(-row[q], ljq, t); }
+    float inv = rsqrtf(fmaxf(d, 1e-30f));
     row[J] = sub == J ? inv : t * inv;                         // lanes below J: junk in the unused upper triangle
 }
 DEVI void chol_rows(float (&row)[13], int sub) {
@@ -498,6 +557,7 @@ DEVI V3 find_pos(const Sup &p0, const Sup &p1, const Sup &p2, const Sup &p3) {
 struct Contact {
     V3 p, n; float dist; int g1, g2, gA, gB; float fs, ft, tran, D0;
     float aref[4], jar[4], jv[4];
+    float J[4][13];             // the contact's constraint Jacobian rows (normal, tangent 1, tangent 2, torsion), built once per step
 };
 
 // Narrow phase of one state, one item per lane and round. Items 0..5: floor vs hull geom item + 1 (support along -z,
@@ -750,47 +810,59 @@ DEVI void make_constraints(const DevModel &m, const Kin &k, const float (&qpos)[
 #pragma unroll
     for (int j = 7; j < 13; j++) { lim.sgn_pad[j] = 0.f; lim.D_pad[j] = 0.f; lim.aref_pad[j] = 0.f; }
 #pragma unroll
-    for (int r = 0; r < 4; r++) { c.aref[r] = 0.f; c.jar[r] = 0.f; c.jv[r] = 0.f; }
+    for (int r = 0; r < 4; r++) {
+        c.aref[r] = 0.f; c.jar[r] = 0.f; c.jv[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 13; i++) c.J[r][i] = 0.f;
+    }
     if (live) {
-        Twist tv; twists(k, qvel, tv);
         V3 t1, t2; make_tangents(c.n, t1, t2);
+        // the only place where the rigid-group case analysis runs: afterwards every pass is 4 x 13 dot products
+        row_add(k, c.J[0], c.gB, c.p, c.n, 1.f, false); row_add(k, c.J[0], c.gA, c.p, c.n, -1.f, false);
+        row_add(k, c.J[1], c.gB, c.p, t1, 1.f, false);  row_add(k, c.J[1], c.gA, c.p, t1, -1.f, false);
+        row_add(k, c.J[2], c.gB, c.p, t2, 1.f, false);  row_add(k, c.J[2], c.gA, c.p, t2, -1.f, false);
+        row_add(k, c.J[3], c.gB, c.p, c.n, 1.f, true);  row_add(k, c.J[3], c.gA, c.p, c.n, -1.f, true);
         float imp = impedance(m.solimp, c.dist, m.margin);
         float R0 = fmaxf(1e-15f, (1.f - imp) * c.tran / imp);
         c.D0 = 1.0f / R0;
-        float vel[4]; contact_rows<false>(k, tv, c, t1, t2, vel);
+        float vel[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < 13; i++) v = fmaf(c.J[r][i], qvel[i], v);
+            vel[r] = v;
+        }
         c.aref[0] = -m.b_con * vel[0] - m.k_con * imp * (c.dist - m.margin);
         c.aref[1] = -m.b_con * vel[1]; c.aref[2] = -m.b_con * vel[2]; c.aref[3] = -m.b_con * vel[3];
     }
 }
 
 // One cooperative pass over all constraints at acceleration x (identical in the 16 lanes): each lane prices ITS contact
-// (jar kept in its registers) and, for j < 7, ITS joint limit; the 16 lanes all-reduce the cost and J^T force. If wantH
-// the contact's six weighted Hessian vectors (rows n, t1, t2, torsion and the two cone combinations) go to the env's
-// LDS slots, from where every lane assembles its own row of H (assemble_rows).
-DEVI float constraint_pass(const DevModel &m, const Kin &k, const Ctx &cx, float lsgn, float lD, float laref, float xi,
-                           const float (&x)[13], Contact &c, bool live, float (&jtf)[13], bool wantH, float &hdiag) {
+// (4 x 13 dot products with the rows in its registers) and, for j < 7, ITS joint limit; the 16 lanes all-reduce the cost and
+// J^T force. The cone of the contact is returned for hessian_vectors().
+DEVI float constraint_pass(const DevModel &m, const Ctx &cx, float lsgn, float lD, float laref, float xi,
+                           const float (&x)[13], Contact &c, bool live, float (&jtf)[13], Cone &cn, float &hdiag) {
     float cost = 0.f;
     float jl[13];
 #pragma unroll
     for (int i = 0; i < 13; i++) jl[i] = 0.f;
-    Cone cn;
 #pragma unroll
     for (int i = 0; i < 4; i++) { cn.grad[i] = 0.f; cn.w[i] = 0.f; cn.a[i] = 0.f; cn.b[i] = 0.f; }
     cn.cost = 0.f; cn.ka = 0.f; cn.kb = 0.f;
-    opaque(c.p.x); opaque(c.n.x);          // keep the per-contact geometry work inside the solver loop (see opaque())
-    V3 t1, t2; make_tangents(c.n, t1, t2);
     if (live) {
-        Twist t; twists(k, x, t);
-        float jar[4]; contact_rows<false>(k, t, c, t1, t2, jar);
+        float jar[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) { jar[r] -= c.aref[r]; c.jar[r] = jar[r]; }
+        for (int r = 0; r < 4; r++) {
+            float v = -c.aref[r];
+#pragma unroll
+            for (int i = 0; i < 13; i++) v = fmaf(c.J[r][i], x[i], v);
+            jar[r] = v; c.jar[r] = v;
+        }
         cone_eval(jar, c.D0, m.impratio, c.fs, c.ft, cn);
         cost = cn.cost;
-        V3 F = c.n * (-cn.grad[0]) + t1 * (-cn.grad[1]) + t2 * (-cn.grad[2]);
-        V3 Tq = c.n * (-cn.grad[3]);
-        Wrench w; wrench_zero(w);
-        wrench_add(k, w, c.gB, c.p, F, Tq, 1.f); wrench_add(k, w, c.gA, c.p, F, Tq, -1.f);
-        wrench_project(k, w, jl);
+#pragma unroll
+        for (int i = 0; i < 13; i++) jl[i] = -(cn.grad[0] * c.J[0][i] + cn.grad[1] * c.J[1][i] + cn.grad[2] * c.J[2][i] + cn.grad[3] * c.J[3][i]);
     }
     // joint limit owned by this lane (lanes 0..6): J = sgn at dof `sub`
     float ljar = lsgn * xi - laref;
@@ -801,30 +873,31 @@ DEVI float constraint_pass(const DevModel &m, const Kin &k, const Ctx &cx, float
     cost = sum16(cost);
 #pragma unroll
     for (int i = 0; i < 13; i++) jtf[i] = sum16(jl[i] + (cx.sub == i ? lforce : 0.f));
-    if (wantH && live) {
-        float *U = cx.envl + EF_U + cx.sub * 6 * U_STRIDE;
-        float ua[13], ub[13];
-#pragma unroll
-        for (int i = 0; i < 13; i++) { ua[i] = 0.f; ub[i] = 0.f; }
-#pragma unroll 1
-        for (int r = 0; r < 4; r++) {
-            float j[13];
-#pragma unroll
-            for (int i = 0; i < 13; i++) j[i] = 0.f;
-            V3 e = r == 1 ? t1 : r == 2 ? t2 : c.n;
-            row_add(k, j, c.gB, c.p, e, 1.f, r == 3); row_add(k, j, c.gA, c.p, e, -1.f, r == 3);
-            float ar = r == 0 ? cn.a[0] : r == 1 ? cn.a[1] : r == 2 ? cn.a[2] : cn.a[3];
-            float br = r == 0 ? cn.b[0] : r == 1 ? cn.b[1] : r == 2 ? cn.b[2] : cn.b[3];
-            float wr = r == 0 ? cn.w[0] : r == 1 ? cn.w[1] : r == 2 ? cn.w[2] : cn.w[3];
-#pragma unroll
-            for (int i = 0; i < 13; i++) { ua[i] = fmaf(ar, j[i], ua[i]); ub[i] = fmaf(br, j[i], ub[i]); U[r * U_STRIDE + i] = j[i]; }
-            U[r * U_STRIDE + 13] = wr;
-        }
-#pragma unroll
-        for (int i = 0; i < 13; i++) { U[4 * U_STRIDE + i] = ua[i]; U[5 * U_STRIDE + i] = ub[i]; }
-        U[4 * U_STRIDE + 13] = cn.ka; U[5 * U_STRIDE + 13] = -cn.kb;
-    }
     return cost;
+}
+
+// The contact's six weighted Hessian vectors  J^T s'' J = sum_r w_r J_r J_r^T + ka ua ua^T - kb ub ub^T  go to the env's
+// LDS slots (rows J_r themselves are already there: written once per step by publish_rows), from where every lane
+// assembles its own row of H (assemble_rows).
+DEVI void hessian_vectors(const Ctx &cx, const Contact &c, bool live, const Cone &cn) {
+    if (!live) return;
+    float *U = cx.envl + EF_U + cx.sub * 6 * U_STRIDE;
+#pragma unroll
+    for (int r = 0; r < 4; r++) U[r * U_STRIDE + 13] = cn.w[r];
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        U[4 * U_STRIDE + i] = cn.a[0] * c.J[0][i] + cn.a[1] * c.J[1][i] + cn.a[2] * c.J[2][i] + cn.a[3] * c.J[3][i];
+        U[5 * U_STRIDE + i] = cn.b[1] * c.J[1][i] + cn.b[2] * c.J[2][i] + cn.b[3] * c.J[3][i];
+    }
+    U[4 * U_STRIDE + 13] = cn.ka; U[5 * U_STRIDE + 13] = -cn.kb;
+}
+DEVI void publish_rows(const Ctx &cx, const Contact &c, bool live) {
+    if (!live) return;
+    float *U = cx.envl + EF_U + cx.sub * 6 * U_STRIDE;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int i = 0; i < 13; i++) U[r * U_STRIDE + i] = c.J[r][i];
 }
 
 // row `sub` of  H = M + sum over the env's contact slots of  w u u^T  (+ this lane's joint-limit term on the diagonal)
@@ -833,14 +906,14 @@ DEVI void assemble_rows(const Ctx &cx, int ncon, const float (&mrow)[13], float 
     for (int j = 0; j < 13; j++) row[j] = mrow[j];
     const int isub = min(cx.sub, 12);
     const float *U = cx.envl + EF_U;
+#pragma unroll 4
     for (int s = 0; s < 6 * ncon; s++) {
-        const float *u = U + s * U_STRIDE;
-        float w = u[13];
-        if (w != 0.f) {
-            float wi = w * u[isub];
+        const float4 *u4 = reinterpret_cast<const float4 *>(U + s * U_STRIDE);
+        float4 a = u4[0], b = u4[1], c4 = u4[2], d = u4[3];
+        float u[13] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c4.x, c4.y, c4.z, c4.w, d.x};
+        float wi = d.y * U[s * U_STRIDE + isub];    // zero weights (inactive cone zones) simply add nothing
 #pragma unroll
-            for (int j = 0; j < 13; j++) row[j] = fmaf(wi, u[j], row[j]);
-        }
+        for (int j = 0; j < 13; j++) row[j] = fmaf(wi, u[j], row[j]);
     }
 #pragma unroll
     for (int j = 0; j < 13; j++) row[j] += cx.sub == j ? hdiag : 0.f;
@@ -876,9 +949,9 @@ DEVI void line_eval(const DevModel &m, float lsgn, float lD, float laref, float 
 // stages >= 2 are Newton iterations: every lane assembles and factorises its own row of the Hessian, the direction comes
 // from the lane-distributed triangular solves, the exact line search all-reduces two scalars per evaluation. All control
 // flow depends only on all-reduced values, so the 16 lanes of an env always agree.
-DEVI void solve_newton(const DevModel &m, const Kin &k, const Ctx &cx, float lsgn, float lD, float laref,
+DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, float laref,
                        const float (&qs)[13], float qsi, const float (&warm)[13], Contact &c, bool live, int ncon,
-                       float (&qacc)[13], float (&jtf)[13], int &fault, int &iters, float *dbgH = nullptr, float *dbgA = nullptr, float *dbgB = nullptr) {
+                       float (&qacc)[13], float (&jtf)[13], int &fault, int &iters, Stamps &st, float *dbgH = nullptr) {
     const float scale = 1.0f / (m.meaninertia * 13.f);
     const float tol = fmaxf(m.tolerance, 1e-5f);            // fp32 noise floor of the scaled gradient is ~1e-6
     float mrow[13]; load_mrow(cx, mrow);
@@ -891,14 +964,15 @@ DEVI void solve_newton(const DevModel &m, const Kin &k, const Ctx &cx, float lsg
     for (int i = 0; i < 13; i++) { qacc[i] = qs[i]; x[i] = qs[i]; }
     while (__any(!done)) {
         if (!done) {
-            const bool wantH = stage >= 2;
             float dq[13];
 #pragma unroll
             for (int i = 0; i < 13; i++) dq[i] = x[i] - qs[i];
             float Mdi = row_dot(mrow, dq);                                  // (M (x - qs))_sub
-            float hdiag;
+            float hdiag; Cone cn;
             float newcost = sum16(0.5f * Mdi * (xi - qsi));
-            newcost += constraint_pass(m, k, cx, lsgn, lD, laref, xi, x, c, live, jtf, wantH, hdiag);
+            STAMP(st, 4);
+            newcost += constraint_pass(m, cx, lsgn, lD, laref, xi, x, c, live, jtf, cn, hdiag);
+            STAMP(st, 6);
             float gi = Mdi - pick13(jtf, cx.sub);                           // gradient component of this lane
             const bool gconv = scale * sqrtf(sum16(gi * gi)) < tol;
             if (stage == 0) {
@@ -926,24 +1000,34 @@ DEVI void solve_newton(const DevModel &m, const Kin &k, const Ctx &cx, float lsg
                 if (!stop && iters >= NEWTON_MAXIT) { stop = true; fault |= 4; }
                 if (stop) done = true;
                 else {
+                    hessian_vectors(cx, c, live, cn);
                     wave_sync();                            // the contact lanes' Hessian vectors are in LDS
                     float row[13];
+                    STAMP(st, 4);
                     assemble_rows(cx, ncon, mrow, hdiag, row);
+                    STAMP(st, 8);
                     if (dbgH && iters == 0 && cx.sub < 13) {
 #pragma unroll
                         for (int j = 0; j < 13; j++) dbgH[cx.sub * 13 + j] = row[j];
                     }
                     if (cx.sub >= 13) row[12] = 1.f;        // harmless: those lanes never take part (sub > 12 masked everywhere)
                     chol_rows(row, cx.sub);
+                    STAMP(st, 9);
                     float pi = chol_solve_rows(row, -gi, cx.sub);
                     float p[13]; gather13(pi, p);
+                    STAMP(st, 7);
                     float Mpi = row_dot(mrow, p);
                     float g0 = sum16(Mpi * (qi - qsi)), g1 = sum16(Mpi * pi);
                     if (live) {
-                        Twist tp; twists(k, p, tp);
-                        V3 t1, t2; make_tangents(c.n, t1, t2);
-                        contact_rows<false>(k, tp, c, t1, t2, c.jv);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            float v = 0.f;
+#pragma unroll
+                            for (int i = 0; i < 13; i++) v = fmaf(c.J[r][i], p[i], v);
+                            c.jv[r] = v;
+                        }
                     }
+                    STAMP(st, 4);
                     // exact line search: safeguarded 1-D Newton on phi'(alpha); one evaluation site
                     float lo = 0.f, hi = -1.f, alpha = 0.f, gtol = 0.f;
                     bool lsdone = false, descent = true;
@@ -954,7 +1038,7 @@ DEVI void solve_newton(const DevModel &m, const Kin &k, const Ctx &cx, float lsg
                             line_eval(m, lsgn, lD, laref, qi, pi, c, live, alpha, g0, g1, dp, hp);
                             if (ls == 0) {
                                 if (dp >= 0.f) { descent = false; lsdone = true; }
-                                gtol = 1e-4f * fabsf(dp) + 1e-30f;
+                                gtol = LS_GTOL * fabsf(dp) + 1e-30f;
                             } else {
                                 if (fabsf(dp) < gtol) lsdone = true;
                                 else {
@@ -969,6 +1053,7 @@ DEVI void solve_newton(const DevModel &m, const Kin &k, const Ctx &cx, float lsg
                             }
                         }
                     }
+                    STAMP(st, 10);
                     if (!descent) done = true;
                     else {
 #pragma unroll
@@ -997,9 +1082,9 @@ DEVI void forward_pos(const DevModel &m, const Ctx &cx, LaneState &s, Kin &k, Co
 // dynamics stage (mj_step2's share up to qacc) on top of forward_pos
 DEVI void forward_acc(const DevModel &m, const Ctx &cx, LaneState &s, float xfrc_z, const Kin &k, Contact &con, int ncon, int &fault,
                       float (&qfrc_smooth)[13], float (&qacc)[13], float (&jtf)[13], int &iters,
-                      float *dbg_qs, float *dbg_bias, Stamps &st, float *dbgH = nullptr, float *dbgA = nullptr, float *dbgB = nullptr) {
-    {   float Mg[28], Mo[21];
-        mass_matrix(m, k, Mg, Mo);
+                      float *dbg_qs, float *dbg_bias, Stamps &st, float *dbgH = nullptr) {
+    float Mg[28], Mo[21];
+    {   mass_matrix(m, k, Mg, Mo);
         if (cx.sub == 0) {                  // one lane publishes the env's mass matrix, every lane then owns a row of it
             float *M = cx.envl + EF_M;
 #pragma unroll
@@ -1021,14 +1106,12 @@ DEVI void forward_acc(const DevModel &m, const Ctx &cx, LaneState &s, float xfrc
     for (int u = 0; u < 7; u++) qfrc_smooth[u] += m.gear[u] * fminf(fmaxf(s.ctrl[u], m.ctrlrange[u][0]), m.ctrlrange[u][1]);
     // xfrc_applied on body ee (force along z at its COM = frame origin): only the z slide sees it
     qfrc_smooth[2] += xfrc_z;
-    // qacc_smooth = M^-1 qfrc_smooth with the lane-distributed Cholesky
+    // qacc_smooth = M^-1 qfrc_smooth: block-diagonal (gripper 7x7, object 6x6), cheap enough to do redundantly in registers
     float qs[13], qsi;
-    {   float row[13]; load_mrow(cx, row);
-        if (cx.sub >= 13) row[12] = 1.f;
-        chol_rows(row, cx.sub);
-        qsi = chol_solve_rows(row, pick13(qfrc_smooth, cx.sub), cx.sub);
-        gather13(qsi, qs);
-    }
+#pragma unroll
+    for (int i = 0; i < 13; i++) qs[i] = qfrc_smooth[i];
+    block_solve(Mg, Mo, qs);
+    qsi = pick13(qs, cx.sub);
     if (dbg_qs) {
 #pragma unroll
         for (int i = 0; i < 13; i++) dbg_qs[i] = qs[i];
@@ -1037,6 +1120,7 @@ DEVI void forward_acc(const DevModel &m, const Ctx &cx, LaneState &s, float xfrc
     Limits lim;
     const bool live = cx.sub < ncon;
     make_constraints(m, k, s.qpos, s.qvel, lim, con, live);
+    publish_rows(cx, con, live);
     // lane j < 7 owns joint limit j
     const float lsgn = cx.sub < 7 ? pick13(reinterpret_cast<const float (&)[13]>(lim.sgn_pad), cx.sub) : 0.f;
     const float lD = pick13(reinterpret_cast<const float (&)[13]>(lim.D_pad), cx.sub);
@@ -1052,7 +1136,7 @@ DEVI void forward_acc(const DevModel &m, const Ctx &cx, LaneState &s, float xfrc
 #pragma unroll
     for (int i = 0; i < 13; i++) { qacc[i] = qs[i]; jtf[i] = 0.f; warm[i] = (i < 7 && !grip) ? qs[i] : s.warm[i]; }
     if (__any(constrained)) {
-        if (constrained) solve_newton(m, k, cx, lsgn, lD, laref, qs, qsi, warm, con, live, ncon, qacc, jtf, fault, iters, dbgH, dbgA, dbgB);
+        if (constrained) solve_newton(m, cx, lsgn, lD, laref, qs, qsi, warm, con, live, ncon, qacc, jtf, fault, iters, st, dbgH);
     }
     STAMP(st, 4);
 }
@@ -1065,19 +1149,19 @@ DEVI void physics_advance(const DevModel &m, const Ctx &cx, LaneState &s, float 
     // semi-implicit Euler with implicit joint damping: (M + h D) a' = qfrc_smooth + J^T f   (mj_Euler). The object block has
     // no damping, so a' = qacc there; the distributed solve covers all 13 dofs at once.
     float acc[13];
-    {   float row[13]; load_mrow(cx, row);
-        float dmp[13];
+    {   float Ag[28], Ao[21];
+        const float *M = cx.envl + EF_M;
 #pragma unroll
-        for (int i = 0; i < 13; i++) dmp[i] = m.damping[i];
+        for (int i = 0; i < 7; i++)
 #pragma unroll
-        for (int j = 0; j < 13; j++) row[j] += cx.sub == j ? h * dmp[j] : 0.f;
-        if (cx.sub >= 13) row[12] = 1.f;
-        chol_rows(row, cx.sub);
-        float rhs[13];
+            for (int j = 0; j <= i; j++) Ag[pidx(i, j)] = M[i * 13 + j] + (i == j ? h * m.damping[i] : 0.f);
 #pragma unroll
-        for (int i = 0; i < 13; i++) rhs[i] = qfs[i] + jtf[i];
-        float ai = chol_solve_rows(row, pick13(rhs, cx.sub), cx.sub);
-        gather13(ai, acc);
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j <= i; j++) Ao[pidx(i, j)] = M[(7 + i) * 13 + 7 + j] + (i == j ? h * m.damping[7 + i] : 0.f);
+#pragma unroll
+        for (int i = 0; i < 13; i++) acc[i] = qfs[i] + jtf[i];
+        block_solve(Ag, Ao, acc);
     }
 #pragma unroll
     for (int i = 0; i < 13; i++) s.warm[i] = qacc[i];

@@ -559,7 +559,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_debug_forward(const DevModel 
     Kin k; Contact con; int ncon = 0, fault = 0, iters = 0;
     forward_pos(m, cx, s, k, con, ncon, fault, stm);
     float qfs[13], qacc[13], jtf[13], qs[13], bias[13];
-    forward_acc(m, cx, s, xfrc_z, k, con, ncon, fault, qfs, qacc, jtf, iters, qs, bias, stm, getenv_dbgH ? M_out + (size_t)e * 169 : nullptr, getenv_dbgH ? bias_out + (size_t)e * 13 : nullptr, getenv_dbgH ? xpos_out + (size_t)e * 24 : nullptr);
+    forward_acc(m, cx, s, xfrc_z, k, con, ncon, fault, qfs, qacc, jtf, iters, qs, bias, stm, getenv_dbgH ? M_out + (size_t)e * 169 : nullptr);
     if (!valid) return;
     if (cx.sub < G_MAXC) {                      // lane c reports contact c
         float *o = con_out + ((size_t)e * G_MAXC + cx.sub) * 10;
@@ -644,7 +644,8 @@ extern "C" int grip_batch_create(const GripModel *m, int n_envs, int device_id, 
     size_t N = (size_t)n_envs;
     HIPCHK(hipMalloc(&b->d_hull, m->hull_blob.size() * sizeof(unsigned)));
     HIPCHK(hipMemcpy(b->d_hull, m->hull_blob.data(), m->hull_blob.size() * sizeof(unsigned), hipMemcpyHostToDevice));
-    b->lds_bytes = (m->hull_blob.size() + GT_FLOATS + (size_t)EPB * ENV_FLOATS) * sizeof(float);
+    b->lds_bytes = ((size_t)LDS_ENV_BASE(m->hull_blob.size()) + (size_t)EPB * ENV_FLOATS) * sizeof(float);
+    static_assert(ENV_FLOATS % 4 == 0 && EF_U % 4 == 0, "Hessian-vector slots must stay 16-byte aligned");
     if (b->lds_bytes > 160 * 1024) return fail("model hull tables do not fit the 160 KiB LDS next to the per-lane contact storage");
     HIPCHK(hipMalloc(&b->d_planes, m->planes.size() * sizeof(float)));
     HIPCHK(hipMemcpy(b->d_planes, m->planes.data(), m->planes.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -851,7 +852,7 @@ extern "C" int grip_batch_observe(GripBatch *b, uint8_t *obs_dev, void *stream) 
 }
 
 #ifdef GRIP_STAMPS
-extern "C" int grip_debug_stamps(unsigned long long *out8) {
+extern "C" int grip_debug_stamps(unsigned long long *out8) {   // NSTAMP entries
     return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp_acc), sizeof(unsigned long long) * NSTAMP) == hipSuccess ? 0 : -1;
 }
 #endif
@@ -868,7 +869,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_test_chol(const float *A, con
     float v[13]; gather13(xi, v);
     if (valid && sub == 0) for (int j = 0; j < 13; j++) x[(size_t)e * 13 + j] = v[j];
 }
-extern "C" int grip_test_chol(const float *A_dev, const float *b_dev, float *x_dev, int n, void *stream) {
+extern "C" int grip_selftest_cholesky(const float *A_dev, const float *b_dev, float *x_dev, int n, void *stream) {
     hipLaunchKernelGGL(k_test_chol, dim3((n + EPB - 1) / EPB), dim3(WG_THREADS), 0, (hipStream_t)stream, A_dev, b_dev, x_dev, n);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

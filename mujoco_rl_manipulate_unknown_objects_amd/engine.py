@@ -31,7 +31,7 @@ def build_library(force=False, verbose=False):
             and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs)):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC", "-o", LIB_PATH,
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-fno-strict-aliasing", "-shared", "-fPIC", "-o", LIB_PATH,
            os.path.join(CSRC, "grip_sim.hip"), os.path.join(CSRC, "grip_render.hip")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode:
@@ -65,7 +65,7 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_destroy", "grip_batch_set_config", "grip_batch_num_envs", "grip_batch_reset", "grip_batch_step",
            "grip_batch_observe", "grip_batch_get_state", "grip_batch_set_state", "grip_batch_get_flags",
            "grip_batch_set_flags", "grip_batch_substep", "grip_batch_debug_forward", "grip_batch_target_pose",
-           "grip_batch_kernel_time"]
+           "grip_batch_kernel_time", "grip_selftest_cholesky"]
 
 
 def lib():
@@ -96,6 +96,7 @@ def lib():
     L.grip_batch_debug_forward.argtypes = [vp] + [vp] * 7 + [vp]
     L.grip_batch_target_pose.argtypes = [vp, vp, vp, vp]
     L.grip_batch_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.grip_selftest_cholesky.argtypes = [vp, vp, vp, C.c_int, vp]
     _lib = L
     return L
 

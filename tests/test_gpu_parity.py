@@ -124,6 +124,24 @@ def test_substep_parity(engine, orc, torch, obj):
     b.close()
 
 
+def test_joint_limit_only_parity(engine, orc, torch):
+    """No contacts, one finger joint pushed past its range: the solver's limit row alone has to hold it
+    (the reference's actuator ctrlrange / joint range, robot xml :62-99). 5 calls of physics.step()."""
+    n, K = 16, 5
+    m = orc.Model("sand_ball"); b = engine.Batch("sand_ball", n)
+    qpos, qvel, ctrl, warm = b.get_state()
+    qpos[:, 9] = 0.5                                  # object in the air
+    qpos[:, 5] = 1.03 + 0.002 * np.arange(n)          # left knuckle hinge beyond its upper limit
+    b.set_state(qpos, qvel, ctrl, warm)
+    b.substep(K); torch.cuda.synchronize()
+    gq, gv, _, _ = b.get_state()
+    for i in range(n):
+        s = oracle_sim(orc, m, qpos[i], qvel[i], ctrl[i], warm[i]); s.step(K)
+        assert np.abs(s.qpos - gq[i]).max() < 2e-5, (i, s.qpos, gq[i])
+        assert np.abs(s.qvel - gv[i]).max() < 2e-2 * max(1.0, np.abs(s.qvel).max()), (i, s.qvel, gv[i])
+    b.close()
+
+
 @pytest.mark.parametrize("obj,direction", [("sand_ball", (1, 0)), ("acorn", (1, 1))])
 def test_macro_step_parity(engine, orc, torch, obj, direction):
     """RobotEnv.step from reset with common float32 actions: same number of physics.step() calls, same
@@ -256,3 +274,18 @@ def test_full_size_batch_properties(engine, torch):
     assert t1 == t2 and np.array_equal(q1, q2) and np.array_equal(v1, v2)
     assert np.abs(np.linalg.norm(q1[:, 10:14], axis=1) - 1).max() < 1e-5
     b.close()
+
+
+def test_distributed_cholesky_selftest(engine, torch):
+    """The solver's row-per-lane 13x13 Cholesky + triangular solves against numpy float64 on random SPD systems
+    (n not a multiple of the 16 envs a workgroup holds: ragged tail)."""
+    n = 37
+    rng = np.random.default_rng(0)
+    A = np.zeros((n, 13, 13), np.float32); b = rng.normal(size=(n, 13)).astype(np.float32)
+    for i in range(n):
+        G = rng.normal(size=(13, 20)); A[i] = (G @ G.T + np.eye(13)).astype(np.float32)
+    At = torch.from_numpy(A).cuda(); bt = torch.from_numpy(b).cuda(); xt = torch.zeros(n, 13, device="cuda")
+    assert engine.lib().grip_selftest_cholesky(At.data_ptr(), bt.data_ptr(), xt.data_ptr(), n, None) == 0
+    torch.cuda.synchronize()
+    ref = np.linalg.solve(A.astype(np.float64), b.astype(np.float64)[..., None])[..., 0]
+    assert np.abs(xt.cpu().numpy() - ref).max() / np.abs(ref).max() < 2e-5
