@@ -98,6 +98,22 @@ int grip_batch_step(GripBatch *b, const float *actions_dev, const GripStepOut *o
  * ([N,4,64,64] when !full_observation). */
 int grip_batch_observe(GripBatch *b, uint8_t *obs_dev, void *stream);
 
+/* ---- asynchronous stepping: the same RobotEnv.step, time-sliced -------------------------------------------------
+ * A macro step takes 17..1200 calls of physics.step() depending on the action (robot_env.py:95-168), so lock-step
+ * batches wait for their slowest env. grip_batch_advance instead gives every env at most `slice` calls of physics.step():
+ *   - an env whose macro step is in flight resumes it;
+ *   - an env that is waiting (after reset, or after finishing a macro step) and that the PREVIOUS call listed in
+ *     ready_list at row r starts a new macro step with slot_actions_dev[r] (float32 [capacity, 6 or 5]);
+ *   - an env that finishes writes its row of `out` (env-major, as grip_batch_step) and waits.
+ * Then the waiting envs are listed: ready_list_dev int32 [capacity] (env ids, -1 padded), *ready_count_dev = how many.
+ * The caller renders them (grip_batch_observe_list), runs the policy on those rows and passes the actions to the next
+ * call. When more than `capacity` envs wait, the rest are listed by later calls (rotating start, nobody starves).
+ * Per env the arithmetic and the results are identical to grip_batch_step; only the schedule differs. */
+int grip_batch_advance(GripBatch *b, const float *slot_actions_dev, int slice, int capacity, const GripStepOut *out,
+                       int32_t *ready_list_dev, int32_t *ready_count_dev, void *stream);
+/* get_observation for the listed envs only: row r of obs_dev (uint8 [capacity,5,64,64]) = env list_dev[r], r < *count_dev. */
+int grip_batch_observe_list(GripBatch *b, const int32_t *list_dev, const int32_t *count_dev, int capacity, uint8_t *obs_dev, void *stream);
+
 /* ---- low-level hooks (the dm_control Physics surface the reference touches; used by tests) ---- */
 /* physics.data.qpos / qvel / ctrl / qacc_warmstart, env-major float32 [N,14],[N,13],[N,7],[N,13];
  * host_or_dev = 0: host pointers (synchronous copy), 1: device pointers. NULL skips a field. */

@@ -71,17 +71,19 @@ __device__ static bool ray_hull(const DevModel &m, const Frames &f, int g, V3 o,
 __device__ static uint8_t to_u8(float v) { v *= 255.f; v = fminf(fmaxf(v, 0.f), 255.f); return (uint8_t)v; }
 
 __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevConfig cfg, const float *qpos, const int *pad_grasp, const int *pad_pher,
-                                                      int n, uint8_t *obs) {
+                                                      int n, const int *list, const int *count, uint8_t *obs) {
+    // list != NULL: block b renders env list[b] into row b of obs, for b < *count (grip_batch_observe_list)
+    if (list && (int)blockIdx.x >= *count) return;
     const DevModel &m = *mp;
     __shared__ Frames fr;
     __shared__ float sdepth[RPIX];
     __shared__ float red[RTHREADS];
     __shared__ int redi[RTHREADS];
-    const int e = blockIdx.x, tid = threadIdx.x;
+    const int e = list ? list[blockIdx.x] : blockIdx.x, tid = threadIdx.x;
     if (tid == 0) compute_frames(m, qpos, n, e, fr);
     __syncthreads();
     const int nch = cfg.full_observation ? 5 : 4;
-    uint8_t *o = obs + (size_t)e * nch * RPIX;
+    uint8_t *o = obs + (size_t)blockIdx.x * nch * RPIX;
     const float tanh_ = tanf(0.5f * m.cam_fovy * 0.017453292519943295f);
     V3 co = ldv(fr.cam_o); M3 Rc = ldm(fr.cam_R);
     V3 L = normalized(v3(-m.light_dir[0][0], -m.light_dir[0][1], -m.light_dir[0][2]));
@@ -137,7 +139,7 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
 }
 
 extern "C" int grip_render_launch(const DevModel *d_model, DevConfig cfg, const float *qpos, const int *pad_grasp, const int *pad_pher, int n,
-                                  uint8_t *obs, hipStream_t s) {
-    hipLaunchKernelGGL(k_observe, dim3(n), dim3(RTHREADS), 0, s, d_model, cfg, qpos, pad_grasp, pad_pher, n, obs);
+                                  const int *list, const int *count, int nblocks, uint8_t *obs, hipStream_t s) {
+    hipLaunchKernelGGL(k_observe, dim3(nblocks), dim3(RTHREADS), 0, s, d_model, cfg, qpos, pad_grasp, pad_pher, n, list, count, obs);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -238,6 +238,8 @@ struct GripBatch {
     float *qpos = nullptr, *qvel = nullptr, *ctrl = nullptr, *warm = nullptr;     // SoA [field][N]
     int *episode_step = nullptr, *status = nullptr, *gripper_open = nullptr;
     int *pad_grasp = nullptr, *pad_pher = nullptr;                              // sensor-pad scalars of the current state
+    int *mc_ints = nullptr, *mc_astate = nullptr, *mc_slot = nullptr, *mc_order = nullptr; float *mc_flts = nullptr;   // suspended macro steps
+    int ticks = 0;
     float *reset_info = nullptr;                                                // grasp0, pher0, objx0, objy0 of the reset state
     float *scratch = nullptr; size_t scratch_bytes = 0;
     float xfrc_z = 0.f;
@@ -250,6 +252,13 @@ static constexpr int LDS_MAX_BYTES = 160 * 1024;
 
 // ---- state load / store (SoA; the 16 lanes of an env read the same words)
 struct StatePtrs { float *qpos, *qvel, *ctrl, *warm; int *episode_step, *status, *gripper_open, *pad_grasp, *pad_pher; int n; };
+
+// A macro step suspended between two time slices (grip_batch_advance): everything k_macro_step keeps in registers across
+// its physics.step() loop, SoA [field][N]. astate: 0 = macro step in flight, 1 = finished, waiting for an action;
+// slot: row of the compact action / observation arrays this waiting env was given by the last k_compact (-1 = none yet).
+struct MacroCtx { int *ints; float *flts; int *astate; int *slot; };
+enum { MC_PHASE = 0, MC_CNT, MC_NSUB, MC_GRASPED, MC_FLAGS, MC_FAULT, MC_NINT };
+enum { MC_TARGET = 0, MC_INITQ = 5, MC_OPENCLOSE = 10, MC_TQ = 11, MC_INITOBJ = 12, MC_NFLT = 15 };
 
 DEVI void ld_state(const StatePtrs &p, int e, LaneState &s) {
 #pragma unroll
@@ -366,7 +375,7 @@ extern __shared__ float lds_dyn[];
 #define STAMPS_INIT
 #endif
 
-__global__ void __launch_bounds__(WG_THREADS, 1) k_reset(const DevModel m, DevConfig cfg, StatePtrs st, const uint8_t *mask, StepOutDev out, float *reset_info) {
+__global__ void __launch_bounds__(WG_THREADS, 1) k_reset(const DevModel m, DevConfig cfg, StatePtrs st, const uint8_t *mask, StepOutDev out, float *reset_info, MacroCtx mc) {
     const Ctx cx = stage_tables(m, lds_dyn);
     STAMPS_DECL
     int e = blockIdx.x * EPB + threadIdx.x / KL;
@@ -382,6 +391,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_reset(const DevModel m, DevCo
     st_state(st, e, s);
     st.episode_step[e] = 0; st.status[e] = 0; st.gripper_open[e] = 1;
     st.pad_grasp[e] = grasp; st.pad_pher[e] = pher;
+    mc.astate[e] = 1; mc.slot[e] = -1;                      // any macro step in flight is dropped
     if (out.achieved_goal) { out.achieved_goal[2 * e] = k.po.x; out.achieved_goal[2 * e + 1] = k.po.y; }
     if (out.desired_goal) { out.desired_goal[2 * e] = cfg.dir_x; out.desired_goal[2 * e + 1] = cfg.dir_y; }
     if (out.object_position) { out.object_position[3 * e] = k.po.x; out.object_position[3 * e + 1] = k.po.y; out.object_position[3 * e + 2] = k.po.z; }
@@ -393,29 +403,56 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_reset(const DevModel m, DevCo
 }
 
 // RobotEnv.step (robot_env.py:77-241): 4 envs per wave, 16 lanes per env
+//
+// slice <= 0: lock-step -- every env starts a macro step with actions[e] and the launch returns when the slowest is done.
+// slice  > 0: time slice of grip_batch_advance -- an env in flight resumes from its MacroCtx, a waiting env that holds a
+// slot starts a macro step with actions[slot], both run at most `slice` calls of physics.step(); envs that finish write
+// their outputs and wait, the others are suspended. The arithmetic per env is the same in both modes.
 __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, DevConfig cfg, StatePtrs st, const float *actions, StepOutDev out,
-                                                              const float *reset_info, float xfrc_z) {
+                                                              const float *reset_info, float xfrc_z, MacroCtx mc, int slice, const int *order) {
     const Ctx cx = stage_tables(m, lds_dyn);
     STAMPS_DECL
     int e = blockIdx.x * EPB + threadIdx.x / KL;
     const bool valid = e < st.n;
     if (!valid) e = st.n - 1;
+    if (order) e = order[e];
     const bool writer = valid && cx.sub == 0;
+    const bool sliced = slice > 0;
+    const int N = st.n;
     LaneState s; ld_state(st, e, s);
     int episode_step = st.episode_step[e], status = st.status[e], gripper_open = st.gripper_open[e];
     const int adim = cfg.include_roll ? 6 : 5;
-    float act[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) act[i] = i < adim ? actions[(size_t)e * adim + i] : 0.f;
+    float act[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     Kin k; Contact con; int ncon = 0, fault = 0;
-    float target[5], init_q[5], open_close = 0.f, delta_pre = 0.f, tq = 0.f;
+    float target[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, init_q[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, open_close = 0.f, delta_pre = 0.f, tq = 0.f;
     V3 init_obj = v3(0, 0, 0);
     int phase = valid ? PH_MOVE : PH_DONE, cnt = 0, nsub = 0, grasped = 0;
     bool reached_target = false, reached_initial = false, first = true;
+    size_t arow = (size_t)e;
+    if (sliced && valid) {
+        if (mc.astate[e] != 0) {                        // waiting: start only when the last compaction gave this env a slot
+            int sl = mc.slot[e];
+            if (sl >= 0) arow = (size_t)sl; else phase = PH_DONE;
+        } else {                                        // in flight: resume
+            phase = mc.ints[(size_t)MC_PHASE * N + e]; cnt = mc.ints[(size_t)MC_CNT * N + e]; nsub = mc.ints[(size_t)MC_NSUB * N + e];
+            grasped = mc.ints[(size_t)MC_GRASPED * N + e]; fault = mc.ints[(size_t)MC_FAULT * N + e];
+            int fl = mc.ints[(size_t)MC_FLAGS * N + e];
+            reached_target = fl & 1; reached_initial = fl & 2; first = false;
+#pragma unroll
+            for (int i = 0; i < 5; i++) { target[i] = mc.flts[(size_t)(MC_TARGET + i) * N + e]; init_q[i] = mc.flts[(size_t)(MC_INITQ + i) * N + e]; }
+            open_close = mc.flts[(size_t)MC_OPENCLOSE * N + e]; tq = mc.flts[(size_t)MC_TQ * N + e];
+            init_obj = v3(mc.flts[(size_t)MC_INITOBJ * N + e], mc.flts[(size_t)(MC_INITOBJ + 1) * N + e], mc.flts[(size_t)(MC_INITOBJ + 2) * N + e]);
+        }
+    }
+    if (first && phase != PH_DONE) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) act[i] = i < adim ? actions[arow * adim + i] : 0.f;
+    }
+    int budget = sliced ? slice : 0x7fffffff;
 
-    while (__any(phase != PH_DONE)) {
-        if (phase != PH_DONE) {
+    while (__any(phase != PH_DONE && (budget > 0 || phase == PH_FINAL))) {
+        if (phase != PH_DONE && (budget > 0 || phase == PH_FINAL)) {
             forward_pos(m, cx, s, k, con, ncon, fault, stm);       // state of "now": contacts as check_grasp sees them
             if (first) {
                 first = false;
@@ -467,6 +504,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
                     st.pad_grasp[e] = pg; st.pad_pher[e] = ph;
                     st_state(st, e, s);
                     st.episode_step[e] = episode_step; st.status[e] = status; st.gripper_open[e] = gripper_open;
+                    if (mc.astate) { mc.astate[e] = 1; mc.slot[e] = -1; }
                 }
                 phase = PH_DONE;
             } else {
@@ -483,7 +521,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
                     if (phase == PH_CLOSE) grasped = check_grasp(cx, con, ncon);       // robot_env.py:155, before the step
                 }
                 physics_advance(m, cx, s, xfrc_z, k, con, ncon, fault, stm);
-                nsub++; cnt++;
+                nsub++; cnt++; budget--;
                 // ---- post-step transitions
                 bool to_gripper = false, to_final = false;
                 if (phase == PH_MOVE || phase == PH_RETURN) {
@@ -526,6 +564,55 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
                 }
             }
         }
+    }
+    if (sliced && writer && phase != PH_DONE) {             // out of budget mid-step: suspend
+        st_state(st, e, s);
+        st.status[e] = status; st.gripper_open[e] = gripper_open;
+        mc.astate[e] = 0;
+        mc.ints[(size_t)MC_PHASE * N + e] = phase; mc.ints[(size_t)MC_CNT * N + e] = cnt; mc.ints[(size_t)MC_NSUB * N + e] = nsub;
+        mc.ints[(size_t)MC_GRASPED * N + e] = grasped; mc.ints[(size_t)MC_FAULT * N + e] = fault;
+        mc.ints[(size_t)MC_FLAGS * N + e] = (reached_target ? 1 : 0) | (reached_initial ? 2 : 0);
+#pragma unroll
+        for (int i = 0; i < 5; i++) { mc.flts[(size_t)(MC_TARGET + i) * N + e] = target[i]; mc.flts[(size_t)(MC_INITQ + i) * N + e] = init_q[i]; }
+        mc.flts[(size_t)MC_OPENCLOSE * N + e] = open_close; mc.flts[(size_t)MC_TQ * N + e] = tq;
+        mc.flts[(size_t)MC_INITOBJ * N + e] = init_obj.x; mc.flts[(size_t)(MC_INITOBJ + 1) * N + e] = init_obj.y; mc.flts[(size_t)(MC_INITOBJ + 2) * N + e] = init_obj.z;
+    }
+}
+
+// Deterministic compaction after a time slice (one 1024-thread block): the waiting envs, scanned from env `rot` on so that
+// nobody starves when more wait than `capacity`, get slots 0..count-1 (list[slot] = env, -1 beyond count); order[] lists the
+// envs that will do work in the next slice (in flight, or holding a slot) first, so that whole workgroups of idle envs retire at once.
+#define CP_THREADS 1024
+__global__ void __launch_bounds__(CP_THREADS) k_compact(MacroCtx mc, int n, int capacity, int rot, int *list, int *count, int *order) {
+    __shared__ int sa[CP_THREADS], sb[CP_THREADS];
+    const int t = threadIdx.x, chunk = (n + CP_THREADS - 1) / CP_THREADS;
+    // pass 1: slots for the waiting envs, in rotated order
+    int c = 0;
+    for (int i = 0; i < chunk; i++) { int v = t * chunk + i; if (v < n) { int e = v + rot; if (e >= n) e -= n; c += mc.astate[e] != 0; } }
+    sa[t] = c; __syncthreads();
+    for (int d = 1; d < CP_THREADS; d <<= 1) { int x = t >= d ? sa[t - d] : 0; __syncthreads(); sa[t] += x; __syncthreads(); }
+    int base = sa[t] - c, total = sa[CP_THREADS - 1];
+    for (int i = 0; i < chunk; i++) {
+        int v = t * chunk + i;
+        if (v < n) {
+            int e = v + rot; if (e >= n) e -= n;
+            if (mc.astate[e] != 0) { int p = base++; if (p < capacity) { mc.slot[e] = p; list[p] = e; } else mc.slot[e] = -1; }
+        }
+    }
+    int cnt = total < capacity ? total : capacity;
+    for (int p = cnt + t; p < capacity; p += CP_THREADS) list[p] = -1;
+    if (t == 0) *count = cnt;
+    __syncthreads();
+    // pass 2: work order for the next slice
+    int a = 0;
+    for (int i = 0; i < chunk; i++) { int e = t * chunk + i; if (e < n) a += (mc.astate[e] == 0 || mc.slot[e] >= 0); }
+    sb[t] = a; __syncthreads();
+    for (int d = 1; d < CP_THREADS; d <<= 1) { int x = t >= d ? sb[t - d] : 0; __syncthreads(); sb[t] += x; __syncthreads(); }
+    int abase = sb[t] - a, nact = sb[CP_THREADS - 1];
+    int ibase = nact + (min(t * chunk, n) - abase);
+    for (int i = 0; i < chunk; i++) {
+        int e = t * chunk + i;
+        if (e < n) { bool act = mc.astate[e] == 0 || mc.slot[e] >= 0; if (act) order[abase++] = e; else order[ibase++] = e; }
     }
 }
 
@@ -619,6 +706,7 @@ static StepOutDev to_dev(const GripStepOut *o) {
     d.n_substeps = o->n_substeps; d.fault = o->fault;
     return d;
 }
+static MacroCtx macro_ctx(GripBatch *b) { MacroCtx c; c.ints = b->mc_ints; c.flts = b->mc_flts; c.astate = b->mc_astate; c.slot = b->mc_slot; return c; }
 static int grid_of(const GripBatch *b) { return (b->n + EPB - 1) / EPB; }
 
 static int ensure_lds_attr() {
@@ -658,6 +746,8 @@ extern "C" int grip_batch_create(const GripModel *m, int n_envs, int device_id, 
     HIPCHK(hipMalloc(&b->episode_step, N * sizeof(int))); HIPCHK(hipMalloc(&b->status, N * sizeof(int)));
     HIPCHK(hipMalloc(&b->gripper_open, N * sizeof(int))); HIPCHK(hipMalloc(&b->pad_grasp, N * sizeof(int)));
     HIPCHK(hipMalloc(&b->pad_pher, N * sizeof(int))); HIPCHK(hipMalloc(&b->reset_info, 4 * sizeof(float)));
+    HIPCHK(hipMalloc(&b->mc_ints, MC_NINT * N * sizeof(int))); HIPCHK(hipMalloc(&b->mc_flts, MC_NFLT * N * sizeof(float)));
+    HIPCHK(hipMalloc(&b->mc_astate, N * sizeof(int))); HIPCHK(hipMalloc(&b->mc_slot, N * sizeof(int))); HIPCHK(hipMalloc(&b->mc_order, N * sizeof(int)));
     b->scratch_bytes = 169 * N * sizeof(float) + 1024;
     HIPCHK(hipMalloc(&b->scratch, b->scratch_bytes));
     // config defaults (config/base_config.py:12-54)
@@ -676,7 +766,8 @@ extern "C" void grip_batch_destroy(GripBatch *b) {
     (void)hipSetDevice(b->device);
     (void)hipDeviceSynchronize();
     void *ptrs[] = {b->d_model, b->d_hull, b->d_planes, b->qpos, b->qvel, b->ctrl, b->warm, b->episode_step, b->status,
-                    b->gripper_open, b->pad_grasp, b->pad_pher, b->reset_info, b->scratch};
+                    b->gripper_open, b->pad_grasp, b->pad_pher, b->reset_info, b->scratch, b->mc_ints, b->mc_flts, b->mc_astate,
+                    b->mc_slot, b->mc_order};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : b->ev0) (void)hipEventDestroy(e);
     for (auto &e : b->ev1) (void)hipEventDestroy(e);
@@ -697,7 +788,7 @@ extern "C" int grip_batch_set_config(GripBatch *b, const GripEnvConfig *c) {
     uint8_t *zero_mask = (uint8_t *)b->scratch;
     HIPCHK(hipMemsetAsync(zero_mask, 0, (size_t)b->n, nullptr));
     StepOutDev none; memset(&none, 0, sizeof none);
-    hipLaunchKernelGGL(k_reset, dim3(1), dim3(WG_THREADS), b->lds_bytes, nullptr, b->hmodel, b->cfg, state_ptrs(b), zero_mask, none, b->reset_info);
+    hipLaunchKernelGGL(k_reset, dim3(1), dim3(WG_THREADS), b->lds_bytes, nullptr, b->hmodel, b->cfg, state_ptrs(b), zero_mask, none, b->reset_info, macro_ctx(b));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(nullptr));
     return 0;
@@ -707,7 +798,7 @@ extern "C" int grip_batch_reset(GripBatch *b, const uint8_t *mask_dev, const Gri
     if (!b) return fail("grip_batch_reset: null batch");
     HIPCHK(hipSetDevice(b->device));
     hipLaunchKernelGGL(k_reset, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, (hipStream_t)stream, b->hmodel, b->cfg, state_ptrs(b), mask_dev,
-                       to_dev(out), b->reset_info);
+                       to_dev(out), b->reset_info, macro_ctx(b));
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -719,10 +810,30 @@ extern "C" int grip_batch_step(GripBatch *b, const float *actions_dev, const Gri
     int slot = b->ev_used % EV_RING;
     HIPCHK(hipEventRecord(b->ev0[slot], s));
     hipLaunchKernelGGL(k_macro_step, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, s, b->hmodel, b->cfg, state_ptrs(b), actions_dev, to_dev(out),
-                       b->reset_info, b->xfrc_z);
+                       b->reset_info, b->xfrc_z, macro_ctx(b), 0, (const int *)nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev1[slot], s));
     b->ev_used++;
+    return 0;
+}
+
+extern "C" int grip_batch_advance(GripBatch *b, const float *slot_actions_dev, int slice, int capacity, const GripStepOut *out,
+                                  int32_t *ready_list_dev, int32_t *ready_count_dev, void *stream) {
+    if (!b || !slot_actions_dev || !ready_list_dev || !ready_count_dev) return fail("grip_batch_advance: null argument");
+    if (slice <= 0 || capacity <= 0 || capacity > b->n) return fail("grip_batch_advance: need slice > 0 and 0 < capacity <= num_envs");
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t s = (hipStream_t)stream;
+    int slot = b->ev_used % EV_RING;
+    HIPCHK(hipEventRecord(b->ev0[slot], s));
+    hipLaunchKernelGGL(k_macro_step, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, s, b->hmodel, b->cfg, state_ptrs(b), slot_actions_dev, to_dev(out),
+                       b->reset_info, b->xfrc_z, macro_ctx(b), slice, b->ticks > 0 ? (const int *)b->mc_order : (const int *)nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(b->ev1[slot], s));
+    b->ev_used++;
+    int rot = (int)(((long long)b->ticks * capacity) % b->n);
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(CP_THREADS), 0, s, macro_ctx(b), b->n, capacity, rot, ready_list_dev, ready_count_dev, b->mc_order);
+    HIPCHK(hipGetLastError());
+    b->ticks++;
     return 0;
 }
 
@@ -843,11 +954,19 @@ extern "C" int grip_batch_target_pose(GripBatch *b, const float *actions_dev, fl
 
 // observation kernels live in grip_render.hip
 extern "C" int grip_render_launch(const DevModel *d_model, DevConfig cfg, const float *qpos, const int *pad_grasp, const int *pad_pher, int n,
-                                  uint8_t *obs, hipStream_t s);
+                                  const int *list, const int *count, int nblocks, uint8_t *obs, hipStream_t s);
 extern "C" int grip_batch_observe(GripBatch *b, uint8_t *obs_dev, void *stream) {
     if (!b || !obs_dev) return fail("grip_batch_observe: null argument");
     HIPCHK(hipSetDevice(b->device));
-    if (grip_render_launch(b->d_model, b->cfg, b->qpos, b->pad_grasp, b->pad_pher, b->n, obs_dev, (hipStream_t)stream)) return fail("render launch failed");
+    if (grip_render_launch(b->d_model, b->cfg, b->qpos, b->pad_grasp, b->pad_pher, b->n, nullptr, nullptr, b->n, obs_dev, (hipStream_t)stream))
+        return fail("render launch failed");
+    return 0;
+}
+extern "C" int grip_batch_observe_list(GripBatch *b, const int32_t *list_dev, const int32_t *count_dev, int capacity, uint8_t *obs_dev, void *stream) {
+    if (!b || !obs_dev || !list_dev || !count_dev || capacity <= 0) return fail("grip_batch_observe_list: bad argument");
+    HIPCHK(hipSetDevice(b->device));
+    if (grip_render_launch(b->d_model, b->cfg, b->qpos, b->pad_grasp, b->pad_pher, b->n, list_dev, count_dev, capacity, obs_dev, (hipStream_t)stream))
+        return fail("render launch failed");
     return 0;
 }
 

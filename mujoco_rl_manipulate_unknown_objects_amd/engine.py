@@ -65,7 +65,7 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_destroy", "grip_batch_set_config", "grip_batch_num_envs", "grip_batch_reset", "grip_batch_step",
            "grip_batch_observe", "grip_batch_get_state", "grip_batch_set_state", "grip_batch_get_flags",
            "grip_batch_set_flags", "grip_batch_substep", "grip_batch_debug_forward", "grip_batch_target_pose",
-           "grip_batch_kernel_time", "grip_selftest_cholesky"]
+           "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list"]
 
 
 def lib():
@@ -97,6 +97,8 @@ def lib():
     L.grip_batch_target_pose.argtypes = [vp, vp, vp, vp]
     L.grip_batch_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.grip_selftest_cholesky.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.grip_batch_advance.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.grip_batch_observe_list.argtypes = [vp, vp, vp, C.c_int, vp, vp]
     _lib = L
     return L
 
@@ -195,6 +197,29 @@ class Batch:
         if obs is None:
             obs = self.torch.empty((self.n, self.obs_channels, 64, 64), dtype=self.torch.uint8, device=self.device)
         _chk(lib().grip_batch_observe(self.ptr, C.c_void_p(obs.data_ptr()), self._stream()))
+        return obs
+
+    # -- asynchronous stepping (grip_sim.h: grip_batch_advance) ------------------------------------
+    def advance(self, slot_actions, slice_len, ready_list, ready_count):
+        """One time slice: at most `slice_len` calls of physics.step() per env. slot_actions float32 [capacity, action_dim]
+        are the actions for the envs the previous call listed; ready_list int32 [capacity] / ready_count int32 [1] receive
+        the envs now waiting for an action. Finished envs' rows of self.out are refreshed."""
+        t = self.torch
+        cap = int(ready_list.numel())
+        if slot_actions.dtype != t.float32 or not slot_actions.is_contiguous() or tuple(slot_actions.shape) != (cap, self.action_dim):
+            raise GripError(f"slot_actions must be contiguous float32 [{cap},{self.action_dim}]")
+        if ready_list.dtype != t.int32 or ready_count.dtype != t.int32:
+            raise GripError("ready_list / ready_count must be int32")
+        _chk(lib().grip_batch_advance(self.ptr, C.c_void_p(slot_actions.data_ptr()), int(slice_len), cap, C.byref(self._outc),
+                                      C.c_void_p(ready_list.data_ptr()), C.c_void_p(ready_count.data_ptr()), self._stream()))
+        return self.out
+
+    def observe_list(self, ready_list, ready_count, obs):
+        cap = int(ready_list.numel())
+        if obs.dtype != self.torch.uint8 or not obs.is_contiguous() or obs.shape[0] < cap:
+            raise GripError("obs must be contiguous uint8 [capacity, C, 64, 64]")
+        _chk(lib().grip_batch_observe_list(self.ptr, C.c_void_p(ready_list.data_ptr()), C.c_void_p(ready_count.data_ptr()), cap,
+                                           C.c_void_p(obs.data_ptr()), self._stream()))
         return obs
 
     # -- low-level hooks ------------------------------------------------------------------------

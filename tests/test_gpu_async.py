@@ -1,0 +1,104 @@
+"""-m gpu: time-sliced stepping (grip_batch_advance) against lock-step grip_batch_step. Same arithmetic per env, other
+schedule: every per-env output has to be bit-identical."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ["reward", "done", "achieved_goal", "desired_goal", "status", "episode_step", "gripper_open", "object_grasped",
+          "position_reached", "total_distance", "line_distance", "gripper_position", "object_position", "init_obj_pos",
+          "n_substeps", "fault"]
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    if not t.cuda.is_available():
+        pytest.skip("no GPU")
+    return t
+
+
+@pytest.fixture(scope="module")
+def engine(torch):
+    from mujoco_rl_manipulate_unknown_objects_amd import engine as e
+    e.lib()
+    return e
+
+
+def lockstep_reference(engine, torch, obj, n, actions, steps):
+    b = engine.Batch(obj, n)
+    outs = []
+    for t in range(steps):
+        o = b.step(torch.from_numpy(actions[t]).cuda())
+        torch.cuda.synchronize()
+        outs.append({k: o[k].cpu().numpy().copy() for k in FIELDS})
+    state = b.get_state()
+    b.close()
+    return outs, state
+
+
+@pytest.mark.parametrize("capacity,slice_len", [(64, 37), (24, 16), (64, 2000)])
+def test_sliced_macro_steps_equal_lockstep(engine, torch, capacity, slice_len):
+    """Each env does `steps` macro steps with its own action sequence, served through a ready list of `capacity` rows
+    (smaller than the batch: envs queue) in slices of `slice_len` physics steps. Outputs of every macro step and the
+    final state are bit-identical to the lock-step batch."""
+    n, steps, obj = 64, 3, "sand_ball"
+    rng = np.random.default_rng(3)
+    actions = rng.uniform(-1, 1, (steps, n, 6)).astype(np.float32)
+    actions[:, :, 0] = np.abs(actions[:, :, 0])
+    ref, ref_state = lockstep_reference(engine, torch, obj, n, actions, steps)
+
+    b = engine.Batch(obj, n)
+    lst = torch.full((capacity,), -1, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    slot_act = torch.zeros(capacity, 6, device="cuda")
+    given = np.zeros(n, int)            # actions handed to env so far
+    got = [[None] * steps for _ in range(n)]
+    final_state = [None] * n
+    parked = np.zeros(n, bool)
+    for tick in range(20000):
+        out = b.advance(slot_act, slice_len, lst, cnt)
+        torch.cuda.synchronize()
+        c = int(cnt.item()); ids = lst.cpu().numpy()
+        assert (ids[c:] == -1).all() and len(set(ids[:c].tolist())) == c
+        o_host = {k: out[k].cpu().numpy() for k in FIELDS}
+        st = b.get_state() if c else None
+        new_act = np.zeros((capacity, 6), np.float32)
+        for r in range(c):
+            e = int(ids[r])
+            if given[e] > 0 and got[e][given[e] - 1] is None:           # just finished macro step number given[e]
+                got[e][given[e] - 1] = {k: o_host[k][e].copy() for k in FIELDS}
+                if given[e] == steps:
+                    final_state[e] = [a[e].copy() for a in st]
+            if given[e] < steps:
+                new_act[r] = actions[given[e], e]; given[e] += 1
+            else:
+                parked[e] = True                                           # gets a zero action: result ignored
+        slot_act.copy_(torch.from_numpy(new_act))
+        if all(g[steps - 1] is not None for g in got):
+            break
+    else:
+        raise AssertionError("envs did not finish")
+    for e in range(n):
+        for t in range(steps):
+            for k in FIELDS:
+                assert np.array_equal(got[e][t][k], ref[t][k][e]), (e, t, k, got[e][t][k], ref[t][k][e])
+        for a, r in zip(final_state[e], ref_state):
+            assert np.array_equal(a, r[e])
+    b.close()
+
+
+def test_observe_list_rows_match_full_observation(engine, torch):
+    n, cap = 48, 16
+    b = engine.Batch("sugar_cube", n)
+    rng = np.random.default_rng(1)
+    b.step(torch.from_numpy(rng.uniform(-1, 1, (n, 6)).astype(np.float32)).cuda())
+    full = b.observe()
+    ids = torch.tensor([5, 47, 0, 13, 22], dtype=torch.int32, device="cuda")
+    lst = torch.full((cap,), -1, dtype=torch.int32, device="cuda"); lst[:5] = ids
+    cnt = torch.tensor([5], dtype=torch.int32, device="cuda")
+    rows = torch.full((cap, 5, 64, 64), 77, dtype=torch.uint8, device="cuda")
+    b.observe_list(lst, cnt, rows)
+    torch.cuda.synchronize()
+    assert torch.equal(rows[:5], full[ids.long()])
+    assert bool((rows[5:] == 77).all())          # rows beyond the count are not touched
+    b.close()
