@@ -3,12 +3,18 @@
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-One "step" = one pass of the hot path over one batch: for every environment of the rank, the
-PPO actor-critic forward (AugmentedNatureCNN + heads) samples an action, the macro-step kernel runs
-RobotEnv.step (controller + all physics.step() sub-steps + reward/done), the observation kernel
-renders the 5x64x64 uint8 observation, the transition is stored in the HBM rollout buffer; every
-`--rollout` steps a full PPO update (GAE, `--epochs` epochs of minibatch forward/backward/Adam, one
-flattened-gradient all-reduce per minibatch when N > 1) runs inside the timed region.
+One "step" = one pass of the hot path over one batch = `--envs` completed env transitions per GPU: the
+PPO actor-critic forward (AugmentedNatureCNN + heads) samples an action, the engine runs RobotEnv.step
+(controller + all physics.step() sub-steps + reward/done), the observation kernel renders the 5x64x64
+uint8 observation, the transition is stored in the HBM rollout buffer; every `--rollout` steps a full
+PPO update (GAE, `--epochs` epochs of minibatch forward/backward/Adam, one flattened-gradient all-reduce
+per minibatch when N > 1) runs inside the timed region.
+
+Default schedule: asynchronous time slices (grip_batch_advance; sb3/async_rollout.py) -- every env runs on
+its own clock, finished envs are re-decided every tick, and a step is counted when `--envs` transitions
+have completed, whichever envs they came from. Only the transitions PPO trains on are counted (the few
+that complete between the last poll and the end of a rollout are not). `--lockstep` runs the classic
+vector-env schedule (all envs step together, the launch waits for the slowest) for comparison.
 Workload = BASELINE.json configs[1]: acorn_env (labelled stand-in hull: the reference checkout has no
 acorn.stl), 4096 envs per GPU, direction 0, default flags; synthetic = deterministic reset state,
 actions from the randomly initialised policy. Weak scaling: per-GPU work is fixed as N grows.
@@ -66,6 +72,9 @@ def main():
     ap.add_argument("--minibatch", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ppo", action="store_true", help="diagnostic: rollout only (INVALID as a headline number)")
+    ap.add_argument("--lockstep", action="store_true", help="classic vector-env schedule instead of asynchronous time slices")
+    ap.add_argument("--slice", type=int, default=16, help="physics.step() calls per env per tick (async schedule)")
+    ap.add_argument("--capacity", type=int, default=1024, help="finished envs decided per tick (async schedule)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
@@ -84,11 +93,27 @@ def main():
     cfg = default_config(sim_env=f"/xmls/{a.object}_env.xml", direction=a.direction)
     env = GpuVecEnv(BatchedRobotEnv(cfg, n_envs=a.envs, device_index=local, auto_reset=True))
     model = PPO("MultiInputPolicy", env, n_steps=a.rollout, batch_size=a.minibatch, n_epochs=a.epochs, seed=1234 + rank,
-                policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]))
+                policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]),
+                async_slice=0 if a.lockstep else a.slice, async_capacity=min(a.capacity, a.envs))
     batch = env.env.batch
+    ar = model._async
+
+    def run_async(nsteps):
+        """nsteps x envs completed transitions, a PPO update after every `rollout` x envs of them."""
+        done_steps = 0
+        while done_steps < nsteps:
+            chunk = min(a.rollout, nsteps - done_steps)
+            ar.target = chunk * a.envs
+            model.collect_rollouts()
+            if not a.no_ppo and chunk == a.rollout:
+                model.train()
+            done_steps += chunk
+        ar.target = a.rollout * a.envs
 
     def run(nsteps):
         """nsteps vec-env steps with a PPO update after every `rollout` of them."""
+        if ar is not None:
+            return run_async(nsteps)
         done_steps = 0; subs = 0
         while done_steps < nsteps:
             # collect_rollouts always does n_steps steps; trim the last chunk
@@ -119,6 +144,8 @@ def main():
         sub_acc.add_(r[3]["n_substeps"].sum())
         return r
     env.step = counted_step
+    if ar is not None:
+        ar.substeps_total.zero_(); ticks0 = ar.total_ticks; ar.done_total = 0
     sync()
     t0 = time.perf_counter()
     run(a.steps)
@@ -126,7 +153,7 @@ def main():
     dt = time.perf_counter() - t0
     env.step = orig_step
     tmax = torch.tensor([dt], dtype=torch.float64, device=env.device)
-    subs = sub_acc.double().reshape(1)
+    subs = (sub_acc if ar is None else ar.substeps_total).double().reshape(1)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dist.all_reduce(subs, op=dist.ReduceOp.SUM)
     dt = float(tmax.item()); total_sub = float(subs.item())
@@ -135,7 +162,10 @@ def main():
     if rank == 0:
         total_env_steps = a.envs * world * a.steps
         value = total_env_steps / dt
-        macro_bytes = MACRO_BYTES_PER_ENV * a.envs
+        # async: one launch = one time slice = state + suspended macro-step context in and out (21 words each way) per env
+        macro_bytes = (MACRO_BYTES_PER_ENV if ar is None else (47 + 40 + 2 * 21) * 4 + 8) * a.envs
+        sched = ("lock-step vector env" if ar is None else
+                 f"asynchronous time slices ({a.slice} physics steps/tick, {min(a.capacity, a.envs)} decisions/tick)")
         achieved = macro_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
             "metric": "env-steps/sec (whole node), acorn_env 4096 envs/GPU", "value": value, "unit": "env-steps/s",
@@ -145,13 +175,16 @@ def main():
             "config": {"workload": f"{a.object}_env ({'stand-in hull; ' if a.object == 'acorn' else ''}direction {a.direction}), "
                                    f"{a.envs} envs/GPU, macro-step + observation + PPO actor-critic fwd each step, "
                                    f"PPO update every {a.rollout} steps ({a.epochs} epochs, minibatch {a.minibatch})",
-                       "envs_per_gpu": a.envs, "parallelism": f"dp{world}", "ppo_in_timed_region": not a.no_ppo},
+                       "envs_per_gpu": a.envs, "parallelism": f"dp{world}", "ppo_in_timed_region": not a.no_ppo, "schedule": sched,
+                       "step": f"{a.envs} completed env transitions per GPU"},
             "mj_substeps_per_s": total_sub / dt, "mean_substeps_per_env_step": total_sub / total_env_steps,
             "roofline": {"bound": "hbm", "kernel": "k_macro_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms_avg": k_ms, "launches": k_n,
                          "algorithmic_bytes_per_launch": macro_bytes,
-                         "note": "lane-per-env macro-step kernel is VALU/latency-bound, not HBM-bound (DESIGN.md §4)"},
+                         "note": "the macro-step kernel is VALU-issue-bound, not HBM-bound (DESIGN.md §4)"},
         }
+        if ar is not None:
+            out["ticks"] = ar.total_ticks - ticks0
         if not a.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(a.object)

@@ -1,0 +1,186 @@
+"""Rollout collection over the time-sliced engine (include/grip_sim.h: grip_batch_advance).
+
+One env macro step (RobotEnv.step, robot_env.py:77-241) costs 17..1200 calls of physics.step() depending on the
+action, so a lock-step vector env spends most of a launch waiting for its slowest member. Here every env runs on its
+own clock: each tick gives all envs a bounded slice of physics, the envs that finished are listed (at most `capacity`
+per tick), only those are rendered and fed to the policy, and their actions go back in with the next tick.
+
+Transitions therefore arrive out of order. They are stored as *decision records* in HBM:
+
+    record r = (env, obs, action, log_prob, value)         written when the policy decides for a listed env
+    reward[r], done[r], next_rec[r]                        filled when that env is listed the next time
+
+Record ids grow with time (carry region [0, N), then `capacity` rows per tick), so next_rec[r] > r and GAE is a
+backward sweep over tick blocks with a gather through next_rec. A record that is still in flight when the rollout is
+full bootstraps its predecessor with its value (as PPO's last_values do) and is carried into rows [0, N) of the next
+rollout -- one record per env at most. Everything below is fixed-shape device work: no host sync inside a tick.
+
+The engine is duck-typed (`advance`, `observe_list`, `num_envs`, `action_dim`, `obs_shape`, `device`) so that the
+bookkeeping is testable on CPU against a scripted engine (tests/test_async_rollout_cpu.py).
+"""
+import torch as th
+
+
+class BatchEngineAdapter:
+    """engine.Batch (via BatchedRobotEnv / GpuVecEnv) as the duck-typed async engine."""
+
+    def __init__(self, env):
+        benv = getattr(env, "env", env)                  # GpuVecEnv -> BatchedRobotEnv
+        self.batch = benv.batch
+        if not self.batch.cfg.auto_reset:
+            self.batch.set_config(auto_reset=1)
+        self.num_envs, self.action_dim, self.device = self.batch.n, self.batch.action_dim, self.batch.device
+        self.obs_shape = (self.batch.obs_channels, 64, 64)
+
+    def reset(self):
+        self.batch.reset()
+
+    def advance(self, slot_actions, slice_len, ready_list, ready_count):
+        return self.batch.advance(slot_actions, slice_len, ready_list, ready_count)
+
+    def observe_list(self, ready_list, ready_count, obs_rows):
+        self.batch.observe_list(ready_list, ready_count, obs_rows)
+
+
+class AsyncRollout:
+    def __init__(self, engine, policy_fn, target, capacity, slice_len, gamma, gae_lambda, max_ticks=None, action_low=None, action_high=None,
+                 poll_every=4):
+        """policy_fn(obs_rows uint8 [C, ...]) -> (actions [C, A], values [C], log_probs [C]) under no_grad.
+        target = completed transitions per rollout; capacity = ready-list rows per tick."""
+        self.eng, self.policy_fn = engine, policy_fn
+        self.N, self.C, self.S, self.A = engine.num_envs, int(capacity), int(slice_len), engine.action_dim
+        self.target, self.gamma, self.lam = int(target), gamma, gae_lambda
+        dev = self.dev = engine.device
+        if max_ticks is None:                            # generous: 4x the ticks a full ready list would need, at least 64
+            max_ticks = max(64, 4 * (self.target + self.C - 1) // self.C)
+        self.max_ticks = int(max_ticks)
+        self.R = self.N + self.max_ticks * self.C        # records; row R is a dump row for masked scatters
+        R1 = self.R + 1
+        self.obs = th.zeros((R1,) + tuple(engine.obs_shape), dtype=th.uint8, device=dev)
+        self.actions = th.zeros(R1, self.A, device=dev)
+        z = lambda dt=th.float32: th.zeros(R1, dtype=dt, device=dev)
+        self.log_probs, self.values, self.rewards, self.dones, self.advantages, self.returns = z(), z(), z(), z(), z(), z()
+        self.next_rec = th.full((R1,), -1, dtype=th.int64, device=dev)
+        self.is_rec = z(th.bool); self.completed = z(th.bool)
+        self.rec_env = th.full((R1,), -1, dtype=th.int64, device=dev)
+        self.rec_of_env = th.full((self.N + 1,), -1, dtype=th.int64, device=dev)      # row N: dump
+        self.lst = th.full((self.C,), -1, dtype=th.int32, device=dev)
+        self.cnt = th.zeros(1, dtype=th.int32, device=dev)
+        self.slot_act = th.zeros(self.C, self.A, device=dev)
+        self.ar_c = th.arange(self.C, device=dev)
+        self.n_completed = th.zeros(1, dtype=th.int64, device=dev)
+        self.low = None if action_low is None else th.as_tensor(action_low, device=dev, dtype=th.float32)
+        self.high = None if action_high is None else th.as_tensor(action_high, device=dev, dtype=th.float32)
+        self.poll_every = poll_every
+        self.tick = 0                                    # ticks of the current rollout
+        self.total_ticks = 0
+        # episode statistics (device side; read with stats())
+        self.ep_ret = th.zeros(self.N + 1, device=dev); self.ep_len = th.zeros(self.N + 1, device=dev)
+        self.ep_ret_sum = th.zeros(1, device=dev); self.ep_len_sum = th.zeros(1, device=dev); self.ep_count = th.zeros(1, device=dev)
+        self.substeps_total = th.zeros(1, dtype=th.int64, device=dev)          # physics.step() calls of the finished macro steps
+        self._started = False
+
+    # ------------------------------------------------------------------ one tick
+    def _tick(self):
+        N, C, R = self.N, self.C, self.R
+        base = N + self.tick * C
+        out = self.eng.advance(self.slot_act, self.S, self.lst, self.cnt)
+        rows = slice(base, base + C)
+        obs_rows = self.obs[rows]
+        self.eng.observe_list(self.lst, self.cnt, obs_rows)
+        valid = self.ar_c < self.cnt                                   # [C]
+        env = th.where(valid, self.lst, N).long()                      # dump env N for empty rows
+        env_c = env.clamp(max=N - 1)
+        actions, values, log_probs = self.policy_fn(obs_rows)
+        act = actions if self.low is None else th.max(th.min(actions, self.high), self.low)
+        self.slot_act.copy_(act)
+        # close the previous decision of every listed env
+        prev = self.rec_of_env[env]
+        had = valid & (prev >= 0)
+        prev_m = th.where(had, prev, R)
+        rew = out["reward"][env_c].float(); dn = out["done"][env_c].float()
+        self.rewards[prev_m] = rew; self.dones[prev_m] = dn
+        self.next_rec[prev_m] = base + self.ar_c
+        self.completed[prev_m] = True
+        self.n_completed += had.sum()
+        if "n_substeps" in out:
+            self.substeps_total += (out["n_substeps"][env_c] * had).sum()
+        # episode bookkeeping
+        self.ep_ret[env] += th.where(had, rew, th.zeros_like(rew)); self.ep_len[env] += had.float()
+        fin = had & (dn > 0)
+        self.ep_ret_sum += (self.ep_ret[env] * fin).sum(); self.ep_len_sum += (self.ep_len[env] * fin).sum(); self.ep_count += fin.sum()
+        keep = (~fin).float()
+        self.ep_ret[env] *= keep; self.ep_len[env] *= keep
+        # open the new decision
+        self.actions[rows] = actions; self.log_probs[rows] = log_probs; self.values[rows] = values
+        self.is_rec[rows] = valid; self.completed[rows] = False; self.next_rec[rows] = -1
+        self.rec_env[rows] = th.where(valid, env, th.full_like(env, -1))
+        self.rec_of_env[env] = base + self.ar_c
+        self.tick += 1; self.total_ticks += 1
+
+    # ------------------------------------------------------------------ rollout
+    def _begin(self):
+        """Carry the in-flight decisions (one per env at most) into rows [0, N) and clear the rest."""
+        N = self.N
+        infl = self.rec_of_env[:N]
+        has = infl >= 0
+        src = th.where(has, infl, self.R)
+        ob = self.obs[src]; ac = self.actions[src]; lp = self.log_probs[src]; va = self.values[src]      # gathers copy: aliasing-safe
+        self.obs[:N] = ob; self.actions[:N] = ac; self.log_probs[:N] = lp; self.values[:N] = va
+        self.is_rec.zero_(); self.completed.zero_(); self.next_rec.fill_(-1); self.advantages.zero_(); self.rec_env.fill_(-1)
+        self.is_rec[:N] = has
+        ar = th.arange(N, device=self.dev)
+        self.rec_env[:N] = th.where(has, ar, th.full_like(ar, -1))
+        self.rec_of_env[:N] = th.where(has, ar, th.full_like(ar, -1))
+        self.n_completed.zero_()
+        self.tick = 0
+
+    def collect(self, on_poll=None):
+        """Run ticks until `target` transitions have completed (checked every `poll_every` ticks) or the tick budget is
+        spent, then compute advantages. Returns the number of completed transitions (host int)."""
+        if not self._started:
+            self.eng.reset(); self._started = True
+        self._begin()
+        done_n = 0
+        while self.tick < self.max_ticks:
+            self._tick()
+            if self.tick % self.poll_every == 0 or self.tick == self.max_ticks:
+                done_n = int(self.n_completed.item())          # the only host sync of the rollout loop
+                if on_poll is not None and on_poll(done_n) is False:
+                    break
+                if done_n >= self.target:
+                    break
+        else:
+            done_n = int(self.n_completed.item())
+        self._gae()
+        return done_n
+
+    def _gae(self):
+        N, C, R = self.N, self.C, self.R
+        g, gl = self.gamma, self.gamma * self.lam
+        blocks = [(0, N)] + [(N + k * C, N + (k + 1) * C) for k in range(self.tick)]
+        for lo, hi in reversed(blocks):
+            nr = self.next_rec[lo:hi]
+            comp = self.completed[lo:hi]
+            nrc = th.where(comp, nr, th.full_like(nr, R))
+            nonterm = 1.0 - self.dones[lo:hi]
+            delta = self.rewards[lo:hi] + g * self.values[nrc] * nonterm - self.values[lo:hi]
+            adv = delta + gl * nonterm * self.advantages[nrc]          # advantages of in-flight records stay 0
+            self.advantages[lo:hi] = th.where(comp, adv, th.zeros_like(adv))
+        self.returns = self.advantages + self.values
+
+    def training_indices(self, generator=None):
+        """Exactly `target` record ids (so that every rank runs the same number of minibatches): the completed records in
+        time order, truncated; with replacement only if the tick budget ran out before the rollout filled."""
+        idx = (self.completed[:self.R] & self.is_rec[:self.R]).nonzero().flatten()
+        if idx.numel() >= self.target:
+            return idx[:self.target]
+        if idx.numel() == 0:
+            raise RuntimeError("async rollout finished without a single completed transition")
+        extra = idx[th.randint(idx.numel(), (self.target - idx.numel(),), device=self.dev, generator=generator)]
+        return th.cat([idx, extra])
+
+    def stats(self):
+        c = float(self.ep_count.item())
+        return {"episodes": c, "ep_rew_mean": float(self.ep_ret_sum.item()) / max(c, 1.0), "ep_len_mean": float(self.ep_len_sum.item()) / max(c, 1.0),
+                "ticks": self.total_ticks}

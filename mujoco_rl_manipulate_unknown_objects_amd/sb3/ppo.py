@@ -63,7 +63,10 @@ class RolloutBuffer:
 class PPO:
     def __init__(self, policy, env, learning_rate=3e-4, n_steps=16, batch_size=4096, n_epochs=4, gamma=0.99, gae_lambda=0.95,
                  clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, policy_kwargs=None, verbose=0, tensorboard_log=None,
-                 device=None, seed=None, autocast_dtype=None):
+                 device=None, seed=None, autocast_dtype=None, async_slice=0, async_capacity=None):
+        """async_slice > 0 switches rollout collection to the time-sliced engine (sb3/async_rollout.py): every tick gives
+        each env at most `async_slice` calls of physics.step(), at most `async_capacity` finished envs (default N/4) are
+        rendered and decided per tick, and a rollout is n_steps * N completed transitions whichever envs they come from."""
         self.env = env
         self.n_envs = getattr(env, "num_envs", 1)
         self.device = th.device(device) if device is not None else getattr(env, "device", th.device("cuda" if th.cuda.is_available() else "cpu"))
@@ -85,7 +88,19 @@ class PPO:
                 dist.broadcast(p.data, src=0)
         self.optimizer = th.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5)
         obs_shape = env.observation_space["observation"].shape
-        self.rollout_buffer = RolloutBuffer(n_steps, self.n_envs, obs_shape, self.policy.action_dim, self.device)
+        self.rollout_buffer = None if (async_slice and async_slice > 0) else RolloutBuffer(n_steps, self.n_envs, obs_shape, self.policy.action_dim, self.device)
+        self._async = None
+        if async_slice and async_slice > 0:
+            from .async_rollout import AsyncRollout, BatchEngineAdapter
+            eng = env if hasattr(env, "advance") else BatchEngineAdapter(env)
+            cap = int(async_capacity) if async_capacity else max(1, self.n_envs // 4)
+
+            def policy_fn(obs_rows):
+                with th.no_grad(), self._ac():
+                    return self.policy({"observation": obs_rows})
+            self._async = AsyncRollout(eng, policy_fn, target=n_steps * self.n_envs, capacity=min(cap, self.n_envs), slice_len=async_slice,
+                                       gamma=gamma, gae_lambda=gae_lambda, action_low=env.action_space.low, action_high=env.action_space.high)
+            self.rollout_buffer = None
         self.num_timesteps = 0
         self._last_obs = None
         self._last_dones = None
@@ -102,6 +117,18 @@ class PPO:
         return th.autocast("cpu", enabled=False)
 
     def collect_rollouts(self, callback=None):
+        if self._async is not None:
+            state = {"n": 0, "ok": True}
+
+            def on_poll(done_n):
+                self.num_timesteps += done_n - state["n"]; state["n"] = done_n
+                if callback is not None and not callback.on_step():
+                    state["ok"] = False
+                    return False
+                return True
+            done_n = self._async.collect(on_poll)
+            self.num_timesteps += done_n - state["n"]
+            return state["ok"]
         buf = self.rollout_buffer
         if self._last_obs is None:
             self._last_obs = self._obs_t(self.env.reset())
@@ -135,15 +162,23 @@ class PPO:
             n = p.numel(); p.grad.copy_(flat[off:off + n].view_as(p.grad)); off += n
 
     def train(self):
-        buf = self.rollout_buffer
         total = self.n_steps * self.n_envs
-        obs = buf.obs.view((total,) + buf.obs.shape[2:]); actions = buf.actions.view(total, -1)
-        old_values, old_logp = buf.values.view(-1), buf.log_probs.view(-1)
-        adv_all, ret_all = buf.advantages.view(-1), buf.returns.view(-1)
+        if self._async is not None:                      # records of the async rollout, addressed through `sel`
+            buf = self._async
+            obs, actions, old_logp, adv_all, ret_all = buf.obs, buf.actions, buf.log_probs, buf.advantages, buf.returns
+            sel = buf.training_indices()
+        else:
+            buf = self.rollout_buffer
+            obs = buf.obs.view((total,) + buf.obs.shape[2:]); actions = buf.actions.view(total, -1)
+            old_logp = buf.log_probs.view(-1)
+            adv_all, ret_all = buf.advantages.view(-1), buf.returns.view(-1)
+            sel = None
         bs = min(self.batch_size, total)
         stats = {}
         for _ in range(self.n_epochs):
             perm = th.randperm(total, device=self.device)
+            if sel is not None:
+                perm = sel[perm]
             for s in range(0, total - bs + 1, bs):
                 idx = perm[s:s + bs]
                 mb_obs = {"observation": obs[idx]}
