@@ -14,6 +14,7 @@
 #define GN_PAIR_MAX 16
 #define G_MAXC 14          // contact slots per env (GRIP_MAXCON)
 #define WAVE 64
+#define RMAXPL 2560        // hull face planes of one env the observation kernel keeps in LDS (40 KiB); bread_crumb_env has 2458
 
 enum { GRP_G = 0, GRP_L = 1, GRP_R = 2, GRP_O = 3, GRP_WORLD = 4 };
 

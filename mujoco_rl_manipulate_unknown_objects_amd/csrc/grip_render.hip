@@ -44,72 +44,103 @@ __device__ static void compute_frames(const DevModel &m, const float *qpos, int 
     for (int i = 0; i < 9; i++) f.cam_R[i] = Rc.m[i];
 }
 
-__device__ static bool ray_hull(const DevModel &m, const Frames &f, int g, V3 o, V3 dir, float &thit, V3 &nrm) {
-    V3 p = ldv(f.p[g - 1]); M3 R = ldm(f.R[g - 1]);
-    V3 c = p + mulv(R, ldv(m.geom_center[g]));
-    V3 oc = o - c;
-    float dd = dot(dir, dir), bq = dot(oc, dir), cq = dot(oc, oc) - m.geom_rbound[g] * m.geom_rbound[g];
-    if (bq * bq - dd * cq < 0.f) return false;
-    V3 ol = multv(R, o - p), dl = multv(R, dir);
-    const float *pl = m.hull_planes + 4 * m.hull_padr[g - 1];
-    int np = m.hull_pnum[g - 1], ent = -1;
-    float tin = -3.0e38f, tout = 3.0e38f;
-    for (int i = 0; i < np; i++) {
-        float nx = pl[4 * i], ny = pl[4 * i + 1], nz = pl[4 * i + 2], dw = pl[4 * i + 3];
-        float den = nx * dl.x + ny * dl.y + nz * dl.z, num = dw - (nx * ol.x + ny * ol.y + nz * ol.z);
-        if (den < 0.f) { float t = num / den; if (t > tin) { tin = t; ent = i; } }
-        else if (den > 0.f) { float t = num / den; if (t < tout) tout = t; }
-        else if (num < 0.f) return false;
-        if (tin > tout) return false;
-    }
-    if (ent < 0 || tin <= 0.f) return false;
-    thit = tin;
-    nrm = mulv(R, v3(pl[4 * ent], pl[4 * ent + 1], pl[4 * ent + 2]));
-    return true;
-}
 
 __device__ static uint8_t to_u8(float v) { v *= 255.f; v = fminf(fmaxf(v, 0.f), 255.f); return (uint8_t)v; }
 
+// Per env, every hull plane n.x <= d (body frame) is first rewritten for rays leaving the camera origin in CAMERA
+// coordinates dc = (x, y, -1):  n.(ol + t dl) <= d  with  dl = Rg^T Rc dc, ol = Rg^T (co - pg)  becomes
+// t (A.dc) <= B,  A = (Rg^T Rc)^T n,  B = d - n.ol  -- one float4 per plane in LDS, 2 FMAs per ray and plane.
+// Hulls whose bounding sphere lies behind the camera plane are dropped for the whole env (the gripper base always is).
 __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevConfig cfg, const float *qpos, const int *pad_grasp, const int *pad_pher,
                                                       int n, const int *list, const int *count, uint8_t *obs) {
     // list != NULL: block b renders env list[b] into row b of obs, for b < *count (grip_batch_observe_list)
     if (list && (int)blockIdx.x >= *count) return;
     const DevModel &m = *mp;
     __shared__ Frames fr;
+    __shared__ float4 spl[RMAXPL];
+    __shared__ float gsph[GN_GEOM][4];          // bounding sphere centre in camera coordinates, radius^2
+    __shared__ int gadr[GN_GEOM], gnum[GN_GEOM];
     __shared__ float sdepth[RPIX];
     __shared__ float red[RTHREADS];
     __shared__ int redi[RTHREADS];
     const int e = list ? list[blockIdx.x] : blockIdx.x, tid = threadIdx.x;
-    if (tid == 0) compute_frames(m, qpos, n, e, fr);
+    if (tid == 0) {
+        compute_frames(m, qpos, n, e, fr);
+        V3 co = ldv(fr.cam_o); M3 Rc = ldm(fr.cam_R);
+        int adr = 0;
+        for (int g = 1; g < GN_GEOM; g++) {
+            V3 p = ldv(fr.p[g - 1]); M3 R = ldm(fr.R[g - 1]);
+            V3 c = multv(Rc, p + mulv(R, ldv(m.geom_center[g])) - co);
+            float r = m.geom_rbound[g];
+            gsph[g][0] = c.x; gsph[g][1] = c.y; gsph[g][2] = c.z; gsph[g][3] = r * r;
+            bool vis = c.z - r < 0.f && adr + m.hull_pnum[g - 1] <= RMAXPL;     // some of the sphere is in front of the camera
+            gadr[g] = adr; gnum[g] = vis ? m.hull_pnum[g - 1] : 0;
+            if (vis) adr += m.hull_pnum[g - 1];
+        }
+    }
+    __syncthreads();
+    const V3 co = ldv(fr.cam_o); const M3 Rc = ldm(fr.cam_R);
+    for (int g = 1; g < GN_GEOM; g++) {
+        const int np = gnum[g];
+        if (np == 0) continue;
+        V3 p = ldv(fr.p[g - 1]); M3 R = ldm(fr.R[g - 1]);
+        M3 Mx = mulm(M3{{R.m[0], R.m[3], R.m[6], R.m[1], R.m[4], R.m[7], R.m[2], R.m[5], R.m[8]}}, Rc);      // Rg^T Rc
+        V3 ol = multv(R, co - p);
+        const float *pl = m.hull_planes + 4 * m.hull_padr[g - 1];
+        for (int i = tid; i < np; i += RTHREADS) {
+            V3 nn = v3(pl[4 * i], pl[4 * i + 1], pl[4 * i + 2]);
+            V3 A = multv(Mx, nn);
+            spl[gadr[g] + i] = make_float4(A.x, A.y, A.z, pl[4 * i + 3] - dot(nn, ol));
+        }
+    }
     __syncthreads();
     const int nch = cfg.full_observation ? 5 : 4;
     uint8_t *o = obs + (size_t)blockIdx.x * nch * RPIX;
     const float tanh_ = tanf(0.5f * m.cam_fovy * 0.017453292519943295f);
-    V3 co = ldv(fr.cam_o); M3 Rc = ldm(fr.cam_R);
     V3 L = normalized(v3(-m.light_dir[0][0], -m.light_dir[0][1], -m.light_dir[0][2]));
     float lmin = 3.0e38f;
     for (int k = 0; k < RPIX / RTHREADS; k++) {
         int px = k * RTHREADS + tid, i = px / RW, j = px % RW;
         float x = (2.0f * (j + 0.5f) / RW - 1.0f) * tanh_, y = (1.0f - 2.0f * (i + 0.5f) / RH) * tanh_;
         V3 dir = mulv(Rc, v3(x, y, -1.f));
-        float best = m.zfar; int hit = -1; V3 nrm = v3(0, 0, 1);
+        float best = m.zfar; int hit = -1, hent = 0;
         if (dir.z < 0.f) { float t = -co.z / dir.z; if (t > m.znear && t < best) { best = t; hit = 0; } }
+        const float dd = x * x + y * y + 1.f;
         for (int g = 1; g < GN_GEOM; g++) {
-            float t; V3 nn;
-            if (ray_hull(m, fr, g, co, dir, t, nn) && t > m.znear && t < best) { best = t; hit = g; nrm = nn; }
+            const int np = gnum[g];
+            if (np == 0) continue;
+            // bounding sphere in camera coordinates: oc = -c
+            float bq = -(gsph[g][0] * x + gsph[g][1] * y - gsph[g][2]);
+            float cq = gsph[g][0] * gsph[g][0] + gsph[g][1] * gsph[g][1] + gsph[g][2] * gsph[g][2] - gsph[g][3];
+            if (bq * bq - dd * cq < 0.f || (bq > 0.f && cq > 0.f)) continue;
+            const float4 *sp = spl + gadr[g];
+            float tin = -3.0e38f, tout = 3.0e38f; int ent = -1; bool miss = false;
+            for (int q = 0; q < np; q++) {
+                float4 P = sp[q];
+                float den = fmaf(P.x, x, fmaf(P.y, y, -P.z));
+                if (den < 0.f) { float t = P.w / den; if (t > tin) { tin = t; ent = q; } }
+                else if (den > 0.f) { float t = P.w / den; tout = fminf(tout, t); }
+                else if (P.w < 0.f) miss = true;
+            }
+            if (miss || tin > tout || ent < 0 || tin <= 0.f) continue;
+            if (tin > m.znear && tin < best) { best = tin; hit = g; hent = ent; }
         }
         float c0, c1, c2;
         if (hit < 0) {
             V3 dn = normalized(dir); float f = 0.5f * (dn.z + 1.0f);
             c0 = m.sky_rgb[3] + f * (m.sky_rgb[0] - m.sky_rgb[3]); c1 = m.sky_rgb[4] + f * (m.sky_rgb[1] - m.sky_rgb[4]); c2 = m.sky_rgb[5] + f * (m.sky_rgb[2] - m.sky_rgb[5]);
         } else {
-            float b0, b1, b2;
+            float b0, b1, b2; V3 nrm = v3(0, 0, 1);
             if (hit == 0) {
                 float pxw = co.x + best * dir.x, pyw = co.y + best * dir.y;
                 int cx = (int)floorf(pxw * 8.0f), cy = (int)floorf(pyw * 8.0f);
                 int off = ((cx + cy) & 1) ? 3 : 0;
                 b0 = m.floor_rgb[off]; b1 = m.floor_rgb[off + 1]; b2 = m.floor_rgb[off + 2];
-            } else { b0 = m.geom_rgba[hit][0]; b1 = m.geom_rgba[hit][1]; b2 = m.geom_rgba[hit][2]; }
+            } else {
+                b0 = m.geom_rgba[hit][0]; b1 = m.geom_rgba[hit][1]; b2 = m.geom_rgba[hit][2];
+                const float *pl = m.hull_planes + 4 * (m.hull_padr[hit - 1] + hent);
+                nrm = mulv(ldm(fr.R[hit - 1]), v3(pl[0], pl[1], pl[2]));
+            }
             float shade = 0.4f + 0.6f * fmaxf(dot(nrm, L), 0.f);
             c0 = b0 * shade; c1 = b1 * shade; c2 = b2 * shade;
         }

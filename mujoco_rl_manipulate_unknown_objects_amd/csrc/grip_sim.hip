@@ -735,6 +735,7 @@ extern "C" int grip_batch_create(const GripModel *m, int n_envs, int device_id, 
     b->lds_bytes = ((size_t)LDS_ENV_BASE(m->hull_blob.size()) + (size_t)EPB * ENV_FLOATS) * sizeof(float);
     static_assert(ENV_FLOATS % 4 == 0 && EF_U % 4 == 0, "Hessian-vector slots must stay 16-byte aligned");
     if (b->lds_bytes > 160 * 1024) return fail("model hull tables do not fit the 160 KiB LDS next to the per-lane contact storage");
+    if (m->planes.size() / 4 > RMAXPL) return fail("model has more hull face planes than the observation kernel's LDS table holds (RMAXPL)");
     HIPCHK(hipMalloc(&b->d_planes, m->planes.size() * sizeof(float)));
     HIPCHK(hipMemcpy(b->d_planes, m->planes.data(), m->planes.size() * sizeof(float), hipMemcpyHostToDevice));
     DevModel hm_ = m->host; hm_.hull_blob = b->d_hull; hm_.hull_planes = b->d_planes;
