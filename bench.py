@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--lockstep", action="store_true", help="classic vector-env schedule instead of asynchronous time slices")
     ap.add_argument("--slice", type=int, default=16, help="physics.step() calls per env per tick (async schedule)")
     ap.add_argument("--capacity", type=int, default=1024, help="finished envs decided per tick (async schedule)")
+    ap.add_argument("--budget-us", type=int, default=0, help="wall-clock cap of a wavefront's slice in microseconds (async schedule; 0 = none)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
@@ -94,7 +95,7 @@ def main():
     env = GpuVecEnv(BatchedRobotEnv(cfg, n_envs=a.envs, device_index=local, auto_reset=True))
     model = PPO("MultiInputPolicy", env, n_steps=a.rollout, batch_size=a.minibatch, n_epochs=a.epochs, seed=1234 + rank,
                 policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]),
-                async_slice=0 if a.lockstep else a.slice, async_capacity=min(a.capacity, a.envs))
+                async_slice=0 if a.lockstep else a.slice, async_capacity=min(a.capacity, a.envs), async_budget_us=a.budget_us)
     batch = env.env.batch
     ar = model._async
 
@@ -165,7 +166,7 @@ def main():
         # async: one launch = one time slice = state + suspended macro-step context in and out (21 words each way) per env
         macro_bytes = (MACRO_BYTES_PER_ENV if ar is None else (47 + 40 + 2 * 21) * 4 + 8) * a.envs
         sched = ("lock-step vector env" if ar is None else
-                 f"asynchronous time slices ({a.slice} physics steps/tick, {min(a.capacity, a.envs)} decisions/tick)")
+                 f"asynchronous time slices (<= {a.slice} physics steps and <= {a.budget_us} us per wavefront and tick, {min(a.capacity, a.envs)} decisions/tick)")
         achieved = macro_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
             "metric": "env-steps/sec (whole node), acorn_env 4096 envs/GPU", "value": value, "unit": "env-steps/s",

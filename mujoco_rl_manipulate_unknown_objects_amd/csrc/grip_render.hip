@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
     if (list && (int)blockIdx.x >= *count) return;
     const DevModel &m = *mp;
     __shared__ Frames fr;
-    __shared__ float4 spl[RMAXPL];
+    extern __shared__ float4 spl[];             // one float4 per hull face plane of the model (sized by the launcher)
     __shared__ float gsph[GN_GEOM][4];          // bounding sphere centre in camera coordinates, radius^2
     __shared__ int gadr[GN_GEOM], gnum[GN_GEOM];
     __shared__ float sdepth[RPIX];
@@ -115,12 +115,17 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
             if (bq * bq - dd * cq < 0.f || (bq > 0.f && cq > 0.f)) continue;
             const float4 *sp = spl + gadr[g];
             float tin = -3.0e38f, tout = 3.0e38f; int ent = -1; bool miss = false;
+            // branch-free Cyrus-Beck step: t = B / (A.dc) by v_rcp_f32 (1 ulp); entering planes (den < 0) raise tin,
+            // leaving planes (den > 0) lower tout, a parallel plane with the origin outside (den == 0, B < 0) is a miss
+#pragma unroll 4
             for (int q = 0; q < np; q++) {
                 float4 P = sp[q];
                 float den = fmaf(P.x, x, fmaf(P.y, y, -P.z));
-                if (den < 0.f) { float t = P.w / den; if (t > tin) { tin = t; ent = q; } }
-                else if (den > 0.f) { float t = P.w / den; tout = fminf(tout, t); }
-                else if (P.w < 0.f) miss = true;
+                float t = P.w * rcp(den);
+                bool in = den < 0.f, up = in && t > tin;
+                tin = up ? t : tin; ent = up ? q : ent;
+                tout = (den > 0.f && t < tout) ? t : tout;
+                miss |= (den == 0.f && P.w < 0.f);
             }
             if (miss || tin > tout || ent < 0 || tin <= 0.f) continue;
             if (tin > m.znear && tin < best) { best = tin; hit = g; hent = ent; }
@@ -170,7 +175,7 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
 }
 
 extern "C" int grip_render_launch(const DevModel *d_model, DevConfig cfg, const float *qpos, const int *pad_grasp, const int *pad_pher, int n,
-                                  const int *list, const int *count, int nblocks, uint8_t *obs, hipStream_t s) {
-    hipLaunchKernelGGL(k_observe, dim3(nblocks), dim3(RTHREADS), 0, s, d_model, cfg, qpos, pad_grasp, pad_pher, n, list, count, obs);
+                                  const int *list, const int *count, int nblocks, int nplanes, uint8_t *obs, hipStream_t s) {
+    hipLaunchKernelGGL(k_observe, dim3(nblocks), dim3(RTHREADS), (size_t)nplanes * sizeof(float4), s, d_model, cfg, qpos, pad_grasp, pad_pher, n, list, count, obs);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

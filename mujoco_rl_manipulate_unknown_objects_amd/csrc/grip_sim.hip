@@ -238,8 +238,8 @@ struct GripBatch {
     float *qpos = nullptr, *qvel = nullptr, *ctrl = nullptr, *warm = nullptr;     // SoA [field][N]
     int *episode_step = nullptr, *status = nullptr, *gripper_open = nullptr;
     int *pad_grasp = nullptr, *pad_pher = nullptr;                              // sensor-pad scalars of the current state
-    int *mc_ints = nullptr, *mc_astate = nullptr, *mc_slot = nullptr, *mc_order = nullptr; float *mc_flts = nullptr;   // suspended macro steps
-    int ticks = 0;
+    int nplanes = 0;
+    int *mc_ints = nullptr, *mc_astate = nullptr, *mc_slot = nullptr, *mc_order = nullptr, *mc_heavy = nullptr, *mc_tick = nullptr; float *mc_flts = nullptr;   // suspended macro steps
     float *reset_info = nullptr;                                                // grasp0, pher0, objx0, objy0 of the reset state
     float *scratch = nullptr; size_t scratch_bytes = 0;
     float xfrc_z = 0.f;
@@ -255,8 +255,9 @@ struct StatePtrs { float *qpos, *qvel, *ctrl, *warm; int *episode_step, *status,
 
 // A macro step suspended between two time slices (grip_batch_advance): everything k_macro_step keeps in registers across
 // its physics.step() loop, SoA [field][N]. astate: 0 = macro step in flight, 1 = finished, waiting for an action;
-// slot: row of the compact action / observation arrays this waiting env was given by the last k_compact (-1 = none yet).
-struct MacroCtx { int *ints; float *flts; int *astate; int *slot; };
+// slot: row of the compact action / observation arrays this waiting env was given by the last k_compact (-1 = none yet);
+// heavy: hull-hull contacts the env had at its last physics.step() -- the cost class k_compact sorts the work order by.
+struct MacroCtx { int *ints; float *flts; int *astate; int *slot; int *heavy; int *tick; };
 enum { MC_PHASE = 0, MC_CNT, MC_NSUB, MC_GRASPED, MC_FLAGS, MC_FAULT, MC_NINT };
 enum { MC_TARGET = 0, MC_INITQ = 5, MC_OPENCLOSE = 10, MC_TQ = 11, MC_INITOBJ = 12, MC_NFLT = 15 };
 
@@ -409,7 +410,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_reset(const DevModel m, DevCo
 // slot starts a macro step with actions[slot], both run at most `slice` calls of physics.step(); envs that finish write
 // their outputs and wait, the others are suspended. The arithmetic per env is the same in both modes.
 __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, DevConfig cfg, StatePtrs st, const float *actions, StepOutDev out,
-                                                              const float *reset_info, float xfrc_z, MacroCtx mc, int slice, const int *order) {
+                                                              const float *reset_info, float xfrc_z, MacroCtx mc, int slice, const int *order, long long budget_ticks) {
     const Ctx cx = stage_tables(m, lds_dyn);
     STAMPS_DECL
     int e = blockIdx.x * EPB + threadIdx.x / KL;
@@ -450,6 +451,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
         for (int i = 0; i < 6; i++) act[i] = i < adim ? actions[arow * adim + i] : 0.f;
     }
     int budget = sliced ? slice : 0x7fffffff;
+    const long long t_start = wall_clock64();           // 100 MHz, wave-uniform
 
     while (__any(phase != PH_DONE && (budget > 0 || phase == PH_FINAL))) {
         if (phase != PH_DONE && (budget > 0 || phase == PH_FINAL)) {
@@ -522,6 +524,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
                 }
                 physics_advance(m, cx, s, xfrc_z, k, con, ncon, fault, stm);
                 nsub++; cnt++; budget--;
+                if (budget_ticks > 0 && wall_clock64() - t_start > budget_ticks) budget = 0;     // the wave's share of the tick is spent
                 // ---- post-step transitions
                 bool to_gripper = false, to_final = false;
                 if (phase == PH_MOVE || phase == PH_RETURN) {
@@ -565,6 +568,10 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
             }
         }
     }
+    if (sliced) {
+        int hv = __popc(group_bits(__ballot(cx.sub < ncon && con.g1 != 0), cx.lane));
+        if (writer && nsub > 0) mc.heavy[e] = hv;
+    }
     if (sliced && writer && phase != PH_DONE) {             // out of budget mid-step: suspend
         st_state(st, e, s);
         st.status[e] = status; st.gripper_open[e] = gripper_open;
@@ -580,11 +587,17 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
 }
 
 // Deterministic compaction after a time slice (one 1024-thread block): the waiting envs, scanned from env `rot` on so that
-// nobody starves when more wait than `capacity`, get slots 0..count-1 (list[slot] = env, -1 beyond count); order[] lists the
-// envs that will do work in the next slice (in flight, or holding a slot) first, so that whole workgroups of idle envs retire at once.
+// nobody starves when more wait than `capacity`, get slots 0..count-1 (list[slot] = env, -1 beyond count). order[] is the
+// work order of the next slice: envs that will run (in flight, or holding a slot) sorted by cost class -- no hull contact,
+// one or two, more -- so that the 4 envs of a wave and the 16 of a workgroup cost about the same per physics.step(), then
+// the idle envs, whose workgroups retire at once.
 #define CP_THREADS 1024
-__global__ void __launch_bounds__(CP_THREADS) k_compact(MacroCtx mc, int n, int capacity, int rot, int *list, int *count, int *order) {
-    __shared__ int sa[CP_THREADS], sb[CP_THREADS];
+#define CP_CLASSES 4
+__global__ void __launch_bounds__(CP_THREADS) k_compact(MacroCtx mc, int n, int capacity, int *list, int *count, int *order) {
+    // the rotation advances with a device-side tick counter, so that a captured (hipGraph) tick keeps rotating
+    const int rot = (int)(((long long)mc.tick[0] * capacity) % n);
+    __shared__ int sa[CP_THREADS];
+    __shared__ int cls_total[CP_CLASSES];
     const int t = threadIdx.x, chunk = (n + CP_THREADS - 1) / CP_THREADS;
     // pass 1: slots for the waiting envs, in rotated order
     int c = 0;
@@ -592,6 +605,7 @@ __global__ void __launch_bounds__(CP_THREADS) k_compact(MacroCtx mc, int n, int 
     sa[t] = c; __syncthreads();
     for (int d = 1; d < CP_THREADS; d <<= 1) { int x = t >= d ? sa[t - d] : 0; __syncthreads(); sa[t] += x; __syncthreads(); }
     int base = sa[t] - c, total = sa[CP_THREADS - 1];
+    __syncthreads();
     for (int i = 0; i < chunk; i++) {
         int v = t * chunk + i;
         if (v < n) {
@@ -603,17 +617,21 @@ __global__ void __launch_bounds__(CP_THREADS) k_compact(MacroCtx mc, int n, int 
     for (int p = cnt + t; p < capacity; p += CP_THREADS) list[p] = -1;
     if (t == 0) *count = cnt;
     __syncthreads();
-    // pass 2: work order for the next slice
-    int a = 0;
-    for (int i = 0; i < chunk; i++) { int e = t * chunk + i; if (e < n) a += (mc.astate[e] == 0 || mc.slot[e] >= 0); }
-    sb[t] = a; __syncthreads();
-    for (int d = 1; d < CP_THREADS; d <<= 1) { int x = t >= d ? sb[t - d] : 0; __syncthreads(); sb[t] += x; __syncthreads(); }
-    int abase = sb[t] - a, nact = sb[CP_THREADS - 1];
-    int ibase = nact + (min(t * chunk, n) - abase);
-    for (int i = 0; i < chunk; i++) {
-        int e = t * chunk + i;
-        if (e < n) { bool act = mc.astate[e] == 0 || mc.slot[e] >= 0; if (act) order[abase++] = e; else order[ibase++] = e; }
+    // pass 2: counting sort of the envs by class (0..2 = running by cost, 3 = idle), stable within a class
+    auto cls_of = [&](int e) { bool run = mc.astate[e] == 0 || mc.slot[e] >= 0; int h = mc.heavy[e]; return !run ? 3 : h == 0 ? 0 : h <= 2 ? 1 : 2; };
+    int mine[CP_CLASSES] = {0, 0, 0, 0}, before[CP_CLASSES];
+    for (int i = 0; i < chunk; i++) { int e = t * chunk + i; if (e < n) mine[cls_of(e)]++; }
+    for (int k = 0; k < CP_CLASSES; k++) {
+        sa[t] = mine[k]; __syncthreads();
+        for (int d = 1; d < CP_THREADS; d <<= 1) { int x = t >= d ? sa[t - d] : 0; __syncthreads(); sa[t] += x; __syncthreads(); }
+        before[k] = sa[t] - mine[k];
+        if (t == CP_THREADS - 1) cls_total[k] = sa[t];
+        __syncthreads();
     }
+    int start = 0;
+    for (int k = 0; k < CP_CLASSES; k++) { before[k] += start; start += cls_total[k]; }
+    for (int i = 0; i < chunk; i++) { int e = t * chunk + i; if (e < n) order[before[cls_of(e)]++] = e; }
+    if (t == 0) mc.tick[0] = mc.tick[0] + 1;      // every thread read the old value before the first barrier
 }
 
 // k calls of physics.step() with the stored ctrl (test hook / micro-benchmark)
@@ -706,7 +724,7 @@ static StepOutDev to_dev(const GripStepOut *o) {
     d.n_substeps = o->n_substeps; d.fault = o->fault;
     return d;
 }
-static MacroCtx macro_ctx(GripBatch *b) { MacroCtx c; c.ints = b->mc_ints; c.flts = b->mc_flts; c.astate = b->mc_astate; c.slot = b->mc_slot; return c; }
+static MacroCtx macro_ctx(GripBatch *b) { MacroCtx c; c.ints = b->mc_ints; c.flts = b->mc_flts; c.astate = b->mc_astate; c.slot = b->mc_slot; c.heavy = b->mc_heavy; c.tick = b->mc_tick; return c; }
 static int grid_of(const GripBatch *b) { return (b->n + EPB - 1) / EPB; }
 
 static int ensure_lds_attr() {
@@ -736,6 +754,7 @@ extern "C" int grip_batch_create(const GripModel *m, int n_envs, int device_id, 
     static_assert(ENV_FLOATS % 4 == 0 && EF_U % 4 == 0, "Hessian-vector slots must stay 16-byte aligned");
     if (b->lds_bytes > 160 * 1024) return fail("model hull tables do not fit the 160 KiB LDS next to the per-lane contact storage");
     if (m->planes.size() / 4 > RMAXPL) return fail("model has more hull face planes than the observation kernel's LDS table holds (RMAXPL)");
+    b->nplanes = (int)(m->planes.size() / 4);
     HIPCHK(hipMalloc(&b->d_planes, m->planes.size() * sizeof(float)));
     HIPCHK(hipMemcpy(b->d_planes, m->planes.data(), m->planes.size() * sizeof(float), hipMemcpyHostToDevice));
     DevModel hm_ = m->host; hm_.hull_blob = b->d_hull; hm_.hull_planes = b->d_planes;
@@ -749,6 +768,10 @@ extern "C" int grip_batch_create(const GripModel *m, int n_envs, int device_id, 
     HIPCHK(hipMalloc(&b->pad_pher, N * sizeof(int))); HIPCHK(hipMalloc(&b->reset_info, 4 * sizeof(float)));
     HIPCHK(hipMalloc(&b->mc_ints, MC_NINT * N * sizeof(int))); HIPCHK(hipMalloc(&b->mc_flts, MC_NFLT * N * sizeof(float)));
     HIPCHK(hipMalloc(&b->mc_astate, N * sizeof(int))); HIPCHK(hipMalloc(&b->mc_slot, N * sizeof(int))); HIPCHK(hipMalloc(&b->mc_order, N * sizeof(int)));
+    HIPCHK(hipMalloc(&b->mc_heavy, N * sizeof(int))); HIPCHK(hipMemset(b->mc_heavy, 0, N * sizeof(int)));
+    HIPCHK(hipMalloc(&b->mc_tick, sizeof(int))); HIPCHK(hipMemset(b->mc_tick, 0, sizeof(int)));
+    {   std::vector<int> ident(N); for (size_t i = 0; i < N; i++) ident[i] = (int)i;          // work order: identity until the first compaction
+        HIPCHK(hipMemcpy(b->mc_order, ident.data(), N * sizeof(int), hipMemcpyHostToDevice)); }
     b->scratch_bytes = 169 * N * sizeof(float) + 1024;
     HIPCHK(hipMalloc(&b->scratch, b->scratch_bytes));
     // config defaults (config/base_config.py:12-54)
@@ -768,7 +791,7 @@ extern "C" void grip_batch_destroy(GripBatch *b) {
     (void)hipDeviceSynchronize();
     void *ptrs[] = {b->d_model, b->d_hull, b->d_planes, b->qpos, b->qvel, b->ctrl, b->warm, b->episode_step, b->status,
                     b->gripper_open, b->pad_grasp, b->pad_pher, b->reset_info, b->scratch, b->mc_ints, b->mc_flts, b->mc_astate,
-                    b->mc_slot, b->mc_order};
+                    b->mc_slot, b->mc_order, b->mc_heavy, b->mc_tick};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : b->ev0) (void)hipEventDestroy(e);
     for (auto &e : b->ev1) (void)hipEventDestroy(e);
@@ -811,30 +834,31 @@ extern "C" int grip_batch_step(GripBatch *b, const float *actions_dev, const Gri
     int slot = b->ev_used % EV_RING;
     HIPCHK(hipEventRecord(b->ev0[slot], s));
     hipLaunchKernelGGL(k_macro_step, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, s, b->hmodel, b->cfg, state_ptrs(b), actions_dev, to_dev(out),
-                       b->reset_info, b->xfrc_z, macro_ctx(b), 0, (const int *)nullptr);
+                       b->reset_info, b->xfrc_z, macro_ctx(b), 0, (const int *)nullptr, 0LL);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev1[slot], s));
     b->ev_used++;
     return 0;
 }
 
-extern "C" int grip_batch_advance(GripBatch *b, const float *slot_actions_dev, int slice, int capacity, const GripStepOut *out,
+extern "C" int grip_batch_advance(GripBatch *b, const float *slot_actions_dev, int slice, int budget_us, int capacity, const GripStepOut *out,
                                   int32_t *ready_list_dev, int32_t *ready_count_dev, void *stream) {
     if (!b || !slot_actions_dev || !ready_list_dev || !ready_count_dev) return fail("grip_batch_advance: null argument");
     if (slice <= 0 || capacity <= 0 || capacity > b->n) return fail("grip_batch_advance: need slice > 0 and 0 < capacity <= num_envs");
     HIPCHK(hipSetDevice(b->device));
     hipStream_t s = (hipStream_t)stream;
+    // launch timing uses events, which a stream under hipGraph capture cannot take: captured ticks are not timed
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (s) HIPCHK(hipStreamIsCapturing(s, &cap));
+    const bool timed = cap == hipStreamCaptureStatusNone;
     int slot = b->ev_used % EV_RING;
-    HIPCHK(hipEventRecord(b->ev0[slot], s));
+    if (timed) HIPCHK(hipEventRecord(b->ev0[slot], s));
     hipLaunchKernelGGL(k_macro_step, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, s, b->hmodel, b->cfg, state_ptrs(b), slot_actions_dev, to_dev(out),
-                       b->reset_info, b->xfrc_z, macro_ctx(b), slice, b->ticks > 0 ? (const int *)b->mc_order : (const int *)nullptr);
+                       b->reset_info, b->xfrc_z, macro_ctx(b), slice, (const int *)b->mc_order, (long long)(budget_us > 0 ? budget_us : 0) * 100LL);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(b->ev1[slot], s));
-    b->ev_used++;
-    int rot = (int)(((long long)b->ticks * capacity) % b->n);
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(CP_THREADS), 0, s, macro_ctx(b), b->n, capacity, rot, ready_list_dev, ready_count_dev, b->mc_order);
+    if (timed) { HIPCHK(hipEventRecord(b->ev1[slot], s)); b->ev_used++; }
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(CP_THREADS), 0, s, macro_ctx(b), b->n, capacity, ready_list_dev, ready_count_dev, b->mc_order);
     HIPCHK(hipGetLastError());
-    b->ticks++;
     return 0;
 }
 
@@ -955,18 +979,18 @@ extern "C" int grip_batch_target_pose(GripBatch *b, const float *actions_dev, fl
 
 // observation kernels live in grip_render.hip
 extern "C" int grip_render_launch(const DevModel *d_model, DevConfig cfg, const float *qpos, const int *pad_grasp, const int *pad_pher, int n,
-                                  const int *list, const int *count, int nblocks, uint8_t *obs, hipStream_t s);
+                                  const int *list, const int *count, int nblocks, int nplanes, uint8_t *obs, hipStream_t s);
 extern "C" int grip_batch_observe(GripBatch *b, uint8_t *obs_dev, void *stream) {
     if (!b || !obs_dev) return fail("grip_batch_observe: null argument");
     HIPCHK(hipSetDevice(b->device));
-    if (grip_render_launch(b->d_model, b->cfg, b->qpos, b->pad_grasp, b->pad_pher, b->n, nullptr, nullptr, b->n, obs_dev, (hipStream_t)stream))
+    if (grip_render_launch(b->d_model, b->cfg, b->qpos, b->pad_grasp, b->pad_pher, b->n, nullptr, nullptr, b->n, b->nplanes, obs_dev, (hipStream_t)stream))
         return fail("render launch failed");
     return 0;
 }
 extern "C" int grip_batch_observe_list(GripBatch *b, const int32_t *list_dev, const int32_t *count_dev, int capacity, uint8_t *obs_dev, void *stream) {
     if (!b || !obs_dev || !list_dev || !count_dev || capacity <= 0) return fail("grip_batch_observe_list: bad argument");
     HIPCHK(hipSetDevice(b->device));
-    if (grip_render_launch(b->d_model, b->cfg, b->qpos, b->pad_grasp, b->pad_pher, b->n, list_dev, count_dev, capacity, obs_dev, (hipStream_t)stream))
+    if (grip_render_launch(b->d_model, b->cfg, b->qpos, b->pad_grasp, b->pad_pher, b->n, list_dev, count_dev, capacity, b->nplanes, obs_dev, (hipStream_t)stream))
         return fail("render launch failed");
     return 0;
 }

@@ -13,7 +13,8 @@ Transitions therefore arrive out of order. They are stored as *decision records*
 Record ids grow with time (carry region [0, N), then `capacity` rows per tick), so next_rec[r] > r and GAE is a
 backward sweep over tick blocks with a gather through next_rec. A record that is still in flight when the rollout is
 full bootstraps its predecessor with its value (as PPO's last_values do) and is carried into rows [0, N) of the next
-rollout -- one record per env at most. Everything below is fixed-shape device work: no host sync inside a tick.
+rollout -- one record per env at most. A tick is fixed-shape, fixed-address device work with no host sync, and on a GPU
+it is captured once into a hipGraph (torch.cuda.CUDAGraph) and replayed: ~100 small launches become one.
 
 The engine is duck-typed (`advance`, `observe_list`, `num_envs`, `action_dim`, `obs_shape`, `device`) so that the
 bookkeeping is testable on CPU against a scripted engine (tests/test_async_rollout_cpu.py).
@@ -24,7 +25,8 @@ import torch as th
 class BatchEngineAdapter:
     """engine.Batch (via BatchedRobotEnv / GpuVecEnv) as the duck-typed async engine."""
 
-    def __init__(self, env):
+    def __init__(self, env, budget_us=0):
+        self.budget_us = int(budget_us)                  # wall-clock cap of a wavefront's slice (grip_sim.h), 0 = none
         benv = getattr(env, "env", env)                  # GpuVecEnv -> BatchedRobotEnv
         self.batch = benv.batch
         if not self.batch.cfg.auto_reset:
@@ -36,7 +38,7 @@ class BatchEngineAdapter:
         self.batch.reset()
 
     def advance(self, slot_actions, slice_len, ready_list, ready_count):
-        return self.batch.advance(slot_actions, slice_len, ready_list, ready_count)
+        return self.batch.advance(slot_actions, slice_len, ready_list, ready_count, self.budget_us)
 
     def observe_list(self, ready_list, ready_count, obs_rows):
         self.batch.observe_list(ready_list, ready_count, obs_rows)
@@ -44,7 +46,7 @@ class BatchEngineAdapter:
 
 class AsyncRollout:
     def __init__(self, engine, policy_fn, target, capacity, slice_len, gamma, gae_lambda, max_ticks=None, action_low=None, action_high=None,
-                 poll_every=4):
+                 poll_every=4, use_graph=True):
         """policy_fn(obs_rows uint8 [C, ...]) -> (actions [C, A], values [C], log_probs [C]) under no_grad.
         target = completed transitions per rollout; capacity = ready-list rows per tick."""
         self.eng, self.policy_fn = engine, policy_fn
@@ -78,20 +80,23 @@ class AsyncRollout:
         self.ep_ret = th.zeros(self.N + 1, device=dev); self.ep_len = th.zeros(self.N + 1, device=dev)
         self.ep_ret_sum = th.zeros(1, device=dev); self.ep_len_sum = th.zeros(1, device=dev); self.ep_count = th.zeros(1, device=dev)
         self.substeps_total = th.zeros(1, dtype=th.int64, device=dev)          # physics.step() calls of the finished macro steps
+        self.base_t = th.full((1,), self.N, dtype=th.int64, device=dev)        # first record row of the current tick
+        self.obs_stage = th.zeros((self.C,) + tuple(engine.obs_shape), dtype=th.uint8, device=dev)
+        self.use_graph, self.graph_after, self.eager_every, self._graph = use_graph, 3, 16, None
         self._started = False
 
     # ------------------------------------------------------------------ one tick
-    def _tick(self):
+    def _tick_body(self):
+        """All of a tick as fixed-shape, fixed-address device work (the record rows of the tick come from the device scalar
+        base_t), so that on a GPU the whole tick is one hipGraph launch."""
         N, C, R = self.N, self.C, self.R
-        base = N + self.tick * C
         out = self.eng.advance(self.slot_act, self.S, self.lst, self.cnt)
-        rows = slice(base, base + C)
-        obs_rows = self.obs[rows]
-        self.eng.observe_list(self.lst, self.cnt, obs_rows)
+        self.eng.observe_list(self.lst, self.cnt, self.obs_stage)
+        rows = self.base_t + self.ar_c                                 # record ids of this tick
         valid = self.ar_c < self.cnt                                   # [C]
         env = th.where(valid, self.lst, N).long()                      # dump env N for empty rows
         env_c = env.clamp(max=N - 1)
-        actions, values, log_probs = self.policy_fn(obs_rows)
+        actions, values, log_probs = self.policy_fn(self.obs_stage)
         act = actions if self.low is None else th.max(th.min(actions, self.high), self.low)
         self.slot_act.copy_(act)
         # close the previous decision of every listed env
@@ -100,8 +105,8 @@ class AsyncRollout:
         prev_m = th.where(had, prev, R)
         rew = out["reward"][env_c].float(); dn = out["done"][env_c].float()
         self.rewards[prev_m] = rew; self.dones[prev_m] = dn
-        self.next_rec[prev_m] = base + self.ar_c
-        self.completed[prev_m] = True
+        self.next_rec[prev_m] = rows
+        self.completed.index_fill_(0, prev_m, True)
         self.n_completed += had.sum()
         if "n_substeps" in out:
             self.substeps_total += (out["n_substeps"][env_c] * had).sum()
@@ -112,11 +117,32 @@ class AsyncRollout:
         keep = (~fin).float()
         self.ep_ret[env] *= keep; self.ep_len[env] *= keep
         # open the new decision
-        self.actions[rows] = actions; self.log_probs[rows] = log_probs; self.values[rows] = values
-        self.is_rec[rows] = valid; self.completed[rows] = False; self.next_rec[rows] = -1
-        self.rec_env[rows] = th.where(valid, env, th.full_like(env, -1))
-        self.rec_of_env[env] = base + self.ar_c
+        self.obs.index_copy_(0, rows, self.obs_stage)
+        self.actions.index_copy_(0, rows, actions); self.log_probs.index_copy_(0, rows, log_probs); self.values.index_copy_(0, rows, values)
+        self.is_rec.index_copy_(0, rows, valid)
+        self.completed.index_fill_(0, rows, False); self.next_rec.index_fill_(0, rows, -1)
+        self.rec_env.index_copy_(0, rows, th.where(valid, env, th.full_like(env, -1)))
+        self.rec_of_env[env] = rows
+        self.base_t += C
+
+    def _tick(self):
+        use_graph = self.use_graph and self.dev.type == "cuda"
+        if use_graph and self._graph is None and self.total_ticks >= self.graph_after:
+            self._capture()
+        # every `eager_every`-th tick runs outside the graph so that the engine can time its kernel with events
+        if use_graph and self._graph is not None and (self.total_ticks % self.eager_every) != 0:
+            self._graph.replay()
+        else:
+            self._tick_body()
         self.tick += 1; self.total_ticks += 1
+
+    def _capture(self):
+        """Capture one tick. Capturing records the launches without running them, so the state is untouched."""
+        th.cuda.synchronize(self.dev)
+        g = th.cuda.CUDAGraph()
+        with th.cuda.graph(g):
+            self._tick_body()
+        self._graph = g
 
     # ------------------------------------------------------------------ rollout
     def _begin(self):
@@ -133,6 +159,7 @@ class AsyncRollout:
         self.rec_env[:N] = th.where(has, ar, th.full_like(ar, -1))
         self.rec_of_env[:N] = th.where(has, ar, th.full_like(ar, -1))
         self.n_completed.zero_()
+        self.base_t.fill_(N)
         self.tick = 0
 
     def collect(self, on_poll=None):

@@ -63,10 +63,11 @@ class RolloutBuffer:
 class PPO:
     def __init__(self, policy, env, learning_rate=3e-4, n_steps=16, batch_size=4096, n_epochs=4, gamma=0.99, gae_lambda=0.95,
                  clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, policy_kwargs=None, verbose=0, tensorboard_log=None,
-                 device=None, seed=None, autocast_dtype=None, async_slice=0, async_capacity=None):
+                 device=None, seed=None, autocast_dtype=None, async_slice=0, async_capacity=None, async_budget_us=0):
         """async_slice > 0 switches rollout collection to the time-sliced engine (sb3/async_rollout.py): every tick gives
         each env at most `async_slice` calls of physics.step(), at most `async_capacity` finished envs (default N/4) are
-        rendered and decided per tick, and a rollout is n_steps * N completed transitions whichever envs they come from."""
+        rendered and decided per tick, and a rollout is n_steps * N completed transitions whichever envs they come from.
+        async_budget_us > 0 also caps a wavefront's slice by wall-clock time (include/grip_sim.h)."""
         self.env = env
         self.n_envs = getattr(env, "num_envs", 1)
         self.device = th.device(device) if device is not None else getattr(env, "device", th.device("cuda" if th.cuda.is_available() else "cpu"))
@@ -92,7 +93,7 @@ class PPO:
         self._async = None
         if async_slice and async_slice > 0:
             from .async_rollout import AsyncRollout, BatchEngineAdapter
-            eng = env if hasattr(env, "advance") else BatchEngineAdapter(env)
+            eng = env if hasattr(env, "advance") else BatchEngineAdapter(env, async_budget_us)
             cap = int(async_capacity) if async_capacity else max(1, self.n_envs // 4)
 
             def policy_fn(obs_rows):

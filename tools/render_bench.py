@@ -1,0 +1,26 @@
+"""Time of the observation kernel alone: full batch and list mode."""
+import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from mujoco_rl_manipulate_unknown_objects_amd import engine
+obj = sys.argv[1] if len(sys.argv) > 1 else "acorn"
+n = 4096
+b = engine.Batch(obj, n, auto_reset=1)
+g = torch.Generator(device="cuda"); g.manual_seed(0)
+def timeit(f, reps=10):
+    f(); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+obs = torch.zeros(n, 5, 64, 64, dtype=torch.uint8, device="cuda")
+print("reset state: full observe %.3f ms" % timeit(lambda: b.observe(obs)))
+for t in range(6):
+    b.step(torch.randn(n, 6, device="cuda", generator=g).clamp(-1, 1))
+print("after 6 random steps: full observe %.3f ms" % timeit(lambda: b.observe(obs)))
+for cnt in (256, 512, 1024):
+    lst = torch.arange(cnt, dtype=torch.int32, device="cuda") * (n // cnt)
+    c = torch.tensor([cnt], dtype=torch.int32, device="cuda")
+    rows = torch.zeros(1024, 5, 64, 64, dtype=torch.uint8, device="cuda")
+    lst_p = torch.full((1024,), -1, dtype=torch.int32, device="cuda"); lst_p[:cnt] = lst
+    print("list of %d: %.3f ms" % (cnt, timeit(lambda: b.observe_list(lst_p, c, rows))))
