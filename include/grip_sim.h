@@ -117,6 +117,33 @@ int grip_batch_advance(GripBatch *b, const float *slot_actions_dev, int slice, i
 /* get_observation for the listed envs only: row r of obs_dev (uint8 [capacity,5,64,64]) = env list_dev[r], r < *count_dev. */
 int grip_batch_observe_list(GripBatch *b, const int32_t *list_dev, const int32_t *count_dev, int capacity, uint8_t *obs_dev, void *stream);
 
+/* ---- rollout recorder: the trainer-side bookkeeping of asynchronous stepping, fused (csrc/grip_rollout.hip) ---------
+ * Decision records live in caller-owned device arrays of n_records + 1 rows (row n_records is a dump row); per-env arrays
+ * have n_envs + 1 rows (row n_envs: dump). One call per tick, after the policy ran on the listed envs:
+ *   for every listed env: its previous record gets reward / done / next_rec and is marked completed (counters and episode
+ *   statistics updated); a new record at row base[0] + r takes the policy outputs of row r; slot_actions[r] = the action
+ *   clipped to [low, high] for the next grip_batch_advance. The stand-in for SB3's RolloutBuffer.add (no reference file:
+ *   the reference trains through stable_baselines3, train_agent.py:82-92). */
+typedef struct {
+    int32_t n_envs, capacity, action_dim; int64_t n_records;
+    const int32_t *ready_list, *ready_count;      /* from grip_batch_advance */
+    const int64_t *base;                          /* [1] first record row of this tick */
+    const float *reward; const uint8_t *done; const int32_t *n_substeps;   /* GripStepOut arrays [n_envs] (n_substeps may be NULL) */
+    const float *actions, *values, *log_probs;    /* policy outputs [capacity, action_dim], [capacity], [capacity] */
+    const float *low, *high;                      /* [action_dim] */
+    float *slot_actions;                          /* [capacity, action_dim] out */
+    int64_t *rec_of_env;                          /* [n_envs + 1] open record of each env, -1 = none */
+    float *rewards, *dones; int64_t *next_rec, *prev_rec, *rec_env; uint8_t *completed, *is_rec;    /* [n_records + 1] */
+    float *actions_buf, *log_probs_buf, *values_buf;                                               /* [n_records + 1, ...] */
+    int64_t *n_completed, *substeps_total;        /* [1] counters */
+    float *ep_ret, *ep_len;                       /* [n_envs + 1] running episode return / length */
+    float *ep_ret_sum, *ep_len_sum, *ep_count;    /* [1] finished-episode statistics */
+} GripRolloutTick;
+int grip_rollout_tick(const GripRolloutTick *args, void *stream);
+/* GAE over every env's record chain, backwards from its open record (whose value bootstraps) along prev_rec. */
+int grip_rollout_gae(int n_envs, const int64_t *rec_of_env, const int64_t *prev_rec, const float *rewards, const float *dones,
+                     const float *values, float gamma, float gae_lambda, float *advantages, float *returns, void *stream);
+
 /* ---- low-level hooks (the dm_control Physics surface the reference touches; used by tests) ---- */
 /* physics.data.qpos / qvel / ctrl / qacc_warmstart, env-major float32 [N,14],[N,13],[N,7],[N,13];
  * host_or_dev = 0: host pointers (synchronous copy), 1: device pointers. NULL skips a field. */

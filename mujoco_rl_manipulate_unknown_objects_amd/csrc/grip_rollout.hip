@@ -1,0 +1,79 @@
+// grip_rollout.hip -- device-side bookkeeping of the asynchronous rollout (sb3/async_rollout.py).
+//
+// The time-sliced engine (grip_batch_advance) hands back, every tick, a list of envs that finished a macro step. The
+// trainer keeps "decision records" in HBM: record r = (env, obs, action, log_prob, value), whose reward / done arrive
+// when the env is listed the next time. Doing that with tensor-library ops costs ~60 launches of a few microseconds per
+// tick; k_rollout_tick does all of it in one launch, k_rollout_gae walks every env's record chain backwards (generalised
+// advantage estimation, Schulman et al. 2016, as SB3's RolloutBuffer.compute_returns_and_advantage does for lock-step
+// buffers). Pure index/scalar work, HBM-resident, one thread per listed env / per env.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/grip_sim.h"
+
+__global__ void k_rollout_tick(GripRolloutTick a) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.capacity) return;
+    const int N = a.n_envs; const long long R = a.n_records;
+    const bool valid = r < a.ready_count[0];
+    const long long row = a.base[0] + r;
+    const int env = valid ? a.ready_list[r] : N;                     // row N / record R: dump rows for masked writes
+    // close the previous decision of this env
+    const long long prev = a.rec_of_env[env];
+    const bool had = valid && prev >= 0;
+    if (had) {
+        const float rew = a.reward[env]; const float dn = a.done[env] ? 1.f : 0.f;
+        a.rewards[prev] = rew; a.dones[prev] = dn; a.next_rec[prev] = row; a.completed[prev] = 1;
+        atomicAdd((unsigned long long *)a.n_completed, 1ULL);
+        if (a.n_substeps) atomicAdd((unsigned long long *)a.substeps_total, (unsigned long long)a.n_substeps[env]);
+        float er = a.ep_ret[env] + rew, el = a.ep_len[env] + 1.f;
+        if (dn > 0.f) { atomicAdd(a.ep_ret_sum, er); atomicAdd(a.ep_len_sum, el); atomicAdd(a.ep_count, 1.f); er = 0.f; el = 0.f; }
+        a.ep_ret[env] = er; a.ep_len[env] = el;
+    }
+    // open the new one
+    for (int i = 0; i < a.action_dim; i++) {
+        float v = a.actions[(size_t)r * a.action_dim + i];
+        a.actions_buf[(size_t)row * a.action_dim + i] = v;
+        a.slot_actions[(size_t)r * a.action_dim + i] = fminf(fmaxf(v, a.low[i]), a.high[i]);
+    }
+    a.log_probs_buf[row] = a.log_probs[r]; a.values_buf[row] = a.values[r];
+    a.is_rec[row] = valid ? 1 : 0; a.completed[row] = 0; a.next_rec[row] = -1;
+    a.prev_rec[row] = had ? prev : -1;
+    a.rec_env[row] = valid ? env : -1;
+    if (valid) a.rec_of_env[env] = row;
+}
+
+extern "C" int grip_rollout_tick(const GripRolloutTick *args, void *stream) {
+    if (!args || args->capacity <= 0) return -1;
+    int threads = 256, blocks = (args->capacity + threads - 1) / threads;
+    hipLaunchKernelGGL(k_rollout_tick, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, *args);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// One thread per env: from the env's open record (not completed: it only supplies the bootstrap value) back along
+// prev_rec to the start of the rollout.  A_r = delta_r + gamma lambda (1 - done_r) A_next,
+// delta_r = reward_r + gamma (1 - done_r) V_next - V_r.
+__global__ void k_rollout_gae(int n_envs, const long long *rec_of_env, const long long *prev_rec, const float *rewards, const float *dones,
+                              const float *values, float gamma, float lam, float *advantages, float *returns) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_envs) return;
+    long long cur = rec_of_env[e];
+    if (cur < 0) return;
+    float a_next = 0.f, v_next = values[cur];
+    advantages[cur] = 0.f; returns[cur] = v_next;
+    for (long long r = prev_rec[cur]; r >= 0; r = prev_rec[r]) {
+        const float nonterm = 1.f - dones[r], v = values[r];
+        const float delta = rewards[r] + gamma * v_next * nonterm - v;
+        const float adv = delta + gamma * lam * nonterm * a_next;
+        advantages[r] = adv; returns[r] = adv + v;
+        a_next = adv; v_next = v;
+    }
+}
+
+extern "C" int grip_rollout_gae(int n_envs, const int64_t *rec_of_env, const int64_t *prev_rec, const float *rewards, const float *dones,
+                                const float *values, float gamma, float gae_lambda, float *advantages, float *returns, void *stream) {
+    if (n_envs <= 0 || !rec_of_env || !prev_rec || !rewards || !dones || !values || !advantages || !returns) return -1;
+    int threads = 128, blocks = (n_envs + threads - 1) / threads;
+    hipLaunchKernelGGL(k_rollout_gae, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, n_envs, (const long long *)rec_of_env, (const long long *)prev_rec,
+                       rewards, dones, values, gamma, gae_lambda, advantages, returns);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -32,13 +32,22 @@ def build_library(force=False, verbose=False):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-fno-strict-aliasing", "-shared", "-fPIC", "-o", LIB_PATH,
-           os.path.join(CSRC, "grip_sim.hip"), os.path.join(CSRC, "grip_render.hip")]
+           os.path.join(CSRC, "grip_sim.hip"), os.path.join(CSRC, "grip_render.hip"), os.path.join(CSRC, "grip_rollout.hip")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode:
         print(r.stdout, r.stderr)
     if r.returncode:
         raise GripError("hipcc failed:\n" + r.stderr[-4000:])
     return LIB_PATH
+
+
+class RolloutTickC(C.Structure):
+    """GripRolloutTick (include/grip_sim.h)."""
+    _fields_ = ([("n_envs", C.c_int32), ("capacity", C.c_int32), ("action_dim", C.c_int32), ("n_records", C.c_int64)] +
+                [(n, C.c_void_p) for n in ("ready_list", "ready_count", "base", "reward", "done", "n_substeps", "actions", "values", "log_probs",
+                                           "low", "high", "slot_actions", "rec_of_env", "rewards", "dones", "next_rec", "prev_rec", "rec_env",
+                                           "completed", "is_rec", "actions_buf", "log_probs_buf", "values_buf", "n_completed", "substeps_total",
+                                           "ep_ret", "ep_len", "ep_ret_sum", "ep_len_sum", "ep_count")])
 
 
 class EnvConfigC(C.Structure):
@@ -65,7 +74,7 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_destroy", "grip_batch_set_config", "grip_batch_num_envs", "grip_batch_reset", "grip_batch_step",
            "grip_batch_observe", "grip_batch_get_state", "grip_batch_set_state", "grip_batch_get_flags",
            "grip_batch_set_flags", "grip_batch_substep", "grip_batch_debug_forward", "grip_batch_target_pose",
-           "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list"]
+           "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae"]
 
 
 def lib():
@@ -99,6 +108,8 @@ def lib():
     L.grip_selftest_cholesky.argtypes = [vp, vp, vp, C.c_int, vp]
     L.grip_batch_advance.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     L.grip_batch_observe_list.argtypes = [vp, vp, vp, C.c_int, vp, vp]
+    L.grip_rollout_tick.argtypes = [vp, vp]
+    L.grip_rollout_gae.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
     _lib = L
     return L
 

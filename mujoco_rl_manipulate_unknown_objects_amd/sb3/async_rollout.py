@@ -46,7 +46,7 @@ class BatchEngineAdapter:
 
 class AsyncRollout:
     def __init__(self, engine, policy_fn, target, capacity, slice_len, gamma, gae_lambda, max_ticks=None, action_low=None, action_high=None,
-                 poll_every=4, use_graph=True):
+                 poll_every=4, use_graph=True, fused=None):
         """policy_fn(obs_rows uint8 [C, ...]) -> (actions [C, A], values [C], log_probs [C]) under no_grad.
         target = completed transitions per rollout; capacity = ready-list rows per tick."""
         self.eng, self.policy_fn = engine, policy_fn
@@ -63,6 +63,7 @@ class AsyncRollout:
         z = lambda dt=th.float32: th.zeros(R1, dtype=dt, device=dev)
         self.log_probs, self.values, self.rewards, self.dones, self.advantages, self.returns = z(), z(), z(), z(), z(), z()
         self.next_rec = th.full((R1,), -1, dtype=th.int64, device=dev)
+        self.prev_rec = th.full((R1,), -1, dtype=th.int64, device=dev)
         self.is_rec = z(th.bool); self.completed = z(th.bool)
         self.rec_env = th.full((R1,), -1, dtype=th.int64, device=dev)
         self.rec_of_env = th.full((self.N + 1,), -1, dtype=th.int64, device=dev)      # row N: dump
@@ -83,6 +84,12 @@ class AsyncRollout:
         self.base_t = th.full((1,), self.N, dtype=th.int64, device=dev)        # first record row of the current tick
         self.obs_stage = th.zeros((self.C,) + tuple(engine.obs_shape), dtype=th.uint8, device=dev)
         self.use_graph, self.graph_after, self.eager_every, self._graph = use_graph, 3, 16, None
+        # bookkeeping: one fused HIP launch per tick on a GPU (csrc/grip_rollout.hip), tensor ops otherwise (CPU tests; the
+        # two are compared on the GPU by tests/test_gpu_async.py)
+        self.fused = (dev.type == "cuda") if fused is None else bool(fused)
+        self._targs = None
+        if self.low is None:
+            self.low = th.full((self.A,), -float("inf"), device=dev); self.high = th.full((self.A,), float("inf"), device=dev)
         self._started = False
 
     # ------------------------------------------------------------------ one tick
@@ -92,13 +99,21 @@ class AsyncRollout:
         N, C, R = self.N, self.C, self.R
         out = self.eng.advance(self.slot_act, self.S, self.lst, self.cnt)
         self.eng.observe_list(self.lst, self.cnt, self.obs_stage)
+        actions, values, log_probs = self.policy_fn(self.obs_stage)
         rows = self.base_t + self.ar_c                                 # record ids of this tick
+        self.obs.index_copy_(0, rows, self.obs_stage)
+        if self.fused:
+            self._fused_tick(out, actions, values, log_probs)
+        else:
+            self._torch_tick(out, rows, actions, values, log_probs)
+        self.base_t += C
+
+    def _torch_tick(self, out, rows, actions, values, log_probs):
+        N, C, R = self.N, self.C, self.R
         valid = self.ar_c < self.cnt                                   # [C]
         env = th.where(valid, self.lst, N).long()                      # dump env N for empty rows
         env_c = env.clamp(max=N - 1)
-        actions, values, log_probs = self.policy_fn(self.obs_stage)
-        act = actions if self.low is None else th.max(th.min(actions, self.high), self.low)
-        self.slot_act.copy_(act)
+        self.slot_act.copy_(th.max(th.min(actions, self.high), self.low))
         # close the previous decision of every listed env
         prev = self.rec_of_env[env]
         had = valid & (prev >= 0)
@@ -117,13 +132,33 @@ class AsyncRollout:
         keep = (~fin).float()
         self.ep_ret[env] *= keep; self.ep_len[env] *= keep
         # open the new decision
-        self.obs.index_copy_(0, rows, self.obs_stage)
         self.actions.index_copy_(0, rows, actions); self.log_probs.index_copy_(0, rows, log_probs); self.values.index_copy_(0, rows, values)
         self.is_rec.index_copy_(0, rows, valid)
         self.completed.index_fill_(0, rows, False); self.next_rec.index_fill_(0, rows, -1)
+        self.prev_rec.index_copy_(0, rows, th.where(had, prev, th.full_like(prev, -1)))
         self.rec_env.index_copy_(0, rows, th.where(valid, env, th.full_like(env, -1)))
         self.rec_of_env[env] = rows
-        self.base_t += C
+
+    def _fused_tick(self, out, actions, values, log_probs):
+        from .. import engine as E
+        import ctypes as C
+        actions = actions.float().contiguous(); values = values.float().contiguous(); log_probs = log_probs.float().contiguous()
+        if self._targs is None:
+            p = lambda t: t.data_ptr()
+            self._targs = E.RolloutTickC(
+                n_envs=self.N, capacity=self.C, action_dim=self.A, n_records=self.R, ready_list=p(self.lst), ready_count=p(self.cnt), base=p(self.base_t),
+                reward=p(out["reward"]), done=p(out["done"]), n_substeps=p(out["n_substeps"]) if "n_substeps" in out else None,
+                low=p(self.low), high=p(self.high), slot_actions=p(self.slot_act), rec_of_env=p(self.rec_of_env), rewards=p(self.rewards),
+                dones=p(self.dones), next_rec=p(self.next_rec), prev_rec=p(self.prev_rec), rec_env=p(self.rec_env), completed=p(self.completed),
+                is_rec=p(self.is_rec), actions_buf=p(self.actions), log_probs_buf=p(self.log_probs), values_buf=p(self.values),
+                n_completed=p(self.n_completed), substeps_total=p(self.substeps_total), ep_ret=p(self.ep_ret), ep_len=p(self.ep_len),
+                ep_ret_sum=p(self.ep_ret_sum), ep_len_sum=p(self.ep_len_sum), ep_count=p(self.ep_count))
+            assert out["reward"].dtype == th.float32 and out["done"].dtype == th.uint8
+        a = self._targs
+        a.actions, a.values, a.log_probs = actions.data_ptr(), values.data_ptr(), log_probs.data_ptr()
+        stream = C.c_void_p(th.cuda.current_stream(self.dev).cuda_stream)
+        if E.lib().grip_rollout_tick(C.byref(a), stream) != 0:
+            raise E.GripError("grip_rollout_tick failed")
 
     def _tick(self):
         use_graph = self.use_graph and self.dev.type == "cuda"
@@ -153,7 +188,7 @@ class AsyncRollout:
         src = th.where(has, infl, self.R)
         ob = self.obs[src]; ac = self.actions[src]; lp = self.log_probs[src]; va = self.values[src]      # gathers copy: aliasing-safe
         self.obs[:N] = ob; self.actions[:N] = ac; self.log_probs[:N] = lp; self.values[:N] = va
-        self.is_rec.zero_(); self.completed.zero_(); self.next_rec.fill_(-1); self.advantages.zero_(); self.rec_env.fill_(-1)
+        self.is_rec.zero_(); self.completed.zero_(); self.next_rec.fill_(-1); self.prev_rec.fill_(-1); self.advantages.zero_(); self.rec_env.fill_(-1)
         self.is_rec[:N] = has
         ar = th.arange(N, device=self.dev)
         self.rec_env[:N] = th.where(has, ar, th.full_like(ar, -1))
@@ -183,6 +218,17 @@ class AsyncRollout:
         return done_n
 
     def _gae(self):
+        if self.fused:
+            from .. import engine as E
+            import ctypes as C_
+            if self.returns.data_ptr() == self.advantages.data_ptr() or not self.returns.is_contiguous():
+                self.returns = th.zeros_like(self.advantages)
+            stream = C_.c_void_p(th.cuda.current_stream(self.dev).cuda_stream)
+            p = lambda t: C_.c_void_p(t.data_ptr())
+            if E.lib().grip_rollout_gae(self.N, p(self.rec_of_env), p(self.prev_rec), p(self.rewards), p(self.dones), p(self.values),
+                                        float(self.gamma), float(self.lam), p(self.advantages), p(self.returns), stream) != 0:
+                raise E.GripError("grip_rollout_gae failed")
+            return
         N, C, R = self.N, self.C, self.R
         g, gl = self.gamma, self.gamma * self.lam
         blocks = [(0, N)] + [(N + k * C, N + (k + 1) * C) for k in range(self.tick)]

@@ -56,7 +56,7 @@ class RolloutBuffer:
             delta = self.rewards[t] + gamma * nextv * nonterm - self.values[t]
             adv = delta + gamma * lam * nonterm * adv
             self.advantages[t] = adv
-        self.returns = self.advantages + self.values
+        th.add(self.advantages, self.values, out=self.returns)      # in place: the update graph holds this storage
         self.pos = 0
 
 
@@ -87,7 +87,11 @@ class PPO:
         if self.distributed:                      # identical initial parameters on every rank
             for p in self.policy.parameters():
                 dist.broadcast(p.data, src=0)
-        self.optimizer = th.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5)
+        # on a GPU the minibatch update is captured into hipGraphs (forward+backward | gradient all-reduce | clip+Adam), which
+        # needs the optimiser's step counter on the device
+        self.graph_update = self.device.type == "cuda"
+        self.optimizer = th.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5, capturable=self.graph_update)
+        self._upd = None
         obs_shape = env.observation_space["observation"].shape
         self.rollout_buffer = None if (async_slice and async_slice > 0) else RolloutBuffer(n_steps, self.n_envs, obs_shape, self.policy.action_dim, self.device)
         self._async = None
@@ -162,17 +166,77 @@ class PPO:
         for p in params:
             n = p.numel(); p.grad.copy_(flat[off:off + n].view_as(p.grad)); off += n
 
+    def _loss_backward(self, src, idx):
+        """Forward + PPO loss + backward of one minibatch `idx` (record / sample ids into the rollout storage `src`)."""
+        obs, actions, old_logp, adv_all, ret_all = src
+        adv = adv_all[idx]
+        adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+        with self._ac():
+            values, logp, entropy = self.policy.evaluate_actions({"observation": obs[idx]}, actions[idx])
+        ratio = th.exp(logp - old_logp[idx])
+        pl = -th.min(adv * ratio, adv * th.clamp(ratio, 1 - self.clip_range, 1 + self.clip_range)).mean()
+        vl = th.nn.functional.mse_loss(ret_all[idx], values)
+        el = -entropy.mean()
+        loss = pl + self.ent_coef * el + self.vf_coef * vl
+        loss.backward()
+        return pl.detach(), vl.detach(), loss.detach()
+
+    def _apply(self):
+        th.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
+        self.optimizer.step()
+
+    def _minibatch_update(self, src, idx):
+        """One optimiser step. Eager on CPU; on a GPU two captured graphs with the (eager) gradient all-reduce between them."""
+        if not self.graph_update:
+            self.optimizer.zero_grad(set_to_none=False)
+            out = self._loss_backward(src, idx)
+            if self.distributed:
+                self._allreduce_grads()
+            self._apply()
+            return out
+        u = self._upd
+        key = tuple(t.data_ptr() for t in src) + (idx.numel(),)
+        if u is None or u["key"] != key:
+            u = self._upd = {"key": key, "idx": th.zeros_like(idx), "warm": 0, "fwd": None, "apply": None, "out": None}
+        u["idx"].copy_(idx)
+        if u["warm"] < 2:                           # two eager steps on a side stream before capturing (PyTorch's capture recipe)
+            cur = th.cuda.current_stream(self.device); side = th.cuda.Stream(self.device); side.wait_stream(cur)
+            with th.cuda.stream(side):
+                self.optimizer.zero_grad(set_to_none=True)
+                out = self._loss_backward(src, u["idx"])
+                if self.distributed:
+                    self._allreduce_grads()
+                self._apply()
+            cur.wait_stream(side)
+            u["warm"] += 1
+            return out
+        if u["fwd"] is None:
+            th.cuda.synchronize(self.device)
+            self.optimizer.zero_grad(set_to_none=True)      # the captured backward allocates .grad from the graph's pool
+            g1 = th.cuda.CUDAGraph()
+            with th.cuda.graph(g1):
+                u["out"] = self._loss_backward(src, u["idx"])
+            g2 = th.cuda.CUDAGraph()
+            with th.cuda.graph(g2):
+                self._apply()
+                self.optimizer.zero_grad(set_to_none=False)
+            u["fwd"], u["apply"] = g1, g2
+        u["fwd"].replay()
+        if self.distributed:
+            self._allreduce_grads()
+        u["apply"].replay()
+        return u["out"]
+
     def train(self):
         total = self.n_steps * self.n_envs
         if self._async is not None:                      # records of the async rollout, addressed through `sel`
             buf = self._async
-            obs, actions, old_logp, adv_all, ret_all = buf.obs, buf.actions, buf.log_probs, buf.advantages, buf.returns
+            src = (buf.obs, buf.actions, buf.log_probs, buf.advantages, buf.returns)
             sel = buf.training_indices()
         else:
             buf = self.rollout_buffer
-            obs = buf.obs.view((total,) + buf.obs.shape[2:]); actions = buf.actions.view(total, -1)
-            old_logp = buf.log_probs.view(-1)
-            adv_all, ret_all = buf.advantages.view(-1), buf.returns.view(-1)
+            src = (buf.obs.view((total,) + buf.obs.shape[2:]), buf.actions.view(total, -1), buf.log_probs.view(-1),
+                   buf.advantages.view(-1), buf.returns.view(-1))
             sel = None
         bs = min(self.batch_size, total)
         stats = {}
@@ -181,24 +245,8 @@ class PPO:
             if sel is not None:
                 perm = sel[perm]
             for s in range(0, total - bs + 1, bs):
-                idx = perm[s:s + bs]
-                mb_obs = {"observation": obs[idx]}
-                adv = adv_all[idx]
-                adv = (adv - adv.mean()) / (adv.std() + 1e-8)
-                with self._ac():
-                    values, logp, entropy = self.policy.evaluate_actions(mb_obs, actions[idx])
-                ratio = th.exp(logp - old_logp[idx])
-                pl = -th.min(adv * ratio, adv * th.clamp(ratio, 1 - self.clip_range, 1 + self.clip_range)).mean()
-                vl = th.nn.functional.mse_loss(ret_all[idx], values)
-                el = -entropy.mean()
-                loss = pl + self.ent_coef * el + self.vf_coef * vl
-                self.optimizer.zero_grad(set_to_none=False)
-                loss.backward()
-                if self.distributed:
-                    self._allreduce_grads()
-                th.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
-                self.optimizer.step()
-                stats = {"policy_loss": pl.detach(), "value_loss": vl.detach(), "loss": loss.detach()}
+                pl, vl, loss = self._minibatch_update(src, perm[s:s + bs])
+                stats = {"policy_loss": pl, "value_loss": vl, "loss": loss}
         self.logger = stats
         return stats
 
