@@ -108,11 +108,15 @@ int grip_batch_observe(GripBatch *b, uint8_t *obs_dev, void *stream);
  * Then the waiting envs are listed: ready_list_dev int32 [capacity] (env ids, -1 padded), *ready_count_dev = how many.
  * The caller renders them (grip_batch_observe_list), runs the policy on those rows and passes the actions to the next
  * call. When more than `capacity` envs wait, the rest are listed by later calls (rotating start, nobody starves).
+ * lag = 1: the envs listed by call k start in call k+1 (render + policy run between two launches).
+ * lag = 2: they start in call k+2, with slot_actions_dev of that call, so that rendering and the policy for list k can run
+ * on another stream WHILE call k+1 advances everybody else (the caller alternates two list / action buffers and orders
+ * the streams with events). Listed envs stand still in between, so their state and `out` rows are stable to read.
  * budget_us > 0 additionally ends a wavefront's slice once that much wall-clock time has passed (checked between calls
  * of physics.step()), so that envs in expensive contact states do not hold the launch back: cheap envs then take up to
  * `slice` steps per tick, expensive ones fewer. The order in which envs finish then depends on timing; per env the
  * arithmetic and the results are identical to grip_batch_step either way -- only the schedule differs. */
-int grip_batch_advance(GripBatch *b, const float *slot_actions_dev, int slice, int budget_us, int capacity, const GripStepOut *out,
+int grip_batch_advance(GripBatch *b, const float *slot_actions_dev, int slice, int budget_us, int lag, int capacity, const GripStepOut *out,
                        int32_t *ready_list_dev, int32_t *ready_count_dev, void *stream);
 /* get_observation for the listed envs only: row r of obs_dev (uint8 [capacity,5,64,64]) = env list_dev[r], r < *count_dev. */
 int grip_batch_observe_list(GripBatch *b, const int32_t *list_dev, const int32_t *count_dev, int capacity, uint8_t *obs_dev, void *stream);

@@ -49,18 +49,21 @@ __device__ static uint8_t to_u8(float v) { v *= 255.f; v = fminf(fmaxf(v, 0.f), 
 
 // Per env, every hull plane n.x <= d (body frame) is first rewritten for rays leaving the camera origin in CAMERA
 // coordinates dc = (x, y, -1):  n.(ol + t dl) <= d  with  dl = Rg^T Rc dc, ol = Rg^T (co - pg)  becomes
-// t (A.dc) <= B,  A = (Rg^T Rc)^T n,  B = d - n.ol  -- one float4 per plane in LDS, 2 FMAs per ray and plane.
+// t (A.dc) <= B,  A = (Rg^T Rc)^T n,  B = d - n.ol.
 // Hulls whose bounding sphere lies behind the camera plane are dropped for the whole env (the gripper base always is).
+// Every thread owns a 4 x 4 pixel tile and keeps its 16 rays' (t_in, t_out, entering plane) in registers, so that a plane is
+// read from LDS once per 16 rays and costs one FMA + rcp + a few selects per ray; depth never leaves registers.
+#define TPX 16              // pixels per thread (4 x 4)
+
 __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevConfig cfg, const float *qpos, const int *pad_grasp, const int *pad_pher,
                                                       int n, const int *list, const int *count, uint8_t *obs) {
     // list != NULL: block b renders env list[b] into row b of obs, for b < *count (grip_batch_observe_list)
     if (list && (int)blockIdx.x >= *count) return;
     const DevModel &m = *mp;
     __shared__ Frames fr;
-    extern __shared__ float4 spl[];             // one float4 per hull face plane of the model (sized by the launcher)
     __shared__ float gsph[GN_GEOM][4];          // bounding sphere centre in camera coordinates, radius^2
+    extern __shared__ float4 spl[];             // camera-space plane table of this env (sized by the launcher: planes x 16 B)
     __shared__ int gadr[GN_GEOM], gnum[GN_GEOM];
-    __shared__ float sdepth[RPIX];
     __shared__ float red[RTHREADS];
     __shared__ int redi[RTHREADS];
     const int e = list ? list[blockIdx.x] : blockIdx.x, tid = threadIdx.x;
@@ -73,13 +76,15 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
             V3 c = multv(Rc, p + mulv(R, ldv(m.geom_center[g])) - co);
             float r = m.geom_rbound[g];
             gsph[g][0] = c.x; gsph[g][1] = c.y; gsph[g][2] = c.z; gsph[g][3] = r * r;
-            bool vis = c.z - r < 0.f && adr + m.hull_pnum[g - 1] <= RMAXPL;     // some of the sphere is in front of the camera
+            bool vis = c.z - r < 0.f;                                   // some of the sphere is in front of the camera
             gadr[g] = adr; gnum[g] = vis ? m.hull_pnum[g - 1] : 0;
             if (vis) adr += m.hull_pnum[g - 1];
         }
     }
     __syncthreads();
     const V3 co = ldv(fr.cam_o); const M3 Rc = ldm(fr.cam_R);
+    // plane n.x <= d of a hull (body frame), rewritten for rays from the camera origin in camera coordinates dc = (x, y, -1):
+    // t (A.dc) <= B with A = (Rg^T Rc)^T n, B = d - n.(Rg^T (co - pg)); one float4 per plane of the visible hulls in LDS
     for (int g = 1; g < GN_GEOM; g++) {
         const int np = gnum[g];
         if (np == 0) continue;
@@ -97,39 +102,73 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
     const int nch = cfg.full_observation ? 5 : 4;
     uint8_t *o = obs + (size_t)blockIdx.x * nch * RPIX;
     const float tanh_ = tanf(0.5f * m.cam_fovy * 0.017453292519943295f);
-    V3 L = normalized(v3(-m.light_dir[0][0], -m.light_dir[0][1], -m.light_dir[0][2]));
-    float lmin = 3.0e38f;
-    for (int k = 0; k < RPIX / RTHREADS; k++) {
-        int px = k * RTHREADS + tid, i = px / RW, j = px % RW;
-        float x = (2.0f * (j + 0.5f) / RW - 1.0f) * tanh_, y = (1.0f - 2.0f * (i + 0.5f) / RH) * tanh_;
-        V3 dir = mulv(Rc, v3(x, y, -1.f));
-        float best = m.zfar; int hit = -1, hent = 0;
-        if (dir.z < 0.f) { float t = -co.z / dir.z; if (t > m.znear && t < best) { best = t; hit = 0; } }
-        const float dd = x * x + y * y + 1.f;
-        for (int g = 1; g < GN_GEOM; g++) {
-            const int np = gnum[g];
-            if (np == 0) continue;
-            // bounding sphere in camera coordinates: oc = -c
-            float bq = -(gsph[g][0] * x + gsph[g][1] * y - gsph[g][2]);
-            float cq = gsph[g][0] * gsph[g][0] + gsph[g][1] * gsph[g][1] + gsph[g][2] * gsph[g][2] - gsph[g][3];
-            if (bq * bq - dd * cq < 0.f || (bq > 0.f && cq > 0.f)) continue;
-            const float4 *sp = spl + gadr[g];
-            float tin = -3.0e38f, tout = 3.0e38f; int ent = -1; bool miss = false;
-            // branch-free Cyrus-Beck step: t = B / (A.dc) by v_rcp_f32 (1 ulp); entering planes (den < 0) raise tin,
-            // leaving planes (den > 0) lower tout, a parallel plane with the origin outside (den == 0, B < 0) is a miss
-#pragma unroll 4
-            for (int q = 0; q < np; q++) {
-                float4 P = sp[q];
-                float den = fmaf(P.x, x, fmaf(P.y, y, -P.z));
-                float t = P.w * rcp(den);
-                bool in = den < 0.f, up = in && t > tin;
-                tin = up ? t : tin; ent = up ? q : ent;
-                tout = (den > 0.f && t < tout) ? t : tout;
-                miss |= (den == 0.f && P.w < 0.f);
-            }
-            if (miss || tin > tout || ent < 0 || tin <= 0.f) continue;
-            if (tin > m.znear && tin < best) { best = tin; hit = g; hent = ent; }
+    // tile of this thread: a wave covers 8 x 8 tiles = a 32 x 32 pixel quadrant
+    const int w = tid >> 6, l = tid & 63;
+    const int tx = (l & 7) + 8 * (w & 1), ty = (l >> 3) + 8 * (w >> 1);
+    float xs[4], ys[4];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        xs[a] = (2.0f * (4 * tx + a + 0.5f) / RW - 1.0f) * tanh_;
+        ys[a] = (1.0f - 2.0f * (4 * ty + a + 0.5f) / RH) * tanh_;
+    }
+    float best[TPX]; int hitent[TPX];                                   // hit geom << 16 | entering plane; -1 = sky
+#pragma unroll
+    for (int q = 0; q < TPX; q++) {
+        float x = xs[q & 3], y = ys[q >> 2];
+        float dz = Rc.m[6] * x + Rc.m[7] * y - Rc.m[8];
+        best[q] = m.zfar; hitent[q] = -1;
+        if (dz < 0.f) { float t = -co.z / dz; if (t > m.znear && t < best[q]) { best[q] = t; hitent[q] = 0; } }
+    }
+    for (int g = 1; g < GN_GEOM; g++) {
+        const int np = gnum[g];
+        if (np == 0) continue;
+        // bounding sphere in camera coordinates (oc = -c), per ray; a thread skips the hull when none of its rays can hit it
+        const float cx_ = gsph[g][0], cy_ = gsph[g][1], cz_ = gsph[g][2];
+        const float cq = cx_ * cx_ + cy_ * cy_ + cz_ * cz_ - gsph[g][3];
+        unsigned mask = 0u;
+#pragma unroll
+        for (int q = 0; q < TPX; q++) {
+            float x = xs[q & 3], y = ys[q >> 2];
+            float bq = -(cx_ * x + cy_ * y - cz_), dd = x * x + y * y + 1.f;
+            bool pass = !(bq * bq - dd * cq < 0.f || (bq > 0.f && cq > 0.f));
+            mask |= pass ? (1u << q) : 0u;
         }
+        if (mask == 0u) continue;
+        const float4 *sp = spl + gadr[g];
+        float tin[TPX], tout[TPX]; int ent[TPX];
+#pragma unroll
+        for (int q = 0; q < TPX; q++) { tin[q] = -3.0e38f; tout[q] = 3.0e38f; ent[q] = -1; }
+        // Cyrus-Beck: u = B / |A.dc| by v_rcp_f32 (1 ulp). Entering planes (A.dc < 0) raise t_in = -u, the others lower
+        // t_out = u; a parallel plane with the origin outside gives u = -inf and so t_in > t_out: a miss, as it must be.
+        for (int pi = 0; pi < np; pi++) {
+            const float4 P = sp[pi];
+            float cxa[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) cxa[a] = fmaf(P.x, xs[a], -P.z);
+#pragma unroll
+            for (int q = 0; q < TPX; q++) {
+                float den = fmaf(P.y, ys[q >> 2], cxa[q & 3]);
+                float u = P.w * rcp(fabsf(den));
+                bool in = den < 0.f, up = in && -u > tin[q];
+                tin[q] = up ? -u : tin[q]; ent[q] = up ? pi : ent[q];
+                tout[q] = (!in && u < tout[q]) ? u : tout[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < TPX; q++) {
+            bool ok = ((mask >> q) & 1u) && !(tin[q] > tout[q]) && ent[q] >= 0 && tin[q] > 0.f && tin[q] > m.znear && tin[q] < best[q];
+            best[q] = ok ? tin[q] : best[q]; hitent[q] = ok ? ((g << 16) | ent[q]) : hitent[q];
+        }
+    }
+    // shading (flat Lambert, headlight-free: the scene's first directional light) and the RGB bytes
+    const V3 L = normalized(v3(-m.light_dir[0][0], -m.light_dir[0][1], -m.light_dir[0][2]));
+    float lmin = 3.0e38f;
+#pragma unroll
+    for (int q = 0; q < TPX; q++) {
+        const int i = 4 * ty + (q >> 2), j = 4 * tx + (q & 3), px = i * RW + j;
+        const float x = xs[q & 3], y = ys[q >> 2];
+        const V3 dir = mulv(Rc, v3(x, y, -1.f));
+        const int hit = hitent[q] < 0 ? -1 : (hitent[q] >> 16);
         float c0, c1, c2;
         if (hit < 0) {
             V3 dn = normalized(dir); float f = 0.5f * (dn.z + 1.0f);
@@ -137,20 +176,20 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
         } else {
             float b0, b1, b2; V3 nrm = v3(0, 0, 1);
             if (hit == 0) {
-                float pxw = co.x + best * dir.x, pyw = co.y + best * dir.y;
+                float pxw = co.x + best[q] * dir.x, pyw = co.y + best[q] * dir.y;
                 int cx = (int)floorf(pxw * 8.0f), cy = (int)floorf(pyw * 8.0f);
                 int off = ((cx + cy) & 1) ? 3 : 0;
                 b0 = m.floor_rgb[off]; b1 = m.floor_rgb[off + 1]; b2 = m.floor_rgb[off + 2];
             } else {
                 b0 = m.geom_rgba[hit][0]; b1 = m.geom_rgba[hit][1]; b2 = m.geom_rgba[hit][2];
-                const float *pl = m.hull_planes + 4 * (m.hull_padr[hit - 1] + hent);
+                const float *pl = m.hull_planes + 4 * (m.hull_padr[hit - 1] + (hitent[q] & 0xffff));
                 nrm = mulv(ldm(fr.R[hit - 1]), v3(pl[0], pl[1], pl[2]));
             }
             float shade = 0.4f + 0.6f * fmaxf(dot(nrm, L), 0.f);
             c0 = b0 * shade; c1 = b1 * shade; c2 = b2 * shade;
         }
         o[px] = to_u8(c0); o[RPIX + px] = to_u8(c1); o[2 * RPIX + px] = to_u8(c2);
-        sdepth[px] = best; lmin = fminf(lmin, best);
+        lmin = fminf(lmin, best[q]);
         o[(nch - 1) * RPIX + px] = 0;
     }
     // transform_depth (utils.py:11-19): depth -= min; depth /= 2 * mean(depth[depth <= 1]); 255 * clip(depth, 0, 1)
@@ -158,14 +197,16 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
     for (int s = RTHREADS / 2; s > 0; s >>= 1) { if (tid < s) red[tid] = fminf(red[tid], red[tid + s]); __syncthreads(); }
     float dmin = red[0]; __syncthreads();
     float lsum = 0.f; int lcnt = 0;
-    for (int k = 0; k < RPIX / RTHREADS; k++) { float d = sdepth[k * RTHREADS + tid] - dmin; if (d <= 1.0f) { lsum += d; lcnt++; } }
+#pragma unroll
+    for (int q = 0; q < TPX; q++) { float d = best[q] - dmin; if (d <= 1.0f) { lsum += d; lcnt++; } }
     red[tid] = lsum; redi[tid] = lcnt; __syncthreads();
     for (int s = RTHREADS / 2; s > 0; s >>= 1) { if (tid < s) { red[tid] += red[tid + s]; redi[tid] += redi[tid + s]; } __syncthreads(); }
     float scale = 2.0f * (red[0] / (float)redi[0]);
     if (cfg.full_observation) {
-        for (int k = 0; k < RPIX / RTHREADS; k++) {
-            int px = k * RTHREADS + tid;
-            float v = (sdepth[px] - dmin) / scale; v = fminf(fmaxf(v, 0.f), 1.f);
+#pragma unroll
+        for (int q = 0; q < TPX; q++) {
+            const int px = (4 * ty + (q >> 2)) * RW + 4 * tx + (q & 3);
+            float v = (best[q] - dmin) / scale; v = fminf(fmaxf(v, 0.f), 1.f);
             float p = 255.0f * v;
             o[3 * RPIX + px] = (p != p) ? (uint8_t)0 : (uint8_t)p;
         }

@@ -239,7 +239,7 @@ struct GripBatch {
     int *episode_step = nullptr, *status = nullptr, *gripper_open = nullptr;
     int *pad_grasp = nullptr, *pad_pher = nullptr;                              // sensor-pad scalars of the current state
     int nplanes = 0;
-    int *mc_ints = nullptr, *mc_astate = nullptr, *mc_slot = nullptr, *mc_order = nullptr, *mc_heavy = nullptr, *mc_tick = nullptr; float *mc_flts = nullptr;   // suspended macro steps
+    int *mc_ints = nullptr, *mc_astate = nullptr, *mc_slot = nullptr, *mc_order = nullptr, *mc_heavy = nullptr, *mc_tick = nullptr, *mc_gen = nullptr; unsigned long long *mc_t0 = nullptr; float *mc_flts = nullptr;   // suspended macro steps
     float *reset_info = nullptr;                                                // grasp0, pher0, objx0, objy0 of the reset state
     float *scratch = nullptr; size_t scratch_bytes = 0;
     float xfrc_z = 0.f;
@@ -256,8 +256,9 @@ struct StatePtrs { float *qpos, *qvel, *ctrl, *warm; int *episode_step, *status,
 // A macro step suspended between two time slices (grip_batch_advance): everything k_macro_step keeps in registers across
 // its physics.step() loop, SoA [field][N]. astate: 0 = macro step in flight, 1 = finished, waiting for an action;
 // slot: row of the compact action / observation arrays this waiting env was given by the last k_compact (-1 = none yet);
-// heavy: hull-hull contacts the env had at its last physics.step() -- the cost class k_compact sorts the work order by.
-struct MacroCtx { int *ints; float *flts; int *astate; int *slot; int *heavy; int *tick; };
+// heavy: hull-hull contacts the env had at its last physics.step() -- the cost class k_compact sorts the work order by;
+// gen: number of the compaction that gave the slot (tick[0] counts compactions): a slot-holder starts `lag` launches later.
+struct MacroCtx { int *ints; float *flts; int *astate; int *slot; int *heavy; int *tick; int *gen; unsigned long long *t0; };
 enum { MC_PHASE = 0, MC_CNT, MC_NSUB, MC_GRASPED, MC_FLAGS, MC_FAULT, MC_NINT };
 enum { MC_TARGET = 0, MC_INITQ = 5, MC_OPENCLOSE = 10, MC_TQ = 11, MC_INITOBJ = 12, MC_NFLT = 15 };
 
@@ -410,7 +411,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_reset(const DevModel m, DevCo
 // slot starts a macro step with actions[slot], both run at most `slice` calls of physics.step(); envs that finish write
 // their outputs and wait, the others are suspended. The arithmetic per env is the same in both modes.
 __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, DevConfig cfg, StatePtrs st, const float *actions, StepOutDev out,
-                                                              const float *reset_info, float xfrc_z, MacroCtx mc, int slice, const int *order, long long budget_ticks) {
+                                                              const float *reset_info, float xfrc_z, MacroCtx mc, int slice, const int *order, long long budget_ticks, int lag) {
     const Ctx cx = stage_tables(m, lds_dyn);
     STAMPS_DECL
     int e = blockIdx.x * EPB + threadIdx.x / KL;
@@ -434,7 +435,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
     if (sliced && valid) {
         if (mc.astate[e] != 0) {                        // waiting: start only when the last compaction gave this env a slot
             int sl = mc.slot[e];
-            if (sl >= 0) arow = (size_t)sl; else phase = PH_DONE;
+            if (sl >= 0 && mc.gen[e] <= mc.tick[0] - lag) arow = (size_t)sl; else phase = PH_DONE;
         } else {                                        // in flight: resume
             phase = mc.ints[(size_t)MC_PHASE * N + e]; cnt = mc.ints[(size_t)MC_CNT * N + e]; nsub = mc.ints[(size_t)MC_NSUB * N + e];
             grasped = mc.ints[(size_t)MC_GRASPED * N + e]; fault = mc.ints[(size_t)MC_FAULT * N + e];
@@ -451,7 +452,18 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
         for (int i = 0; i < 6; i++) act[i] = i < adim ? actions[arow * adim + i] : 0.f;
     }
     int budget = sliced ? slice : 0x7fffffff;
-    const long long t_start = wall_clock64();           // 100 MHz, wave-uniform
+    // the wall-clock budget runs from the moment the FIRST workgroup of the launch started (k_compact clears the stamp), so
+    // that a workgroup that was placed late -- other streams' kernels were using its CU -- does not stretch the launch
+    unsigned long long t0v = 0ULL;
+    if (budget_ticks > 0) {
+        if (cx.lane == 0) {
+            unsigned long long now = (unsigned long long)wall_clock64();          // 100 MHz
+            unsigned long long old = atomicCAS(mc.t0, 0ULL, now);
+            t0v = old ? old : now;
+        }
+        t0v = __shfl(t0v, 0);
+    }
+    const long long t_start = (long long)t0v;
 
     while (__any(phase != PH_DONE && (budget > 0 || phase == PH_FINAL))) {
         if (phase != PH_DONE && (budget > 0 || phase == PH_FINAL)) {
@@ -586,7 +598,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
     }
 }
 
-// Deterministic compaction after a time slice (one 1024-thread block): the waiting envs, scanned from env `rot` on so that
+// Deterministic compaction after a time slice (one 1024-thread block): the waiting envs that hold no slot yet, scanned from env `rot` on so that
 // nobody starves when more wait than `capacity`, get slots 0..count-1 (list[slot] = env, -1 beyond count). order[] is the
 // work order of the next slice: envs that will run (in flight, or holding a slot) sorted by cost class -- no hull contact,
 // one or two, more -- so that the 4 envs of a wave and the 16 of a workgroup cost about the same per physics.step(), then
@@ -601,7 +613,8 @@ __global__ void __launch_bounds__(CP_THREADS) k_compact(MacroCtx mc, int n, int 
     const int t = threadIdx.x, chunk = (n + CP_THREADS - 1) / CP_THREADS;
     // pass 1: slots for the waiting envs, in rotated order
     int c = 0;
-    for (int i = 0; i < chunk; i++) { int v = t * chunk + i; if (v < n) { int e = v + rot; if (e >= n) e -= n; c += mc.astate[e] != 0; } }
+    const int tick = mc.tick[0];
+    for (int i = 0; i < chunk; i++) { int v = t * chunk + i; if (v < n) { int e = v + rot; if (e >= n) e -= n; c += (mc.astate[e] != 0 && mc.slot[e] < 0); } }
     sa[t] = c; __syncthreads();
     for (int d = 1; d < CP_THREADS; d <<= 1) { int x = t >= d ? sa[t - d] : 0; __syncthreads(); sa[t] += x; __syncthreads(); }
     int base = sa[t] - c, total = sa[CP_THREADS - 1];
@@ -610,7 +623,7 @@ __global__ void __launch_bounds__(CP_THREADS) k_compact(MacroCtx mc, int n, int 
         int v = t * chunk + i;
         if (v < n) {
             int e = v + rot; if (e >= n) e -= n;
-            if (mc.astate[e] != 0) { int p = base++; if (p < capacity) { mc.slot[e] = p; list[p] = e; } else mc.slot[e] = -1; }
+            if (mc.astate[e] != 0 && mc.slot[e] < 0) { int p = base++; if (p < capacity) { mc.slot[e] = p; mc.gen[e] = tick; list[p] = e; } }
         }
     }
     int cnt = total < capacity ? total : capacity;
@@ -631,7 +644,7 @@ __global__ void __launch_bounds__(CP_THREADS) k_compact(MacroCtx mc, int n, int 
     int start = 0;
     for (int k = 0; k < CP_CLASSES; k++) { before[k] += start; start += cls_total[k]; }
     for (int i = 0; i < chunk; i++) { int e = t * chunk + i; if (e < n) order[before[cls_of(e)]++] = e; }
-    if (t == 0) mc.tick[0] = mc.tick[0] + 1;      // every thread read the old value before the first barrier
+    if (t == 0) { mc.tick[0] = mc.tick[0] + 1; mc.t0[0] = 0ULL; }     // every thread read the old tick before the first barrier
 }
 
 // k calls of physics.step() with the stored ctrl (test hook / micro-benchmark)
@@ -724,7 +737,7 @@ static StepOutDev to_dev(const GripStepOut *o) {
     d.n_substeps = o->n_substeps; d.fault = o->fault;
     return d;
 }
-static MacroCtx macro_ctx(GripBatch *b) { MacroCtx c; c.ints = b->mc_ints; c.flts = b->mc_flts; c.astate = b->mc_astate; c.slot = b->mc_slot; c.heavy = b->mc_heavy; c.tick = b->mc_tick; return c; }
+static MacroCtx macro_ctx(GripBatch *b) { MacroCtx c; c.ints = b->mc_ints; c.flts = b->mc_flts; c.astate = b->mc_astate; c.slot = b->mc_slot; c.heavy = b->mc_heavy; c.tick = b->mc_tick; c.gen = b->mc_gen; c.t0 = b->mc_t0; return c; }
 static int grid_of(const GripBatch *b) { return (b->n + EPB - 1) / EPB; }
 
 static int ensure_lds_attr() {
@@ -770,6 +783,8 @@ extern "C" int grip_batch_create(const GripModel *m, int n_envs, int device_id, 
     HIPCHK(hipMalloc(&b->mc_astate, N * sizeof(int))); HIPCHK(hipMalloc(&b->mc_slot, N * sizeof(int))); HIPCHK(hipMalloc(&b->mc_order, N * sizeof(int)));
     HIPCHK(hipMalloc(&b->mc_heavy, N * sizeof(int))); HIPCHK(hipMemset(b->mc_heavy, 0, N * sizeof(int)));
     HIPCHK(hipMalloc(&b->mc_tick, sizeof(int))); HIPCHK(hipMemset(b->mc_tick, 0, sizeof(int)));
+    HIPCHK(hipMalloc(&b->mc_gen, N * sizeof(int))); HIPCHK(hipMemset(b->mc_gen, 0, N * sizeof(int)));
+    HIPCHK(hipMalloc(&b->mc_t0, sizeof(unsigned long long))); HIPCHK(hipMemset(b->mc_t0, 0, sizeof(unsigned long long)));
     {   std::vector<int> ident(N); for (size_t i = 0; i < N; i++) ident[i] = (int)i;          // work order: identity until the first compaction
         HIPCHK(hipMemcpy(b->mc_order, ident.data(), N * sizeof(int), hipMemcpyHostToDevice)); }
     b->scratch_bytes = 169 * N * sizeof(float) + 1024;
@@ -791,7 +806,7 @@ extern "C" void grip_batch_destroy(GripBatch *b) {
     (void)hipDeviceSynchronize();
     void *ptrs[] = {b->d_model, b->d_hull, b->d_planes, b->qpos, b->qvel, b->ctrl, b->warm, b->episode_step, b->status,
                     b->gripper_open, b->pad_grasp, b->pad_pher, b->reset_info, b->scratch, b->mc_ints, b->mc_flts, b->mc_astate,
-                    b->mc_slot, b->mc_order, b->mc_heavy, b->mc_tick};
+                    b->mc_slot, b->mc_order, b->mc_heavy, b->mc_tick, b->mc_gen, b->mc_t0};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : b->ev0) (void)hipEventDestroy(e);
     for (auto &e : b->ev1) (void)hipEventDestroy(e);
@@ -834,17 +849,18 @@ extern "C" int grip_batch_step(GripBatch *b, const float *actions_dev, const Gri
     int slot = b->ev_used % EV_RING;
     HIPCHK(hipEventRecord(b->ev0[slot], s));
     hipLaunchKernelGGL(k_macro_step, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, s, b->hmodel, b->cfg, state_ptrs(b), actions_dev, to_dev(out),
-                       b->reset_info, b->xfrc_z, macro_ctx(b), 0, (const int *)nullptr, 0LL);
+                       b->reset_info, b->xfrc_z, macro_ctx(b), 0, (const int *)nullptr, 0LL, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev1[slot], s));
     b->ev_used++;
     return 0;
 }
 
-extern "C" int grip_batch_advance(GripBatch *b, const float *slot_actions_dev, int slice, int budget_us, int capacity, const GripStepOut *out,
+extern "C" int grip_batch_advance(GripBatch *b, const float *slot_actions_dev, int slice, int budget_us, int lag, int capacity, const GripStepOut *out,
                                   int32_t *ready_list_dev, int32_t *ready_count_dev, void *stream) {
     if (!b || !slot_actions_dev || !ready_list_dev || !ready_count_dev) return fail("grip_batch_advance: null argument");
     if (slice <= 0 || capacity <= 0 || capacity > b->n) return fail("grip_batch_advance: need slice > 0 and 0 < capacity <= num_envs");
+    if (lag != 1 && lag != 2) return fail("grip_batch_advance: lag must be 1 (decide between launches) or 2 (decide during the next launch)");
     HIPCHK(hipSetDevice(b->device));
     hipStream_t s = (hipStream_t)stream;
     // launch timing uses events, which a stream under hipGraph capture cannot take: captured ticks are not timed
@@ -854,7 +870,7 @@ extern "C" int grip_batch_advance(GripBatch *b, const float *slot_actions_dev, i
     int slot = b->ev_used % EV_RING;
     if (timed) HIPCHK(hipEventRecord(b->ev0[slot], s));
     hipLaunchKernelGGL(k_macro_step, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, s, b->hmodel, b->cfg, state_ptrs(b), slot_actions_dev, to_dev(out),
-                       b->reset_info, b->xfrc_z, macro_ctx(b), slice, (const int *)b->mc_order, (long long)(budget_us > 0 ? budget_us : 0) * 100LL);
+                       b->reset_info, b->xfrc_z, macro_ctx(b), slice, (const int *)b->mc_order, (long long)(budget_us > 0 ? budget_us : 0) * 100LL, lag);
     HIPCHK(hipGetLastError());
     if (timed) { HIPCHK(hipEventRecord(b->ev1[slot], s)); b->ev_used++; }
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(CP_THREADS), 0, s, macro_ctx(b), b->n, capacity, ready_list_dev, ready_count_dev, b->mc_order);

@@ -106,7 +106,7 @@ def lib():
     L.grip_batch_target_pose.argtypes = [vp, vp, vp, vp]
     L.grip_batch_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.grip_selftest_cholesky.argtypes = [vp, vp, vp, C.c_int, vp]
-    L.grip_batch_advance.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.grip_batch_advance.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     L.grip_batch_observe_list.argtypes = [vp, vp, vp, C.c_int, vp, vp]
     L.grip_rollout_tick.argtypes = [vp, vp]
     L.grip_rollout_gae.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
@@ -211,7 +211,7 @@ class Batch:
         return obs
 
     # -- asynchronous stepping (grip_sim.h: grip_batch_advance) ------------------------------------
-    def advance(self, slot_actions, slice_len, ready_list, ready_count, budget_us=0):
+    def advance(self, slot_actions, slice_len, ready_list, ready_count, budget_us=0, lag=1):
         """One time slice: at most `slice_len` calls of physics.step() per env. slot_actions float32 [capacity, action_dim]
         are the actions for the envs the previous call listed; ready_list int32 [capacity] / ready_count int32 [1] receive
         the envs now waiting for an action. Finished envs' rows of self.out are refreshed."""
@@ -221,7 +221,7 @@ class Batch:
             raise GripError(f"slot_actions must be contiguous float32 [{cap},{self.action_dim}]")
         if ready_list.dtype != t.int32 or ready_count.dtype != t.int32:
             raise GripError("ready_list / ready_count must be int32")
-        _chk(lib().grip_batch_advance(self.ptr, C.c_void_p(slot_actions.data_ptr()), int(slice_len), int(budget_us), cap, C.byref(self._outc),
+        _chk(lib().grip_batch_advance(self.ptr, C.c_void_p(slot_actions.data_ptr()), int(slice_len), int(budget_us), int(lag), cap, C.byref(self._outc),
                                       C.c_void_p(ready_list.data_ptr()), C.c_void_p(ready_count.data_ptr()), self._stream()))
         return self.out
 

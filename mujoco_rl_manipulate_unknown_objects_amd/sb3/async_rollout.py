@@ -37,8 +37,8 @@ class BatchEngineAdapter:
     def reset(self):
         self.batch.reset()
 
-    def advance(self, slot_actions, slice_len, ready_list, ready_count):
-        return self.batch.advance(slot_actions, slice_len, ready_list, ready_count, self.budget_us)
+    def advance(self, slot_actions, slice_len, ready_list, ready_count, lag=1):
+        return self.batch.advance(slot_actions, slice_len, ready_list, ready_count, self.budget_us, lag)
 
     def observe_list(self, ready_list, ready_count, obs_rows):
         self.batch.observe_list(ready_list, ready_count, obs_rows)
@@ -46,7 +46,7 @@ class BatchEngineAdapter:
 
 class AsyncRollout:
     def __init__(self, engine, policy_fn, target, capacity, slice_len, gamma, gae_lambda, max_ticks=None, action_low=None, action_high=None,
-                 poll_every=4, use_graph=True, fused=None):
+                 poll_every=4, use_graph=True, fused=None, pipeline=None):
         """policy_fn(obs_rows uint8 [C, ...]) -> (actions [C, A], values [C], log_probs [C]) under no_grad.
         target = completed transitions per rollout; capacity = ready-list rows per tick."""
         self.eng, self.policy_fn = engine, policy_fn
@@ -83,11 +83,23 @@ class AsyncRollout:
         self.substeps_total = th.zeros(1, dtype=th.int64, device=dev)          # physics.step() calls of the finished macro steps
         self.base_t = th.full((1,), self.N, dtype=th.int64, device=dev)        # first record row of the current tick
         self.obs_stage = th.zeros((self.C,) + tuple(engine.obs_shape), dtype=th.uint8, device=dev)
+        import os
+        if os.environ.get("GRIP_ASYNC_GRAPH") == "0":
+            use_graph = False
         self.use_graph, self.graph_after, self.eager_every, self._graph = use_graph, 3, 16, None
         # bookkeeping: one fused HIP launch per tick on a GPU (csrc/grip_rollout.hip), tensor ops otherwise (CPU tests; the
         # two are compared on the GPU by tests/test_gpu_async.py)
         self.fused = (dev.type == "cuda") if fused is None else bool(fused)
-        self._targs = None
+        self._targs = [None, None]
+        # pipeline: decisions for the envs listed by tick t are made on a side stream WHILE tick t+1 advances everybody else
+        # (grip_batch_advance lag = 2); two alternating sets of list / action / staging buffers, ordered with events
+        # Measured on MI355X (tools/overlap_test2.py): the physics kernel already keeps every SIMD's VALU busy, the side work
+        # only fills its latency gaps, and the extra tick of lag costs more than that gains -- off by default.
+        self.pipeline = False if pipeline is None else bool(pipeline)
+        if self.pipeline:
+            self.lst2 = [self.lst, th.full_like(self.lst, -1)]; self.cnt2 = [self.cnt, th.zeros_like(self.cnt)]
+            self.slot_act2 = [self.slot_act, th.zeros_like(self.slot_act)]; self.obs_stage2 = [self.obs_stage, th.zeros_like(self.obs_stage)]
+            self.side = th.cuda.Stream(dev); self.ev_side = [None, None]; self._side_graph = [None, None]
         if self.low is None:
             self.low = th.full((self.A,), -float("inf"), device=dev); self.high = th.full((self.A,), float("inf"), device=dev)
         self._started = False
@@ -96,24 +108,49 @@ class AsyncRollout:
     def _tick_body(self):
         """All of a tick as fixed-shape, fixed-address device work (the record rows of the tick come from the device scalar
         base_t), so that on a GPU the whole tick is one hipGraph launch."""
-        N, C, R = self.N, self.C, self.R
         out = self.eng.advance(self.slot_act, self.S, self.lst, self.cnt)
-        self.eng.observe_list(self.lst, self.cnt, self.obs_stage)
-        actions, values, log_probs = self.policy_fn(self.obs_stage)
-        rows = self.base_t + self.ar_c                                 # record ids of this tick
-        self.obs.index_copy_(0, rows, self.obs_stage)
-        if self.fused:
-            self._fused_tick(out, actions, values, log_probs)
-        else:
-            self._torch_tick(out, rows, actions, values, log_probs)
-        self.base_t += C
+        self._decide(out, self.lst, self.cnt, self.obs_stage, self.slot_act, 0)
 
-    def _torch_tick(self, out, rows, actions, values, log_probs):
+    def _decide(self, out, lst, cnt, obs_stage, slot_act, p):
+        """Render the listed envs, run the policy on them, record the decisions; writes slot_act for the next start."""
+        self.eng.observe_list(lst, cnt, obs_stage)
+        actions, values, log_probs = self.policy_fn(obs_stage)
+        rows = self.base_t + self.ar_c                                 # record ids of this tick
+        self.obs.index_copy_(0, rows, obs_stage)
+        if self.fused:
+            self._fused_tick(out, lst, cnt, slot_act, p, actions, values, log_probs)
+        else:
+            self._torch_tick(out, lst, cnt, slot_act, rows, actions, values, log_probs)
+        self.base_t += self.C
+
+    def _tick_pipelined(self):
+        p = self.total_ticks % 2
+        main = th.cuda.current_stream(self.dev)
+        if self.ev_side[p] is not None:
+            main.wait_event(self.ev_side[p])                           # the actions this launch starts envs with are ready
+        out = self.eng.advance(self.slot_act2[p], self.S, self.lst2[p], self.cnt2[p], lag=2)
+        ev = th.cuda.Event(); ev.record(main)
+        with th.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            if self.use_graph and self._side_graph[p] is None and self.total_ticks >= 2 * self.graph_after:
+                g = th.cuda.CUDAGraph()
+                with th.cuda.graph(g, stream=self.side):
+                    self._decide(out, self.lst2[p], self.cnt2[p], self.obs_stage2[p], self.slot_act2[p], p)
+                self._side_graph[p] = g
+            if self._side_graph[p] is not None:
+                self._side_graph[p].replay()
+            else:
+                self._decide(out, self.lst2[p], self.cnt2[p], self.obs_stage2[p], self.slot_act2[p], p)
+            e2 = th.cuda.Event(); e2.record(self.side)
+            self.ev_side[p] = e2
+        self.tick += 1; self.total_ticks += 1
+
+    def _torch_tick(self, out, lst, cnt, slot_act, rows, actions, values, log_probs):
         N, C, R = self.N, self.C, self.R
-        valid = self.ar_c < self.cnt                                   # [C]
-        env = th.where(valid, self.lst, N).long()                      # dump env N for empty rows
+        valid = self.ar_c < cnt                                        # [C]
+        env = th.where(valid, lst, N).long()                           # dump env N for empty rows
         env_c = env.clamp(max=N - 1)
-        self.slot_act.copy_(th.max(th.min(actions, self.high), self.low))
+        slot_act.copy_(th.max(th.min(actions, self.high), self.low))
         # close the previous decision of every listed env
         prev = self.rec_of_env[env]
         had = valid & (prev >= 0)
@@ -139,28 +176,32 @@ class AsyncRollout:
         self.rec_env.index_copy_(0, rows, th.where(valid, env, th.full_like(env, -1)))
         self.rec_of_env[env] = rows
 
-    def _fused_tick(self, out, actions, values, log_probs):
+    def _fused_tick(self, out, lst, cnt, slot_act, p, actions, values, log_probs):
         from .. import engine as E
         import ctypes as C
         actions = actions.float().contiguous(); values = values.float().contiguous(); log_probs = log_probs.float().contiguous()
-        if self._targs is None:
+        if self._targs[p] is None:
+            slot = p
             p = lambda t: t.data_ptr()
-            self._targs = E.RolloutTickC(
-                n_envs=self.N, capacity=self.C, action_dim=self.A, n_records=self.R, ready_list=p(self.lst), ready_count=p(self.cnt), base=p(self.base_t),
+            self._targs[slot] = E.RolloutTickC(
+                n_envs=self.N, capacity=self.C, action_dim=self.A, n_records=self.R, ready_list=p(lst), ready_count=p(cnt), base=p(self.base_t),
                 reward=p(out["reward"]), done=p(out["done"]), n_substeps=p(out["n_substeps"]) if "n_substeps" in out else None,
-                low=p(self.low), high=p(self.high), slot_actions=p(self.slot_act), rec_of_env=p(self.rec_of_env), rewards=p(self.rewards),
+                low=p(self.low), high=p(self.high), slot_actions=p(slot_act), rec_of_env=p(self.rec_of_env), rewards=p(self.rewards),
                 dones=p(self.dones), next_rec=p(self.next_rec), prev_rec=p(self.prev_rec), rec_env=p(self.rec_env), completed=p(self.completed),
                 is_rec=p(self.is_rec), actions_buf=p(self.actions), log_probs_buf=p(self.log_probs), values_buf=p(self.values),
                 n_completed=p(self.n_completed), substeps_total=p(self.substeps_total), ep_ret=p(self.ep_ret), ep_len=p(self.ep_len),
                 ep_ret_sum=p(self.ep_ret_sum), ep_len_sum=p(self.ep_len_sum), ep_count=p(self.ep_count))
             assert out["reward"].dtype == th.float32 and out["done"].dtype == th.uint8
-        a = self._targs
+            p = slot
+        a = self._targs[p]
         a.actions, a.values, a.log_probs = actions.data_ptr(), values.data_ptr(), log_probs.data_ptr()
         stream = C.c_void_p(th.cuda.current_stream(self.dev).cuda_stream)
         if E.lib().grip_rollout_tick(C.byref(a), stream) != 0:
             raise E.GripError("grip_rollout_tick failed")
 
     def _tick(self):
+        if self.pipeline:
+            return self._tick_pipelined()
         use_graph = self.use_graph and self.dev.type == "cuda"
         if use_graph and self._graph is None and self.total_ticks >= self.graph_after:
             self._capture()
@@ -207,12 +248,17 @@ class AsyncRollout:
         while self.tick < self.max_ticks:
             self._tick()
             if self.tick % self.poll_every == 0 or self.tick == self.max_ticks:
+                if self.pipeline:
+                    th.cuda.synchronize(self.dev)
                 done_n = int(self.n_completed.item())          # the only host sync of the rollout loop
                 if on_poll is not None and on_poll(done_n) is False:
                     break
                 if done_n >= self.target:
                     break
         else:
+            done_n = int(self.n_completed.item())
+        if self.pipeline:
+            th.cuda.synchronize(self.dev)                      # side stream drained: records complete, safe to train
             done_n = int(self.n_completed.item())
         self._gae()
         return done_n

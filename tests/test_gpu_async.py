@@ -104,9 +104,11 @@ def test_observe_list_rows_match_full_observation(engine, torch):
     b.close()
 
 
-def test_fused_recorder_and_graph_replay_match_tensor_op_bookkeeping(engine, torch):
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_fused_recorder_and_graph_replay_match_tensor_op_bookkeeping(engine, torch, pipeline):
     """AsyncRollout three ways on identical batches with a deterministic policy: tensor-op bookkeeping (the CPU-tested
-    reference), the fused HIP recorder, and the fused recorder replayed from a captured hipGraph. Same records, same GAE."""
+    reference), the fused HIP recorder, and the fused recorder replayed from a captured hipGraph. Same records, same GAE.
+    pipeline=True: decisions run on a side stream while the next slice advances (lag 2) -- another schedule, checked the same way."""
     from mujoco_rl_manipulate_unknown_objects_amd.sb3.async_rollout import AsyncRollout, BatchEngineAdapter
     from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import BatchedRobotEnv, default_config
 
@@ -120,7 +122,7 @@ def test_fused_recorder_and_graph_replay_match_tensor_op_bookkeeping(engine, tor
     def run(fused, graph):
         env = BatchedRobotEnv(default_config(sim_env="/xmls/sand_ball_env.xml"), n_envs=96, device_index=0, auto_reset=True)
         ro = AsyncRollout(BatchEngineAdapter(env), policy, target=96 * 3, capacity=32, slice_len=24, gamma=0.99, gae_lambda=0.95,
-                          action_low=[-1] * 6, action_high=[1] * 6, poll_every=2, use_graph=graph, fused=fused)
+                          action_low=[-1] * 6, action_high=[1] * 6, poll_every=2, use_graph=graph, fused=fused, pipeline=pipeline)
         res = []
         for _ in range(2):
             n = ro.collect()
