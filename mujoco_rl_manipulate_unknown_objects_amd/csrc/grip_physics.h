@@ -54,7 +54,7 @@
 
 // diagnostic build only (-DGRIP_STAMPS): per-phase cycle accounting with s_memtime, never in the shipped library
 #ifdef GRIP_STAMPS
-#define NSTAMP 12
+#define NSTAMP 14
 __device__ unsigned long long g_stamp_acc[NSTAMP];
 struct Stamps { unsigned long long t; unsigned long long acc[NSTAMP]; };
 DEVI unsigned long long stamp_now() { __builtin_amdgcn_sched_barrier(0); unsigned long long t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); return t; }

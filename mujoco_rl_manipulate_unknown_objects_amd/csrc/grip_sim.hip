@@ -466,6 +466,10 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
     const long long t_start = (long long)t0v;
 
     while (__any(phase != PH_DONE && (budget > 0 || phase == PH_FINAL))) {
+#ifdef GRIP_STAMPS
+        stm.acc[12] += __popcll(__ballot(cx.sub == 0 && phase != PH_DONE && (budget > 0 || phase == PH_FINAL)));   // envs of the wave still working
+        stm.acc[13] += 1;
+#endif
         if (phase != PH_DONE && (budget > 0 || phase == PH_FINAL)) {
             forward_pos(m, cx, s, k, con, ncon, fault, stm);       // state of "now": contacts as check_grasp sees them
             if (first) {
@@ -536,6 +540,9 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
                 }
                 physics_advance(m, cx, s, xfrc_z, k, con, ncon, fault, stm);
                 nsub++; cnt++; budget--;
+#ifdef GRIP_STAMPS
+                stm.acc[11] += 1;               // env-substeps of this lane (lane 0 of each wave is reported)
+#endif
                 if (budget_ticks > 0 && wall_clock64() - t_start > budget_ticks) budget = 0;     // the wave's share of the tick is spent
                 // ---- post-step transitions
                 bool to_gripper = false, to_final = false;
@@ -580,6 +587,9 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
             }
         }
     }
+#ifdef GRIP_STAMPS
+    if (cx.lane == 0) for (int i = 0; i < NSTAMP; i++) atomicAdd(&g_stamp_acc[i], stm.acc[i]);      // whole-GPU phase totals (diagnostic build)
+#endif
     if (sliced) {
         int hv = __popc(group_bits(__ballot(cx.sub < ncon && con.g1 != 0), cx.lane));
         if (writer && nsub > 0) mc.heavy[e] = hv;
@@ -1013,7 +1023,10 @@ extern "C" int grip_batch_observe_list(GripBatch *b, const int32_t *list_dev, co
 
 #ifdef GRIP_STAMPS
 extern "C" int grip_debug_stamps(unsigned long long *out8) {   // NSTAMP entries
-    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp_acc), sizeof(unsigned long long) * NSTAMP) == hipSuccess ? 0 : -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp_acc), sizeof(unsigned long long) * NSTAMP) != hipSuccess) return -1;
+    unsigned long long zero[NSTAMP] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_acc), zero, sizeof zero) == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -1,0 +1,24 @@
+"""Diagnostic: whole-GPU per-phase cycle shares of the physics kernel in the time-sliced workload (random actions).
+Uses the -DGRIP_STAMPS build (libgrip_sim_stamps.so), never the shipped library."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np, torch
+from mujoco_rl_manipulate_unknown_objects_amd import engine
+engine.LIB_PATH = os.path.join(engine.CSRC, "libgrip_sim_stamps.so")
+obj = sys.argv[1] if len(sys.argv) > 1 else "acorn"
+n, cap = 4096, 1024
+b = engine.Batch(obj, n, auto_reset=1)
+lst = torch.full((cap,), -1, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+g = torch.Generator(device="cuda"); g.manual_seed(0)
+out = (C.c_ulonglong * 14)()
+def ticks(k):
+    for _ in range(k):
+        b.advance(torch.randn(cap, 6, device="cuda", generator=g).clamp(-1, 1), 96, lst, cnt, 3000)
+ticks(150); engine.lib().grip_debug_stamps(out)
+ticks(100); engine.lib().grip_debug_stamps(out)
+names = ["kinematics", "collide", "mass+bias+qs", "make_constraints", "solve: other (bookkeeping)", "integrate", "solve: constraint pass", "solve: tri-solves+gather", "solve: assemble rows", "solve: cholesky", "solve: line search"]
+tot = sum(out[:11])
+for nm, v in zip(names, out):
+    print(f"{nm:34s} {100 * v / tot:5.1f} %")
+print("wave-cycles per lane-0 env-substep:", tot / max(1, out[11]))
+print("mean envs at work per wave loop trip: %.2f of 4;  wave-cycles per loop trip: %.0f" % (out[12] / max(1, out[13]), tot / max(1, out[13])))
