@@ -510,12 +510,24 @@ DEVI int support_vertex(const Tables &T, int h, int base, V3 dl, V3 &vout) {
 }
 
 struct Sup { V3 v, v1, v2; };
+// field-by-field copy: a whole-struct assignment becomes llvm.memcpy between stack slots, which SROA then leaves in scratch
+// memory -- and the MPR loop pays a scratch round trip per portal update
+DEVI void sup_set(Sup &d, const Sup &s) {
+    d.v.x = s.v.x; d.v.y = s.v.y; d.v.z = s.v.z; d.v1.x = s.v1.x; d.v1.y = s.v1.y; d.v1.z = s.v1.z; d.v2.x = s.v2.x; d.v2.y = s.v2.y; d.v2.z = s.v2.z;
+}
 
+DEVI void sup_sel(Sup &d, bool c, const Sup &s) {
+    d.v.x = c ? s.v.x : d.v.x; d.v.y = c ? s.v.y : d.v.y; d.v.z = c ? s.v.z : d.v.z;
+    d.v1.x = c ? s.v1.x : d.v1.x; d.v1.y = c ? s.v1.y : d.v1.y; d.v1.z = c ? s.v1.z : d.v1.z;
+    d.v2.x = c ? s.v2.x : d.v2.x; d.v2.y = c ? s.v2.y : d.v2.y; d.v2.z = c ? s.v2.z : d.v2.z;
+}
 DEVI V3 portal_dir(const Sup &a, const Sup &b, const Sup &c) { return normalized(cross(b.v - a.v, c.v - a.v)); }
 DEVI void expand_portal(const Sup &p0, Sup &p1, Sup &p2, Sup &p3, const Sup &p4) {
     V3 v4v0 = cross(p4.v, p0.v);
-    if (dot(p1.v, v4v0) > 0.f) { if (dot(p2.v, v4v0) > 0.f) p1 = p4; else p3 = p4; }
-    else { if (dot(p3.v, v4v0) > 0.f) p2 = p4; else p1 = p4; }
+    // value selects, not "pick a destination, then store": selected pointers keep the portal in scratch memory
+    const bool d1 = dot(p1.v, v4v0) > 0.f, d2 = dot(p2.v, v4v0) > 0.f, d3 = dot(p3.v, v4v0) > 0.f;
+    const bool to1 = d1 ? d2 : !d3, to2 = !d1 && d3, to3 = d1 && !d2;
+    sup_sel(p1, to1, p4); sup_sel(p2, to2, p4); sup_sel(p3, to3, p4);
 }
 DEVI bool reach_tol(const Sup &p1, const Sup &p2, const Sup &p3, const Sup &p4, V3 dir) {
     float d4 = dot(p4.v, dir);
@@ -631,7 +643,7 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault) {
                     cnt++;
                     bool hit = false; float depth = 0.f; V3 nrm = v3(0, 0, 0), pos = v3(0, 0, 0);
                     if (phase == 0) {
-                        s1 = s;
+                        sup_set(s1, s);
                         if (dot(s1.v, dir) <= 0.f) phase = -1;
                         else {
                             V3 d = cross(s0.v, s1.v);
@@ -641,18 +653,18 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault) {
                             } else { dir = normalized(d); phase = 1; }
                         }
                     } else if (phase == 1) {
-                        s2 = s;
+                        sup_set(s2, s);
                         if (dot(s2.v, dir) <= 0.f) phase = -1;
                         else {
                             dir = normalized(cross(s1.v - s0.v, s2.v - s0.v));
-                            if (dot(dir, s0.v) > 0.f) { Sup t = s1; s1 = s2; s2 = t; dir = -dir; }
+                            if (dot(dir, s0.v) > 0.f) { Sup t; sup_set(t, s1); sup_set(s1, s2); sup_set(s2, t); dir = -dir; }
                             phase = 2; cnt = 0;
                         }
                     } else if (phase == 2) {
-                        s3 = s;
+                        sup_set(s3, s);
                         if (dot(s3.v, dir) <= 0.f || cnt > 4 * MPR_MAXIT) phase = -1;
-                        else if (dot(cross(s1.v, s3.v), s0.v) < -EPSD) { s2 = s3; dir = normalized(cross(s1.v - s0.v, s2.v - s0.v)); }
-                        else if (dot(cross(s3.v, s2.v), s0.v) < -EPSD) { s1 = s3; dir = normalized(cross(s1.v - s0.v, s2.v - s0.v)); }
+                        else if (dot(cross(s1.v, s3.v), s0.v) < -EPSD) { sup_set(s2, s3); dir = normalized(cross(s1.v - s0.v, s2.v - s0.v)); }
+                        else if (dot(cross(s3.v, s2.v), s0.v) < -EPSD) { sup_set(s1, s3); dir = normalized(cross(s1.v - s0.v, s2.v - s0.v)); }
                         else {
                             dir = portal_dir(s1, s2, s3);
                             phase = dot(dir, s1.v) >= -EPSD ? 4 : 3; cnt = 0;
@@ -838,41 +850,36 @@ DEVI void make_constraints(const DevModel &m, const Kin &k, const float (&qpos)[
     }
 }
 
-// One cooperative pass over all constraints at acceleration x (identical in the 16 lanes): each lane prices ITS contact
-// (4 x 13 dot products with the rows in its registers) and, for j < 7, ITS joint limit; the 16 lanes all-reduce the cost and
-// J^T force. The cone of the contact is returned for hessian_vectors().
-DEVI float constraint_pass(const DevModel &m, const Ctx &cx, float lsgn, float lD, float laref, float xi,
-                           const float (&x)[13], Contact &c, bool live, float (&jtf)[13], Cone &cn, float &hdiag) {
-    float cost = 0.f;
-    float jl[13];
-#pragma unroll
-    for (int i = 0; i < 13; i++) jl[i] = 0.f;
+// Pricing of the constraints at the current point, row-distributed. Contact lane c evaluates its cone at jar (kept up to
+// date incrementally: jar += alpha jv, as mj_solNewton does) and publishes its force f = -grad (4 floats) to LDS; dof lane
+// i then reads the force of every contact and column i of its Jacobian rows (already in LDS for the Hessian) and gets
+// (J^T f)_i directly -- a reduce-scatter through LDS instead of 13 sixteen-lane all-reduces. Lane j < 7 adds its joint limit.
+#define EF_FORCE EF_STAGE               // [G_MAXC][4] contact forces; the staging area is free once collide() is done
+#define EF_P (EF_STAGE + 64)            // [16] search direction, one component per dof lane
+DEVI float price_constraints(const DevModel &m, const Ctx &cx, float lsgn, float lD, float laref, float xi, int ncon,
+                             const Contact &c, bool live, Cone &cn, float &jtfi, float &hdiag) {
 #pragma unroll
     for (int i = 0; i < 4; i++) { cn.grad[i] = 0.f; cn.w[i] = 0.f; cn.a[i] = 0.f; cn.b[i] = 0.f; }
     cn.cost = 0.f; cn.ka = 0.f; cn.kb = 0.f;
     if (live) {
-        float jar[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            float v = -c.aref[r];
-#pragma unroll
-            for (int i = 0; i < 13; i++) v = fmaf(c.J[r][i], x[i], v);
-            jar[r] = v; c.jar[r] = v;
-        }
-        cone_eval(jar, c.D0, m.impratio, c.fs, c.ft, cn);
-        cost = cn.cost;
-#pragma unroll
-        for (int i = 0; i < 13; i++) jl[i] = -(cn.grad[0] * c.J[0][i] + cn.grad[1] * c.J[1][i] + cn.grad[2] * c.J[2][i] + cn.grad[3] * c.J[3][i]);
+        cone_eval(c.jar, c.D0, m.impratio, c.fs, c.ft, cn);
+        *reinterpret_cast<float4 *>(cx.envl + EF_FORCE + 4 * cx.sub) = make_float4(-cn.grad[0], -cn.grad[1], -cn.grad[2], -cn.grad[3]);
     }
+    float cost = cn.cost;
     // joint limit owned by this lane (lanes 0..6): J = sgn at dof `sub`
     float ljar = lsgn * xi - laref;
     bool lact = lsgn != 0.f && ljar < 0.f;
-    float lforce = lact ? -lD * ljar * lsgn : 0.f;
+    float jt = lact ? -lD * ljar * lsgn : 0.f;
     cost += lact ? 0.5f * lD * ljar * ljar : 0.f;
     hdiag = lact ? lD : 0.f;
-    cost = sum16(cost);
-#pragma unroll
-    for (int i = 0; i < 13; i++) jtf[i] = sum16(jl[i] + (cx.sub == i ? lforce : 0.f));
+    wave_sync();
+    const int isub = min(cx.sub, 12);
+    for (int k = 0; k < ncon; k++) {
+        const float4 f = *reinterpret_cast<const float4 *>(cx.envl + EF_FORCE + 4 * k);
+        const float *u = cx.envl + EF_U + k * 6 * U_STRIDE + isub;
+        jt = fmaf(u[0], f.x, jt); jt = fmaf(u[U_STRIDE], f.y, jt); jt = fmaf(u[2 * U_STRIDE], f.z, jt); jt = fmaf(u[3 * U_STRIDE], f.w, jt);
+    }
+    jtfi = cx.sub < 13 ? jt : 0.f;
     return cost;
 }
 
@@ -943,12 +950,14 @@ DEVI void line_eval(const DevModel &m, float lsgn, float lD, float laref, float 
     dphi = sum16(dp) + g0 + alpha * g1; ddphi = sum16(hp) + g1;
 }
 
-// Primal Newton solve of  min 1/2 (a - a_s)^T M (a - a_s) + s(J a - aref)   (mj_solNewton's problem), cooperatively.
-// Staged loop with ONE constraint-pass site: stage 0 prices qacc_smooth, stage 1 prices qacc_warmstart (the better
-// one is the start, as MuJoCo does) and stops right there when the start already satisfies the gradient tolerance;
-// stages >= 2 are Newton iterations: every lane assembles and factorises its own row of the Hessian, the direction comes
-// from the lane-distributed triangular solves, the exact line search all-reduces two scalars per evaluation. All control
-// flow depends only on all-reduced values, so the 16 lanes of an env always agree.
+// Primal Newton solve of  min 1/2 (a - a_s)^T M (a - a_s) + s(J a - aref)   (mj_solNewton's problem), cooperatively and
+// row-distributed: dof lane i carries x_i, (M (x - a_s))_i and its gradient component, contact lane c carries jar_c; full
+// 13-vectors exist only transiently (the search direction, read back from LDS for J p and M p). Staged loop with ONE
+// pricing site: stage 0 prices qacc_smooth, stage 1 prices qacc_warmstart (the better one is the start, as MuJoCo does)
+// and stops right there when the start already satisfies the gradient tolerance; stages >= 2 are Newton iterations: every
+// lane assembles and factorises its own row of the Hessian, the direction comes from the lane-distributed triangular
+// solves, the exact line search all-reduces two scalars per evaluation. All control flow depends only on all-reduced
+// values, so the 16 lanes of an env always agree.
 DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, float laref,
                        const float (&qs)[13], float qsi, const float (&warm)[13], Contact &c, bool live, int ncon,
                        float (&qacc)[13], float (&jtf)[13], int &fault, int &iters, Stamps &st, float *dbgH = nullptr) {
@@ -956,41 +965,51 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
     const float tol = fmaxf(m.tolerance, 1e-5f);            // fp32 noise floor of the scaled gradient is ~1e-6
     float mrow[13]; load_mrow(cx, mrow);
     const float warmi = pick13(warm, cx.sub);
-    float x[13], xi = qsi, qi = qsi;                        // x: evaluation point (all lanes); xi / qi: own component of x / qacc
+    // the two candidate starts: jar = J x - aref and M (x - a_s) for x = qacc_smooth and x = qacc_warmstart
+    float jar_s[4] = {0.f, 0.f, 0.f, 0.f}, jar_w[4] = {0.f, 0.f, 0.f, 0.f}, Md_w;
+    {   float dw[13];
+#pragma unroll
+        for (int i = 0; i < 13; i++) dw[i] = warm[i] - qs[i];
+        Md_w = row_dot(mrow, dw);
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float vs = -c.aref[r], vw = 0.f;
+#pragma unroll
+                for (int i = 0; i < 13; i++) { vs = fmaf(c.J[r][i], qs[i], vs); vw = fmaf(c.J[r][i], dw[i], vw); }
+                jar_s[r] = vs; jar_w[r] = vs + vw;
+            }
+        }
+    }
+    float xi = qsi, Mdi = 0.f, jtfi = 0.f;                  // current point, row-distributed
+#pragma unroll
+    for (int r = 0; r < 4; r++) c.jar[r] = jar_s[r];
     float cost = 0.f, cs = 0.f;
     int stage = 0; bool done = false;
     iters = 0;
-#pragma unroll
-    for (int i = 0; i < 13; i++) { qacc[i] = qs[i]; x[i] = qs[i]; }
     while (__any(!done)) {
         if (!done) {
-            float dq[13];
-#pragma unroll
-            for (int i = 0; i < 13; i++) dq[i] = x[i] - qs[i];
-            float Mdi = row_dot(mrow, dq);                                  // (M (x - qs))_sub
             float hdiag; Cone cn;
-            float newcost = sum16(0.5f * Mdi * (xi - qsi));
             STAMP(st, 4);
-            newcost += constraint_pass(m, cx, lsgn, lD, laref, xi, x, c, live, jtf, cn, hdiag);
-            STAMP(st, 6);
-            float gi = Mdi - pick13(jtf, cx.sub);                           // gradient component of this lane
+            float lc = price_constraints(m, cx, lsgn, lD, laref, xi, ncon, c, live, cn, jtfi, hdiag);
+            float newcost = sum16(0.5f * Mdi * (xi - qsi) + lc);
+            float gi = Mdi - jtfi;                                          // gradient component of this lane
             const bool gconv = scale * sqrtf(sum16(gi * gi)) < tol;
+            STAMP(st, 6);
             if (stage == 0) {
                 cs = newcost; stage = 1;
-#pragma unroll
-                for (int i = 0; i < 13; i++) x[i] = warm[i];
-                xi = warmi;
                 if (gconv) done = true;                     // qacc_smooth already optimal (constraints inactive)
+                else {
+                    xi = warmi; Mdi = Md_w;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) c.jar[r] = jar_w[r];
+                }
             } else if (stage == 1) {
-                if (newcost < cs) {
+                if (newcost < cs) { if (gconv) done = true; }
+                else {
+                    xi = qsi; Mdi = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 13; i++) qacc[i] = warm[i];
-                    qi = warmi;
-                    if (gconv) done = true;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 13; i++) x[i] = qs[i];
-                    xi = qsi;
+                    for (int r = 0; r < 4; r++) c.jar[r] = jar_s[r];
                 }
                 stage = 2;
             } else {
@@ -1014,10 +1033,16 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
                     chol_rows(row, cx.sub);
                     STAMP(st, 9);
                     float pi = chol_solve_rows(row, -gi, cx.sub);
-                    float p[13]; gather13(pi, p);
+                    cx.envl[EF_P + cx.sub] = pi;            // lanes 13..15 publish 0
+                    wave_sync();
+                    float p[13];
+                    {   const float4 *p4 = reinterpret_cast<const float4 *>(cx.envl + EF_P);
+                        float4 a = p4[0], b = p4[1], c4 = p4[2]; float d = cx.envl[EF_P + 12];
+                        p[0] = a.x; p[1] = a.y; p[2] = a.z; p[3] = a.w; p[4] = b.x; p[5] = b.y; p[6] = b.z; p[7] = b.w;
+                        p[8] = c4.x; p[9] = c4.y; p[10] = c4.z; p[11] = c4.w; p[12] = d; }
                     STAMP(st, 7);
                     float Mpi = row_dot(mrow, p);
-                    float g0 = sum16(Mpi * (qi - qsi)), g1 = sum16(Mpi * pi);
+                    float g0 = sum16(Mpi * (xi - qsi)), g1 = sum16(Mpi * pi);
                     if (live) {
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
@@ -1035,7 +1060,7 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
                         if (!__any(!lsdone)) break;
                         if (!lsdone) {
                             float dp, hp;
-                            line_eval(m, lsgn, lD, laref, qi, pi, c, live, alpha, g0, g1, dp, hp);
+                            line_eval(m, lsgn, lD, laref, xi, pi, c, live, alpha, g0, g1, dp, hp);
                             if (ls == 0) {
                                 if (dp >= 0.f) { descent = false; lsdone = true; }
                                 gtol = LS_GTOL * fabsf(dp) + 1e-30f;
@@ -1056,15 +1081,17 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
                     STAMP(st, 10);
                     if (!descent) done = true;
                     else {
+                        xi = fmaf(alpha, pi, xi); Mdi = fmaf(alpha, Mpi, Mdi);
 #pragma unroll
-                        for (int i = 0; i < 13; i++) { qacc[i] = fmaf(alpha, p[i], qacc[i]); x[i] = qacc[i]; }
-                        qi = fmaf(alpha, pi, qi); xi = qi;
+                        for (int r = 0; r < 4; r++) c.jar[r] = fmaf(alpha, c.jv[r], c.jar[r]);
                         iters++; stage++;
                     }
                 }
             }
         }
     }
+    // the optimum and its constraint force as full vectors (Euler step and warm start want them in every lane)
+    gather13(xi, qacc); gather13(jtfi, jtf);
 }
 
 // ---------------------------------------------------------------- one physics.step()

@@ -1,6 +1,6 @@
 // grip_render.hip -- observation kernel: RobotEnv.get_observation (robot_env.py:275-293).
 //
-// One 256-thread workgroup per environment, 16 pixels per thread. Rays from `gripper_camera`
+// One 1024-thread workgroup per environment, a 2 x 2 pixel tile per thread. Rays from `gripper_camera`
 // (robot xml :60) are clipped against the floor plane and the six convex hulls (Cyrus-Beck over
 // the hull face planes, read with workgroup-uniform indices, after a per-ray bounding-sphere
 // test); flat Lambert shading gives RGB (sensor.py:64-66), the distance along the optical axis
@@ -14,7 +14,7 @@
 
 #define RW 64
 #define RH 64
-#define RTHREADS 256
+#define RTHREADS 1024
 #define RPIX (RW * RH)
 
 struct Frames { float p[6][3]; float R[6][9]; float cam_o[3]; float cam_R[9]; };
@@ -51,9 +51,10 @@ __device__ static uint8_t to_u8(float v) { v *= 255.f; v = fminf(fmaxf(v, 0.f), 
 // coordinates dc = (x, y, -1):  n.(ol + t dl) <= d  with  dl = Rg^T Rc dc, ol = Rg^T (co - pg)  becomes
 // t (A.dc) <= B,  A = (Rg^T Rc)^T n,  B = d - n.ol.
 // Hulls whose bounding sphere lies behind the camera plane are dropped for the whole env (the gripper base always is).
-// Every thread owns a 4 x 4 pixel tile and keeps its 16 rays' (t_in, t_out, entering plane) in registers, so that a plane is
+// Every thread owns a TW x TW pixel tile (1024 threads per env) and keeps its rays' (t_in, t_out, entering plane) in registers, so that a plane is
 // read from LDS once per 16 rays and costs one FMA + rcp + a few selects per ray; depth never leaves registers.
-#define TPX 16              // pixels per thread (4 x 4)
+#define TW 2                // tile width: every thread owns a TW x TW pixel tile
+#define TPX (TW * TW)
 
 __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevConfig cfg, const float *qpos, const int *pad_grasp, const int *pad_pher,
                                                       int n, const int *list, const int *count, uint8_t *obs) {
@@ -102,19 +103,20 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
     const int nch = cfg.full_observation ? 5 : 4;
     uint8_t *o = obs + (size_t)blockIdx.x * nch * RPIX;
     const float tanh_ = tanf(0.5f * m.cam_fovy * 0.017453292519943295f);
-    // tile of this thread: a wave covers 8 x 8 tiles = a 32 x 32 pixel quadrant
+    // tile of this thread: a wave covers 8 x 8 tiles = a square block of (8 TW)^2 pixels
+    constexpr int WPR = RW / (8 * TW);          // waves per row of wave blocks
     const int w = tid >> 6, l = tid & 63;
-    const int tx = (l & 7) + 8 * (w & 1), ty = (l >> 3) + 8 * (w >> 1);
-    float xs[4], ys[4];
+    const int tx = (l & 7) + 8 * (w % WPR), ty = (l >> 3) + 8 * (w / WPR);
+    float xs[TW], ys[TW];
 #pragma unroll
-    for (int a = 0; a < 4; a++) {
-        xs[a] = (2.0f * (4 * tx + a + 0.5f) / RW - 1.0f) * tanh_;
-        ys[a] = (1.0f - 2.0f * (4 * ty + a + 0.5f) / RH) * tanh_;
+    for (int a = 0; a < TW; a++) {
+        xs[a] = (2.0f * (TW * tx + a + 0.5f) / RW - 1.0f) * tanh_;
+        ys[a] = (1.0f - 2.0f * (TW * ty + a + 0.5f) / RH) * tanh_;
     }
     float best[TPX]; int hitent[TPX];                                   // hit geom << 16 | entering plane; -1 = sky
 #pragma unroll
     for (int q = 0; q < TPX; q++) {
-        float x = xs[q & 3], y = ys[q >> 2];
+        float x = xs[q % TW], y = ys[q / TW];
         float dz = Rc.m[6] * x + Rc.m[7] * y - Rc.m[8];
         best[q] = m.zfar; hitent[q] = -1;
         if (dz < 0.f) { float t = -co.z / dz; if (t > m.znear && t < best[q]) { best[q] = t; hitent[q] = 0; } }
@@ -128,7 +130,7 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
         unsigned mask = 0u;
 #pragma unroll
         for (int q = 0; q < TPX; q++) {
-            float x = xs[q & 3], y = ys[q >> 2];
+            float x = xs[q % TW], y = ys[q / TW];
             float bq = -(cx_ * x + cy_ * y - cz_), dd = x * x + y * y + 1.f;
             bool pass = !(bq * bq - dd * cq < 0.f || (bq > 0.f && cq > 0.f));
             mask |= pass ? (1u << q) : 0u;
@@ -142,12 +144,12 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
         // t_out = u; a parallel plane with the origin outside gives u = -inf and so t_in > t_out: a miss, as it must be.
         for (int pi = 0; pi < np; pi++) {
             const float4 P = sp[pi];
-            float cxa[4];
+            float cxa[TW];
 #pragma unroll
-            for (int a = 0; a < 4; a++) cxa[a] = fmaf(P.x, xs[a], -P.z);
+            for (int a = 0; a < TW; a++) cxa[a] = fmaf(P.x, xs[a], -P.z);
 #pragma unroll
             for (int q = 0; q < TPX; q++) {
-                float den = fmaf(P.y, ys[q >> 2], cxa[q & 3]);
+                float den = fmaf(P.y, ys[q / TW], cxa[q % TW]);
                 float u = P.w * rcp(fabsf(den));
                 bool in = den < 0.f, up = in && -u > tin[q];
                 tin[q] = up ? -u : tin[q]; ent[q] = up ? pi : ent[q];
@@ -165,8 +167,8 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
     float lmin = 3.0e38f;
 #pragma unroll
     for (int q = 0; q < TPX; q++) {
-        const int i = 4 * ty + (q >> 2), j = 4 * tx + (q & 3), px = i * RW + j;
-        const float x = xs[q & 3], y = ys[q >> 2];
+        const int i = TW * ty + q / TW, j = TW * tx + q % TW, px = i * RW + j;
+        const float x = xs[q % TW], y = ys[q / TW];
         const V3 dir = mulv(Rc, v3(x, y, -1.f));
         const int hit = hitent[q] < 0 ? -1 : (hitent[q] >> 16);
         float c0, c1, c2;
@@ -205,7 +207,7 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
     if (cfg.full_observation) {
 #pragma unroll
         for (int q = 0; q < TPX; q++) {
-            const int px = (4 * ty + (q >> 2)) * RW + 4 * tx + (q & 3);
+            const int px = (TW * ty + q / TW) * RW + TW * tx + q % TW;
             float v = (best[q] - dmin) / scale; v = fminf(fmaxf(v, 0.f), 1.f);
             float p = 255.0f * v;
             o[3 * RPIX + px] = (p != p) ? (uint8_t)0 : (uint8_t)p;
