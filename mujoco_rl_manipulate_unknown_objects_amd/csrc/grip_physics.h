@@ -54,7 +54,7 @@
 
 // diagnostic build only (-DGRIP_STAMPS): per-phase cycle accounting with s_memtime, never in the shipped library
 #ifdef GRIP_STAMPS
-#define NSTAMP 14
+#define NSTAMP 20
 __device__ unsigned long long g_stamp_acc[NSTAMP];
 struct Stamps { unsigned long long t; unsigned long long acc[NSTAMP]; };
 DEVI unsigned long long stamp_now() { __builtin_amdgcn_sched_barrier(0); unsigned long long t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); return t; }
@@ -981,6 +981,7 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
             }
         }
     }
+    STAMP(st, 14);
     float xi = qsi, Mdi = 0.f, jtfi = 0.f;                  // current point, row-distributed
 #pragma unroll
     for (int r = 0; r < 4; r++) c.jar[r] = jar_s[r];
@@ -1019,10 +1020,11 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
                 if (!stop && iters >= NEWTON_MAXIT) { stop = true; fault |= 4; }
                 if (stop) done = true;
                 else {
+                    STAMP(st, 15);
                     hessian_vectors(cx, c, live, cn);
                     wave_sync();                            // the contact lanes' Hessian vectors are in LDS
                     float row[13];
-                    STAMP(st, 4);
+                    STAMP(st, 16);
                     assemble_rows(cx, ncon, mrow, hdiag, row);
                     STAMP(st, 8);
                     if (dbgH && iters == 0 && cx.sub < 13) {
@@ -1052,7 +1054,7 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
                             c.jv[r] = v;
                         }
                     }
-                    STAMP(st, 4);
+                    STAMP(st, 17);
                     // exact line search: safeguarded 1-D Newton on phi'(alpha); one evaluation site
                     float lo = 0.f, hi = -1.f, alpha = 0.f, gtol = 0.f;
                     bool lsdone = false, descent = true;
@@ -1091,7 +1093,9 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
         }
     }
     // the optimum and its constraint force as full vectors (Euler step and warm start want them in every lane)
+    STAMP(st, 18);
     gather13(xi, qacc); gather13(jtfi, jtf);
+    STAMP(st, 19);
 }
 
 // ---------------------------------------------------------------- one physics.step()
@@ -1169,9 +1173,11 @@ DEVI void forward_acc(const DevModel &m, const Ctx &cx, LaneState &s, float xfrc
 }
 
 // dynamics + integration of one physics.step(); forward_pos must have run on the current state
-DEVI void physics_advance(const DevModel &m, const Ctx &cx, LaneState &s, float xfrc_z, const Kin &k, Contact &con, int ncon, int &fault, Stamps &st) {
+DEVI void physics_advance(const DevModel &m, const Ctx &cx, LaneState &s, float xfrc_z, const Kin &k, Contact &con, int ncon, int &fault, Stamps &st,
+                          int *newton_iters = nullptr) {
     float qfs[13], qacc[13], jtf[13]; int iters;
     forward_acc(m, cx, s, xfrc_z, k, con, ncon, fault, qfs, qacc, jtf, iters, nullptr, nullptr, st);
+    if (newton_iters) *newton_iters = iters;
     const float h = m.timestep;
     // semi-implicit Euler with implicit joint damping: (M + h D) a' = qfrc_smooth + J^T f   (mj_Euler). The object block has
     // no damping, so a' = qacc there; the distributed solve covers all 13 dofs at once.

@@ -364,6 +364,7 @@ DEVI float agent_reward(V3 o0, V3 o1, const DevConfig &c, int gripper_open, floa
 }
 
 enum { PH_MOVE = 0, PH_RETURN, PH_OPEN, PH_CLOSE, PH_FINAL, PH_DONE };
+#define CP_CLASSES 8        // work-order classes of k_compact: cost 0..6 of running envs, 7 = idle
 
 // ------------------------------------------------------------------------------------------------
 // kernels: 256-thread workgroups = 16 environments x 16 cooperating lanes (grip_physics.h)
@@ -451,7 +452,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
 #pragma unroll
         for (int i = 0; i < 6; i++) act[i] = i < adim ? actions[arow * adim + i] : 0.f;
     }
-    int budget = sliced ? slice : 0x7fffffff;
+    int budget = sliced ? slice : 0x7fffffff, last_iters = 0;
     // the wall-clock budget runs from the moment the FIRST workgroup of the launch started (k_compact clears the stamp), so
     // that a workgroup that was placed late -- other streams' kernels were using its CU -- does not stretch the launch
     unsigned long long t0v = 0ULL;
@@ -538,7 +539,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
                     delta_pre = fmaxf(fabsf(tq - s.qpos[5]), fabsf(tq - s.qpos[6]));
                     if (phase == PH_CLOSE) grasped = check_grasp(cx, con, ncon);       // robot_env.py:155, before the step
                 }
-                physics_advance(m, cx, s, xfrc_z, k, con, ncon, fault, stm);
+                physics_advance(m, cx, s, xfrc_z, k, con, ncon, fault, stm, &last_iters);
                 nsub++; cnt++; budget--;
 #ifdef GRIP_STAMPS
                 stm.acc[11] += 1;               // env-substeps of this lane (lane 0 of each wave is reported)
@@ -591,8 +592,10 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
     if (cx.lane == 0) for (int i = 0; i < NSTAMP; i++) atomicAdd(&g_stamp_acc[i], stm.acc[i]);      // whole-GPU phase totals (diagnostic build)
 #endif
     if (sliced) {
+        // cost estimate of this env's next physics.step(), in units of roughly half a plain step: Newton iterations of the
+        // last solve plus 1.5 per hull-hull contact (MPR refinement); k_compact sorts the work order by it
         int hv = __popc(group_bits(__ballot(cx.sub < ncon && con.g1 != 0), cx.lane));
-        if (writer && nsub > 0) mc.heavy[e] = hv;
+        if (writer && nsub > 0) mc.heavy[e] = min(CP_CLASSES - 2, last_iters + (3 * hv + 1) / 2);
     }
     if (sliced && writer && phase != PH_DONE) {             // out of budget mid-step: suspend
         st_state(st, e, s);
@@ -614,7 +617,6 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
 // one or two, more -- so that the 4 envs of a wave and the 16 of a workgroup cost about the same per physics.step(), then
 // the idle envs, whose workgroups retire at once.
 #define CP_THREADS 1024
-#define CP_CLASSES 4
 __global__ void __launch_bounds__(CP_THREADS) k_compact(MacroCtx mc, int n, int capacity, int *list, int *count, int *order) {
     // the rotation advances with a device-side tick counter, so that a captured (hipGraph) tick keeps rotating
     const int rot = (int)(((long long)mc.tick[0] * capacity) % n);
@@ -641,8 +643,9 @@ __global__ void __launch_bounds__(CP_THREADS) k_compact(MacroCtx mc, int n, int 
     if (t == 0) *count = cnt;
     __syncthreads();
     // pass 2: counting sort of the envs by class (0..2 = running by cost, 3 = idle), stable within a class
-    auto cls_of = [&](int e) { bool run = mc.astate[e] == 0 || mc.slot[e] >= 0; int h = mc.heavy[e]; return !run ? 3 : h == 0 ? 0 : h <= 2 ? 1 : 2; };
-    int mine[CP_CLASSES] = {0, 0, 0, 0}, before[CP_CLASSES];
+    auto cls_of = [&](int e) { bool run = mc.astate[e] == 0 || mc.slot[e] >= 0; return !run ? CP_CLASSES - 1 : min(max(mc.heavy[e], 0), CP_CLASSES - 2); };
+    int mine[CP_CLASSES], before[CP_CLASSES];
+    for (int k = 0; k < CP_CLASSES; k++) mine[k] = 0;
     for (int i = 0; i < chunk; i++) { int e = t * chunk + i; if (e < n) mine[cls_of(e)]++; }
     for (int k = 0; k < CP_CLASSES; k++) {
         sa[t] = mine[k]; __syncthreads();

@@ -10,15 +10,19 @@ n, cap = 4096, 1024
 b = engine.Batch(obj, n, auto_reset=1)
 lst = torch.full((cap,), -1, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
 g = torch.Generator(device="cuda"); g.manual_seed(0)
-out = (C.c_ulonglong * 14)()
+out = (C.c_ulonglong * 20)()
 def ticks(k):
     for _ in range(k):
         b.advance(torch.randn(cap, 6, device="cuda", generator=g).clamp(-1, 1), 96, lst, cnt, 3000)
 ticks(150); engine.lib().grip_debug_stamps(out)
 ticks(100); engine.lib().grip_debug_stamps(out)
 names = ["kinematics", "collide", "mass+bias+qs", "make_constraints", "solve: other (bookkeeping)", "integrate", "solve: constraint pass", "solve: tri-solves+gather", "solve: assemble rows", "solve: cholesky", "solve: line search"]
-tot = sum(out[:11])
+names2 = {14: "solve: prologue (mrow, jar of both starts)", 15: "solve: stage logic after pricing", 16: "solve: hessian_vectors + sync",
+          17: "solve: p readback, M p, J p, g0/g1", 18: "solve: loop exit", 19: "solve: final gathers"}
+tot = sum(out[:11]) + sum(out[14:20])
 for nm, v in zip(names, out):
     print(f"{nm:34s} {100 * v / tot:5.1f} %")
+for i, nm in names2.items():
+    print(f"{nm:44s} {100 * out[i] / tot:5.1f} %")
 print("wave-cycles per lane-0 env-substep:", tot / max(1, out[11]))
 print("mean envs at work per wave loop trip: %.2f of 4;  wave-cycles per loop trip: %.0f" % (out[12] / max(1, out[13]), tot / max(1, out[13])))
