@@ -26,7 +26,8 @@ class ScriptedEngine:
     """N envs; env e's k-th macro step lasts duration(e, k) ticks, pays reward_of(e, k), ends an episode every HORIZON steps.
     Observations encode (env, k) so that the fake policy can answer value_of(env, k)."""
 
-    def __init__(self, n, capacity):
+    def __init__(self, n, capacity, slow=1):
+        self.slow = slow
         self.num_envs, self.action_dim, self.obs_shape, self.device = n, 6, (5, 64, 64), th.device("cpu")
         self.cap = capacity
         self.k = np.zeros(n, int)                 # macro steps finished so far
@@ -44,7 +45,7 @@ class ScriptedEngine:
         for e in range(n):
             if self.left[e] == 0 and self.slot[e] >= 0:
                 self.started_with[(e, self.k[e])] = slot_actions[self.slot[e]].clone()
-                self.left[e] = duration(e, self.k[e]); self.slot[e] = -1
+                self.left[e] = self.slow * duration(e, self.k[e]); self.slot[e] = -1
             if self.left[e] > 0:
                 self.left[e] -= 1
                 if self.left[e] == 0:
@@ -139,3 +140,53 @@ def test_ppo_learns_on_scripted_async_engine_cpu():
     assert np.isfinite(float(stats["loss"]))
     assert model.num_timesteps >= 2 * 24
     assert any(not th.equal(a, b) for a, b in zip(before, model.policy.parameters()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1: ranks whose envs finish at different speeds still run the same number of optimiser steps (exactly n_steps * N
+# training records per rollout on every rank), so the per-minibatch gradient all-reduce never deadlocks and the replicas
+# stay bit-identical.
+def _async_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3 import PPO
+    from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    th.manual_seed(10 + rank)
+
+    class Env(ScriptedEngine):
+        def __init__(self):
+            super().__init__(6, 3, slow=1 + 2 * rank)           # rank 1's macro steps take three times as many ticks
+            self.observation_space = spaces.Dict({"observation": spaces.Box(0, 255, (5, 64, 64), np.uint8)})
+            self.action_space = spaces.Box(-1.0, 1.0, (6,), np.float32)
+
+    model = PPO("MultiInputPolicy", Env(), n_steps=3, batch_size=6, n_epochs=1, device="cpu", async_slice=8, async_capacity=3,
+                policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[16]))
+    ticks = []
+    for _ in range(2):
+        model.collect_rollouts(); ticks.append(model._async.tick); model.train()
+    p = th.cat([x.detach().reshape(-1) for x in model.policy.parameters()])
+    q.put((rank, p.numpy(), ticks, model.num_timesteps))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_async_rollouts_keep_replicas_identical():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_async_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, p, ticks, nts = q.get(timeout=300)
+        res[r] = (p, ticks, nts)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][0], res[1][0])                 # same parameters after two distributed updates
+    assert res[0][1] != res[1][1]                               # although the ranks' rollouts took different numbers of ticks
+    assert res[0][2] >= 2 * 18 and res[1][2] >= 2 * 18
