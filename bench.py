@@ -82,10 +82,17 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    # rehearsal of the N > 1 code path on a one-GPU box: every rank on device 0, gloo instead of RCCL (never a headline number)
+    rehearsal = os.environ.get("GRIP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import BatchedRobotEnv, default_config
     from mujoco_rl_manipulate_unknown_objects_amd.sb3 import PPO, GpuVecEnv

@@ -134,7 +134,7 @@ class AsyncRollout:
             self.side.wait_event(ev)
             if self.use_graph and self._side_graph[p] is None and self.total_ticks >= 2 * self.graph_after:
                 g = th.cuda.CUDAGraph()
-                with th.cuda.graph(g, stream=self.side):
+                with th.cuda.graph(g, stream=self.side, capture_error_mode="thread_local"):
                     self._decide(out, self.lst2[p], self.cnt2[p], self.obs_stage2[p], self.slot_act2[p], p)
                 self._side_graph[p] = g
             if self._side_graph[p] is not None:
@@ -213,12 +213,19 @@ class AsyncRollout:
         self.tick += 1; self.total_ticks += 1
 
     def _capture(self):
-        """Capture one tick. Capturing records the launches without running them, so the state is untouched."""
+        """Capture one tick. Capturing records the launches without running them, so the state is untouched. If the runtime
+        refuses the capture the rollout goes on eagerly (slower, same results)."""
         th.cuda.synchronize(self.dev)
-        g = th.cuda.CUDAGraph()
-        with th.cuda.graph(g):
-            self._tick_body()
-        self._graph = g
+        try:
+            g = th.cuda.CUDAGraph()
+            with th.cuda.graph(g, capture_error_mode="thread_local"):
+                self._tick_body()
+            self._graph = g
+        except Exception as ex:                                   # noqa: BLE001 -- any capture failure means "no graph"
+            import warnings
+            warnings.warn(f"hipGraph capture of the rollout tick failed ({ex}); continuing without graphs")
+            th.cuda.synchronize(self.dev)
+            self.use_graph = False; self._graph = None
 
     # ------------------------------------------------------------------ rollout
     def _begin(self):

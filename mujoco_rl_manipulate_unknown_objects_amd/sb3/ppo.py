@@ -212,15 +212,22 @@ class PPO:
             return out
         if u["fwd"] is None:
             th.cuda.synchronize(self.device)
-            self.optimizer.zero_grad(set_to_none=True)      # the captured backward allocates .grad from the graph's pool
-            g1 = th.cuda.CUDAGraph()
-            with th.cuda.graph(g1):
-                u["out"] = self._loss_backward(src, u["idx"])
-            g2 = th.cuda.CUDAGraph()
-            with th.cuda.graph(g2):
-                self._apply()
-                self.optimizer.zero_grad(set_to_none=False)
-            u["fwd"], u["apply"] = g1, g2
+            try:
+                self.optimizer.zero_grad(set_to_none=True)      # the captured backward allocates .grad from the graph's pool
+                g1 = th.cuda.CUDAGraph()
+                with th.cuda.graph(g1, capture_error_mode="thread_local"):
+                    u["out"] = self._loss_backward(src, u["idx"])
+                g2 = th.cuda.CUDAGraph()
+                with th.cuda.graph(g2, capture_error_mode="thread_local"):
+                    self._apply()
+                    self.optimizer.zero_grad(set_to_none=False)
+                u["fwd"], u["apply"] = g1, g2
+            except Exception as ex:                               # noqa: BLE001 -- fall back to the eager update
+                import warnings
+                warnings.warn(f"hipGraph capture of the PPO update failed ({ex}); continuing eagerly")
+                th.cuda.synchronize(self.device)
+                self.graph_update = False; self._upd = None
+                return self._minibatch_update(src, idx)
         u["fwd"].replay()
         if self.distributed:
             self._allreduce_grads()
