@@ -46,7 +46,7 @@ class BatchEngineAdapter:
 
 class AsyncRollout:
     def __init__(self, engine, policy_fn, target, capacity, slice_len, gamma, gae_lambda, max_ticks=None, action_low=None, action_high=None,
-                 poll_every=4, use_graph=True, fused=None, pipeline=None):
+                 poll_every=8, use_graph=True, fused=None, pipeline=None):
         """policy_fn(obs_rows uint8 [C, ...]) -> (actions [C, A], values [C], log_probs [C]) under no_grad.
         target = completed transitions per rollout; capacity = ready-list rows per tick."""
         self.eng, self.policy_fn = engine, policy_fn
@@ -252,9 +252,10 @@ class AsyncRollout:
             self.eng.reset(); self._started = True
         self._begin()
         done_n = 0
+        next_poll = self.poll_every
         while self.tick < self.max_ticks:
             self._tick()
-            if self.tick % self.poll_every == 0 or self.tick == self.max_ticks:
+            if self.tick >= next_poll or self.tick == self.max_ticks:
                 if self.pipeline:
                     th.cuda.synchronize(self.dev)
                 done_n = int(self.n_completed.item())          # the only host sync of the rollout loop
@@ -262,6 +263,10 @@ class AsyncRollout:
                     break
                 if done_n >= self.target:
                     break
+                # poll again when the rollout should be about full (every tick near the end): a late poll costs a tick of
+                # transitions nobody trains on, an early one a pipeline bubble
+                rate = max(1.0, done_n / self.tick)
+                next_poll = self.tick + max(1, min(self.poll_every, int((self.target - done_n) / rate)))
         else:
             done_n = int(self.n_completed.item())
         if self.pipeline:
