@@ -193,6 +193,17 @@ def main():
         }
         if ar is not None:
             out["ticks"] = ar.total_ticks - ticks0
+            # HBM traffic and issue statistics cannot be read from inside the process: they come from the committed rocprofv3
+            # --pmc passes of this same command (profiles/r01_pmc_summary.json; separate passes, gfx950 FETCH_SIZE correction)
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["kernels"]["k_macro_step"]
+                out["roofline"]["traffic"] = pm["hbm_bytes_per_launch_fetch_doubled"]
+                out["roofline"]["traffic_source"] = ("profiles/r01_pmc_summary.json: (2 x FETCH_SIZE + WRITE_SIZE) per launch; raw "
+                                                     f"{pm['hbm_bytes_per_launch_raw']:.0f} B")
+                out["roofline"]["valu_active_frac"] = pm["active_inst_valu_frac"]
+                out["roofline"]["wait_frac"] = pm["wait_any_frac"]
+            except Exception:
+                pass
         if not a.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(a.object)
