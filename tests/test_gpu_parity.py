@@ -289,3 +289,86 @@ def test_distributed_cholesky_selftest(engine, torch):
     torch.cuda.synchronize()
     ref = np.linalg.solve(A.astype(np.float64), b.astype(np.float64)[..., None])[..., 0]
     assert np.abs(xt.cpu().numpy() - ref).max() / np.abs(ref).max() < 2e-5
+
+
+@pytest.mark.parametrize("variant", ["no_roll", "her", "short_loops", "time_limit", "rgbd_only"])
+def test_macro_step_config_variants(engine, orc, torch, variant):
+    """The flags of config/base_config.py the hot path reads: --include_roll False (5-d actions, actuator.py:30-44),
+    --her_buffer (reward + e^-|dg - ag|, robot_env.py:268-271), small --max_steps (MOVE runs out: RETURN / FAIL branches,
+    robot_env.py:112-132), small --time_horizon (TIME_LIMIT, robot_env.py:201-206), --full_observation False (4 channels,
+    sensor.py:33-54). Same checks as the default-config test."""
+    cfgs = {"no_roll": dict(include_roll=0), "her": dict(her_buffer=1), "short_loops": dict(max_steps=40),
+            "time_limit": dict(time_horizon=2), "rgbd_only": dict(full_observation=0)}
+    cfg = cfgs[variant]
+    n, obj = 32, "sugar_cube"
+    adim = 5 if variant == "no_roll" else 6
+    m = orc.Model(obj); b = engine.Batch(obj, n, **cfg)
+    b.reset()
+    envs = [orc.EnvOracle(m, **cfg) for _ in range(n)]
+    for e in envs:
+        e.reset()
+    rng = np.random.default_rng(9)
+    statuses = set()
+    for t in range(3):
+        acts = rng.uniform(-1, 1, (n, adim)).astype(np.float32)
+        out = b.step(torch.from_numpy(acts).cuda()); torch.cuda.synchronize()
+        o_np = {k: v.cpu().numpy() for k, v in out.items()}
+        for i, e in enumerate(envs):
+            if e.out.done and t > 0:
+                continue                       # the reference env would have been reset by its caller: lane no longer compared
+            o = e.step(acts[i])
+            statuses.add(int(o.status))
+            assert o.n_substeps == o_np["n_substeps"][i], (variant, t, i)
+            assert (o.done, o.status, o.episode_step, o.gripper_open) == (o_np["done"][i], o_np["status"][i], o_np["episode_step"][i], o_np["gripper_open"][i])
+            assert o_np["position_reached"][i] == o.reached_target + 2 * o.reached_initial + 4 * o.reached_fail
+            assert abs(o.reward - o_np["reward"][i]) < 2e-3
+            tolp = 1e-5 if t == 0 else 2e-4
+            assert np.abs(np.array(o.gripper_pos) - o_np["gripper_position"][i]).max() < tolp
+            assert np.abs(np.array(o.final_obj_pos) - o_np["object_position"][i]).max() < 5 * tolp
+    if variant == "short_loops":
+        assert 1 in statuses                  # some envs failed to reach either pose: Status.FAIL
+    if variant == "time_limit":
+        assert 2 in statuses                  # Status.TIME_LIMIT
+    if variant == "rgbd_only":
+        obs = b.observe()
+        assert tuple(obs.shape) == (n, 4, 64, 64)
+    b.close()
+
+
+@pytest.mark.parametrize("n", [1, 17, 63])
+def test_ragged_batch_sizes(engine, orc, torch, n):
+    """Batches that do not fill a workgroup (16 envs) or a wavefront (4 envs): every env still equals the oracle, lock-step
+    and time-sliced, and nothing is written past the batch."""
+    m = orc.Model("sand_ball"); b = engine.Batch("sand_ball", n)
+    rng = np.random.default_rng(4)
+    acts = rng.uniform(-1, 1, (n, 6)).astype(np.float32); acts[:, 0] = np.abs(acts[:, 0])
+    out = b.step(torch.from_numpy(acts).cuda()); torch.cuda.synchronize()
+    got = {k: v.cpu().numpy().copy() for k, v in out.items()}
+    for i in range(n):
+        e = orc.EnvOracle(m); e.reset(); o = e.step(acts[i])
+        assert o.n_substeps == got["n_substeps"][i]
+        assert np.abs(np.array(o.final_obj_pos) - got["object_position"][i]).max() < 5e-5
+    # the same macro step through time slices on a fresh batch
+    b2 = engine.Batch("sand_ball", n)
+    cap = max(1, n // 2)
+    lst = torch.full((cap,), -1, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    slot_act = torch.zeros(cap, 6, device="cuda")
+    given = np.zeros(n, bool); seen = np.zeros(n, bool)
+    for tick in range(5000):
+        o2 = b2.advance(slot_act, 23, lst, cnt); torch.cuda.synchronize()
+        c = int(cnt.item()); ids = lst.cpu().numpy()
+        assert c <= cap and (ids[c:] == -1).all() and ((ids[:c] >= 0) & (ids[:c] < n)).all()
+        new = np.zeros((cap, 6), np.float32)
+        for r in range(c):
+            e = int(ids[r])
+            if given[e] and not seen[e]:
+                seen[e] = True
+                for k in ("reward", "n_substeps", "object_position", "gripper_position", "done"):
+                    assert np.array_equal(o2[k][e].cpu().numpy(), got[k][e]), (k, e)
+            if not given[e]:
+                new[r] = acts[e]; given[e] = True
+        slot_act.copy_(torch.from_numpy(new))
+        if seen.all():
+            break
+    assert seen.all()
+    b.close(); b2.close()
