@@ -87,6 +87,22 @@ DEVI float norm(V3 a) { return sqrtf(dot(a, a)); }
 // and keep them live across everything else.
 DEVI void opaque(float &x) { asm volatile("" : "+v"(x)); }
 DEVI float rcp(float x) { return __builtin_amdgcn_rcpf(x); }          // v_rcp_f32, 1 ulp
+// sin and cos of a joint angle (|x| of a few pi at most: hinge ranges are +-pi, qpos never winds up). Quadrant reduction with
+// a three-term Cody-Waite pi/2 and the Cephes single-precision kernels on [-pi/4, pi/4]: within 1-2 ulp there, ~40
+// instructions instead of the ~250 of the library's full-range sincosf (Payne-Hanek path included).
+DEVI void sincos_joint(float x, float &s, float &c) {
+    float q = rintf(x * 0.63661977236758134308f);                      // nearest multiple of pi/2
+    float r = fmaf(q, -1.5703125f, x);                                   // pi/2 = 1.5703125 + 4.837512969970703125e-4 + 7.54978995489188216e-8
+    r = fmaf(q, -4.837512969970703125e-4f, r);
+    r = fmaf(q, -7.54978995489188216e-8f, r);
+    float z = r * r;
+    float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+    float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+    int n = (int)q;
+    float ss = (n & 1) ? cp : sp, cc = (n & 1) ? sp : cp;
+    s = (n & 2) ? -ss : ss;
+    c = ((n + 1) & 2) ? -cc : cc;
+}
 DEVI V3 normalized(V3 a) {
     float d = dot(a, a);
     if (d < 1e-38f) return v3(1.f, 0.f, 0.f);

@@ -174,7 +174,7 @@ DEVI void kinematics(const DevModel &m, float (&qpos)[14], Kin &k, const Ctx &cx
     else { float iq = 1.0f / qn; qpos[10] *= iq; qpos[11] *= iq; qpos[12] *= iq; qpos[13] *= iq; }
     k.pe = v3(m.ee_pos0[0] + qpos[0], m.ee_pos0[1] + qpos[1], m.ee_pos0[2] + qpos[2]);
     float sr, cr, sy, cy;
-    sincosf(qpos[3], &sr, &cr); sincosf(qpos[4], &sy, &cy);
+    sincos_joint(qpos[3], sr, cr); sincos_joint(qpos[4], sy, cy);
     // Re = Rx(roll) * Rz(yaw)
     k.Re.m[0] = cy;      k.Re.m[1] = -sy;     k.Re.m[2] = 0.f;
     k.Re.m[3] = cr * sy; k.Re.m[4] = cr * cy; k.Re.m[5] = -sr;
@@ -189,7 +189,7 @@ DEVI void kinematics(const DevModel &m, float (&qpos)[14], Kin &k, const Ctx &cx
         V3 pk = pb + mulv(Rb, ldv(m.kn_pos[s]));
         M3 Rk0 = mulm(Rb, ldm(m.kn_R[s]));
         k.pk[s] = pk; k.ak[s] = col(Rk0, 1);
-        float sq, cq; sincosf(qpos[5 + s], &sq, &cq);
+        float sq, cq; sincos_joint(qpos[5 + s], sq, cq);
         M3 Ry; Ry.m[0] = cq; Ry.m[1] = 0; Ry.m[2] = sq; Ry.m[3] = 0; Ry.m[4] = 1; Ry.m[5] = 0; Ry.m[6] = -sq; Ry.m[7] = 0; Ry.m[8] = cq;
         M3 Rk = mulm(Rk0, Ry);
         V3 pf = pk + mulv(Rk, ldv(m.fin_pos[s]));
@@ -1206,7 +1206,7 @@ DEVI void physics_advance(const DevModel &m, const Ctx &cx, LaneState &s, float 
     float ang = norm(w) * h;
     if (ang > 0.f) {
         V3 ax = normalized(w);
-        float sh, ch; sincosf(0.5f * ang, &sh, &ch);
+        float sh, ch; sincos_joint(0.5f * ang, sh, ch);
         float bw = ch, bx = ax.x * sh, by = ax.y * sh, bz = ax.z * sh;
         float aw = s.qpos[10], axx = s.qpos[11], ay = s.qpos[12], az = s.qpos[13];
         float rw = aw * bw - axx * bx - ay * by - az * bz;
