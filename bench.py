@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--lockstep", action="store_true", help="classic vector-env schedule instead of asynchronous time slices")
     ap.add_argument("--slice", type=int, default=96, help="physics.step() calls per env per tick (async schedule)")
     ap.add_argument("--capacity", type=int, default=1024, help="finished envs decided per tick (async schedule)")
+    ap.add_argument("--pipeline", action="store_true", help="decide for tick t on a side stream while tick t+1 advances (lag 2)")
     ap.add_argument("--budget-us", type=int, default=3000, help="wall-clock cap of a wavefront's slice in microseconds (async schedule; 0 = none)")
     a = ap.parse_args()
 
@@ -105,6 +106,8 @@ def main():
                 async_slice=0 if a.lockstep else a.slice, async_capacity=min(a.capacity, a.envs), async_budget_us=a.budget_us)
     batch = env.env.batch
     ar = model._async
+    if ar is not None and a.pipeline:
+        ar.enable_pipeline()
 
     def run_async(nsteps):
         """nsteps x envs completed transitions, a PPO update after every `rollout` x envs of them."""

@@ -31,13 +31,14 @@ def build_library(force=False, verbose=False):
             and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs)):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-fno-strict-aliasing", "-shared", "-fPIC", "-o", LIB_PATH,
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-fno-strict-aliasing", "-shared", "-fPIC", "-o", LIB_PATH + f".tmp{os.getpid()}",
            os.path.join(CSRC, "grip_sim.hip"), os.path.join(CSRC, "grip_render.hip"), os.path.join(CSRC, "grip_rollout.hip")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode:
         print(r.stdout, r.stderr)
     if r.returncode:
         raise GripError("hipcc failed:\n" + r.stderr[-4000:])
+    os.replace(LIB_PATH + f".tmp{os.getpid()}", LIB_PATH)      # atomic: concurrent builders never see a half-written library
     return LIB_PATH
 
 

@@ -95,14 +95,20 @@ class AsyncRollout:
         # (grip_batch_advance lag = 2); two alternating sets of list / action / staging buffers, ordered with events
         # Measured on MI355X (tools/overlap_test2.py): the physics kernel already keeps every SIMD's VALU busy, the side work
         # only fills its latency gaps, and the extra tick of lag costs more than that gains -- off by default.
-        self.pipeline = False if pipeline is None else bool(pipeline)
-        if self.pipeline:
+        self.pipeline = False
+        self._started = False
+        if pipeline:
+            self.enable_pipeline()
+        if self.low is None:
+            self.low = th.full((self.A,), -float("inf"), device=dev); self.high = th.full((self.A,), float("inf"), device=dev)
+
+    def enable_pipeline(self):
+        dev = self.dev
+        if not self.pipeline:
+            self.pipeline = True
             self.lst2 = [self.lst, th.full_like(self.lst, -1)]; self.cnt2 = [self.cnt, th.zeros_like(self.cnt)]
             self.slot_act2 = [self.slot_act, th.zeros_like(self.slot_act)]; self.obs_stage2 = [self.obs_stage, th.zeros_like(self.obs_stage)]
             self.side = th.cuda.Stream(dev); self.ev_side = [None, None]; self._side_graph = [None, None]
-        if self.low is None:
-            self.low = th.full((self.A,), -float("inf"), device=dev); self.high = th.full((self.A,), float("inf"), device=dev)
-        self._started = False
 
     # ------------------------------------------------------------------ one tick
     def _tick_body(self):
