@@ -148,6 +148,13 @@ int grip_rollout_tick(const GripRolloutTick *args, void *stream);
 int grip_rollout_gae(int n_envs, const int64_t *rec_of_env, const int64_t *prev_rec, const float *rewards, const float *dones,
                      const float *values, float gamma, float gae_lambda, float *advantages, float *returns, void *stream);
 
+/* IntrinsicReward.intrinsic_reward (reward.py:57-77, --im_reward): reward_dev[e] += sum rel_entr(hist(old), hist(new)) over
+ * grey levels (and depth with full_observation, averaged). Pair r = (old_obs_dev row old_rows_dev[r] or r when NULL, a
+ * negative row skips the pair; new_obs_dev row r), result added to reward_dev[list_dev[r]] (or [r] when list_dev is NULL);
+ * with count_dev only pairs r < *count_dev are evaluated. Observations are uint8 [rows, channels, 64, 64]. */
+int grip_intrinsic_reward(const uint8_t *old_obs_dev, const int64_t *old_rows_dev, const uint8_t *new_obs_dev, const int32_t *list_dev,
+                          const int32_t *count_dev, int n_pairs, int channels, int full_observation, float *reward_dev, void *stream);
+
 /* ---- low-level hooks (the dm_control Physics surface the reference touches; used by tests) ---- */
 /* physics.data.qpos / qvel / ctrl / qacc_warmstart, env-major float32 [N,14],[N,13],[N,7],[N,13];
  * host_or_dev = 0: host pointers (synchronous copy), 1: device pointers. NULL skips a field. */

@@ -222,3 +222,46 @@ extern "C" int grip_render_launch(const DevModel *d_model, DevConfig cfg, const 
     hipLaunchKernelGGL(k_observe, dim3(nblocks), dim3(RTHREADS), (size_t)nplanes * sizeof(float4), s, d_model, cfg, qpos, pad_grasp, pad_pher, n, list, count, obs);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// IntrinsicReward.intrinsic_reward (reward.py:57-77): sum of rel_entr between the 256-bin grey-level histograms of the
+// previous and the new observation (and, with --full_observation, of their depth channels; the two sums averaged), added to
+// the env's reward. One 256-thread block per pair: four LDS histograms by atomics, then one bin per thread and a block sum.
+// cv2.cvtColor(BGR2GRAY) on uint8 as OpenCV 4.8.1 does it (fixed point, 15 bits: (B*3735 + G*19235 + R*9798 + 2^14) >> 15,
+// channel 0 taken as B); make_pdf (utils.py:5-8) = counts / 4096 in float32.
+__global__ void __launch_bounds__(256) k_intrinsic_reward(const uint8_t *old_obs, const long long *old_rows, const uint8_t *new_obs,
+                                                          const int *list, const int *count, int channels, int full_observation, float *reward) {
+    const int r = blockIdx.x, tid = threadIdx.x;
+    if (count && r >= *count) return;
+    const long long orow = old_rows ? old_rows[r] : (long long)r;
+    if (orow < 0) return;                                   // no previous observation (first decision of this env)
+    __shared__ int h[4][256];
+    __shared__ float red[256];
+    for (int k = 0; k < 4; k++) h[k][tid] = 0;
+    __syncthreads();
+    const uint8_t *a = old_obs + (size_t)orow * channels * RPIX, *b = new_obs + (size_t)r * channels * RPIX;
+    for (int px = tid; px < RPIX; px += 256) {
+        int ga = (a[px] * 3735 + a[RPIX + px] * 19235 + a[2 * RPIX + px] * 9798 + (1 << 14)) >> 15;
+        int gb = (b[px] * 3735 + b[RPIX + px] * 19235 + b[2 * RPIX + px] * 9798 + (1 << 14)) >> 15;
+        atomicAdd(&h[0][ga], 1); atomicAdd(&h[1][gb], 1);
+        if (full_observation) { atomicAdd(&h[2][a[3 * RPIX + px]], 1); atomicAdd(&h[3][b[3 * RPIX + px]], 1); }
+    }
+    __syncthreads();
+    auto term = [](int co, int cn) {
+        float p = (float)co / (float)RPIX, q = (float)cn / (float)RPIX;
+        return (p > 0.f && q > 0.f) ? p * logf(p / q) : 0.f;           // rel_entr; inf (q == 0 < p) is set to 0 by reward.py:66
+    };
+    float t_rgb = term(h[0][tid], h[1][tid]), t_dep = full_observation ? term(h[2][tid], h[3][tid]) : 0.f;
+    red[tid] = full_observation ? 0.5f * (t_rgb + t_dep) : t_rgb;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
+    if (tid == 0) reward[list ? list[r] : r] += red[0];
+}
+
+extern "C" int grip_intrinsic_reward(const uint8_t *old_obs_dev, const int64_t *old_rows_dev, const uint8_t *new_obs_dev, const int32_t *list_dev,
+                                     const int32_t *count_dev, int n_pairs, int channels, int full_observation, float *reward_dev, void *stream) {
+    if (!old_obs_dev || !new_obs_dev || !reward_dev || n_pairs <= 0 || (channels != 4 && channels != 5)) return -1;
+    hipLaunchKernelGGL(k_intrinsic_reward, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, old_obs_dev, (const long long *)old_rows_dev, new_obs_dev,
+                       list_dev, count_dev, channels, full_observation, reward_dev);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

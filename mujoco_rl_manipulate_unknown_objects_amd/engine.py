@@ -75,7 +75,7 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_destroy", "grip_batch_set_config", "grip_batch_num_envs", "grip_batch_reset", "grip_batch_step",
            "grip_batch_observe", "grip_batch_get_state", "grip_batch_set_state", "grip_batch_get_flags",
            "grip_batch_set_flags", "grip_batch_substep", "grip_batch_debug_forward", "grip_batch_target_pose",
-           "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae"]
+           "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward"]
 
 
 def lib():
@@ -109,6 +109,7 @@ def lib():
     L.grip_selftest_cholesky.argtypes = [vp, vp, vp, C.c_int, vp]
     L.grip_batch_advance.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     L.grip_batch_observe_list.argtypes = [vp, vp, vp, C.c_int, vp, vp]
+    L.grip_intrinsic_reward.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.grip_rollout_tick.argtypes = [vp, vp]
     L.grip_rollout_gae.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
     _lib = L
@@ -233,6 +234,17 @@ class Batch:
         _chk(lib().grip_batch_observe_list(self.ptr, C.c_void_p(ready_list.data_ptr()), C.c_void_p(ready_count.data_ptr()), cap,
                                            C.c_void_p(obs.data_ptr()), self._stream()))
         return obs
+
+    def add_intrinsic_reward(self, old_obs, new_obs, reward, old_rows=None, ready_list=None, ready_count=None):
+        """reward[e] += IntrinsicReward.intrinsic_reward(old, new) (reward.py:57-77) for every pair; see grip_sim.h."""
+        t = self.torch
+        assert old_obs.dtype == t.uint8 and new_obs.dtype == t.uint8 and reward.dtype == t.float32
+        n_pairs = int(new_obs.shape[0]) if ready_list is None else int(ready_list.numel())
+        p = lambda x: None if x is None else C.c_void_p(x.data_ptr())
+        rc = lib().grip_intrinsic_reward(p(old_obs), p(old_rows), p(new_obs), p(ready_list), p(ready_count), n_pairs, int(new_obs.shape[1]),
+                                         int(self.cfg.full_observation), p(reward), self._stream())
+        if rc != 0:
+            raise GripError("grip_intrinsic_reward failed")
 
     # -- low-level hooks ------------------------------------------------------------------------
     def get_state(self):

@@ -33,6 +33,11 @@ class BatchEngineAdapter:
             self.batch.set_config(auto_reset=1)
         self.num_envs, self.action_dim, self.device = self.batch.n, self.batch.action_dim, self.batch.device
         self.obs_shape = (self.batch.obs_channels, 64, 64)
+        self.im_reward = bool(getattr(benv, "im_reward", False))
+
+    def add_intrinsic_reward(self, obs_records, old_rows, obs_rows, ready_list, ready_count, reward):
+        """--im_reward: reward of every listed env += intrinsic_reward(obs of its previous decision record, new obs)."""
+        self.batch.add_intrinsic_reward(obs_records, obs_rows, reward, old_rows=old_rows, ready_list=ready_list, ready_count=ready_count)
 
     def reset(self):
         self.batch.reset()
@@ -120,6 +125,9 @@ class AsyncRollout:
     def _decide(self, out, lst, cnt, obs_stage, slot_act, p):
         """Render the listed envs, run the policy on them, record the decisions; writes slot_act for the next start."""
         self.eng.observe_list(lst, cnt, obs_stage)
+        if getattr(self.eng, "im_reward", False):
+            env = th.where(self.ar_c < cnt, lst, self.N).long()
+            self.eng.add_intrinsic_reward(self.obs, self.rec_of_env[env], obs_stage, lst, cnt, out["reward"])
         actions, values, log_probs = self.policy_fn(obs_stage)
         rows = self.base_t + self.ar_c                                 # record ids of this tick
         self.obs.index_copy_(0, rows, obs_stage)

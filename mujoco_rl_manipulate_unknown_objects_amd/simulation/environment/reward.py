@@ -36,7 +36,34 @@ class Reward:
 
 
 class IntrinsicReward(Reward):
-    """reward.py:44-77 (KL of grey-level histograms). SURVEY.md §8(f) n2: next, not built yet."""
+    """reward.py:44-77: progress reward + KL-style novelty of the observation (grey-level and depth histograms).
+
+    Host mirror in numpy for ``compute_reward``; the rollout path adds the same quantity on the GPU
+    (csrc/grip_render.hip: k_intrinsic_reward). cv2 is not a dependency here: BGR2GRAY on uint8 is OpenCV 4.8's fixed-point
+    formula and calcHist an exact count (see oracle/grip_render.c for the provenance)."""
 
     def __init__(self, robot=None, config=None):
-        raise NotImplementedError("IntrinsicReward (--im_reward) is not built yet: SURVEY.md §8(f) n2")
+        super().__init__(robot, config)
+
+    def __call__(self, obs, new_obs, init_obj_pos, final_obj_pos, target_dir, gripper_open, controls, object_grasped):
+        return (self.agent_reward(init_obj_pos, final_obj_pos, target_dir, gripper_open, controls, object_grasped)
+                + self.intrinsic_reward(obs, new_obs))
+
+    @staticmethod
+    def _pdf(img):
+        hist = np.bincount(np.asarray(img, dtype=np.uint8).reshape(-1), minlength=256).astype(np.float32)
+        return hist / hist.sum()
+
+    @staticmethod
+    def _rel_entr_sum(p, q):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = np.where((p > 0) & (q > 0), p * np.log(p / np.where(q > 0, q, 1)), 0.0).astype(np.float32)
+        return float(t.sum())
+
+    def intrinsic_reward(self, obs, new_obs):
+        obs = np.asarray(obs); new_obs = np.asarray(new_obs)                      # CHW uint8
+        grey = lambda o: ((o[0].astype(np.int64) * 3735 + o[1].astype(np.int64) * 19235 + o[2].astype(np.int64) * 9798 + (1 << 14)) >> 15)
+        reward = self._rel_entr_sum(self._pdf(grey(obs)), self._pdf(grey(new_obs)))
+        if self.config is None or getattr(self.config, "full_observation", True):
+            reward = (reward + self._rel_entr_sum(self._pdf(obs[3]), self._pdf(new_obs[3]))) / 2
+        return float(reward)

@@ -45,8 +45,7 @@ class BatchedRobotEnv:
     def __init__(self, config, n_envs=1, device_index=0, auto_reset=False):
         self.config = config
         self.n_envs = int(n_envs)
-        if getattr(config, "im_reward", False):
-            raise NotImplementedError("--im_reward (IntrinsicReward) is not built yet: SURVEY.md §8(f) n2")
+        self.im_reward = bool(getattr(config, "im_reward", False))          # robot_env.py:39-42
         if config.width_capture != 64 or config.height_capture != 64:
             raise ValueError("the observation kernel renders 64x64 (config/base_config.py:18-19 defaults)")
         if config.direction == 0:                      # robot_env.py:30-33
@@ -65,9 +64,10 @@ class BatchedRobotEnv:
         self.device = self.batch.device
         self._sensor = RGBDSensor(config=config)
         self._actuator = Actuator(config=config)
-        self._reward_fn = Reward(config=config)
+        self._reward_fn = IntrinsicReward(config=config) if self.im_reward else Reward(config=config)
         self.setup_spaces()
         self._obs = self.batch.torch.empty((self.n_envs, self.batch.obs_channels, 64, 64), dtype=self.batch.torch.uint8, device=self.device)
+        self._obs_prev = self.batch.torch.empty_like(self._obs) if self.im_reward else None
 
     def setup_spaces(self):
         self.action_space = self._actuator.setup_action_space()
@@ -84,7 +84,12 @@ class BatchedRobotEnv:
     def step(self, actions):
         """robot_env.py:77-241 for every env. Returns (obs, reward[N], done[N] bool, info dict of tensors)."""
         out = self.batch.step(actions)
+        if self.im_reward:                                   # robot_env.py:186-197: old_obs = the observation before this step
+            self._obs, self._obs_prev = self._obs_prev, self._obs
         obs = self._obs_dict(out)
+        if self.im_reward:
+            # with auto-reset the new observation of a finished env is its reset state, as DummyVecEnv would return it
+            self.batch.add_intrinsic_reward(self._obs_prev, self._obs, out["reward"])
         return obs, out["reward"], out["done"].bool(), out
 
     def compute_reward(self, achieved_goal, desired_goal, info):

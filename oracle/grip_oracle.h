@@ -143,6 +143,8 @@ void orc_render(const OrcModel *m, const OrcData *d, int width, int height,
                 unsigned char *rgb /*h*w*3*/, float *depth /*h*w metres*/);
 void orc_transform_depth(float *depth, int n, unsigned char *out);
 void orc_observation(const OrcModel *m, const OrcEnvConfig *c, const OrcData *d, unsigned char *obs /*5*64*64*/);
+/* reward.py:57-77 (IntrinsicReward.intrinsic_reward) on two CHW uint8 observations */
+double orc_intrinsic_reward(const unsigned char *old_obs, const unsigned char *new_obs, int full_observation);
 
 unsigned long orc_sizeof_data(void);
 unsigned long orc_sizeof_env(void);

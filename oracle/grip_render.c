@@ -125,3 +125,35 @@ void orc_observation(const OrcModel *m, const OrcEnvConfig *c, const OrcData *d,
     obs[(nch - 1) * W * H + 0] = (unsigned char)orc_check_grasp(d);
     obs[(nch - 1) * W * H + 1] = (unsigned char)orc_pheromone_level(d, c->target_dir);
 }
+
+
+/* reward.py:57-77 IntrinsicReward.intrinsic_reward on two CHW uint8 observations: grey-level (and, with
+ * --full_observation, depth) histograms of 256 bins as probability vectors, sum of scipy.special.rel_entr(p_old, p_new)
+ * with infinities zeroed, the two sums averaged. cv2 is not installed here: cv2.cvtColor(BGR2GRAY) on uint8 is restated
+ * from OpenCV 4.8.1 (setup.py pins opencv-python==4.8.1.78; modules/imgproc/src/color_rgb.simd.hpp, RGB2Gray<uchar>:
+ * (B*3735 + G*19235 + R*9798 + (1 << 14)) >> 15 with channel 0 taken as B), cv2.calcHist as exact counts in float32,
+ * make_pdf (utils.py:5-8) as hist / hist.sum() in float32 -- parity of this row is UNPINNED for lack of cv2. */
+static double hist_rel_entr(const int *ho, const int *hn, int npx) {
+    double s = 0;
+    for (int i = 0; i < 256; i++) {
+        float p = (float)ho[i] / (float)npx, q = (float)hn[i] / (float)npx;
+        if (p > 0.f && q > 0.f) s += (double)(float)(p * logf(p / q));      /* rel_entr on float32 arrays */
+        /* p == 0: 0;  p > 0 and q == 0: inf, set to 0 by reward.py:66 */
+    }
+    return s;
+}
+double orc_intrinsic_reward(const unsigned char *old_obs, const unsigned char *new_obs, int full_observation) {
+    enum { NPX = 64 * 64 };
+    int ho[256] = {0}, hn[256] = {0};
+    for (int px = 0; px < NPX; px++) {
+        ho[(old_obs[px] * 3735 + old_obs[NPX + px] * 19235 + old_obs[2 * NPX + px] * 9798 + (1 << 14)) >> 15]++;
+        hn[(new_obs[px] * 3735 + new_obs[NPX + px] * 19235 + new_obs[2 * NPX + px] * 9798 + (1 << 14)) >> 15]++;
+    }
+    double r = hist_rel_entr(ho, hn, NPX);
+    if (full_observation) {
+        int dO[256] = {0}, dN[256] = {0};
+        for (int px = 0; px < NPX; px++) { dO[old_obs[3 * NPX + px]]++; dN[new_obs[3 * NPX + px]]++; }
+        r = (r + hist_rel_entr(dO, dN, NPX)) / 2;
+    }
+    return r;
+}

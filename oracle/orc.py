@@ -206,6 +206,15 @@ class EnvOracle:
         return self.e.d
 
 
+def intrinsic_reward(old_obs, new_obs, full_observation=True):
+    """reward.py:57-77 on two CHW uint8 observations (oracle restatement, see grip_render.c)."""
+    L = lib()
+    L.orc_intrinsic_reward.restype = C.c_double
+    L.orc_intrinsic_reward.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    a = np.ascontiguousarray(old_obs, dtype=np.uint8); b = np.ascontiguousarray(new_obs, dtype=np.uint8)
+    return float(L.orc_intrinsic_reward(a.ctypes.data, b.ctypes.data, int(bool(full_observation))))
+
+
 class BatchOracle:
     """n independent oracle envs stepped with OpenMP (cpu_baseline / property tests)."""
 

@@ -149,3 +149,50 @@ def test_fused_recorder_and_graph_replay_match_tensor_op_bookkeeping(engine, tor
                 assert torch.equal(a[k][c], b[k][c]), k
             for k in ("advantages", "returns"):
                 assert torch.allclose(a[k][c], b[k][c], rtol=1e-5, atol=1e-6), k
+
+
+def test_intrinsic_reward_lockstep_and_async(engine, torch):
+    """--im_reward (reward.py:44-77): the GPU adds intrinsic_reward(old_obs, new_obs) to the progress reward. Checked against
+    the C oracle on the rendered observations, for the lock-step env and for the decision records of the async rollout."""
+    from oracle import orc
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3.async_rollout import AsyncRollout, BatchEngineAdapter
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import BatchedRobotEnv, default_config
+    n = 24
+    rng = np.random.default_rng(5)
+    plain = BatchedRobotEnv(default_config(sim_env="/xmls/sugar_cube_env.xml"), n_envs=n, device_index=0)
+    novel = BatchedRobotEnv(default_config(sim_env="/xmls/sugar_cube_env.xml", im_reward=True), n_envs=n, device_index=0)
+    o0 = plain.reset()["observation"].clone(); novel.reset()
+    for t in range(2):
+        a = torch.from_numpy(rng.uniform(-1, 1, (n, 6)).astype(np.float32)).cuda()
+        o1, r_plain, _, _ = plain.step(a); o1 = o1["observation"].clone(); r_plain = r_plain.clone()
+        _, r_novel, _, _ = novel.step(a)
+        torch.cuda.synchronize()
+        for i in range(n):
+            want = float(r_plain[i]) + orc.intrinsic_reward(o0[i].cpu().numpy(), o1[i].cpu().numpy(), True)
+            assert abs(float(r_novel[i]) - want) < 1e-4 * max(1.0, abs(want)), (t, i, float(r_novel[i]), want)
+        o0 = o1
+    plain.close(); novel.close()
+
+    def policy(rows):
+        x = rows.float().mean(dim=(1, 2, 3))
+        k = torch.arange(1, 7, device=rows.device).float()
+        act = torch.cos(x[:, None] * k[None, :] * 0.37); act[:, 0] = act[:, 0].abs()
+        return act, x / 255.0, -x / 100.0
+
+    def run(im):
+        env = BatchedRobotEnv(default_config(sim_env="/xmls/sugar_cube_env.xml", im_reward=im), n_envs=32, device_index=0, auto_reset=True)
+        ro = AsyncRollout(BatchEngineAdapter(env), policy, target=64, capacity=16, slice_len=24, gamma=0.99, gae_lambda=0.95,
+                          action_low=[-1] * 6, action_high=[1] * 6, poll_every=2)
+        ro.collect(); torch.cuda.synchronize()
+        keep = ro.N + ro.tick * ro.C
+        res = {k: getattr(ro, k)[:keep].clone().cpu() for k in ("rewards", "completed", "is_rec", "next_rec", "obs")}
+        env.close()
+        return res
+    base, nov = run(False), run(True)
+    assert torch.equal(base["completed"], nov["completed"]) and torch.equal(base["obs"], nov["obs"])
+    idx = (base["completed"] & base["is_rec"]).nonzero().flatten().tolist()
+    assert len(idx) >= 64
+    for r in idx[:40]:
+        nr = int(base["next_rec"][r])
+        want = float(base["rewards"][r]) + orc.intrinsic_reward(base["obs"][r].numpy(), base["obs"][nr].numpy(), True)
+        assert abs(float(nov["rewards"][r]) - want) < 1e-4 * max(1.0, abs(want)), (r, float(nov["rewards"][r]), want)

@@ -149,3 +149,33 @@ def test_mesh_inertia_of_a_cube():
     tris = v[ConvexHull(v).simplices]
     V, com, I = compiler.mesh_inertia_legacy(tris)
     assert V == pytest.approx(1.0) and np.allclose(com, 0.5) and np.allclose(I, np.eye(3) / 6, atol=1e-12)
+
+
+def test_intrinsic_reward_restatements_agree(orc):
+    """reward.py:57-77 three ways: the C oracle, the numpy host mirror, and scipy.special.rel_entr on exact histograms
+    (the reference's own formula with cv2.calcHist / cvtColor replaced by their definitions)."""
+    from scipy.special import rel_entr
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.reward import IntrinsicReward
+    rng = np.random.default_rng(0)
+    for full in (True, False):
+        nch = 5 if full else 4
+        a = rng.integers(0, 256, (nch, 64, 64), dtype=np.uint8)
+        b = a.copy(); b[:, 10:40, 5:50] = rng.integers(0, 64, (nch, 30, 45), dtype=np.uint8)     # some bins empty in one image only
+
+        def pdf(img):
+            h = np.bincount(img.reshape(-1), minlength=256).astype(np.float32)
+            return h / h.sum()
+
+        def grey(o):
+            return ((o[0].astype(np.int64) * 3735 + o[1].astype(np.int64) * 19235 + o[2].astype(np.int64) * 9798 + (1 << 14)) >> 15).astype(np.uint8)
+        kl = rel_entr(pdf(grey(a)), pdf(grey(b))); kl[np.isinf(kl)] = 0.0
+        ref = float(sum(kl))
+        if full:
+            kd = rel_entr(pdf(a[3]), pdf(b[3])); kd[np.isinf(kd)] = 0.0
+            ref = (ref + float(sum(kd))) / 2
+
+        class Cfg:
+            full_observation = full
+        assert abs(orc.intrinsic_reward(a, b, full) - ref) < 1e-5 * max(1.0, abs(ref))
+        assert abs(IntrinsicReward(config=Cfg())(a, b, np.zeros(3), np.zeros(3), np.array([1, 0]), True, np.zeros(2), 0) - ref) < 1e-5 * max(1.0, abs(ref))
+        assert orc.intrinsic_reward(a, a, full) == 0.0
