@@ -1,0 +1,376 @@
+"""SAC with Stable-Baselines3's call shape -- the algorithm the reference actually trains (train_agent.py:58-92):
+
+    SAC("MultiInputPolicy", env, policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN,
+        share_features_extractor=True, net_arch=[256, 256]), buffer_size=..., batch_size=..., verbose=1,
+        tensorboard_log=..., [replay_buffer_class=HerReplayBuffer, replay_buffer_kwargs=dict(n_sampled_goal=4,
+        goal_selection_strategy='future', online_sampling=True, max_episode_length=...), learning_starts=...])
+    model.learn(total_timesteps, callback=[...]);  model.predict(obs, deterministic=True);  model.save / SAC.load
+
+SB3 defaults are kept (lr 3e-4, tau 0.005, gamma 0.99, train_freq 1, gradient_steps 1, ent_coef 'auto' with target
+entropy -|A|, state-dependent log_std clipped to [-20, 2], tanh-squashed Gaussian, twin Q networks with ReLU MLPs, the
+shared features extractor trained by the critic loss only). MI355X layout: the replay buffer lives in HBM as uint8
+observations (500 k x 20 KB = 10 GB, next observations stored once per step for all envs), sampling, HER relabelling and
+the update are device work; with world_size > 1 the gradients of a step are flattened and all-reduced once, like PPO's.
+Works with the batched GPU env (GpuVecEnv: tensors in / out) and with the one-env numpy DummyVecEnv.
+"""
+import io
+import math
+import os
+import time
+import zipfile
+
+import numpy as np
+import torch as th
+import torch.distributed as dist
+from torch import nn
+
+from .callbacks import CallbackList
+
+LOG_STD_MIN, LOG_STD_MAX = -20.0, 2.0
+
+
+def _to_t(x, device, dtype=None):
+    t = x.to(device) if isinstance(x, th.Tensor) else th.as_tensor(np.asarray(x), device=device)
+    return t if dtype is None else t.to(dtype)
+
+
+def _mlp(in_dim, arch, out_dim=None):
+    layers, d = [], in_dim
+    for h in arch:
+        layers += [nn.Linear(d, h), nn.ReLU()]
+        d = h
+    if out_dim is not None:
+        layers.append(nn.Linear(d, out_dim))
+    return nn.Sequential(*layers), d
+
+
+class SACPolicy(nn.Module):
+    """Actor + twin critics + target critics over one features extractor class (MultiInputPolicy of the reference call)."""
+
+    def __init__(self, observation_space, action_space, features_extractor_class=None, features_extractor_kwargs=None,
+                 share_features_extractor=True, net_arch=(256, 256), n_critics=2, normalize_images=True):
+        super().__init__()
+        if features_extractor_class is None:
+            from ..models.feature_extractor import AugmentedNatureCNN as features_extractor_class
+        kw = features_extractor_kwargs or {}
+        self.normalize_images = normalize_images
+        self.share_features_extractor = share_features_extractor
+        self.action_dim = int(np.prod(action_space.shape))
+        mk = lambda: features_extractor_class(observation_space, **kw)
+        self.actor_features = mk()
+        self.critic_features = self.actor_features if share_features_extractor else mk()
+        self.critic_target_features = mk()
+        fd = self.actor_features.features_dim
+        arch = list(net_arch["pi"] if isinstance(net_arch, dict) else net_arch)
+        qarch = list(net_arch["qf"] if isinstance(net_arch, dict) else net_arch)
+        self.latent_pi, pd = _mlp(fd, arch)
+        self.mu = nn.Linear(pd, self.action_dim); self.log_std = nn.Linear(pd, self.action_dim)
+        self.q_nets = nn.ModuleList([_mlp(fd + self.action_dim, qarch, 1)[0] for _ in range(n_critics)])
+        self.q_targets = nn.ModuleList([_mlp(fd + self.action_dim, qarch, 1)[0] for _ in range(n_critics)])
+        self.critic_target_features.load_state_dict(self.critic_features.state_dict())
+        self.q_targets.load_state_dict(self.q_nets.state_dict())
+        for p in list(self.critic_target_features.parameters()) + list(self.q_targets.parameters()):
+            p.requires_grad_(False)
+
+    def _prep(self, obs):
+        o = obs["observation"]
+        if o.dtype == th.uint8:
+            o = o.float()
+            if self.normalize_images:
+                o = o / 255.0
+        return {"observation": o}
+
+    # ---- actor
+    def actor_parameters(self):
+        ps = list(self.latent_pi.parameters()) + list(self.mu.parameters()) + list(self.log_std.parameters())
+        if not self.share_features_extractor:
+            ps += list(self.actor_features.parameters())
+        return ps
+
+    def critic_parameters(self):
+        return list(self.critic_features.parameters()) + list(self.q_nets.parameters())
+
+    def action_log_prob(self, obs, deterministic=False, detach_features=None):
+        f = self.actor_features(self._prep(obs))
+        if self.share_features_extractor if detach_features is None else detach_features:
+            f = f.detach()                                    # SB3: with a shared extractor only the critic loss trains it
+        h = self.latent_pi(f)
+        mean = self.mu(h); log_std = self.log_std(h).clamp(LOG_STD_MIN, LOG_STD_MAX)
+        if deterministic:
+            return th.tanh(mean), None
+        std = log_std.exp()
+        g = mean + std * th.randn_like(mean)
+        a = th.tanh(g)
+        logp = (-0.5 * ((g - mean) / std) ** 2 - log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+        logp = logp - th.log(1.0 - a * a + 1e-6).sum(-1)      # tanh change of variables (SB3's SquashedDiagGaussian epsilon)
+        return a, logp
+
+    # ---- critics
+    def q_values(self, obs, actions, target=False):
+        fe, nets = (self.critic_target_features, self.q_targets) if target else (self.critic_features, self.q_nets)
+        x = th.cat([fe(self._prep(obs)), actions], dim=1)
+        return [q(x).squeeze(-1) for q in nets]
+
+    @th.no_grad()
+    def polyak(self, tau):
+        for src, dst in ((self.critic_features, self.critic_target_features), (self.q_nets, self.q_targets)):
+            for p, pt in zip(src.parameters(), dst.parameters()):
+                pt.mul_(1.0 - tau).add_(p.detach(), alpha=tau)
+            for b, bt in zip(src.buffers(), dst.buffers()):
+                bt.copy_(b)
+
+
+class ReplayBuffer:
+    """Transitions of N parallel envs in device memory: uint8 observations [T, N, ...], next observation stored beside it
+    (the auto-reset env returns the reset observation after a done, so obs[t + 1] is not the successor there)."""
+
+    def __init__(self, buffer_size, observation_space, action_space, device, n_envs=1, **_):
+        self.n_envs, self.device = n_envs, device
+        self.T = max(1, buffer_size // n_envs)
+        shp = tuple(observation_space["observation"].shape)
+        A = int(np.prod(action_space.shape))
+        z = lambda *s, dt=th.float32: th.zeros((self.T, n_envs) + s, dtype=dt, device=device)
+        self.obs, self.next_obs = z(*shp, dt=th.uint8), z(*shp, dt=th.uint8)
+        self.actions, self.rewards, self.dones = z(A), z(), z()
+        self.achieved, self.desired, self.next_achieved = z(2), z(2), z(2)
+        self.pos, self.full = 0, False
+
+    def size(self):
+        return (self.T if self.full else self.pos) * self.n_envs
+
+    def add(self, obs, next_obs, action, reward, done, infos=None):
+        t = self.pos
+        self.obs[t].copy_(obs["observation"]); self.next_obs[t].copy_(next_obs["observation"])
+        self.actions[t].copy_(action); self.rewards[t].copy_(reward); self.dones[t].copy_(done)
+        if "achieved_goal" in obs:
+            self.achieved[t].copy_(obs["achieved_goal"]); self.desired[t].copy_(obs["desired_goal"])
+            self.next_achieved[t].copy_(next_obs["achieved_goal"])
+        self.pos += 1
+        if self.pos == self.T:
+            self.pos, self.full = 0, True
+
+    def _indices(self, batch_size, generator=None):
+        hi = self.T if self.full else self.pos
+        t = th.randint(0, hi, (batch_size,), device=self.device, generator=generator)
+        e = th.randint(0, self.n_envs, (batch_size,), device=self.device, generator=generator)
+        return t, e
+
+    def sample(self, batch_size, generator=None):
+        t, e = self._indices(batch_size, generator)
+        return dict(obs={"observation": self.obs[t, e]}, next_obs={"observation": self.next_obs[t, e]}, actions=self.actions[t, e],
+                    rewards=self.rewards[t, e], dones=self.dones[t, e])
+
+
+class HerReplayBuffer(ReplayBuffer):
+    """Hindsight relabelling with SB3's HerReplayBuffer arguments (train_agent.py:63-69): for n_sampled_goal out of
+    n_sampled_goal + 1 sampled transitions the desired goal is replaced by a goal achieved later in the same episode
+    ('future') and the reward recomputed. For this env only the `her_buffer` term e^-|dg - ag| of the reward depends on the
+    goal (robot_env.py:268-271), so the relabelled reward is the stored one minus the old term plus the new one."""
+
+    def __init__(self, buffer_size, observation_space, action_space, device, n_envs=1, n_sampled_goal=4,
+                 goal_selection_strategy="future", online_sampling=True, max_episode_length=None, **_):
+        super().__init__(buffer_size, observation_space, action_space, device, n_envs)
+        if str(goal_selection_strategy).lower().split(".")[-1] != "future":
+            raise NotImplementedError("only goal_selection_strategy='future' (the reference's choice) is built")
+        self.her_ratio = 1.0 - 1.0 / (n_sampled_goal + 1)
+        self.max_episode_length = max_episode_length
+        self.ep_end = th.full((self.T, n_envs), -1, dtype=th.int64, device=device)    # buffer row of the episode's last step, -1 = open
+        self._ep_start = th.zeros(n_envs, dtype=th.int64, device=device)              # row where each env's running episode began
+
+    def add(self, obs, next_obs, action, reward, done, infos=None):
+        t = self.pos
+        self.ep_end[t] = -1
+        super().add(obs, next_obs, action, reward, done, infos)
+        fin = done > 0
+        if bool(fin.any()):
+            # close the finished episodes: every row of the episode learns where it ends (rows may wrap around the ring)
+            for e in fin.nonzero().flatten().tolist():
+                s = int(self._ep_start[e]); rows = th.arange(s, s + ((t - s) % self.T) + 1, device=self.device) % self.T
+                self.ep_end[rows, e] = t
+                self._ep_start[e] = (t + 1) % self.T
+        # rows of old episodes are overwritten oldest first, so the [t, end] range of a surviving row stays intact
+
+    @staticmethod
+    def her_term(desired, achieved):
+        return th.exp(-th.linalg.norm(desired - achieved, dim=-1))
+
+    def sample(self, batch_size, generator=None):
+        t, e = self._indices(batch_size, generator)
+        rewards = self.rewards[t, e].clone()
+        end = self.ep_end[t, e]
+        relabel = (th.rand(batch_size, device=self.device, generator=generator) < self.her_ratio) & (end >= 0)
+        # 'future': a uniformly drawn step between this one and the end of its episode (ring distance)
+        span = (end - t) % self.T
+        off = (th.rand(batch_size, device=self.device, generator=generator) * (span + 1).float()).long().clamp(max=self.T - 1)
+        ft = (t + th.minimum(off, span)) % self.T
+        new_goal = self.next_achieved[ft, e]
+        old = self.her_term(self.desired[t, e], self.next_achieved[t, e]); new = self.her_term(new_goal, self.next_achieved[t, e])
+        rewards = th.where(relabel, rewards - old + new, rewards)
+        desired = th.where(relabel[:, None], new_goal, self.desired[t, e])
+        return dict(obs={"observation": self.obs[t, e], "achieved_goal": self.achieved[t, e], "desired_goal": desired},
+                    next_obs={"observation": self.next_obs[t, e], "achieved_goal": self.next_achieved[t, e], "desired_goal": desired},
+                    actions=self.actions[t, e], rewards=rewards, dones=self.dones[t, e], relabelled=relabel)
+
+
+class SAC:
+    def __init__(self, policy, env, learning_rate=3e-4, buffer_size=1_000_000, learning_starts=100, batch_size=256, tau=0.005, gamma=0.99,
+                 train_freq=1, gradient_steps=1, replay_buffer_class=None, replay_buffer_kwargs=None, ent_coef="auto", target_entropy="auto",
+                 policy_kwargs=None, verbose=0, tensorboard_log=None, device=None, seed=None):
+        self.env = env
+        self.n_envs = getattr(env, "num_envs", 1)
+        self.device = th.device(device) if device is not None else getattr(env, "device", th.device("cuda" if th.cuda.is_available() else "cpu"))
+        self.gamma, self.tau, self.batch_size = gamma, tau, batch_size
+        self.learning_starts, self.train_freq, self.gradient_steps = learning_starts, train_freq, gradient_steps
+        self.verbose, self.tensorboard_log = verbose, tensorboard_log
+        self.policy_kwargs = dict(policy_kwargs or {})
+        if seed is not None:
+            th.manual_seed(seed)
+        policy_class = SACPolicy if isinstance(policy, str) else policy
+        self.policy = policy_class(env.observation_space, env.action_space, **self.policy_kwargs).to(self.device)
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if self.distributed:
+            for p in self.policy.parameters():
+                dist.broadcast(p.data, src=0)
+        self.actor_opt = th.optim.Adam(self.policy.actor_parameters(), lr=learning_rate)
+        self.critic_opt = th.optim.Adam(self.policy.critic_parameters(), lr=learning_rate)
+        A = self.policy.action_dim
+        self.target_entropy = -float(A) if target_entropy == "auto" else float(target_entropy)
+        self.auto_ent = isinstance(ent_coef, str) and ent_coef.startswith("auto")
+        init = float(ent_coef.split("_")[1]) if self.auto_ent and "_" in ent_coef else 1.0
+        self.log_ent_coef = th.log(th.ones(1, device=self.device) * (init if self.auto_ent else float(ent_coef))).requires_grad_(self.auto_ent)
+        self.ent_opt = th.optim.Adam([self.log_ent_coef], lr=learning_rate) if self.auto_ent else None
+        rb = replay_buffer_class or ReplayBuffer
+        self.replay_buffer = rb(buffer_size, env.observation_space, env.action_space, self.device, n_envs=self.n_envs, **(replay_buffer_kwargs or {}))
+        self.num_timesteps, self._n_updates = 0, 0
+        self._last_obs = None
+        self.logger = {}
+        self._tensor_env = hasattr(env, "device")
+
+    # ------------------------------------------------------------------ helpers
+    def _obs_t(self, obs):
+        return {k: _to_t(v, self.device) for k, v in obs.items() if k in ("observation", "achieved_goal", "desired_goal")}
+
+    def _scale(self, a):            # policy space [-1, 1] -> env action space
+        low = th.as_tensor(self.env.action_space.low, device=self.device); high = th.as_tensor(self.env.action_space.high, device=self.device)
+        return low + 0.5 * (a + 1.0) * (high - low)
+
+    def _allreduce(self, params):
+        grads = [p.grad for p in params if p.grad is not None]
+        if not grads:
+            return
+        flat = th.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM); flat /= dist.get_world_size()
+        off = 0
+        for g in grads:
+            n = g.numel(); g.copy_(flat[off:off + n].view_as(g)); off += n
+
+    # ------------------------------------------------------------------ one gradient step (SB3 SAC.train)
+    def train(self, gradient_steps=1, batch_size=None):
+        bs = batch_size or self.batch_size
+        pol = self.policy
+        for _ in range(gradient_steps):
+            b = self.replay_buffer.sample(bs)
+            obs, nobs = b["obs"], b["next_obs"]
+            a_pi, logp = pol.action_log_prob(obs)
+            ent_coef = self.log_ent_coef.exp().detach()
+            if self.auto_ent:
+                ent_loss = -(self.log_ent_coef * (logp + self.target_entropy).detach()).mean()
+                self.ent_opt.zero_grad(); ent_loss.backward(); self.ent_opt.step()
+            with th.no_grad():
+                na, nlogp = pol.action_log_prob(nobs)
+                q_next = th.min(th.stack(pol.q_values(nobs, na, target=True)), dim=0).values - ent_coef * nlogp
+                target_q = b["rewards"] + (1.0 - b["dones"]) * self.gamma * q_next
+            qs = pol.q_values(obs, b["actions"])
+            critic_loss = 0.5 * sum(nn.functional.mse_loss(q, target_q) for q in qs)
+            self.critic_opt.zero_grad(); critic_loss.backward()
+            if self.distributed:
+                self._allreduce(pol.critic_parameters())
+            self.critic_opt.step()
+            # actor: the critics (and, shared, their extractor) are not updated by this loss
+            with th.no_grad():
+                f = pol.critic_features(pol._prep(obs))
+            q_pi = th.min(th.stack([q(th.cat([f, a_pi], dim=1)).squeeze(-1) for q in pol.q_nets]), dim=0).values
+            actor_loss = (ent_coef * logp - q_pi).mean()
+            self.actor_opt.zero_grad(); actor_loss.backward()
+            if self.distributed:
+                self._allreduce(pol.actor_parameters())
+            self.actor_opt.step()
+            pol.polyak(self.tau)
+            self._n_updates += 1
+        self.logger = {"actor_loss": actor_loss.detach(), "critic_loss": critic_loss.detach(), "ent_coef": ent_coef, "n_updates": self._n_updates}
+        return self.logger
+
+    # ------------------------------------------------------------------ SB3 surface
+    def learn(self, total_timesteps, callback=None, reset_num_timesteps=True, log_interval=4):
+        if isinstance(callback, (list, tuple)):
+            callback = CallbackList(list(callback))
+        if callback is not None:
+            callback.init_callback(self); callback.on_training_start(locals(), globals())
+        if reset_num_timesteps:
+            self.num_timesteps = 0
+        if self._last_obs is None:
+            self._last_obs = self._obs_t(self.env.reset())
+        t0, step = time.time(), 0
+        while self.num_timesteps < total_timesteps:
+            if self.num_timesteps < self.learning_starts:
+                a = th.rand(self.n_envs, self.policy.action_dim, device=self.device) * 2 - 1      # warm-up: uniform actions
+            else:
+                with th.no_grad():
+                    a, _ = self.policy.action_log_prob(self._last_obs)
+            env_a = self._scale(a)
+            new_obs, rew, done, infos = self.env.step(env_a if self._tensor_env else env_a.cpu().numpy())
+            new_obs = self._obs_t(new_obs)
+            self.replay_buffer.add(self._last_obs, new_obs, a, _to_t(rew, self.device, th.float32), _to_t(done, self.device, th.float32), infos)
+            self._last_obs = new_obs
+            self.num_timesteps += self.n_envs; step += 1
+            if callback is not None and not callback.on_step():
+                break
+            if self.num_timesteps >= self.learning_starts and step % self.train_freq == 0 and self.replay_buffer.size() >= self.batch_size:
+                self.train(self.gradient_steps)
+            if self.verbose and step % (log_interval * 100) == 0:
+                print(f"[sac] timesteps {self.num_timesteps} fps {self.num_timesteps / max(1e-9, time.time() - t0):.0f} updates {self._n_updates}")
+        if callback is not None:
+            callback.on_training_end()
+        return self
+
+    def predict(self, observation, state=None, episode_start=None, deterministic=False):
+        obs = observation["observation"]
+        single = (obs.ndim == 3)
+        o = _to_t(obs, self.device)
+        if single:
+            o = o.unsqueeze(0)
+        with th.no_grad():
+            a, _ = self.policy.action_log_prob({"observation": o}, deterministic=deterministic)
+        a = self._scale(a).cpu().numpy()
+        return (a[0] if single else a), state
+
+    def save(self, path):
+        if not path.endswith(".zip"):
+            path = path + ".zip"
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        with zipfile.ZipFile(path, "w") as z:
+            items = (("policy.pth", self.policy.state_dict()), ("actor.optimizer.pth", self.actor_opt.state_dict()),
+                     ("critic.optimizer.pth", self.critic_opt.state_dict()),
+                     ("data.pth", dict(num_timesteps=self.num_timesteps, log_ent_coef=self.log_ent_coef.detach().cpu(), gamma=self.gamma, tau=self.tau,
+                                       batch_size=self.batch_size, n_updates=self._n_updates)))
+            for name, obj in items:
+                b = io.BytesIO(); th.save(obj, b); z.writestr(name, b.getvalue())
+
+    @classmethod
+    def load(cls, path, env=None, custom_objects=None, device=None, **kwargs):
+        if not path.endswith(".zip"):
+            path = path + ".zip"
+        kw = dict(kwargs)
+        if custom_objects and "policy_kwargs" in custom_objects:
+            kw["policy_kwargs"] = custom_objects["policy_kwargs"]
+        kw.setdefault("buffer_size", 1)
+        with zipfile.ZipFile(path) as z:
+            meta = th.load(io.BytesIO(z.read("data.pth")), weights_only=False)
+            model = cls("MultiInputPolicy", env, device=device, gamma=meta["gamma"], tau=meta["tau"], batch_size=meta["batch_size"], **kw)
+            model.policy.load_state_dict(th.load(io.BytesIO(z.read("policy.pth")), map_location=model.device))
+            model.actor_opt.load_state_dict(th.load(io.BytesIO(z.read("actor.optimizer.pth")), map_location=model.device))
+            model.critic_opt.load_state_dict(th.load(io.BytesIO(z.read("critic.optimizer.pth")), map_location=model.device))
+            with th.no_grad():
+                model.log_ent_coef.copy_(meta["log_ent_coef"].to(model.device))
+            model.num_timesteps, model._n_updates = meta["num_timesteps"], meta["n_updates"]
+        return model
