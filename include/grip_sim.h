@@ -155,6 +155,11 @@ int grip_rollout_gae(int n_envs, const int64_t *rec_of_env, const int64_t *prev_
 int grip_intrinsic_reward(const uint8_t *old_obs_dev, const int64_t *old_rows_dev, const uint8_t *new_obs_dev, const int32_t *list_dev,
                           const int32_t *count_dev, int n_pairs, int channels, int full_observation, float *reward_dev, void *stream);
 
+/* Policy input in one pass (models/feature_extractor.py:41-49): uint8 [n, channels, 64, 64] -> image channels as float32 / 255
+ * in NHWC ([n, 64, 64, channels - 1], i.e. a channels-last [n, channels - 1, 64, 64] tensor) + the two sensor-pad scalars
+ * of the last channel / 255 ([n, 2]). */
+int grip_obs_preprocess(const uint8_t *obs_dev, int n, int channels, float *img_nhwc_dev, float *other_dev, void *stream);
+
 /* ---- low-level hooks (the dm_control Physics surface the reference touches; used by tests) ---- */
 /* physics.data.qpos / qvel / ctrl / qacc_warmstart, env-major float32 [N,14],[N,13],[N,7],[N,13];
  * host_or_dev = 0: host pointers (synchronous copy), 1: device pointers. NULL skips a field. */

@@ -265,3 +265,31 @@ extern "C" int grip_intrinsic_reward(const uint8_t *old_obs_dev, const int64_t *
                        list_dev, count_dev, channels, full_observation, reward_dev);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Policy input in one pass: uint8 CHW observation -> float32 / 255 image channels in NHWC (the layout MIOpen's implicit-GEMM
+// convolutions want: one 16-byte store per pixel for the 4 image channels) + the two sensor-pad scalars / 255
+// (models/feature_extractor.py:41-49 reads them from the last channel). Replaces cast, scale and layout copy (three
+// full passes over 4x the bytes).
+__global__ void __launch_bounds__(256) k_obs_preprocess(const uint8_t *obs, int n, int channels, float *img, float *other) {
+    const int nimg = channels - 1;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;              // pixel index over n * 4096
+    if (i >= (size_t)n * RPIX) return;
+    const size_t b = i / RPIX; const int px = (int)(i % RPIX);
+    const uint8_t *o = obs + b * channels * RPIX;
+    const float s = 1.0f / 255.0f;
+    if (nimg == 4) {
+        float4 v = make_float4(o[px] * s, o[RPIX + px] * s, o[2 * RPIX + px] * s, o[3 * RPIX + px] * s);
+        reinterpret_cast<float4 *>(img)[i] = v;
+    } else {
+        for (int c = 0; c < nimg; c++) img[i * nimg + c] = o[c * RPIX + px] * s;
+    }
+    if (px < 2) other[b * 2 + px] = o[(size_t)nimg * RPIX + px] * s;
+}
+
+extern "C" int grip_obs_preprocess(const uint8_t *obs_dev, int n, int channels, float *img_nhwc_dev, float *other_dev, void *stream) {
+    if (!obs_dev || !img_nhwc_dev || !other_dev || n <= 0 || (channels != 4 && channels != 5)) return -1;
+    size_t total = (size_t)n * RPIX;
+    hipLaunchKernelGGL(k_obs_preprocess, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs_dev, n, channels, img_nhwc_dev, other_dev);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -75,7 +75,7 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_destroy", "grip_batch_set_config", "grip_batch_num_envs", "grip_batch_reset", "grip_batch_step",
            "grip_batch_observe", "grip_batch_get_state", "grip_batch_set_state", "grip_batch_get_flags",
            "grip_batch_set_flags", "grip_batch_substep", "grip_batch_debug_forward", "grip_batch_target_pose",
-           "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward"]
+           "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward", "grip_obs_preprocess"]
 
 
 def lib():
@@ -110,6 +110,7 @@ def lib():
     L.grip_batch_advance.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     L.grip_batch_observe_list.argtypes = [vp, vp, vp, C.c_int, vp, vp]
     L.grip_intrinsic_reward.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.grip_obs_preprocess.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.grip_rollout_tick.argtypes = [vp, vp]
     L.grip_rollout_gae.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
     _lib = L
@@ -127,6 +128,20 @@ def asset_path(obj):
     if not os.path.exists(p):
         raise GripError(f"no compiled model for '{obj}' under {ASSETS}")
     return p
+
+
+def obs_preprocess(obs):
+    """uint8 CUDA observation [n, C, 64, 64] -> (float32 / 255 image channels as a channels-last [n, C - 1, 64, 64] tensor,
+    the two sensor-pad scalars / 255 as [n, 2]) in one kernel (grip_obs_preprocess)."""
+    import torch
+    assert obs.is_cuda and obs.dtype == torch.uint8 and obs.is_contiguous() and obs.shape[2:] == (64, 64)
+    n, ch = int(obs.shape[0]), int(obs.shape[1])
+    img = torch.empty((n, ch - 1, 64, 64), dtype=torch.float32, device=obs.device, memory_format=torch.channels_last)
+    other = torch.empty((n, 2), dtype=torch.float32, device=obs.device)
+    stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
+    if lib().grip_obs_preprocess(C.c_void_p(obs.data_ptr()), n, ch, C.c_void_p(img.data_ptr()), C.c_void_p(other.data_ptr()), stream) != 0:
+        raise GripError("grip_obs_preprocess failed")
+    return img, other
 
 
 class Model:

@@ -13,6 +13,8 @@ from ..sb3.torch_layers import BaseFeaturesExtractor
 
 
 class AugmentedNatureCNN(BaseFeaturesExtractor):
+    accepts_raw_uint8 = True        # forward() normalises raw uint8 CUDA observations itself (one fused kernel)
+
     def __init__(self, observation_space, features_dim: int = 514):
         super().__init__(observation_space, features_dim)
         shape = observation_space["observation"].shape
@@ -28,6 +30,12 @@ class AugmentedNatureCNN(BaseFeaturesExtractor):
 
     def forward(self, observations, num_direct_features: int = 2) -> th.Tensor:
         obs = observations["observation"]
+        if obs.dtype == th.uint8 and obs.is_cuda and num_direct_features == 2 and obs.shape[2:] == (64, 64):
+            # raw uint8 observation on the GPU (the policies pass it through un-normalised): cast, / 255 and the NHWC layout
+            # in one kernel instead of three passes (csrc/grip_render.hip: k_obs_preprocess)
+            from ..engine import obs_preprocess
+            x, other = obs_preprocess(obs.contiguous())
+            return th.cat((self.linear(self.cnn(x)), other), dim=1)
         other = obs[:, -1, 0, :num_direct_features]        # grasp code, pheromone level (already / 255)
         # the channel slice is a strided view: MIOpen only has a naive kernel for non-packed inputs (157 ms vs 2 ms
         # per 4096-sample fwd+bwd on MI355X), so pack it first

@@ -35,6 +35,7 @@ class ActorCriticPolicy(nn.Module):
         kw = features_extractor_kwargs or {}
         self.features_extractor = features_extractor_class(observation_space, **kw)
         self.vf_features_extractor = None if share_features_extractor else features_extractor_class(observation_space, **kw)
+        self._fused_preprocess = bool(getattr(self.features_extractor, "accepts_raw_uint8", False))
         fd = self.features_extractor.features_dim
         if isinstance(net_arch, dict):
             pi_arch, vf_arch = net_arch.get("pi", []), net_arch.get("vf", [])
@@ -62,6 +63,8 @@ class ActorCriticPolicy(nn.Module):
     def _prep(self, obs):
         o = obs["observation"]
         if o.dtype == th.uint8:
+            if o.is_cuda and self.normalize_images and getattr(self, "_fused_preprocess", False):
+                return {"observation": o}        # AugmentedNatureCNN normalises and lays out raw uint8 in one kernel
             o = o.float()
             if self.normalize_images:
                 o = o / 255.0

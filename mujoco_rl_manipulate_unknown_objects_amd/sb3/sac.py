@@ -60,6 +60,7 @@ class SACPolicy(nn.Module):
         self.actor_features = mk()
         self.critic_features = self.actor_features if share_features_extractor else mk()
         self.critic_target_features = mk()
+        self._fused_preprocess = bool(getattr(self.actor_features, "accepts_raw_uint8", False))
         fd = self.actor_features.features_dim
         arch = list(net_arch["pi"] if isinstance(net_arch, dict) else net_arch)
         qarch = list(net_arch["qf"] if isinstance(net_arch, dict) else net_arch)
@@ -75,6 +76,8 @@ class SACPolicy(nn.Module):
     def _prep(self, obs):
         o = obs["observation"]
         if o.dtype == th.uint8:
+            if o.is_cuda and self.normalize_images and getattr(self, "_fused_preprocess", False):
+                return {"observation": o}        # AugmentedNatureCNN normalises and lays out raw uint8 in one kernel
             o = o.float()
             if self.normalize_images:
                 o = o / 255.0
