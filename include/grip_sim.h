@@ -118,8 +118,11 @@ int grip_batch_observe(GripBatch *b, uint8_t *obs_dev, void *stream);
  * arithmetic and the results are identical to grip_batch_step either way -- only the schedule differs. */
 int grip_batch_advance(GripBatch *b, const float *slot_actions_dev, int slice, int budget_us, int lag, int capacity, const GripStepOut *out,
                        int32_t *ready_list_dev, int32_t *ready_count_dev, void *stream);
-/* get_observation for the listed envs only: row r of obs_dev (uint8 [capacity,5,64,64]) = env list_dev[r], r < *count_dev. */
-int grip_batch_observe_list(GripBatch *b, const int32_t *list_dev, const int32_t *count_dev, int capacity, uint8_t *obs_dev, void *stream);
+/* get_observation for the listed envs only: row r of obs_dev (uint8 [capacity,5,64,64]) = env list_dev[r], r < *count_dev.
+ * records_dev != NULL: the same bytes are also written to row record_row_dev[0] + r of records_dev (a trainer's observation
+ * store; the row base is read on the device so that a captured hipGraph can advance it). */
+int grip_batch_observe_list(GripBatch *b, const int32_t *list_dev, const int32_t *count_dev, int capacity, uint8_t *obs_dev,
+                            uint8_t *records_dev, const int64_t *record_row_dev, void *stream);
 
 /* ---- rollout recorder: the trainer-side bookkeeping of asynchronous stepping, fused (csrc/grip_rollout.hip) ---------
  * Decision records live in caller-owned device arrays of n_records + 1 rows (row n_records is a dump row); per-env arrays

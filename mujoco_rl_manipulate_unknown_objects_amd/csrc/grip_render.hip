@@ -57,8 +57,9 @@ __device__ static uint8_t to_u8(float v) { v *= 255.f; v = fminf(fmaxf(v, 0.f), 
 #define TPX (TW * TW)
 
 __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevConfig cfg, const float *qpos, const int *pad_grasp, const int *pad_pher,
-                                                      int n, const int *list, const int *count, uint8_t *obs) {
-    // list != NULL: block b renders env list[b] into row b of obs, for b < *count (grip_batch_observe_list)
+                                                      int n, const int *list, const int *count, uint8_t *obs, uint8_t *obs2, const long long *row2) {
+    // list != NULL: block b renders env list[b] into row b of obs, for b < *count (grip_batch_observe_list); obs2 != NULL: the
+    // same bytes also go to row row2[0] + b of obs2 (the trainer's record buffer), saving a 20 KB-per-env copy kernel
     if (list && (int)blockIdx.x >= *count) return;
     const DevModel &m = *mp;
     __shared__ Frames fr;
@@ -102,6 +103,7 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
     __syncthreads();
     const int nch = cfg.full_observation ? 5 : 4;
     uint8_t *o = obs + (size_t)blockIdx.x * nch * RPIX;
+    uint8_t *o2 = obs2 ? obs2 + (size_t)(row2[0] + blockIdx.x) * nch * RPIX : nullptr;
     const float tanh_ = tanf(0.5f * m.cam_fovy * 0.017453292519943295f);
     // tile of this thread: a wave covers 8 x 8 tiles = a square block of (8 TW)^2 pixels
     constexpr int WPR = RW / (8 * TW);          // waves per row of wave blocks
@@ -191,6 +193,7 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
             c0 = b0 * shade; c1 = b1 * shade; c2 = b2 * shade;
         }
         o[px] = to_u8(c0); o[RPIX + px] = to_u8(c1); o[2 * RPIX + px] = to_u8(c2);
+        if (o2) { o2[px] = to_u8(c0); o2[RPIX + px] = to_u8(c1); o2[2 * RPIX + px] = to_u8(c2); o2[(nch - 1) * RPIX + px] = 0; }
         lmin = fminf(lmin, best[q]);
         o[(nch - 1) * RPIX + px] = 0;
     }
@@ -211,15 +214,19 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
             float v = (best[q] - dmin) / scale; v = fminf(fmaxf(v, 0.f), 1.f);
             float p = 255.0f * v;
             o[3 * RPIX + px] = (p != p) ? (uint8_t)0 : (uint8_t)p;
+            if (o2) o2[3 * RPIX + px] = (p != p) ? (uint8_t)0 : (uint8_t)p;
         }
     }
     __syncthreads();
-    if (tid == 0) { o[(nch - 1) * RPIX] = (uint8_t)pad_grasp[e]; o[(nch - 1) * RPIX + 1] = (uint8_t)pad_pher[e]; }
+    if (tid == 0) {
+        o[(nch - 1) * RPIX] = (uint8_t)pad_grasp[e]; o[(nch - 1) * RPIX + 1] = (uint8_t)pad_pher[e];
+        if (o2) { o2[(nch - 1) * RPIX] = (uint8_t)pad_grasp[e]; o2[(nch - 1) * RPIX + 1] = (uint8_t)pad_pher[e]; }
+    }
 }
 
 extern "C" int grip_render_launch(const DevModel *d_model, DevConfig cfg, const float *qpos, const int *pad_grasp, const int *pad_pher, int n,
-                                  const int *list, const int *count, int nblocks, int nplanes, uint8_t *obs, hipStream_t s) {
-    hipLaunchKernelGGL(k_observe, dim3(nblocks), dim3(RTHREADS), (size_t)nplanes * sizeof(float4), s, d_model, cfg, qpos, pad_grasp, pad_pher, n, list, count, obs);
+                                  const int *list, const int *count, int nblocks, int nplanes, uint8_t *obs, uint8_t *obs2, const long long *row2, hipStream_t s) {
+    hipLaunchKernelGGL(k_observe, dim3(nblocks), dim3(RTHREADS), (size_t)nplanes * sizeof(float4), s, d_model, cfg, qpos, pad_grasp, pad_pher, n, list, count, obs, obs2, row2);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

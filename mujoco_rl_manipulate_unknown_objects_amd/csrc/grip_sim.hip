@@ -1008,18 +1008,19 @@ extern "C" int grip_batch_target_pose(GripBatch *b, const float *actions_dev, fl
 
 // observation kernels live in grip_render.hip
 extern "C" int grip_render_launch(const DevModel *d_model, DevConfig cfg, const float *qpos, const int *pad_grasp, const int *pad_pher, int n,
-                                  const int *list, const int *count, int nblocks, int nplanes, uint8_t *obs, hipStream_t s);
+                                  const int *list, const int *count, int nblocks, int nplanes, uint8_t *obs, uint8_t *obs2, const long long *row2, hipStream_t s);
 extern "C" int grip_batch_observe(GripBatch *b, uint8_t *obs_dev, void *stream) {
     if (!b || !obs_dev) return fail("grip_batch_observe: null argument");
     HIPCHK(hipSetDevice(b->device));
-    if (grip_render_launch(b->d_model, b->cfg, b->qpos, b->pad_grasp, b->pad_pher, b->n, nullptr, nullptr, b->n, b->nplanes, obs_dev, (hipStream_t)stream))
+    if (grip_render_launch(b->d_model, b->cfg, b->qpos, b->pad_grasp, b->pad_pher, b->n, nullptr, nullptr, b->n, b->nplanes, obs_dev, nullptr, nullptr, (hipStream_t)stream))
         return fail("render launch failed");
     return 0;
 }
-extern "C" int grip_batch_observe_list(GripBatch *b, const int32_t *list_dev, const int32_t *count_dev, int capacity, uint8_t *obs_dev, void *stream) {
-    if (!b || !obs_dev || !list_dev || !count_dev || capacity <= 0) return fail("grip_batch_observe_list: bad argument");
+extern "C" int grip_batch_observe_list(GripBatch *b, const int32_t *list_dev, const int32_t *count_dev, int capacity, uint8_t *obs_dev,
+                                       uint8_t *records_dev, const int64_t *record_row_dev, void *stream) {
+    if (!b || !obs_dev || !list_dev || !count_dev || capacity <= 0 || (records_dev && !record_row_dev)) return fail("grip_batch_observe_list: bad argument");
     HIPCHK(hipSetDevice(b->device));
-    if (grip_render_launch(b->d_model, b->cfg, b->qpos, b->pad_grasp, b->pad_pher, b->n, list_dev, count_dev, capacity, b->nplanes, obs_dev, (hipStream_t)stream))
+    if (grip_render_launch(b->d_model, b->cfg, b->qpos, b->pad_grasp, b->pad_pher, b->n, list_dev, count_dev, capacity, b->nplanes, obs_dev, records_dev, (const long long *)record_row_dev, (hipStream_t)stream))
         return fail("render launch failed");
     return 0;
 }

@@ -108,7 +108,7 @@ def lib():
     L.grip_batch_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.grip_selftest_cholesky.argtypes = [vp, vp, vp, C.c_int, vp]
     L.grip_batch_advance.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
-    L.grip_batch_observe_list.argtypes = [vp, vp, vp, C.c_int, vp, vp]
+    L.grip_batch_observe_list.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
     L.grip_intrinsic_reward.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.grip_obs_preprocess.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.grip_rollout_tick.argtypes = [vp, vp]
@@ -242,12 +242,16 @@ class Batch:
                                       C.c_void_p(ready_list.data_ptr()), C.c_void_p(ready_count.data_ptr()), self._stream()))
         return self.out
 
-    def observe_list(self, ready_list, ready_count, obs):
+    def observe_list(self, ready_list, ready_count, obs, records=None, record_row=None):
+        """Render the listed envs into obs rows 0..count-1; with `records` (uint8 [R, C, 64, 64]) and `record_row` (int64 [1])
+        also into records[record_row + r]."""
         cap = int(ready_list.numel())
         if obs.dtype != self.torch.uint8 or not obs.is_contiguous() or obs.shape[0] < cap:
             raise GripError("obs must be contiguous uint8 [capacity, C, 64, 64]")
+        rp = None if records is None else C.c_void_p(records.data_ptr())
+        rr = None if record_row is None else C.c_void_p(record_row.data_ptr())
         _chk(lib().grip_batch_observe_list(self.ptr, C.c_void_p(ready_list.data_ptr()), C.c_void_p(ready_count.data_ptr()), cap,
-                                           C.c_void_p(obs.data_ptr()), self._stream()))
+                                           C.c_void_p(obs.data_ptr()), rp, rr, self._stream()))
         return obs
 
     def add_intrinsic_reward(self, old_obs, new_obs, reward, old_rows=None, ready_list=None, ready_count=None):

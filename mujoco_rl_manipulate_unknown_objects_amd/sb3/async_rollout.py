@@ -45,8 +45,8 @@ class BatchEngineAdapter:
     def advance(self, slot_actions, slice_len, ready_list, ready_count, lag=1):
         return self.batch.advance(slot_actions, slice_len, ready_list, ready_count, self.budget_us, lag)
 
-    def observe_list(self, ready_list, ready_count, obs_rows):
-        self.batch.observe_list(ready_list, ready_count, obs_rows)
+    def observe_list(self, ready_list, ready_count, obs_rows, records=None, record_row=None):
+        self.batch.observe_list(ready_list, ready_count, obs_rows, records, record_row)
 
 
 class AsyncRollout:
@@ -124,13 +124,18 @@ class AsyncRollout:
 
     def _decide(self, out, lst, cnt, obs_stage, slot_act, p):
         """Render the listed envs, run the policy on them, record the decisions; writes slot_act for the next start."""
-        self.eng.observe_list(lst, cnt, obs_stage)
+        dual = getattr(self.eng, "batch", None) is not None       # the GPU engine writes the record rows itself
+        if dual:
+            self.eng.observe_list(lst, cnt, obs_stage, self.obs, self.base_t)
+        else:
+            self.eng.observe_list(lst, cnt, obs_stage)
         if getattr(self.eng, "im_reward", False):
             env = th.where(self.ar_c < cnt, lst, self.N).long()
             self.eng.add_intrinsic_reward(self.obs, self.rec_of_env[env], obs_stage, lst, cnt, out["reward"])
         actions, values, log_probs = self.policy_fn(obs_stage)
         rows = self.base_t + self.ar_c                                 # record ids of this tick
-        self.obs.index_copy_(0, rows, obs_stage)
+        if not dual:
+            self.obs.index_copy_(0, rows, obs_stage)
         if self.fused:
             self._fused_tick(out, lst, cnt, slot_act, p, actions, values, log_probs)
         else:
