@@ -145,6 +145,10 @@ typedef struct {
     int64_t *n_completed, *substeps_total;        /* [1] counters */
     float *ep_ret, *ep_len;                       /* [n_envs + 1] running episode return / length */
     float *ep_ret_sum, *ep_len_sum, *ep_count;    /* [1] finished-episode statistics */
+    /* optional fused Gaussian head: when noise != NULL, `actions` holds the policy MEAN [capacity, action_dim], noise is
+     * N(0,1) of the same shape and log_std [action_dim] the policy's state-independent log standard deviation; the kernel
+     * forms action = mean + exp(log_std) * noise and its log-probability itself (`log_probs` is then ignored) */
+    const float *noise, *log_std;
 } GripRolloutTick;
 int grip_rollout_tick(const GripRolloutTick *args, void *stream);
 /* GAE over every env's record chain, backwards from its open record (whose value bootstraps) along prev_rec. */

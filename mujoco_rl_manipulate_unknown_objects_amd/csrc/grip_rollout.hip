@@ -29,13 +29,19 @@ __global__ void k_rollout_tick(GripRolloutTick a) {
         if (dn > 0.f) { atomicAdd(a.ep_ret_sum, er); atomicAdd(a.ep_len_sum, el); atomicAdd(a.ep_count, 1.f); er = 0.f; el = 0.f; }
         a.ep_ret[env] = er; a.ep_len[env] = el;
     }
-    // open the new one
+    // open the new one (with the fused Gaussian head: sample = mean + std * noise, log N(sample | mean, std))
+    float logp = a.noise ? 0.f : a.log_probs[r];
     for (int i = 0; i < a.action_dim; i++) {
         float v = a.actions[(size_t)r * a.action_dim + i];
+        if (a.noise) {
+            const float z = a.noise[(size_t)r * a.action_dim + i], ls = a.log_std[i];
+            v = fmaf(expf(ls), z, v);
+            logp += -0.5f * z * z - ls - 0.91893853320467274178f;          // 0.5 log(2 pi)
+        }
         a.actions_buf[(size_t)row * a.action_dim + i] = v;
         a.slot_actions[(size_t)r * a.action_dim + i] = fminf(fmaxf(v, a.low[i]), a.high[i]);
     }
-    a.log_probs_buf[row] = a.log_probs[r]; a.values_buf[row] = a.values[r];
+    a.log_probs_buf[row] = logp; a.values_buf[row] = a.values[r];
     a.is_rec[row] = valid ? 1 : 0; a.completed[row] = 0; a.next_rec[row] = -1;
     a.prev_rec[row] = had ? prev : -1;
     a.rec_env[row] = valid ? env : -1;

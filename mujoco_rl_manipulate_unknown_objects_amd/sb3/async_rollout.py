@@ -51,10 +51,11 @@ class BatchEngineAdapter:
 
 class AsyncRollout:
     def __init__(self, engine, policy_fn, target, capacity, slice_len, gamma, gae_lambda, max_ticks=None, action_low=None, action_high=None,
-                 poll_every=8, use_graph=True, fused=None, pipeline=None):
+                 poll_every=8, use_graph=True, fused=None, pipeline=None, policy_parts_fn=None):
         """policy_fn(obs_rows uint8 [C, ...]) -> (actions [C, A], values [C], log_probs [C]) under no_grad.
         target = completed transitions per rollout; capacity = ready-list rows per tick."""
         self.eng, self.policy_fn = engine, policy_fn
+        self.policy_parts_fn = policy_parts_fn          # obs rows -> (mean, log_std, values): sampling fused into the recorder kernel
         self.N, self.C, self.S, self.A = engine.num_envs, int(capacity), int(slice_len), engine.action_dim
         self.target, self.gamma, self.lam = int(target), gamma, gae_lambda
         dev = self.dev = engine.device
@@ -132,12 +133,17 @@ class AsyncRollout:
         if getattr(self.eng, "im_reward", False):
             env = th.where(self.ar_c < cnt, lst, self.N).long()
             self.eng.add_intrinsic_reward(self.obs, self.rec_of_env[env], obs_stage, lst, cnt, out["reward"])
-        actions, values, log_probs = self.policy_fn(obs_stage)
+        noise = log_std = None
+        if self.fused and self.policy_parts_fn is not None:
+            actions, log_std, values = self.policy_parts_fn(obs_stage)                 # `actions` is the mean here
+            noise = th.randn_like(actions); log_probs = values
+        else:
+            actions, values, log_probs = self.policy_fn(obs_stage)
         rows = self.base_t + self.ar_c                                 # record ids of this tick
         if not dual:
             self.obs.index_copy_(0, rows, obs_stage)
         if self.fused:
-            self._fused_tick(out, lst, cnt, slot_act, p, actions, values, log_probs)
+            self._fused_tick(out, lst, cnt, slot_act, p, actions, values, log_probs, noise, log_std)
         else:
             self._torch_tick(out, lst, cnt, slot_act, rows, actions, values, log_probs)
         self.base_t += self.C
@@ -195,7 +201,7 @@ class AsyncRollout:
         self.rec_env.index_copy_(0, rows, th.where(valid, env, th.full_like(env, -1)))
         self.rec_of_env[env] = rows
 
-    def _fused_tick(self, out, lst, cnt, slot_act, p, actions, values, log_probs):
+    def _fused_tick(self, out, lst, cnt, slot_act, p, actions, values, log_probs, noise=None, log_std=None):
         from .. import engine as E
         import ctypes as C
         actions = actions.float().contiguous(); values = values.float().contiguous(); log_probs = log_probs.float().contiguous()
@@ -214,6 +220,11 @@ class AsyncRollout:
             p = slot
         a = self._targs[p]
         a.actions, a.values, a.log_probs = actions.data_ptr(), values.data_ptr(), log_probs.data_ptr()
+        if noise is not None:
+            noise = noise.float().contiguous(); log_std = log_std.float().contiguous()
+            a.noise, a.log_std = noise.data_ptr(), log_std.data_ptr()
+        else:
+            a.noise, a.log_std = None, None
         stream = C.c_void_p(th.cuda.current_stream(self.dev).cuda_stream)
         if E.lib().grip_rollout_tick(C.byref(a), stream) != 0:
             raise E.GripError("grip_rollout_tick failed")

@@ -88,6 +88,11 @@ class ActorCriticPolicy(nn.Module):
         actions = mean if deterministic else mean + th.randn_like(mean) * th.exp(log_std)
         return actions, values, self._log_prob(mean, log_std, actions)
 
+    def forward_parts(self, obs):
+        """(mean, log_std, values): the Gaussian head left un-sampled, for callers that sample and score in a fused kernel."""
+        lp, lv = self._latents(obs)
+        return self.action_net(lp).float(), self.log_std.float(), self.value_net(lv).float().squeeze(-1)
+
     def evaluate_actions(self, obs, actions):
         lp, lv = self._latents(obs)
         mean = self.action_net(lp).float(); values = self.value_net(lv).float().squeeze(-1)

@@ -103,7 +103,11 @@ class PPO:
             def policy_fn(obs_rows):
                 with th.no_grad(), self._ac():
                     return self.policy({"observation": obs_rows})
-            self._async = AsyncRollout(eng, policy_fn, target=n_steps * self.n_envs, capacity=min(cap, self.n_envs), slice_len=async_slice,
+            def policy_parts_fn(obs_rows):
+                with th.no_grad(), self._ac():
+                    return self.policy.forward_parts({"observation": obs_rows})
+            parts = policy_parts_fn if hasattr(self.policy, "forward_parts") else None
+            self._async = AsyncRollout(eng, policy_fn, policy_parts_fn=parts, target=n_steps * self.n_envs, capacity=min(cap, self.n_envs), slice_len=async_slice,
                                        gamma=gamma, gae_lambda=gae_lambda, action_low=env.action_space.low, action_high=env.action_space.high)
             self.rollout_buffer = None
         self.num_timesteps = 0
