@@ -577,7 +577,11 @@ struct Contact {
 // refinement (XenoCollide) on the margin-inflated hulls as a per-lane phase machine (0/1 seed the portal, 2 discover,
 // 3 refine, 4 penetrate) around the ONE support evaluation. The contacts found by the 16 lanes are compacted through
 // the env's LDS staging area (deterministic order: round, then lane); lane c then owns contact c.
-DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault) {
+// `sep` is this lane's memory between calls: the direction along which its hull pair was last proven apart (Minkowski
+// support <= 0). Bodies move little in 2 ms, so the next call first tests that one direction (phase 6, one support pair) and
+// usually is done -- the exact separating-axis argument MPR itself ends with, so no result changes; only when it fails does
+// the portal search start from scratch.
+DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, V3 &sep) {
     const float EPS2 = 1e-12f, EPSD = 1e-10f;
     const float infl = 0.5f * m.margin;
     const Tables &T = cx.T;
@@ -605,10 +609,16 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault) {
             V3 c1 = p1 + mulv(R1, v3(t1[0], t1[1], t1[2]));
             V3 dc = c2 - c1;
             float bound = t1[3] + t2[3] + m.margin;
+#ifdef GRIP_EXPERIMENT_NO_MPR
+            phase = -1;
+#else
             phase = dot(dc, dc) > bound * bound ? -1 : 0;
+#endif
+            if (phase < 0) sep = v3(0, 0, 0);
             s0.v1 = c1; s0.v2 = c2; s0.v = c1 - c2;
             if (dot(s0.v, s0.v) < EPS2) s0.v.x += 1e-5f;
             dir = normalized(-s0.v);
+            if (phase == 0 && dot(sep, sep) > 0.5f) { dir = sep; phase = 6; }
         }
         // results of this lane's item: up to 4 contacts
         V3 rp0 = v3(0, 0, 0), rp1 = rp0, rp2 = rp0, rp3 = rp0; float rd0 = 0.f, rd1 = 0.f, rd2 = 0.f, rd3 = 0.f;
@@ -642,9 +652,12 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault) {
                     s.v = s.v1 - s.v2;
                     cnt++;
                     bool hit = false; float depth = 0.f; V3 nrm = v3(0, 0, 0), pos = v3(0, 0, 0);
-                    if (phase == 0) {
+                    if (phase == 6) {
+                        if (dot(s.v, dir) <= 0.f) phase = -1;                 // still apart along the remembered direction
+                        else { sep = v3(0, 0, 0); dir = normalized(-s0.v); phase = 0; cnt = 0; }
+                    } else if (phase == 0) {
                         sup_set(s1, s);
-                        if (dot(s1.v, dir) <= 0.f) phase = -1;
+                        if (dot(s1.v, dir) <= 0.f) { phase = -1; sep = dir; }
                         else {
                             V3 d = cross(s0.v, s1.v);
                             if (dot(d, d) < EPS2 * 1e-2f) {      // origin on the ray v0 -> v1
@@ -654,7 +667,7 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault) {
                         }
                     } else if (phase == 1) {
                         sup_set(s2, s);
-                        if (dot(s2.v, dir) <= 0.f) phase = -1;
+                        if (dot(s2.v, dir) <= 0.f) { phase = -1; sep = dir; }
                         else {
                             dir = normalized(cross(s1.v - s0.v, s2.v - s0.v));
                             if (dot(dir, s0.v) > 0.f) { Sup t; sup_set(t, s1); sup_set(s1, s2); sup_set(s2, t); dir = -dir; }
@@ -662,7 +675,8 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault) {
                         }
                     } else if (phase == 2) {
                         sup_set(s3, s);
-                        if (dot(s3.v, dir) <= 0.f || cnt > 4 * MPR_MAXIT) phase = -1;
+                        if (dot(s3.v, dir) <= 0.f) { phase = -1; sep = dir; }
+                        else if (cnt > 4 * MPR_MAXIT) phase = -1;
                         else if (dot(cross(s1.v, s3.v), s0.v) < -EPSD) { sup_set(s2, s3); dir = normalized(cross(s1.v - s0.v, s2.v - s0.v)); }
                         else if (dot(cross(s3.v, s2.v), s0.v) < -EPSD) { sup_set(s1, s3); dir = normalized(cross(s1.v - s0.v, s2.v - s0.v)); }
                         else {
@@ -670,7 +684,8 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault) {
                             phase = dot(dir, s1.v) >= -EPSD ? 4 : 3; cnt = 0;
                         }
                     } else if (phase == 3) {
-                        if (dot(s.v, dir) < 0.f || reach_tol(s1, s2, s3, s, dir) || cnt > MPR_MAXIT) phase = -1;
+                        if (dot(s.v, dir) < 0.f) { phase = -1; sep = dir; }
+                        else if (reach_tol(s1, s2, s3, s, dir) || cnt > MPR_MAXIT) phase = -1;
                         else {
                             expand_portal(s0, s1, s2, s3, s);
                             dir = portal_dir(s1, s2, s3);
@@ -1102,11 +1117,11 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
 struct LaneState { float qpos[14], qvel[13], ctrl[7], warm[13]; };
 
 // position stage (mj_step1's share): kinematics + collision of the current state; lane c then owns contact c.
-DEVI void forward_pos(const DevModel &m, const Ctx &cx, LaneState &s, Kin &k, Contact &con, int &ncon, int &fault, Stamps &st) {
+DEVI void forward_pos(const DevModel &m, const Ctx &cx, LaneState &s, Kin &k, Contact &con, int &ncon, int &fault, Stamps &st, V3 &sep) {
     kinematics(m, s.qpos, k, cx, true);
     wave_sync();
     STAMP(st, 0);
-    ncon = collide(m, cx, con, fault);
+    ncon = collide(m, cx, con, fault, sep);
     STAMP(st, 1);
 }
 
