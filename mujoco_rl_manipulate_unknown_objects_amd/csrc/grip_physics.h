@@ -36,7 +36,7 @@
 #define U_STRIDE 16                    // 13 entries + weight, padded to 64 B so a slot is four ds_read_b128
 #define ENV_FLOATS (EF_U + G_MAXC * 6 * U_STRIDE)
 // per-workgroup geom table (floats per geom): centre3, rbound, fs, ft, invweight, group, hull_vadr
-#define GT_STRIDE 9
+#define GT_STRIDE 10
 #define GT_FLOATS (GN_GEOM * GT_STRIDE)
 #define LDS_ENV_BASE(hull_words) (((hull_words) + GT_FLOATS + 3) & ~3)      // float offset of the first env region (16-byte aligned)
 
@@ -138,7 +138,8 @@ DEVI Ctx stage_tables(const DevModel &m, float *lds) {
         else if (f == 5) v = m.geom_friction[g][1];
         else if (f == 6) v = m.geom_invweight[g];
         else if (f == 7) v = __int_as_float(m.geom_group[g]);
-        else v = __int_as_float(g >= 1 ? m.hull_vadr[g - 1] : 0);
+        else if (f == 8) v = __int_as_float(g >= 1 ? m.hull_vadr[g - 1] : 0);
+        else v = __int_as_float(g >= 1 ? m.hull_vnum[g - 1] : 0);
         gt[i] = v;
     }
     __syncthreads();
@@ -509,6 +510,24 @@ DEVI int support_vertex(const Tables &T, int h, int base, V3 dl, V3 &vout) {
     return cur;
 }
 
+// Support vertex of a hull by all 16 lanes of the env: lane j scans vertices j, j + 16, ... of the LDS vertex table, then a
+// 16-lane arg-max (ties: lowest index, as an exhaustive scan would give). ~n/16 LDS reads per lane with no dependent chain,
+// against ~3 dependent neighbour hops per step of the per-lane hill climb it replaces in collide().
+template <int CTRL> DEVI int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, false); }
+DEVI int coop_support(const Tables &T, int base, int n, V3 dl, int sub) {
+    float bv = -3.0e38f; int bi = 0x7fffffff;
+    const float4 *v4 = reinterpret_cast<const float4 *>(T.v) + base;
+    for (int i = sub; i < n; i += KL) {
+        const float4 v = v4[i];
+        const float s = fmaf(v.x, dl.x, fmaf(v.y, dl.y, v.z * dl.z));
+        if (s > bv) { bv = s; bi = i; }
+    }
+#define COOP_STEP(R) { float ov = dpp_f<DPP_ROW_ROR(R)>(bv); int oi = dpp_i<DPP_ROW_ROR(R)>(bi); bool t = ov > bv || (ov == bv && oi < bi); bv = t ? ov : bv; bi = t ? oi : bi; }
+    COOP_STEP(8) COOP_STEP(4) COOP_STEP(2) COOP_STEP(1)
+#undef COOP_STEP
+    return bi;
+}
+
 struct Sup { V3 v, v1, v2; };
 // field-by-field copy: a whole-struct assignment becomes llvm.memcpy between stack slots, which SROA then leaves in scratch
 // memory -- and the MPR loop pays a scratch round trip per portal update
@@ -624,10 +643,44 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, V3 
         V3 rp0 = v3(0, 0, 0), rp1 = rp0, rp2 = rp0, rp3 = rp0; float rd0 = 0.f, rd1 = 0.f, rd2 = 0.f, rd3 = 0.f;
         V3 rn = v3(0, 0, 1); int rc = 0;
         int cnt = 0;
+        // Two ways to evaluate supports. While any item of the env is in its opening moves (floor test, remembered direction,
+        // portal seeding: a few trips, most pairs end there) every lane hill-climbs for its own item, in parallel. Once only
+        // portal refinements are left (10-30 more trips for a touching pair, usually one or two pairs per env) the 16 lanes
+        // serve them one at a time: the lowest-numbered refining lane (the "owner") publishes its two local directions and
+        // hull ranges, everybody scans a sixteenth of the vertices, the owner takes the arg-max and advances its portal.
+        const int nv2 = __float_as_int(t2[9]), nv1 = __float_as_int(t1[9]);
         while (__any(phase >= 0)) {
-            if (phase >= 0) {
+            const unsigned actm = group_bits(__ballot(phase >= 0), cx.lane);
+            const unsigned early = group_bits(__ballot(phase >= 0 && phase != 3 && phase != 4), cx.lane);
+            const bool coop = actm != 0u && early == 0u;
+            const int owner = coop ? (__ffs((int)actm) - 1) : -1;
+            const bool mine = coop ? owner == cx.sub : phase >= 0;
+            V3 vl = v3(0, 0, 0), vl1 = v3(0, 0, 0); int vi2 = 0;
+            if (__any(coop)) {
+                float *qs = cx.envl + EF_M;                 // query slot: the mass-matrix area is not in use yet
+                if (coop && mine) {
+                    V3 d2 = multv(R2, -dir), d1 = multv(R1, dir);
+                    qs[0] = d2.x; qs[1] = d2.y; qs[2] = d2.z; qs[3] = __int_as_float(base2); qs[4] = __int_as_float(nv2);
+                    qs[5] = d1.x; qs[6] = d1.y; qs[7] = d1.z; qs[8] = __int_as_float(base1); qs[9] = __int_as_float(nv1);
+                }
+                wave_sync();
+                if (coop) {
+                    V3 d2 = v3(qs[0], qs[1], qs[2]), d1 = v3(qs[5], qs[6], qs[7]);
+                    const int qb2 = __float_as_int(qs[3]), qn2 = __float_as_int(qs[4]), qb1 = __float_as_int(qs[8]), qn1 = __float_as_int(qs[9]);
+                    int b2i = coop_support(T, qb2, qn2, d2, cx.sub), b1i = coop_support(T, qb1, qn1, d1, cx.sub);
+                    if (mine) {
+                        const float *vp2 = T.v + 4 * (base2 + b2i), *vp1 = T.v + 4 * (base1 + b1i);
+                        vl = v3(vp2[0], vp2[1], vp2[2]); vl1 = v3(vp1[0], vp1[1], vp1[2]); vi2 = b2i;
+                    }
+                }
+                wave_sync();
+            }
+            if (!coop && mine) {
+                vi2 = support_vertex(T, g2 - 1, base2, multv(R2, plane ? dir : -dir), vl);
+                if (!plane) support_vertex(T, g1 - 1, base1, multv(R1, dir), vl1);
+            }
+            if (mine) {
                 Sup s;
-                V3 vl; int vi2 = support_vertex(T, g2 - 1, base2, multv(R2, plane ? dir : -dir), vl);
                 s.v2 = p2 + mulv(R2, vl);
                 if (plane) {
                     if (s.v2.z <= m.margin) {
@@ -647,7 +700,6 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, V3 
                     phase = -1;
                 } else {
                     s.v2 = s.v2 - dir * infl;
-                    V3 vl1; support_vertex(T, g1 - 1, base1, multv(R1, dir), vl1);
                     s.v1 = p1 + mulv(R1, vl1) + dir * infl;
                     s.v = s.v1 - s.v2;
                     cnt++;
