@@ -628,11 +628,7 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, V3 
             V3 c1 = p1 + mulv(R1, v3(t1[0], t1[1], t1[2]));
             V3 dc = c2 - c1;
             float bound = t1[3] + t2[3] + m.margin;
-#ifdef GRIP_EXPERIMENT_NO_MPR
-            phase = -1;
-#else
             phase = dot(dc, dc) > bound * bound ? -1 : 0;
-#endif
             if (phase < 0) sep = v3(0, 0, 0);
             s0.v1 = c1; s0.v2 = c2; s0.v = c1 - c2;
             if (dot(s0.v, s0.v) < EPS2) s0.v.x += 1e-5f;

@@ -206,18 +206,16 @@ class AsyncRollout:
         import ctypes as C
         actions = actions.float().contiguous(); values = values.float().contiguous(); log_probs = log_probs.float().contiguous()
         if self._targs[p] is None:
-            slot = p
-            p = lambda t: t.data_ptr()
-            self._targs[slot] = E.RolloutTickC(
-                n_envs=self.N, capacity=self.C, action_dim=self.A, n_records=self.R, ready_list=p(lst), ready_count=p(cnt), base=p(self.base_t),
-                reward=p(out["reward"]), done=p(out["done"]), n_substeps=p(out["n_substeps"]) if "n_substeps" in out else None,
-                low=p(self.low), high=p(self.high), slot_actions=p(slot_act), rec_of_env=p(self.rec_of_env), rewards=p(self.rewards),
-                dones=p(self.dones), next_rec=p(self.next_rec), prev_rec=p(self.prev_rec), rec_env=p(self.rec_env), completed=p(self.completed),
-                is_rec=p(self.is_rec), actions_buf=p(self.actions), log_probs_buf=p(self.log_probs), values_buf=p(self.values),
-                n_completed=p(self.n_completed), substeps_total=p(self.substeps_total), ep_ret=p(self.ep_ret), ep_len=p(self.ep_len),
-                ep_ret_sum=p(self.ep_ret_sum), ep_len_sum=p(self.ep_len_sum), ep_count=p(self.ep_count))
+            ptr = lambda t: t.data_ptr()
+            self._targs[p] = E.RolloutTickC(
+                n_envs=self.N, capacity=self.C, action_dim=self.A, n_records=self.R, ready_list=ptr(lst), ready_count=ptr(cnt), base=ptr(self.base_t),
+                reward=ptr(out["reward"]), done=ptr(out["done"]), n_substeps=ptr(out["n_substeps"]) if "n_substeps" in out else None,
+                low=ptr(self.low), high=ptr(self.high), slot_actions=ptr(slot_act), rec_of_env=ptr(self.rec_of_env), rewards=ptr(self.rewards),
+                dones=ptr(self.dones), next_rec=ptr(self.next_rec), prev_rec=ptr(self.prev_rec), rec_env=ptr(self.rec_env), completed=ptr(self.completed),
+                is_rec=ptr(self.is_rec), actions_buf=ptr(self.actions), log_probs_buf=ptr(self.log_probs), values_buf=ptr(self.values),
+                n_completed=ptr(self.n_completed), substeps_total=ptr(self.substeps_total), ep_ret=ptr(self.ep_ret), ep_len=ptr(self.ep_len),
+                ep_ret_sum=ptr(self.ep_ret_sum), ep_len_sum=ptr(self.ep_len_sum), ep_count=ptr(self.ep_count))
             assert out["reward"].dtype == th.float32 and out["done"].dtype == th.uint8
-            p = slot
         a = self._targs[p]
         a.actions, a.values, a.log_probs = actions.data_ptr(), values.data_ptr(), log_probs.data_ptr()
         if noise is not None:
