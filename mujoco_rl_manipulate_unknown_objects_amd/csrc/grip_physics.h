@@ -54,7 +54,7 @@
 
 // diagnostic build only (-DGRIP_STAMPS): per-phase cycle accounting with s_memtime, never in the shipped library
 #ifdef GRIP_STAMPS
-#define NSTAMP 20
+#define NSTAMP 24
 __device__ unsigned long long g_stamp_acc[NSTAMP];
 struct Stamps { unsigned long long t; unsigned long long acc[NSTAMP]; };
 DEVI unsigned long long stamp_now() { __builtin_amdgcn_sched_barrier(0); unsigned long long t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); return t; }
@@ -472,7 +472,7 @@ DEVI void make_tangents(V3 n, V3 &t1, V3 &t2) {
 // Support vertex of the hull starting at vertex offset `base` (cube-map table `h`) for the LOCAL direction dl:
 // start at the table entry and hill-climb the edge graph to the best neighbour until none improves. Four
 // neighbour tests per iteration so that their dependent index -> vertex LDS hops overlap.
-DEVI int support_vertex(const Tables &T, int h, int base, V3 dl, V3 &vout) {
+DEVI int support_vertex(const Tables &T, int h, int base, V3 dl, V3 &vout, int hint = -1) {
     float ax = fabsf(dl.x), ay = fabsf(dl.y), az = fabsf(dl.z);
     int axis = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
     float mj = axis == 0 ? dl.x : axis == 1 ? dl.y : dl.z;
@@ -482,7 +482,7 @@ DEVI int support_vertex(const Tables &T, int h, int base, V3 dl, V3 &vout) {
     int iv = min(LUT_RES - 1, max(0, (int)((v * im + 1.f) * (0.5f * LUT_RES))));
     int cell = (2 * axis + (mj < 0.f ? 1 : 0)) * (LUT_RES * LUT_RES) + iu * LUT_RES + iv;
     const float *vb = T.v + 4 * base;
-    int cur = T.lut[h * LUT_CELLS + cell];
+    int cur = hint >= 0 ? hint : T.lut[h * LUT_CELLS + cell];       // any start climbs to the same maximum on a convex hull
     float bx = vb[4 * cur], by = vb[4 * cur + 1], bz = vb[4 * cur + 2];
     float bv = fmaf(bx, dl.x, fmaf(by, dl.y, bz * dl.z));
     int e = T.nadr[base + cur], eend = T.nadr[base + cur + 1];
@@ -517,10 +517,20 @@ template <int CTRL> DEVI int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0
 DEVI int coop_support(const Tables &T, int base, int n, V3 dl, int sub) {
     float bv = -3.0e38f; int bi = 0x7fffffff;
     const float4 *v4 = reinterpret_cast<const float4 *>(T.v) + base;
-    for (int i = sub; i < n; i += KL) {
-        const float4 v = v4[i];
-        const float s = fmaf(v.x, dl.x, fmaf(v.y, dl.y, v.z * dl.z));
-        if (s > bv) { bv = s; bi = i; }
+    // four independent LDS reads in flight per iteration (indices past the end are clamped: a duplicate of the last vertex
+    // cannot win a tie against itself)
+    for (int i = sub; i < n; i += 4 * KL) {
+        int j[4]; float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) j[q] = min(i + q * KL, n - 1);
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = v4[j[q]];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float s = fmaf(v[q].x, dl.x, fmaf(v[q].y, dl.y, v[q].z * dl.z));
+            const bool t = s > bv || (s == bv && j[q] < bi);
+            bv = t ? s : bv; bi = t ? j[q] : bi;
+        }
     }
 #define COOP_STEP(R) { float ov = dpp_f<DPP_ROW_ROR(R)>(bv); int oi = dpp_i<DPP_ROW_ROR(R)>(bi); bool t = ov > bv || (ov == bv && oi < bi); bv = t ? ov : bv; bi = t ? oi : bi; }
     COOP_STEP(8) COOP_STEP(4) COOP_STEP(2) COOP_STEP(1)
@@ -585,6 +595,10 @@ DEVI V3 find_pos(const Sup &p0, const Sup &p1, const Sup &p2, const Sup &p3) {
 }
 
 // a contact owned by one lane
+// what a pair lane of collide() remembers between calls: the direction that last separated its pair and the two support
+// vertices that proved it (the hill climbs of the next check start there: same direction, bodies moved by one 2 ms step)
+struct PairMemo { V3 sep; int h1, h2; };
+
 struct Contact {
     V3 p, n; float dist; int g1, g2, gA, gB; float fs, ft, tran, D0;
     float aref[4], jar[4], jv[4];
@@ -600,11 +614,18 @@ struct Contact {
 // support <= 0). Bodies move little in 2 ms, so the next call first tests that one direction (phase 6, one support pair) and
 // usually is done -- the exact separating-axis argument MPR itself ends with, so no result changes; only when it fails does
 // the portal search start from scratch.
-DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, V3 &sep) {
+DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, PairMemo &memo, Stamps &st) {
+    V3 &sep = memo.sep;
     const float EPS2 = 1e-12f, EPSD = 1e-10f;
     const float infl = 0.5f * m.margin;
     const Tables &T = cx.T;
     int total = 0;
+#ifdef GRIP_STAMPS
+    unsigned long long tc_ = stamp_now();
+#define CST(i) do { unsigned long long n_ = stamp_now(); st.acc[i] += n_ - tc_; tc_ = n_; } while (0)
+#else
+#define CST(i) do { } while (0)
+#endif
 #pragma unroll 1
     for (int round = 0; round < 2; round++) {
         const int item = m.coop_items[cx.sub][round];
@@ -645,10 +666,12 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, V3 
         // serve them one at a time: the lowest-numbered refining lane (the "owner") publishes its two local directions and
         // hull ranges, everybody scans a sixteenth of the vertices, the owner takes the arg-max and advances its portal.
         const int nv2 = __float_as_int(t2[9]), nv1 = __float_as_int(t1[9]);
+        CST(20);
         while (__any(phase >= 0)) {
             const unsigned actm = group_bits(__ballot(phase >= 0), cx.lane);
             const unsigned early = group_bits(__ballot(phase >= 0 && phase != 3 && phase != 4), cx.lane);
             const bool coop = actm != 0u && early == 0u;
+            const bool anycoop_ = __any(coop);
             const int owner = coop ? (__ffs((int)actm) - 1) : -1;
             const bool mine = coop ? owner == cx.sub : phase >= 0;
             V3 vl = v3(0, 0, 0), vl1 = v3(0, 0, 0); int vi2 = 0;
@@ -671,9 +694,11 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, V3 
                 }
                 wave_sync();
             }
+            int vi1 = 0;
             if (!coop && mine) {
-                vi2 = support_vertex(T, g2 - 1, base2, multv(R2, plane ? dir : -dir), vl);
-                if (!plane) support_vertex(T, g1 - 1, base1, multv(R1, dir), vl1);
+                const bool rem = phase == 6;
+                vi2 = support_vertex(T, g2 - 1, base2, multv(R2, plane ? dir : -dir), vl, rem ? memo.h2 : -1);
+                if (!plane) vi1 = support_vertex(T, g1 - 1, base1, multv(R1, dir), vl1, rem ? memo.h1 : -1);
             }
             if (mine) {
                 Sup s;
@@ -701,11 +726,11 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, V3 
                     cnt++;
                     bool hit = false; float depth = 0.f; V3 nrm = v3(0, 0, 0), pos = v3(0, 0, 0);
                     if (phase == 6) {
-                        if (dot(s.v, dir) <= 0.f) phase = -1;                 // still apart along the remembered direction
+                        if (dot(s.v, dir) <= 0.f) { phase = -1; memo.h1 = vi1; memo.h2 = vi2; }     // still apart along the remembered direction
                         else { sep = v3(0, 0, 0); dir = normalized(-s0.v); phase = 0; cnt = 0; }
                     } else if (phase == 0) {
                         sup_set(s1, s);
-                        if (dot(s1.v, dir) <= 0.f) { phase = -1; sep = dir; }
+                        if (dot(s1.v, dir) <= 0.f) { phase = -1; sep = dir; memo.h1 = vi1; memo.h2 = vi2; }
                         else {
                             V3 d = cross(s0.v, s1.v);
                             if (dot(d, d) < EPS2 * 1e-2f) {      // origin on the ray v0 -> v1
@@ -715,7 +740,7 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, V3 
                         }
                     } else if (phase == 1) {
                         sup_set(s2, s);
-                        if (dot(s2.v, dir) <= 0.f) { phase = -1; sep = dir; }
+                        if (dot(s2.v, dir) <= 0.f) { phase = -1; sep = dir; memo.h1 = vi1; memo.h2 = vi2; }
                         else {
                             dir = normalized(cross(s1.v - s0.v, s2.v - s0.v));
                             if (dot(dir, s0.v) > 0.f) { Sup t; sup_set(t, s1); sup_set(s1, s2); sup_set(s2, t); dir = -dir; }
@@ -723,7 +748,7 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, V3 
                         }
                     } else if (phase == 2) {
                         sup_set(s3, s);
-                        if (dot(s3.v, dir) <= 0.f) { phase = -1; sep = dir; }
+                        if (dot(s3.v, dir) <= 0.f) { phase = -1; sep = dir; memo.h1 = vi1; memo.h2 = vi2; }
                         else if (cnt > 4 * MPR_MAXIT) phase = -1;
                         else if (dot(cross(s1.v, s3.v), s0.v) < -EPSD) { sup_set(s2, s3); dir = normalized(cross(s1.v - s0.v, s2.v - s0.v)); }
                         else if (dot(cross(s3.v, s2.v), s0.v) < -EPSD) { sup_set(s1, s3); dir = normalized(cross(s1.v - s0.v, s2.v - s0.v)); }
@@ -732,7 +757,7 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, V3 
                             phase = dot(dir, s1.v) >= -EPSD ? 4 : 3; cnt = 0;
                         }
                     } else if (phase == 3) {
-                        if (dot(s.v, dir) < 0.f) { phase = -1; sep = dir; }
+                        if (dot(s.v, dir) < 0.f) { phase = -1; sep = dir; memo.h1 = -1; memo.h2 = -1; }
                         else if (reach_tol(s1, s2, s3, s, dir) || cnt > MPR_MAXIT) phase = -1;
                         else {
                             expand_portal(s0, s1, s2, s3, s);
@@ -759,6 +784,7 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, V3 
                     }
                 }
             }
+            if (anycoop_) CST(22); else CST(21);
         }
         // ---- compaction: exclusive prefix of rc over the env's 16 lanes (rc <= 4: three ballots)
         unsigned b0 = group_bits(__ballot(rc & 1), cx.lane), b1 = group_bits(__ballot(rc & 2), cx.lane), b2 = group_bits(__ballot(rc & 4), cx.lane);
@@ -781,6 +807,7 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, V3 
             }
         }
     }
+    CST(23);
     if (total > G_MAXC) { fault |= 2; total = G_MAXC; }
     wave_sync();
     // lane c takes contact c
@@ -1165,11 +1192,11 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
 struct LaneState { float qpos[14], qvel[13], ctrl[7], warm[13]; };
 
 // position stage (mj_step1's share): kinematics + collision of the current state; lane c then owns contact c.
-DEVI void forward_pos(const DevModel &m, const Ctx &cx, LaneState &s, Kin &k, Contact &con, int &ncon, int &fault, Stamps &st, V3 &sep) {
+DEVI void forward_pos(const DevModel &m, const Ctx &cx, LaneState &s, Kin &k, Contact &con, int &ncon, int &fault, Stamps &st, PairMemo &sep) {
     kinematics(m, s.qpos, k, cx, true);
     wave_sync();
     STAMP(st, 0);
-    ncon = collide(m, cx, con, fault, sep);
+    ncon = collide(m, cx, con, fault, sep, st);
     STAMP(st, 1);
 }
 

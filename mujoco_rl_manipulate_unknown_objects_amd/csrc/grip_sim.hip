@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_reset(const DevModel m, DevCo
     bool doit = valid && (mask == nullptr || mask[e] != 0);
     LaneState s; reset_lane(m, s);
     Kin k; Contact con; int ncon = 0, fault = 0;
-    V3 sep = v3(0, 0, 0);
+    PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1;
     forward_pos(m, cx, s, k, con, ncon, fault, stm, sep);
     int grasp = check_grasp(cx, con, ncon), pher = pheromone_level(k.pe, cfg);
     if (blockIdx.x == 0 && threadIdx.x == 0 && reset_info) { reset_info[0] = (float)grasp; reset_info[1] = (float)pher; reset_info[2] = k.po.x; reset_info[3] = k.po.y; }
@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
         for (int i = 0; i < 6; i++) act[i] = i < adim ? actions[arow * adim + i] : 0.f;
     }
     int budget = sliced ? slice : 0x7fffffff, last_iters = 0;
-    V3 sep = v3(0, 0, 0);                                   // collide()'s per-lane memory of its pair's separating direction
+    PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1;   // collide()'s per-lane memory of its pair's separating direction
     // the wall-clock budget runs from the moment the FIRST workgroup of the launch started (k_compact clears the stamp), so
     // that a workgroup that was placed late -- other streams' kernels were using its CU -- does not stretch the launch
     unsigned long long t0v = 0ULL;
@@ -671,7 +671,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_substep(const DevModel m, Sta
     if (!valid) e = st.n - 1;
     LaneState s; ld_state(st, e, s);
     Kin k; Contact con; int ncon = 0, fault = 0;
-    V3 sep = v3(0, 0, 0);
+    PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1;
     for (int i = 0; i < nsteps; i++) {
         forward_pos(m, cx, s, k, con, ncon, fault, stm, sep);
         physics_advance(m, cx, s, xfrc_z, k, con, ncon, fault, stm);
@@ -691,7 +691,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_debug_forward(const DevModel 
     if (!valid) e = st.n - 1;
     LaneState s; ld_state(st, e, s);
     Kin k; Contact con; int ncon = 0, fault = 0, iters = 0;
-    V3 sep = v3(0, 0, 0);
+    PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1;
     forward_pos(m, cx, s, k, con, ncon, fault, stm, sep);
     float qfs[13], qacc[13], jtf[13], qs[13], bias[13];
     forward_acc(m, cx, s, xfrc_z, k, con, ncon, fault, qfs, qacc, jtf, iters, qs, bias, stm, getenv_dbgH ? M_out + (size_t)e * 169 : nullptr);

@@ -12,7 +12,7 @@ if mode == "push":
     q, v, c, w = b.get_state(); q[:, 0] = 0.2; q[:, 2] = 0.05; b.set_state(qpos=q)
     c[:, 0] = 1.0; b.set_state(ctrl=c); b.substep(60); torch.cuda.synchronize()
 b.substep(k); torch.cuda.synchronize()
-out = (C.c_ulonglong * 20)()
+out = (C.c_ulonglong * 24)()
 assert engine.lib().grip_debug_stamps(out) == 0
 names = ["kinematics", "collide", "mass+bias+qs", "make_constraints", "solve: other (LS, bookkeeping)", "integrate", "solve: constraint pass", "solve: tri-solves+gather", "solve: assemble rows", "solve: cholesky", "solve: line search", "-"]
 tot = sum(out)
