@@ -1088,22 +1088,25 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
             const bool gconv = scale * sqrtf(sum16(gi * gi)) < tol;
             STAMP(st, 6);
             if (stage == 0) {
-                cs = newcost; stage = 1;
+                cs = newcost;
                 if (gconv) done = true;                     // qacc_smooth already optimal (constraints inactive)
                 else {
                     xi = warmi; Mdi = Md_w;
 #pragma unroll
                     for (int r = 0; r < 4; r++) c.jar[r] = jar_w[r];
                 }
-            } else if (stage == 1) {
-                if (newcost < cs) { if (gconv) done = true; }
-                else {
+            }
+            bool newton = stage >= 2;
+            if (stage == 1) {
+                stage = 2;
+                if (newcost < cs) { if (gconv) done = true; else newton = true; }   // the warm start is priced: iterate from it right away
+                else {                                                              // back to qacc_smooth, priced again next pass
                     xi = qsi; Mdi = 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; r++) c.jar[r] = jar_s[r];
                 }
-                stage = 2;
-            } else {
+            } else if (stage == 0) stage = 1;
+            if (newton && !done) {
                 bool stop = gconv;
                 if (stage > 2 && scale * (cost - newcost) < tol) stop = true;
                 cost = newcost;
