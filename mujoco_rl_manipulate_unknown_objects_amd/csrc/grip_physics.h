@@ -41,6 +41,10 @@
 #define LDS_ENV_BASE(hull_words) (((hull_words) + GT_FLOATS + 3) & ~3)      // float offset of the first env region (16-byte aligned)
 
 #define NEWTON_MAXIT 20
+#ifndef NEWTON_TOL
+#define NEWTON_TOL 1e-5f
+#endif
+#define NEWTON_GRAD_NOISE 3e-6f  // a gradient below this fraction of the two terms it is the difference of is fp32 rounding noise
 #ifndef LS_MAXIT
 #define LS_MAXIT 16
 #endif
@@ -1052,7 +1056,7 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
                        const float (&qs)[13], float qsi, const float (&warm)[13], Contact &c, bool live, int ncon,
                        float (&qacc)[13], float (&jtf)[13], int &fault, int &iters, Stamps &st, float *dbgH = nullptr) {
     const float scale = 1.0f / (m.meaninertia * 13.f);
-    const float tol = fmaxf(m.tolerance, 1e-5f);            // fp32 noise floor of the scaled gradient is ~1e-6
+    const float tol = fmaxf(m.tolerance, NEWTON_TOL);       // fp32 noise floor of the scaled gradient is ~1e-6
     float mrow[13]; load_mrow(cx, mrow);
     const float warmi = pick13(warm, cx.sub);
     // the two candidate starts: jar = J x - aref and M (x - a_s) for x = qacc_smooth and x = qacc_warmstart
@@ -1085,7 +1089,10 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
             float lc = price_constraints(m, cx, lsgn, lD, laref, xi, ncon, c, live, cn, jtfi, hdiag);
             float newcost = sum16(0.5f * Mdi * (xi - qsi) + lc);
             float gi = Mdi - jtfi;                                          // gradient component of this lane
-            const bool gconv = scale * sqrtf(sum16(gi * gi)) < tol;
+            // converged when the scaled gradient is below the model's tolerance -- or below what fp32 can resolve: g = M(x - a_s) - J^T f
+            // is a difference of two O(force) vectors, each carrying ~1e-6 relative rounding error
+            const float g2 = sum16(gi * gi), t2 = sum16(Mdi * Mdi + jtfi * jtfi);
+            const bool gconv = scale * sqrtf(g2) < tol || g2 < NEWTON_GRAD_NOISE * NEWTON_GRAD_NOISE * t2;
             STAMP(st, 6);
             if (stage == 0) {
                 cs = newcost;
