@@ -416,13 +416,15 @@ DEVI void block_solve(float (&Ag)[28], float (&Ao)[21], float (&x)[13]) {
 // ---------------------------------------------------------------- dense algebra, one matrix row per lane
 // Lane i (i < 13) of an env holds row i of a symmetric positive definite 13 x 13 matrix. Cholesky in place: on exit
 // row[q < i] = L[i][q] and row[i] = 1 / L[i][i]. Row j is handed to the other lanes with ds_swizzle broadcasts.
-template <int J>
+// LO > 0: the matrix is block diagonal with a leading LO x LO block that the caller does not need (rows >= LO have zeros in
+// columns < LO): only the trailing block is factorised / solved, lanes < LO are left alone (their solution component is 0).
+template <int J, int LO = 0>
 DEVI void chol_col(float (&row)[13], int sub) {
     // one ds_swizzle round trip per column: lane J's L[J][0..J-1] and A[J][J] go to everyone, every lane then forms both its
     // own entry and the pivot 1 / L[J][J] (redundantly, bit-identically)
     float d = bcast16<J>(row[J]), t = row[J];
 #pragma unroll
-    for (int q = 0; q < J; q++) { float ljq = bcast16<J>(row[q]); d = fmaf(-ljq, ljq, d); t = fmaf(-row[q], ljq, t); }
+    for (int q = LO; q < J; q++) { float ljq = bcast16<J>(row[q]); d = fmaf(-ljq, ljq, d); t = fmaf(-row[q], ljq, t); }
     float inv = rsqrtf(fmaxf(d, 1e-30f));
     row[J] = sub == J ? inv : t * inv;                         // lanes below J: junk in the unused upper triangle
 }
@@ -430,6 +432,10 @@ DEVI void chol_rows(float (&row)[13], int sub) {
     chol_col<0>(row, sub); chol_col<1>(row, sub); chol_col<2>(row, sub); chol_col<3>(row, sub); chol_col<4>(row, sub);
     chol_col<5>(row, sub); chol_col<6>(row, sub); chol_col<7>(row, sub); chol_col<8>(row, sub); chol_col<9>(row, sub);
     chol_col<10>(row, sub); chol_col<11>(row, sub); chol_col<12>(row, sub);
+}
+DEVI void chol_rows_obj(float (&row)[13], int sub) {            // trailing 6 x 6 (object) block only
+    chol_col<7, 7>(row, sub); chol_col<8, 7>(row, sub); chol_col<9, 7>(row, sub); chol_col<10, 7>(row, sub); chol_col<11, 7>(row, sub);
+    chol_col<12, 7>(row, sub);
 }
 // solves L L^T x = b with b_i in lane i; returns x_i in lane i (0 in lanes 13..15)
 template <int J> DEVI void fwd_step(const float (&row)[13], int sub, float &acc, float &y) {
@@ -452,6 +458,14 @@ DEVI float chol_solve_rows(const float (&row)[13], float b, int sub) {
     bwd_step<4>(row, sub, y, x); bwd_step<3>(row, sub, y, x); bwd_step<2>(row, sub, y, x); bwd_step<1>(row, sub, y, x);
     bwd_step<0>(row, sub, y, x);
     return x;
+}
+DEVI float chol_solve_rows_obj(const float (&row)[13], float b, int sub) {
+    float acc = b, y = 0.f, x = 0.f;
+    fwd_step<7>(row, sub, acc, y); fwd_step<8>(row, sub, acc, y); fwd_step<9>(row, sub, acc, y); fwd_step<10>(row, sub, acc, y);
+    fwd_step<11>(row, sub, acc, y); fwd_step<12>(row, sub, acc, y);
+    bwd_step<12>(row, sub, y, x); bwd_step<11>(row, sub, y, x); bwd_step<10>(row, sub, y, x); bwd_step<9>(row, sub, y, x);
+    bwd_step<8>(row, sub, y, x); bwd_step<7>(row, sub, y, x);
+    return sub >= 7 ? x : 0.f;
 }
 // this lane's row of the env's mass matrix (zero in lanes 13..15)
 DEVI void load_mrow(const Ctx &cx, float (&mrow)[13]) {
@@ -1054,7 +1068,7 @@ DEVI void line_eval(const DevModel &m, float lsgn, float lD, float laref, float 
 // values, so the 16 lanes of an env always agree.
 DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, float laref,
                        const float (&qs)[13], float qsi, const float (&warm)[13], Contact &c, bool live, int ncon,
-                       float (&qacc)[13], float (&jtf)[13], int &fault, int &iters, Stamps &st, float *dbgH = nullptr) {
+                       float (&qacc)[13], float (&jtf)[13], int &fault, int &iters, Stamps &st, bool objonly, float *dbgH = nullptr) {
     const float scale = 1.0f / (m.meaninertia * 13.f);
     const float tol = fmaxf(m.tolerance, NEWTON_TOL);       // fp32 noise floor of the scaled gradient is ~1e-6
     float mrow[13]; load_mrow(cx, mrow);
@@ -1132,9 +1146,12 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
                         for (int j = 0; j < 13; j++) dbgH[cx.sub * 13 + j] = row[j];
                     }
                     if (cx.sub >= 13) row[12] = 1.f;        // harmless: those lanes never take part (sub > 12 masked everywhere)
-                    chol_rows(row, cx.sub);
+                    // no limit and only floor-object contacts in every env of the wave that is still iterating: H is block
+                    // diagonal and the gripper block's gradient is exactly zero, so only the object's 6 x 6 block is solved
+                    const bool full = __any(!objonly);
+                    if (full) chol_rows(row, cx.sub); else chol_rows_obj(row, cx.sub);
                     STAMP(st, 9);
-                    float pi = chol_solve_rows(row, -gi, cx.sub);
+                    float pi = full ? chol_solve_rows(row, -gi, cx.sub) : chol_solve_rows_obj(row, -gi, cx.sub);
                     cx.envl[EF_P + cx.sub] = pi;            // lanes 13..15 publish 0
                     wave_sync();
                     float p[13];
@@ -1267,7 +1284,7 @@ DEVI void forward_acc(const DevModel &m, const Ctx &cx, LaneState &s, float xfrc
 #pragma unroll
     for (int i = 0; i < 13; i++) { qacc[i] = qs[i]; jtf[i] = 0.f; warm[i] = (i < 7 && !grip) ? qs[i] : s.warm[i]; }
     if (__any(constrained)) {
-        if (constrained) solve_newton(m, cx, lsgn, lD, laref, qs, qsi, warm, con, live, ncon, qacc, jtf, fault, iters, st, dbgH);
+        if (constrained) solve_newton(m, cx, lsgn, lD, laref, qs, qsi, warm, con, live, ncon, qacc, jtf, fault, iters, st, !grip, dbgH);
     }
     STAMP(st, 4);
 }
