@@ -861,7 +861,6 @@ DEVI float impedance(const float *si, float pos, float margin) {
     return si[0] + y * (si[1] - si[0]);
 }
 
-struct Limits { float sgn_pad[13], D_pad[13], aref_pad[13]; };      // entries 0..6 used (one joint limit per dof), rest 0
 
 // Elliptic condim-4 contact in jar space:  s(jar) = (D0 / 2 mu^2) dist^2(U, K), U = diag(mu, fs, fs, ft) jar,
 // K = {U0 >= mu |U_t|}. Returns the cost and gradient, plus the Hessian in rank-structured form
@@ -916,19 +915,21 @@ DEVI void contact_rows(const Kin &k, const Twist &t, const Contact &c, V3 t1, V3
 
 // reference accelerations and regularisation (mj_makeConstraint / mj_makeImpedance): limits redundantly, this lane's contact
 DEVI void make_constraints(const DevModel &m, const Kin &k, const float (&qpos)[14], const float (&qvel)[13],
-                           Limits &lim, Contact &c, bool live) {
+                           int sub, float &lsgn, float &lD, float &laref, Contact &c, bool live) {
+    // joint limit of dof `sub` (lanes 0..6; mj_instantiateLimit + mj_makeImpedance): only the owning lane needs it
+    {   const int j = min(sub, 6);
+        float qj = 0.f, vj = 0.f, r0 = 0.f, r1 = 0.f, iw = 0.f;
 #pragma unroll
-    for (int j = 0; j < 7; j++) {
-        float lo = qpos[j] - m.range[j][0], hi = m.range[j][1] - qpos[j];
+        for (int q = 0; q < 7; q++) { bool h = j == q; qj = h ? qpos[q] : qj; vj = h ? qvel[q] : vj; r0 = h ? m.range[q][0] : r0; r1 = h ? m.range[q][1] : r1; iw = h ? m.dof_invweight0[q] : iw; }
+        float lo = qj - r0, hi = r1 - qj;
         float sgn = 0.f, dist = 0.f;
         if (lo < 0.f) { sgn = 1.f; dist = lo; } else if (hi < 0.f) { sgn = -1.f; dist = hi; }
         float imp = impedance(m.lim_solimp, dist, 0.f);
-        float R = fmaxf(1e-15f, (1.f - imp) * m.dof_invweight0[j] / imp);
-        lim.sgn_pad[j] = sgn; lim.D_pad[j] = 1.0f / R;
-        lim.aref_pad[j] = -m.b_lim * (sgn * qvel[j]) - m.k_lim * imp * dist;
+        float R = fmaxf(1e-15f, (1.f - imp) * iw / imp);
+        const bool own = sub < 7;
+        lsgn = own ? sgn : 0.f; lD = own ? 1.0f / R : 0.f;
+        laref = own ? -m.b_lim * (sgn * vj) - m.k_lim * imp * dist : 0.f;
     }
-#pragma unroll
-    for (int j = 7; j < 13; j++) { lim.sgn_pad[j] = 0.f; lim.D_pad[j] = 0.f; lim.aref_pad[j] = 0.f; }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         c.aref[r] = 0.f; c.jar[r] = 0.f; c.jv[r] = 0.f;
@@ -1265,15 +1266,11 @@ DEVI void forward_acc(const DevModel &m, const Ctx &cx, LaneState &s, float xfrc
         for (int i = 0; i < 13; i++) dbg_qs[i] = qs[i];
     }
     STAMP(st, 2);
-    Limits lim;
+    float lsgn, lD, laref;
     const bool live = cx.sub < ncon;
-    make_constraints(m, k, s.qpos, s.qvel, lim, con, live);
+    make_constraints(m, k, s.qpos, s.qvel, cx.sub, lsgn, lD, laref, con, live);
     publish_rows(cx, con, live);
     // lane j < 7 owns joint limit j
-    const float lsgn = cx.sub < 7 ? pick13(reinterpret_cast<const float (&)[13]>(lim.sgn_pad), cx.sub) : 0.f;
-    const float lD = pick13(reinterpret_cast<const float (&)[13]>(lim.D_pad), cx.sub);
-    const float laref = pick13(reinterpret_cast<const float (&)[13]>(lim.aref_pad), cx.sub);
-    STAMP(st, 3);
     const bool anylim = group_bits(__ballot(lsgn != 0.f), cx.lane) != 0u;
     iters = 0;
     const bool constrained = ncon > 0 || anylim;
