@@ -1296,19 +1296,33 @@ DEVI void physics_advance(const DevModel &m, const Ctx &cx, LaneState &s, float 
     // semi-implicit Euler with implicit joint damping: (M + h D) a' = qfrc_smooth + J^T f   (mj_Euler). The object block has
     // no damping, so a' = qacc there; the distributed solve covers all 13 dofs at once.
     float acc[13];
-    {   float Ag[28], Ao[21];
+    {   float Ag[28];
         const float *M = cx.envl + EF_M;
 #pragma unroll
         for (int i = 0; i < 7; i++)
 #pragma unroll
             for (int j = 0; j <= i; j++) Ag[pidx(i, j)] = M[i * 13 + j] + (i == j ? h * m.damping[i] : 0.f);
 #pragma unroll
-        for (int i = 0; i < 6; i++)
-#pragma unroll
-            for (int j = 0; j <= i; j++) Ao[pidx(i, j)] = M[(7 + i) * 13 + 7 + j] + (i == j ? h * m.damping[7 + i] : 0.f);
-#pragma unroll
         for (int i = 0; i < 13; i++) acc[i] = qfs[i] + jtf[i];
-        block_solve(Ag, Ao, acc);
+        const bool obj_damped = (m.damping[7] != 0.f) | (m.damping[8] != 0.f) | (m.damping[9] != 0.f) | (m.damping[10] != 0.f) |
+                                (m.damping[11] != 0.f) | (m.damping[12] != 0.f);
+        if (obj_damped) {                                   // not the case for a <freejoint/> (no defaults apply), kept for generality
+            float Ao[21];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j <= i; j++) Ao[pidx(i, j)] = M[(7 + i) * 13 + 7 + j] + (i == j ? h * m.damping[7 + i] : 0.f);
+            block_solve(Ag, Ao, acc);
+        } else {                                            // M a = qfrc_smooth + J^T f is what qacc solves: a' = qacc for the object
+            float xg[7];
+#pragma unroll
+            for (int i = 0; i < 7; i++) xg[i] = acc[i];
+            chol_packed<7>(Ag); chol_solve_packed<7>(Ag, xg);
+#pragma unroll
+            for (int i = 0; i < 7; i++) acc[i] = xg[i];
+#pragma unroll
+            for (int i = 7; i < 13; i++) acc[i] = qacc[i];
+        }
     }
 #pragma unroll
     for (int i = 0; i < 13; i++) s.warm[i] = qacc[i];
