@@ -58,7 +58,7 @@
 
 // diagnostic build only (-DGRIP_STAMPS): per-phase cycle accounting with s_memtime, never in the shipped library
 #ifdef GRIP_STAMPS
-#define NSTAMP 24
+#define NSTAMP 20
 __device__ unsigned long long g_stamp_acc[NSTAMP];
 struct Stamps { unsigned long long t; unsigned long long acc[NSTAMP]; };
 DEVI unsigned long long stamp_now() { __builtin_amdgcn_sched_barrier(0); unsigned long long t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); return t; }
@@ -632,18 +632,12 @@ struct Contact {
 // support <= 0). Bodies move little in 2 ms, so the next call first tests that one direction (phase 6, one support pair) and
 // usually is done -- the exact separating-axis argument MPR itself ends with, so no result changes; only when it fails does
 // the portal search start from scratch.
-DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, PairMemo &memo, Stamps &st) {
+DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, PairMemo &memo) {
     V3 &sep = memo.sep;
     const float EPS2 = 1e-12f, EPSD = 1e-10f;
     const float infl = 0.5f * m.margin;
     const Tables &T = cx.T;
     int total = 0;
-#ifdef GRIP_STAMPS
-    unsigned long long tc_ = stamp_now();
-#define CST(i) do { unsigned long long n_ = stamp_now(); st.acc[i] += n_ - tc_; tc_ = n_; } while (0)
-#else
-#define CST(i) do { } while (0)
-#endif
 #pragma unroll 1
     for (int round = 0; round < 2; round++) {
         const int item = m.coop_items[cx.sub][round];
@@ -684,12 +678,10 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
         // serve them one at a time: the lowest-numbered refining lane (the "owner") publishes its two local directions and
         // hull ranges, everybody scans a sixteenth of the vertices, the owner takes the arg-max and advances its portal.
         const int nv2 = __float_as_int(t2[9]), nv1 = __float_as_int(t1[9]);
-        CST(20);
         while (__any(phase >= 0)) {
             const unsigned actm = group_bits(__ballot(phase >= 0), cx.lane);
             const unsigned early = group_bits(__ballot(phase >= 0 && phase != 3 && phase != 4), cx.lane);
             const bool coop = actm != 0u && early == 0u;
-            const bool anycoop_ = __any(coop);
             const int owner = coop ? (__ffs((int)actm) - 1) : -1;
             const bool mine = coop ? owner == cx.sub : phase >= 0;
             V3 vl = v3(0, 0, 0), vl1 = v3(0, 0, 0); int vi2 = 0;
@@ -802,7 +794,6 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
                     }
                 }
             }
-            if (anycoop_) CST(22); else CST(21);
         }
         // ---- compaction: exclusive prefix of rc over the env's 16 lanes (rc <= 4: three ballots)
         unsigned b0 = group_bits(__ballot(rc & 1), cx.lane), b1 = group_bits(__ballot(rc & 2), cx.lane), b2 = group_bits(__ballot(rc & 4), cx.lane);
@@ -825,7 +816,6 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
             }
         }
     }
-    CST(23);
     if (total > G_MAXC) { fault |= 2; total = G_MAXC; }
     wave_sync();
     // lane c takes contact c
@@ -1224,7 +1214,7 @@ DEVI void forward_pos(const DevModel &m, const Ctx &cx, LaneState &s, Kin &k, Co
     kinematics(m, s.qpos, k, cx, true);
     wave_sync();
     STAMP(st, 0);
-    ncon = collide(m, cx, con, fault, sep, st);
+    ncon = collide(m, cx, con, fault, sep);
     STAMP(st, 1);
 }
 
@@ -1270,6 +1260,7 @@ DEVI void forward_acc(const DevModel &m, const Ctx &cx, LaneState &s, float xfrc
     const bool live = cx.sub < ncon;
     make_constraints(m, k, s.qpos, s.qvel, cx.sub, lsgn, lD, laref, con, live);
     publish_rows(cx, con, live);
+    STAMP(st, 3);
     // lane j < 7 owns joint limit j
     const bool anylim = group_bits(__ballot(lsgn != 0.f), cx.lane) != 0u;
     iters = 0;

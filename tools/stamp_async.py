@@ -10,7 +10,7 @@ n, cap = 4096, 1024
 b = engine.Batch(obj, n, auto_reset=1)
 lst = torch.full((cap,), -1, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
 g = torch.Generator(device="cuda"); g.manual_seed(0)
-out = (C.c_ulonglong * 24)()
+out = (C.c_ulonglong * 20)()
 def ticks(k):
     for _ in range(k):
         b.advance(torch.randn(cap, 6, device="cuda", generator=g).clamp(-1, 1), 96, lst, cnt, 3000)
@@ -25,5 +25,4 @@ for nm, v in zip(names, out):
 for i, nm in names2.items():
     print(f"{nm:44s} {100 * out[i] / tot:5.1f} %")
 print("wave-cycles per lane-0 env-substep:", tot / max(1, out[11]))
-print("collide cycles per wave-substep: setup %.0f, per-lane trips %.0f, cooperative trips %.0f, compaction %.0f" % tuple(out[i] / max(1, out[13]) for i in (20, 21, 22, 23)))
 print("mean envs at work per wave loop trip: %.2f of 4;  wave-cycles per loop trip: %.0f" % (out[12] / max(1, out[13]), tot / max(1, out[13])))
