@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--slice", type=int, default=96, help="physics.step() calls per env per tick (async schedule)")
     ap.add_argument("--capacity", type=int, default=1024, help="finished envs decided per tick (async schedule)")
     ap.add_argument("--pipeline", action="store_true", help="decide for tick t on a side stream while tick t+1 advances (lag 2)")
-    ap.add_argument("--budget-us", type=int, default=3000, help="wall-clock cap of a wavefront's slice in microseconds (async schedule; 0 = none)")
+    ap.add_argument("--budget-us", type=int, default=2000, help="wall-clock cap of a wavefront's slice in microseconds (async schedule; 0 = none)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
