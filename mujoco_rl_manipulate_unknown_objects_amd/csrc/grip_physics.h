@@ -1007,11 +1007,22 @@ DEVI void publish_rows(const Ctx &cx, const Contact &c, bool live) {
 }
 
 // row `sub` of  H = M + sum over the env's contact slots of  w u u^T  (+ this lane's joint-limit term on the diagonal)
-DEVI void assemble_rows(const Ctx &cx, int ncon, const float (&mrow)[13], float hdiag, float (&row)[13]) {
+// full = false: only columns 7..12 (the object block) are needed -- chol_rows_obj reads nothing else
+DEVI void assemble_rows(const Ctx &cx, int ncon, const float (&mrow)[13], float hdiag, float (&row)[13], bool full) {
 #pragma unroll
     for (int j = 0; j < 13; j++) row[j] = mrow[j];
     const int isub = min(cx.sub, 12);
     const float *U = cx.envl + EF_U;
+    if (!full) {
+#pragma unroll 4
+        for (int s = 0; s < 6 * ncon; s++) {
+            const float4 *u4 = reinterpret_cast<const float4 *>(U + s * U_STRIDE);
+            float4 b = u4[1], c4 = u4[2], d = u4[3];
+            float wi = d.y * U[s * U_STRIDE + isub];
+            row[7] = fmaf(wi, b.w, row[7]); row[8] = fmaf(wi, c4.x, row[8]); row[9] = fmaf(wi, c4.y, row[9]);
+            row[10] = fmaf(wi, c4.z, row[10]); row[11] = fmaf(wi, c4.w, row[11]); row[12] = fmaf(wi, d.x, row[12]);
+        }
+    } else
 #pragma unroll 4
     for (int s = 0; s < 6 * ncon; s++) {
         const float4 *u4 = reinterpret_cast<const float4 *>(U + s * U_STRIDE);
@@ -1130,16 +1141,16 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
                     wave_sync();                            // the contact lanes' Hessian vectors are in LDS
                     float row[13];
                     STAMP(st, 16);
-                    assemble_rows(cx, ncon, mrow, hdiag, row);
+                    // no limit and only floor-object contacts in every env of the wave that is still iterating: H is block
+                    // diagonal and the gripper block's gradient is exactly zero, so only the object's 6 x 6 block is needed
+                    const bool full = __any(!objonly);
+                    assemble_rows(cx, ncon, mrow, hdiag, row, full);
                     STAMP(st, 8);
                     if (dbgH && iters == 0 && cx.sub < 13) {
 #pragma unroll
                         for (int j = 0; j < 13; j++) dbgH[cx.sub * 13 + j] = row[j];
                     }
                     if (cx.sub >= 13) row[12] = 1.f;        // harmless: those lanes never take part (sub > 12 masked everywhere)
-                    // no limit and only floor-object contacts in every env of the wave that is still iterating: H is block
-                    // diagonal and the gripper block's gradient is exactly zero, so only the object's 6 x 6 block is solved
-                    const bool full = __any(!objonly);
                     if (full) chol_rows(row, cx.sub); else chol_rows_obj(row, cx.sub);
                     STAMP(st, 9);
                     float pi = full ? chol_solve_rows(row, -gi, cx.sub) : chol_solve_rows_obj(row, -gi, cx.sub);
