@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--lockstep", action="store_true", help="classic vector-env schedule instead of asynchronous time slices")
     ap.add_argument("--slice", type=int, default=96, help="physics.step() calls per env per tick (async schedule)")
     ap.add_argument("--capacity", type=int, default=1024, help="finished envs decided per tick (async schedule)")
+    ap.add_argument("--policy-dtype", choices=["f32", "bf16"], default="f32", help="autocast dtype of the policy / PPO update (physics is always f32)")
     ap.add_argument("--pipeline", action="store_true", help="decide for tick t on a side stream while tick t+1 advances (lag 2)")
     ap.add_argument("--budget-us", type=int, default=2000, help="wall-clock cap of a wavefront's slice in microseconds (async schedule; 0 = none)")
     a = ap.parse_args()
@@ -103,7 +104,8 @@ def main():
     env = GpuVecEnv(BatchedRobotEnv(cfg, n_envs=a.envs, device_index=local, auto_reset=True))
     model = PPO("MultiInputPolicy", env, n_steps=a.rollout, batch_size=a.minibatch, n_epochs=a.epochs, seed=1234 + rank,
                 policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]),
-                async_slice=0 if a.lockstep else a.slice, async_capacity=min(a.capacity, a.envs), async_budget_us=a.budget_us)
+                async_slice=0 if a.lockstep else a.slice, async_capacity=min(a.capacity, a.envs), async_budget_us=a.budget_us,
+                autocast_dtype=torch.bfloat16 if a.policy_dtype == "bf16" else None)
     batch = env.env.batch
     ar = model._async
     if ar is not None and a.pipeline:
@@ -181,7 +183,7 @@ def main():
         out = {
             "metric": "env-steps/sec (whole node), acorn_env 4096 envs/GPU", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.policy_dtype == "f32" else "f32 physics / bf16 policy",
             "data": "synthetic (deterministic reset state, actions sampled from the randomly initialised PPO policy)",
             "config": {"workload": f"{a.object}_env ({'stand-in hull; ' if a.object == 'acorn' else ''}direction {a.direction}), "
                                    f"{a.envs} envs/GPU, macro-step + observation + PPO actor-critic fwd each step, "
