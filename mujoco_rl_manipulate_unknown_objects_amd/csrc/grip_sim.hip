@@ -463,6 +463,9 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
             unsigned long long now = (unsigned long long)wall_clock64();          // 100 MHz
             unsigned long long old = atomicCAS(mc.t0, 0ULL, now);
             t0v = old ? old : now;
+            // more workgroups than the chip holds at once (> 4096 envs): the later rounds start when the first ones are done and
+            // get a budget of their own; a workgroup that is merely placed a little late still ends with the launch
+            if (now - t0v > (unsigned long long)(budget_ticks / 2)) t0v = now;
         }
         t0v = __shfl(t0v, 0);
     }
