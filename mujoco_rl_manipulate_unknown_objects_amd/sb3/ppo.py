@@ -22,7 +22,7 @@ import torch as th
 import torch.distributed as dist
 
 from .policies import ActorCriticPolicy
-from .callbacks import BaseCallback, CallbackList
+from .callbacks import CallbackList
 
 
 def _to_t(x, device):

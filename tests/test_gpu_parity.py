@@ -1,8 +1,5 @@
 """-m gpu: the HIP path, called through the C ABI (engine.Batch -> libgrip_sim.so), against the CPU oracle
 on identical inputs. fp32 kernels vs fp64 oracle: tolerances are stated per test."""
-import json
-import os
-
 import numpy as np
 import pytest
 

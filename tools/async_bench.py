@@ -1,6 +1,6 @@
 """Raw throughput of the time-sliced engine (random actions, no policy): env-steps/s vs slice length and list capacity."""
 import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from mujoco_rl_manipulate_unknown_objects_amd import engine
 
 obj = sys.argv[1] if len(sys.argv) > 1 else "acorn"

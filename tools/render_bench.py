@@ -1,6 +1,6 @@
 """Time of the observation kernel alone: full batch and list mode."""
-import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
 from mujoco_rl_manipulate_unknown_objects_amd import engine
 obj = sys.argv[1] if len(sys.argv) > 1 else "acorn"
 n = 4096

@@ -2,7 +2,7 @@
 Uses the -DGRIP_STAMPS build (libgrip_sim_stamps.so), never the shipped library."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-import numpy as np, torch
+import torch
 from mujoco_rl_manipulate_unknown_objects_amd import engine
 engine.LIB_PATH = os.path.join(engine.CSRC, "libgrip_sim_stamps.so")
 obj = sys.argv[1] if len(sys.argv) > 1 else "acorn"

@@ -1,6 +1,5 @@
 """Sanity probe: PPO over the time-sliced engine for a minute; prints episode return / length and losses per rollout."""
 import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
 from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import BatchedRobotEnv, default_config
 from mujoco_rl_manipulate_unknown_objects_amd.sb3 import PPO, GpuVecEnv
 from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
