@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--slice", type=int, default=96, help="physics.step() calls per env per tick (async schedule)")
     ap.add_argument("--capacity", type=int, default=1024, help="finished envs decided per tick (async schedule)")
     ap.add_argument("--policy-dtype", choices=["f32", "bf16"], default="f32", help="autocast dtype of the policy / PPO update (physics is always f32)")
+    ap.add_argument("--overlap-update", action="store_true", help="PPO update of rollout i on a second stream while rollout i+1 is collected (one update of policy lag)")
     ap.add_argument("--pipeline", action="store_true", help="decide for tick t on a side stream while tick t+1 advances (lag 2)")
     ap.add_argument("--budget-us", type=int, default=2000, help="wall-clock cap of a wavefront's slice in microseconds (async schedule; 0 = none)")
     a = ap.parse_args()
@@ -105,7 +106,7 @@ def main():
     model = PPO("MultiInputPolicy", env, n_steps=a.rollout, batch_size=a.minibatch, n_epochs=a.epochs, seed=1234 + rank,
                 policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]),
                 async_slice=0 if a.lockstep else a.slice, async_capacity=min(a.capacity, a.envs), async_budget_us=a.budget_us,
-                autocast_dtype=torch.bfloat16 if a.policy_dtype == "bf16" else None)
+                autocast_dtype=torch.bfloat16 if a.policy_dtype == "bf16" else None, overlap_update=a.overlap_update and not a.lockstep)
     batch = env.env.batch
     ar = model._async
     if ar is not None and a.pipeline:
@@ -177,8 +178,10 @@ def main():
         value = total_env_steps / dt
         # async: one launch = one time slice = state + suspended macro-step context in and out (21 words each way) per env
         macro_bytes = (MACRO_BYTES_PER_ENV if ar is None else (47 + 40 + 2 * 21) * 4 + 8) * a.envs
+        if ar is not None and a.overlap_update:
+            pass
         sched = ("lock-step vector env" if ar is None else
-                 f"asynchronous time slices (<= {a.slice} physics steps and <= {a.budget_us} us per wavefront and tick, {min(a.capacity, a.envs)} decisions/tick)")
+                 f"asynchronous time slices (<= {a.slice} physics steps and <= {a.budget_us} us per wavefront and tick, {min(a.capacity, a.envs)} decisions/tick)" + ("; PPO update overlapped with the next rollout (policy lag 1)" if a.overlap_update else ""))
         achieved = macro_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
             "metric": "env-steps/sec (whole node), acorn_env 4096 envs/GPU", "value": value, "unit": "env-steps/s",

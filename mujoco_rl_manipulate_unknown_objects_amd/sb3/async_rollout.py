@@ -10,9 +10,9 @@ Transitions therefore arrive out of order. They are stored as *decision records*
     record r = (env, obs, action, log_prob, value)         written when the policy decides for a listed env
     reward[r], done[r], next_rec[r]                        filled when that env is listed the next time
 
-Record ids grow with time (carry region [0, N), then `capacity` rows per tick), so next_rec[r] > r and GAE is a
+Record ids grow with time (N carry rows, then `capacity` rows per tick, in one of two alternating windows), so next_rec[r] > r and GAE is a
 backward sweep over tick blocks with a gather through next_rec. A record that is still in flight when the rollout is
-full bootstraps its predecessor with its value (as PPO's last_values do) and is carried into rows [0, N) of the next
+full bootstraps its predecessor with its value (as PPO's last_values do) and is carried into the carry rows of the next
 rollout -- one record per env at most. A tick is fixed-shape, fixed-address device work with no host sync, and on a GPU
 it is captured once into a hipGraph (torch.cuda.CUDAGraph) and replayed: ~100 small launches become one.
 
@@ -62,7 +62,11 @@ class AsyncRollout:
         if max_ticks is None:                            # generous: 4x the ticks a full ready list would need, at least 64
             max_ticks = max(64, 4 * (self.target + self.C - 1) // self.C)
         self.max_ticks = int(max_ticks)
-        self.R = self.N + self.max_ticks * self.C        # records; row R is a dump row for masked scatters
+        # two record windows (carry rows + max_ticks tick blocks each), used by alternate rollouts, so that an update may
+        # still read rollout i while rollout i + 1 is being recorded; row R is a dump row for masked scatters
+        self.W = self.N + self.max_ticks * self.C
+        self.R = 2 * self.W
+        self.win = 1                                      # the first _begin() flips to window 0
         R1 = self.R + 1
         self.obs = th.zeros((R1,) + tuple(engine.obs_shape), dtype=th.uint8, device=dev)
         self.actions = th.zeros(R1, self.A, device=dev)
@@ -87,7 +91,7 @@ class AsyncRollout:
         self.ep_ret = th.zeros(self.N + 1, device=dev); self.ep_len = th.zeros(self.N + 1, device=dev)
         self.ep_ret_sum = th.zeros(1, device=dev); self.ep_len_sum = th.zeros(1, device=dev); self.ep_count = th.zeros(1, device=dev)
         self.substeps_total = th.zeros(1, dtype=th.int64, device=dev)          # physics.step() calls of the finished macro steps
-        self.base_t = th.full((1,), self.N, dtype=th.int64, device=dev)        # first record row of the current tick
+        self.base_t = th.full((1,), self.N, dtype=th.int64, device=dev)        # first record row of the current tick (set by _begin)
         self.obs_stage = th.zeros((self.C,) + tuple(engine.obs_shape), dtype=th.uint8, device=dev)
         import os
         if os.environ.get("GRIP_ASYNC_GRAPH") == "0":
@@ -256,21 +260,37 @@ class AsyncRollout:
             self.use_graph = False; self._graph = None
 
     # ------------------------------------------------------------------ rollout
+    @property
+    def carry0(self):
+        return self.win * self.W
+
+    @property
+    def tick0(self):
+        return self.win * self.W + self.N
+
+    def window_rows(self):
+        """Record rows of the current rollout: its carry rows, then the tick blocks written so far."""
+        return th.arange(self.carry0, self.tick0 + self.tick * self.C, device=self.dev)
+
     def _begin(self):
-        """Carry the in-flight decisions (one per env at most) into rows [0, N) and clear the rest."""
+        """Switch to the other record window, carry the in-flight decisions (one per env at most) into its first N rows and
+        clear the rest of it. The previous window is left untouched (an update may still be reading it)."""
         N = self.N
         infl = self.rec_of_env[:N]
         has = infl >= 0
         src = th.where(has, infl, self.R)
-        ob = self.obs[src]; ac = self.actions[src]; lp = self.log_probs[src]; va = self.values[src]      # gathers copy: aliasing-safe
-        self.obs[:N] = ob; self.actions[:N] = ac; self.log_probs[:N] = lp; self.values[:N] = va
-        self.is_rec.zero_(); self.completed.zero_(); self.next_rec.fill_(-1); self.prev_rec.fill_(-1); self.advantages.zero_(); self.rec_env.fill_(-1)
-        self.is_rec[:N] = has
+        ob = self.obs[src]; ac = self.actions[src]; lp = self.log_probs[src]; va = self.values[src]
+        self.win ^= 1
+        c0, w1 = self.carry0, self.carry0 + self.W
+        self.obs[c0:c0 + N] = ob; self.actions[c0:c0 + N] = ac; self.log_probs[c0:c0 + N] = lp; self.values[c0:c0 + N] = va
+        self.is_rec[c0:w1] = False; self.completed[c0:w1] = False; self.next_rec[c0:w1] = -1; self.prev_rec[c0:w1] = -1
+        self.advantages[c0:w1] = 0; self.rec_env[c0:w1] = -1
+        self.is_rec[c0:c0 + N] = has
         ar = th.arange(N, device=self.dev)
-        self.rec_env[:N] = th.where(has, ar, th.full_like(ar, -1))
-        self.rec_of_env[:N] = th.where(has, ar, th.full_like(ar, -1))
+        self.rec_env[c0:c0 + N] = th.where(has, ar, th.full_like(ar, -1))
+        self.rec_of_env[:N] = th.where(has, ar + c0, th.full_like(ar, -1))
         self.n_completed.zero_()
-        self.base_t.fill_(N)
+        self.base_t.fill_(self.tick0)
         self.tick = 0
 
     def collect(self, on_poll=None):
@@ -317,7 +337,7 @@ class AsyncRollout:
             return
         N, C, R = self.N, self.C, self.R
         g, gl = self.gamma, self.gamma * self.lam
-        blocks = [(0, N)] + [(N + k * C, N + (k + 1) * C) for k in range(self.tick)]
+        blocks = [(self.carry0, self.tick0)] + [(self.tick0 + k * C, self.tick0 + (k + 1) * C) for k in range(self.tick)]
         for lo, hi in reversed(blocks):
             nr = self.next_rec[lo:hi]
             comp = self.completed[lo:hi]
@@ -331,7 +351,8 @@ class AsyncRollout:
     def training_indices(self, generator=None):
         """Exactly `target` record ids (so that every rank runs the same number of minibatches): the completed records in
         time order, truncated; with replacement only if the tick budget ran out before the rollout filled."""
-        idx = (self.completed[:self.R] & self.is_rec[:self.R]).nonzero().flatten()
+        lo, hi = self.carry0, self.carry0 + self.W
+        idx = (self.completed[lo:hi] & self.is_rec[lo:hi]).nonzero().flatten() + lo
         if idx.numel() >= self.target:
             return idx[:self.target]
         if idx.numel() == 0:

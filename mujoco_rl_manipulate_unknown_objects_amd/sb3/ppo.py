@@ -63,11 +63,14 @@ class RolloutBuffer:
 class PPO:
     def __init__(self, policy, env, learning_rate=3e-4, n_steps=16, batch_size=4096, n_epochs=4, gamma=0.99, gae_lambda=0.95,
                  clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, policy_kwargs=None, verbose=0, tensorboard_log=None,
-                 device=None, seed=None, autocast_dtype=None, async_slice=0, async_capacity=None, async_budget_us=0):
+                 device=None, seed=None, autocast_dtype=None, async_slice=0, async_capacity=None, async_budget_us=0, overlap_update=False):
         """async_slice > 0 switches rollout collection to the time-sliced engine (sb3/async_rollout.py): every tick gives
         each env at most `async_slice` calls of physics.step(), at most `async_capacity` finished envs (default N/4) are
         rendered and decided per tick, and a rollout is n_steps * N completed transitions whichever envs they come from.
-        async_budget_us > 0 also caps a wavefront's slice by wall-clock time (include/grip_sim.h)."""
+        async_budget_us > 0 also caps a wavefront's slice by wall-clock time (include/grip_sim.h).
+        overlap_update (async, GPU only): the update of rollout i runs on a second stream WHILE rollout i + 1 is collected,
+        with a frozen copy of the policy (the parameters after update i - 1: one update of policy lag, as in asynchronous
+        PPO variants); the records of the two rollouts live in AsyncRollout's two windows."""
         self.env = env
         self.n_envs = getattr(env, "num_envs", 1)
         self.device = th.device(device) if device is not None else getattr(env, "device", th.device("cuda" if th.cuda.is_available() else "cpu"))
@@ -95,6 +98,13 @@ class PPO:
         obs_shape = env.observation_space["observation"].shape
         self.rollout_buffer = None if (async_slice and async_slice > 0) else RolloutBuffer(n_steps, self.n_envs, obs_shape, self.policy.action_dim, self.device)
         self._async = None
+        self.overlap_update = bool(overlap_update) and bool(async_slice and async_slice > 0) and self.device.type == "cuda"
+        self.policy_rollout = self.policy
+        if self.overlap_update:
+            import copy
+            self.policy_rollout = copy.deepcopy(self.policy).requires_grad_(False)
+            self._upd_stream = th.cuda.Stream(self.device)
+            self._ev_copy = None
         if async_slice and async_slice > 0:
             from .async_rollout import AsyncRollout, BatchEngineAdapter
             eng = env if hasattr(env, "advance") else BatchEngineAdapter(env, async_budget_us)
@@ -102,10 +112,10 @@ class PPO:
 
             def policy_fn(obs_rows):
                 with th.no_grad(), self._ac():
-                    return self.policy({"observation": obs_rows})
+                    return self.policy_rollout({"observation": obs_rows})
             def policy_parts_fn(obs_rows):
                 with th.no_grad(), self._ac():
-                    return self.policy.forward_parts({"observation": obs_rows})
+                    return self.policy_rollout.forward_parts({"observation": obs_rows})
             parts = policy_parts_fn if hasattr(self.policy, "forward_parts") else None
             self._async = AsyncRollout(eng, policy_fn, policy_parts_fn=parts, target=n_steps * self.n_envs, capacity=min(cap, self.n_envs), slice_len=async_slice,
                                        gamma=gamma, gae_lambda=gae_lambda, action_low=env.action_space.low, action_high=env.action_space.high)
@@ -127,6 +137,10 @@ class PPO:
 
     def collect_rollouts(self, callback=None):
         if self._async is not None:
+            if self.overlap_update and self._ev_copy is not None:
+                # rollout weights of this rollout are in place; in stream order this also means the update before the last
+                # one is done, i.e. the record window this rollout is about to overwrite is free
+                th.cuda.current_stream(self.device).wait_event(self._ev_copy)
             state = {"n": 0, "ok": True}
 
             def on_poll(done_n):
@@ -249,6 +263,30 @@ class PPO:
             src = (buf.obs.view((total,) + buf.obs.shape[2:]), buf.actions.view(total, -1), buf.log_probs.view(-1),
                    buf.advantages.view(-1), buf.returns.view(-1))
             sel = None
+        if not self.overlap_update:
+            return self._train_on(src, sel, total)
+        # overlapped: on the update stream, after the rollout's data is complete -- first hand the current parameters to the
+        # rollout copy (nobody is ticking: the next collect_rollouts waits for that copy), then update while it collects
+        main = th.cuda.current_stream(self.device)
+        ready = th.cuda.Event(); ready.record(main)
+        if sel is not None:
+            sel.record_stream(self._upd_stream)          # allocated on this stream, read by the other: keep the allocator off it
+            self._sel_in_flight = sel
+        with th.cuda.stream(self._upd_stream):
+            self._upd_stream.wait_event(ready)
+            with th.no_grad():
+                th._foreach_copy_(list(self.policy_rollout.parameters()), list(self.policy.parameters()))
+            ev = th.cuda.Event(); ev.record(self._upd_stream); self._ev_copy = ev
+            stats = self._train_on(src, sel, total)
+        return stats
+
+    def finish_updates(self):
+        """Wait (on the current stream) for an overlapped update still in flight."""
+        if self.overlap_update:
+            done = th.cuda.Event(); done.record(self._upd_stream)
+            th.cuda.current_stream(self.device).wait_event(done)
+
+    def _train_on(self, src, sel, total):
         bs = min(self.batch_size, total)
         stats = {}
         for _ in range(self.n_epochs):
@@ -279,6 +317,7 @@ class PPO:
             if self.verbose and it % log_interval == 0:
                 fps = self.num_timesteps / max(1e-9, time.time() - t0)
                 print(f"[ppo] iter {it} timesteps {self.num_timesteps} fps {fps:.0f} loss {float(self.logger.get('loss', 0)):.4f}")
+        self.finish_updates()
         if callback is not None:
             callback.on_training_end()
         return self
@@ -296,6 +335,7 @@ class PPO:
         return (a[0] if single else a), state
 
     def save(self, path):
+        self.finish_updates()
         if not path.endswith(".zip"):
             path = path + ".zip"
         os.makedirs(os.path.dirname(path) or ".", exist_ok=True)

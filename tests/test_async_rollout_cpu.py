@@ -92,7 +92,8 @@ def test_records_chain_rewards_and_gae_over_two_rollouts():
     for rollout in range(3):
         got = ro.collect()
         assert got >= 40
-        comp = (ro.completed[:ro.R] & ro.is_rec[:ro.R]).nonzero().flatten().tolist()
+        rows = ro.window_rows()
+        comp = rows[(ro.completed[rows] & ro.is_rec[rows])].tolist()
         assert len(comp) == got
         per_env = {}
         for r in comp:

@@ -127,8 +127,8 @@ def test_fused_recorder_and_graph_replay_match_tensor_op_bookkeeping(engine, tor
         for _ in range(2):
             n = ro.collect()
             torch.cuda.synchronize()
-            keep = ro.N + ro.tick * ro.C
-            res.append(dict(n=n, ticks=ro.tick, **{k: getattr(ro, k)[:keep].clone() for k in
+            keep = ro.window_rows()
+            res.append(dict(n=n, ticks=ro.tick, **{k: getattr(ro, k)[keep].clone() for k in
                             ("rewards", "dones", "next_rec", "completed", "is_rec", "rec_env", "actions", "log_probs", "values", "advantages", "returns", "obs")}))
         st = ro.stats(); sub = int(ro.substeps_total.item())
         env.close()
@@ -184,8 +184,9 @@ def test_intrinsic_reward_lockstep_and_async(engine, torch):
         ro = AsyncRollout(BatchEngineAdapter(env), policy, target=64, capacity=16, slice_len=24, gamma=0.99, gae_lambda=0.95,
                           action_low=[-1] * 6, action_high=[1] * 6, poll_every=2)
         ro.collect(); torch.cuda.synchronize()
-        keep = ro.N + ro.tick * ro.C
-        res = {k: getattr(ro, k)[:keep].clone().cpu() for k in ("rewards", "completed", "is_rec", "next_rec", "obs")}
+        keep = ro.window_rows()
+        res = {k: getattr(ro, k)[keep].clone().cpu() for k in ("rewards", "completed", "is_rec", "next_rec", "obs")}
+        res["next_rec"] = res["next_rec"] - ro.carry0          # window-relative ids
         env.close()
         return res
     base, nov = run(False), run(True)
@@ -222,8 +223,8 @@ def test_fused_gaussian_head_matches_tensor_ops(engine, torch):
         ro = AsyncRollout(BatchEngineAdapter(env), sampled, policy_parts_fn=parts if fused_head else None, target=96, capacity=16, slice_len=24,
                           gamma=0.99, gae_lambda=0.95, action_low=[-1] * 6, action_high=[1] * 6, poll_every=2, use_graph=False, fused=True)
         ro.collect(); torch.cuda.synchronize()
-        keep = ro.N + ro.tick * ro.C
-        res = {k: getattr(ro, k)[:keep].clone() for k in ("actions", "log_probs", "values", "is_rec", "rewards", "completed")}
+        keep = ro.window_rows()
+        res = {k: getattr(ro, k)[keep].clone() for k in ("actions", "log_probs", "values", "is_rec", "rewards", "completed")}
         env.close()
         return res
     a, b = run(False), run(True)

@@ -5,9 +5,10 @@ from mujoco_rl_manipulate_unknown_objects_amd.sb3 import PPO, GpuVecEnv
 from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
 obj = sys.argv[1] if len(sys.argv) > 1 else "sand_ball"
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 60
+overlap = len(sys.argv) > 3 and sys.argv[3] == "overlap"
 cfg = default_config(sim_env=f"/xmls/{obj}_env.xml", time_horizon=50)
 env = GpuVecEnv(BatchedRobotEnv(cfg, n_envs=4096, device_index=0, auto_reset=True))
-model = PPO("MultiInputPolicy", env, n_steps=8, batch_size=4096, n_epochs=2, seed=0, async_slice=96, async_capacity=1024, async_budget_us=2000, ent_coef=0.0,
+model = PPO("MultiInputPolicy", env, n_steps=8, batch_size=4096, n_epochs=2, seed=0, async_slice=96, async_capacity=1024, async_budget_us=2000, ent_coef=0.0, overlap_update=overlap,
             policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]))
 ar = model._async
 t0 = time.time(); it = 0; last = (0.0, 0.0, 0.0)
@@ -19,4 +20,5 @@ while time.time() - t0 < secs:
         print(f"iter {it:4d} t {time.time() - t0:6.1f}s timesteps {model.num_timesteps:9d} episodes {int(c):7d} ep_rew_mean(last window) {(r - last[1]) / dc:8.4f} "
               f"ep_len {(l - last[2]) / dc:6.1f} loss {float(st['loss']):9.4f} value_loss {float(st['value_loss']):9.4f}", flush=True)
         last = (c, r, l)
-print("fps", model.num_timesteps / (time.time() - t0))
+model.finish_updates()
+print("fps", model.num_timesteps / (time.time() - t0), "overlap_update", overlap)
