@@ -145,7 +145,29 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # priming, before the W warm-up steps and never timed: one full rollout + update, so that MIOpen's algorithm search and
+    # the hipGraph captures (tick, minibatch update) are behind us whatever W and K are. The policy and optimiser are put
+    # back afterwards (in place: the graphs keep their addresses), so the timed steps see the same training progress as
+    # without priming; only the envs have moved on.
+    snap_p = [p.detach().clone() for p in model.policy.parameters()]
+    run(a.rollout)
+    if hasattr(model, "finish_updates"):
+        model.finish_updates()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        for p, q in zip(model.policy.parameters(), snap_p):
+            p.copy_(q)
+        for st in model.optimizer.state.values():
+            for v in st.values():
+                if torch.is_tensor(v):
+                    v.zero_()
+        if getattr(model, "overlap_update", False):
+            for p, q in zip(model.policy_rollout.parameters(), snap_p):
+                p.copy_(q)
+    del snap_p
     run(a.warmup)
+    if hasattr(model, "finish_updates"):
+        model.finish_updates()
     sync()
     batch.kernel_time(reset=True)
     sub_before = None
