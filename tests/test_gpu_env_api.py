@@ -106,3 +106,29 @@ def test_overlapped_update_keeps_one_update_of_lag(torch):
         assert not torch.equal(history[i + 1], history[i]) and bool(torch.isfinite(history[i + 1]).all())
     assert m.num_timesteps >= 4 * 128
     env.close()
+
+
+def test_eval_agent_loop_shape(torch, tmp_path):
+    """eval_agent.py:28-70 of the reference against this package: SAC.load(best_model, env=env, custom_objects=...), then the
+    deterministic predict / step loop reading the info keys it accumulates, and render(mode='rgb_array')."""
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import RobotEnv, default_config
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3 import SAC, DummyVecEnv
+    from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
+    kw = dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256])
+    env = RobotEnv(default_config(sim_env="/xmls/sugar_cube_env.xml", time_horizon=4))
+    SAC("MultiInputPolicy", DummyVecEnv([lambda: env]), policy_kwargs=kw, buffer_size=8, device="cuda").save(str(tmp_path / "best_model"))
+    model = SAC.load(str(tmp_path / "best_model"), env=env, custom_objects={"policy_kwargs": kw})
+    total_step, line_step, robot_step, obj_step, frames = [], [], [], [], []
+    obs = env.reset()
+    for i in range(10):
+        action, _states = model.predict(obs, deterministic=True)
+        obs, rewards, dones, info = env.step(action)
+        total_step.append(info["total_distance"]); line_step.append(info["line_distance"])
+        robot_step.append(info["gripper_position"].copy()); obj_step.append(info["object_position"].copy())
+        frames.append(env.render(mode='rgb_array'))
+        if dones:
+            break
+    assert i == 3 and dones and info["status"].name == "TIME_LIMIT"           # time_horizon = 4
+    assert frames[0].shape == (64, 64, 3) and frames[0].dtype == np.uint8
+    assert np.isfinite(sum(total_step)) and np.isfinite(sum(line_step)) and robot_step[0].shape == (3,) and obj_step[0].shape == (3,)
+    env.close()
