@@ -132,3 +132,28 @@ def test_eval_agent_loop_shape(torch, tmp_path):
     assert frames[0].shape == (64, 64, 3) and frames[0].dtype == np.uint8
     assert np.isfinite(sum(total_step)) and np.isfinite(sum(line_step)) and robot_step[0].shape == (3,) and obj_step[0].shape == (3,)
     env.close()
+
+
+@pytest.mark.parametrize("extra", [[], ["--lockstep", "--no-cpu-baseline"], ["--overlap-update", "--no-cpu-baseline"]])
+def test_bench_json_contract(torch, extra):
+    """bench.py prints exactly one JSON line with the driver's keys, the roofline object and (N = 1) the cpu baseline."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--envs", "256", "--steps", "4", "--warmup", "2", "--rollout", "2", "--minibatch", "256",
+           "--capacity", "64", "--object", "sand_ball"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["value"] > 0
+    assert "workload" in d["config"] and "model" not in d["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-12
+    if "--no-cpu-baseline" not in extra:
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in d["cpu_baseline"], k
