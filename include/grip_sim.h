@@ -65,7 +65,8 @@ typedef struct {
     float *object_position;   /* [N,3] :238 */
     float *init_obj_pos;      /* [N,3] :87 */
     int32_t *n_substeps;      /* [N]   physics.step() calls this macro step */
-    int32_t *fault;           /* [N]   bit0 NaN state, bit1 contact-list overflow, bit2 solver hit iteration cap */
+    int32_t *fault;           /* [N]   bit0 diverged (NaN / runaway state: the episode ends as FAIL with reward 0 and the env is
+                               *       reset -- dm_control's PhysicsError), bit1 contact-list overflow, bit2 solver hit iteration cap */
 } GripStepOut;
 
 const char *grip_last_error(void);

@@ -495,6 +495,11 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
                 float line;
                 float reward = agent_reward(init_obj, fo, cfg, gripper_open, s.ctrl[5], s.ctrl[6], grasped, line);
                 if (cfg.her_buffer) { float gx = dgx - fo.x, gy = dgy - fo.y; reward += 1.0f / expf(sqrtf(gx * gx + gy * gy)); }
+                // a diverged env (NaN / runaway state, fault bit 0) is what dm_control reports as PhysicsError: the episode ends as a
+                // failure with zero reward and finite outputs, and the state is reset even without auto_reset -- one bad env
+                // must not poison a batch of thousands through a NaN reward
+                const bool diverged = (fault & 1) != 0 || !(reward == reward) || !(dxy == dxy);
+                if (diverged) { fault |= 1; status = 1; reward = 0.f; line = 0.f; fo = v3(0, 0, 0); fe = v3(0, 0, 0); dgx = cfg.dir_x; dgy = cfg.dir_y; init_obj = v3(0, 0, 0); }
                 int done;
                 if (status != 0) done = 1;
                 else if (episode_step == cfg.time_horizon - 1) { done = 1; status = 2; }
@@ -518,7 +523,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
                     if (out.fault) out.fault[e] = fault;
                 }
                 float agx = fo.x, agy = fo.y;
-                if (done && cfg.auto_reset) {
+                if (done && (cfg.auto_reset || diverged)) {
                     reset_lane(m, s); episode_step = 0; status = 0; gripper_open = 1;
                     pg = (int)reset_info[0]; ph = (int)reset_info[1]; agx = reset_info[2]; agy = reset_info[3]; dgx = cfg.dir_x; dgy = cfg.dir_y;
                 }

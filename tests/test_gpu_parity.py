@@ -369,3 +369,26 @@ def test_ragged_batch_sizes(engine, orc, torch, n):
             break
     assert seen.all()
     b.close(); b2.close()
+
+
+def test_diverged_env_ends_its_episode_and_is_reset(engine, torch):
+    """An env whose state became NaN (what dm_control raises PhysicsError for) ends its episode as a failure with zero reward and
+    finite outputs, reports fault bit 0 and is reset; its neighbours are untouched."""
+    n = 32
+    b = engine.Batch("sand_ball", n); ref = engine.Batch("sand_ball", n)
+    qpos, qvel, ctrl, warm = b.get_state()
+    qvel[5, 9] = np.nan; qpos[17, 2] = np.inf
+    b.set_state(qpos, qvel, ctrl, warm)
+    rng = np.random.default_rng(0)
+    acts = torch.from_numpy(rng.uniform(-1, 1, (n, 6)).astype(np.float32)).cuda()
+    out = {k: v.clone() for k, v in b.step(acts).items()}; oref = ref.step(acts)
+    torch.cuda.synchronize()
+    bad = torch.tensor([5, 17], device="cuda"); good = torch.tensor([i for i in range(n) if i not in (5, 17)], device="cuda")
+    assert bool((out["fault"][bad] & 1).all()) and bool((out["done"][bad] == 1).all()) and bool((out["status"][bad] == 1).all())
+    assert bool((out["reward"][bad] == 0).all())
+    for k, v in out.items():
+        assert bool(torch.isfinite(v.float()).all()), k
+        assert torch.equal(v[good], oref[k][good]), k
+    q2, v2, _, _ = b.get_state(); q0, v0, _, _ = engine.Batch("sand_ball", 1).get_state()
+    assert np.array_equal(q2[5], q0[0]) and np.array_equal(q2[17], q0[0]) and np.isfinite(q2).all() and np.isfinite(v2).all()
+    b.close(); ref.close()
