@@ -17,7 +17,9 @@ while time.time() - t0 < secs:
     if it % 5 == 0:
         c, r, l = float(ar.ep_count.item()), float(ar.ep_ret_sum.item()), float(ar.ep_len_sum.item())
         dc = max(1.0, c - last[0])
-        print(f"iter {it:4d} t {time.time() - t0:6.1f}s timesteps {model.num_timesteps:9d} episodes {int(c):7d} ep_rew_mean(last window) {(r - last[1]) / dc:8.4f} "
+        f = env.env.batch.out["fault"]
+        faults = [int((f & b).ne(0).sum()) for b in (1, 2, 4)]
+        print(f"iter {it:4d} faults(div/ovf/cap) {faults} t {time.time() - t0:6.1f}s timesteps {model.num_timesteps:9d} episodes {int(c):7d} ep_rew_mean(last window) {(r - last[1]) / dc:8.4f} "
               f"ep_len {(l - last[2]) / dc:6.1f} loss {float(st['loss']):9.4f} value_loss {float(st['value_loss']):9.4f}", flush=True)
         last = (c, r, l)
 model.finish_updates()
