@@ -13,7 +13,7 @@ g = torch.Generator(device="cuda"); g.manual_seed(0)
 out = (C.c_ulonglong * 20)()
 def ticks(k):
     for _ in range(k):
-        b.advance(torch.randn(cap, 6, device="cuda", generator=g).clamp(-1, 1), 96, lst, cnt, 3000)
+        b.advance(torch.randn(cap, 6, device="cuda", generator=g).clamp(-1, 1), 96, lst, cnt, 2000)
 ticks(150); engine.lib().grip_debug_stamps(out)
 ticks(100); engine.lib().grip_debug_stamps(out)
 names = ["kinematics", "collide", "mass+bias+qs", "make_constraints", "solve: other (bookkeeping)", "integrate", "solve: constraint pass", "solve: tri-solves+gather", "solve: assemble rows", "solve: cholesky", "solve: line search"]
