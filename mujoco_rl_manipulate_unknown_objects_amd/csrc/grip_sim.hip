@@ -364,7 +364,7 @@ DEVI float agent_reward(V3 o0, V3 o1, const DevConfig &c, int gripper_open, floa
 }
 
 enum { PH_MOVE = 0, PH_RETURN, PH_OPEN, PH_CLOSE, PH_FINAL, PH_DONE };
-#define CP_CLASSES 8        // work-order classes of k_compact: cost 0..6 of running envs, 7 = idle
+#define CP_CLASSES 16       // work-order classes of k_compact: cost 0..14 of running envs, 15 = idle
 
 // ------------------------------------------------------------------------------------------------
 // kernels: 256-thread workgroups = 16 environments x 16 cooperating lanes (grip_physics.h)
@@ -453,7 +453,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
 #pragma unroll
         for (int i = 0; i < 6; i++) act[i] = i < adim ? actions[arow * adim + i] : 0.f;
     }
-    int budget = sliced ? slice : 0x7fffffff, last_iters = 0;
+    int budget = sliced ? slice : 0x7fffffff, last_iters = 0, sum_iters = 0, nsub_slice = 0;
     PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1;   // collide()'s per-lane memory of its pair's separating direction
     // the wall-clock budget runs from the moment the FIRST workgroup of the launch started (k_compact clears the stamp), so
     // that a workgroup that was placed late -- other streams' kernels were using its CU -- does not stretch the launch
@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
                     if (phase == PH_CLOSE) grasped = check_grasp(cx, con, ncon);       // robot_env.py:155, before the step
                 }
                 physics_advance(m, cx, s, xfrc_z, k, con, ncon, fault, stm, &last_iters);
-                nsub++; cnt++; budget--;
+                nsub++; cnt++; budget--; sum_iters += last_iters; nsub_slice++;
 #ifdef GRIP_STAMPS
                 stm.acc[11] += 1;               // env-substeps of this lane (lane 0 of each wave is reported)
 #endif
@@ -605,7 +605,8 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
         // cost estimate of this env's next physics.step(), in units of roughly half a plain step: Newton iterations of the
         // last solve plus 1.5 per hull-hull contact (MPR refinement); k_compact sorts the work order by it
         int hv = __popc(group_bits(__ballot(cx.sub < ncon && con.g1 != 0), cx.lane));
-        if (writer && nsub > 0) mc.heavy[e] = min(CP_CLASSES - 2, last_iters + (3 * hv + 1) / 2);
+        // (twice the mean Newton iteration count of this slice: single steps alternate between 1 and 2 iterations)
+        if (writer && nsub_slice > 0) mc.heavy[e] = min(CP_CLASSES - 2, (2 * sum_iters + nsub_slice / 2) / nsub_slice + 3 * min(hv, 3));
     }
     if (sliced && writer && phase != PH_DONE) {             // out of budget mid-step: suspend
         st_state(st, e, s);
