@@ -10,7 +10,16 @@
 // the sensor pad scalars pad[0,0] = check_grasp, pad[0,1] = pheromone_level (robot_env.py:281-283)
 // that the step kernel left in pad_grasp / pad_pher.
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include "grip_device.h"
+
+int grip_fail(const char *msg);                     // grip_sim.hip: records the message grip_last_error() returns, yields -1
+static int launch_status(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return 0;
+    char buf[256]; snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    return grip_fail(buf);
+}
 
 #define RW 64
 #define RH 64
@@ -227,7 +236,7 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
 extern "C" int grip_render_launch(const DevModel *d_model, DevConfig cfg, const float *qpos, const int *pad_grasp, const int *pad_pher, int n,
                                   const int *list, const int *count, int nblocks, int nplanes, uint8_t *obs, uint8_t *obs2, const long long *row2, hipStream_t s) {
     hipLaunchKernelGGL(k_observe, dim3(nblocks), dim3(RTHREADS), (size_t)nplanes * sizeof(float4), s, d_model, cfg, qpos, pad_grasp, pad_pher, n, list, count, obs, obs2, row2);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return launch_status("grip_render_launch");
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -267,10 +276,10 @@ __global__ void __launch_bounds__(256) k_intrinsic_reward(const uint8_t *old_obs
 
 extern "C" int grip_intrinsic_reward(const uint8_t *old_obs_dev, const int64_t *old_rows_dev, const uint8_t *new_obs_dev, const int32_t *list_dev,
                                      const int32_t *count_dev, int n_pairs, int channels, int full_observation, float *reward_dev, void *stream) {
-    if (!old_obs_dev || !new_obs_dev || !reward_dev || n_pairs <= 0 || (channels != 4 && channels != 5)) return -1;
+    if (!old_obs_dev || !new_obs_dev || !reward_dev || n_pairs <= 0 || (channels != 4 && channels != 5)) return grip_fail("grip_intrinsic_reward: bad argument");
     hipLaunchKernelGGL(k_intrinsic_reward, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, old_obs_dev, (const long long *)old_rows_dev, new_obs_dev,
                        list_dev, count_dev, channels, full_observation, reward_dev);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return launch_status("grip_intrinsic_reward");
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -295,8 +304,8 @@ __global__ void __launch_bounds__(256) k_obs_preprocess(const uint8_t *obs, int 
 }
 
 extern "C" int grip_obs_preprocess(const uint8_t *obs_dev, int n, int channels, float *img_nhwc_dev, float *other_dev, void *stream) {
-    if (!obs_dev || !img_nhwc_dev || !other_dev || n <= 0 || (channels != 4 && channels != 5)) return -1;
+    if (!obs_dev || !img_nhwc_dev || !other_dev || n <= 0 || (channels != 4 && channels != 5)) return grip_fail("grip_obs_preprocess: bad argument");
     size_t total = (size_t)n * RPIX;
     hipLaunchKernelGGL(k_obs_preprocess, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs_dev, n, channels, img_nhwc_dev, other_dev);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return launch_status("grip_obs_preprocess");
 }

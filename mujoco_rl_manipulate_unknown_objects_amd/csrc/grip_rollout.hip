@@ -8,7 +8,16 @@
 // buffers). Pure index/scalar work, HBM-resident, one thread per listed env / per env.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdio>
 #include "../../include/grip_sim.h"
+
+int grip_fail(const char *msg);                     // grip_sim.hip: records the message grip_last_error() returns, yields -1
+static int launch_status(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return 0;
+    char buf[256]; snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    return grip_fail(buf);
+}
 
 __global__ void k_rollout_tick(GripRolloutTick a) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -49,10 +58,10 @@ __global__ void k_rollout_tick(GripRolloutTick a) {
 }
 
 extern "C" int grip_rollout_tick(const GripRolloutTick *args, void *stream) {
-    if (!args || args->capacity <= 0) return -1;
+    if (!args || args->capacity <= 0) return grip_fail("grip_rollout_tick: bad argument");
     int threads = 256, blocks = (args->capacity + threads - 1) / threads;
     hipLaunchKernelGGL(k_rollout_tick, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, *args);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return launch_status("grip_rollout_tick");
 }
 
 // One thread per env: from the env's open record (not completed: it only supplies the bootstrap value) back along
@@ -77,9 +86,9 @@ __global__ void k_rollout_gae(int n_envs, const long long *rec_of_env, const lon
 
 extern "C" int grip_rollout_gae(int n_envs, const int64_t *rec_of_env, const int64_t *prev_rec, const float *rewards, const float *dones,
                                 const float *values, float gamma, float gae_lambda, float *advantages, float *returns, void *stream) {
-    if (n_envs <= 0 || !rec_of_env || !prev_rec || !rewards || !dones || !values || !advantages || !returns) return -1;
+    if (n_envs <= 0 || !rec_of_env || !prev_rec || !rewards || !dones || !values || !advantages || !returns) return grip_fail("grip_rollout_gae: bad argument");
     int threads = 128, blocks = (n_envs + threads - 1) / threads;
     hipLaunchKernelGGL(k_rollout_gae, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, n_envs, (const long long *)rec_of_env, (const long long *)prev_rec,
                        rewards, dones, values, gamma, gae_lambda, advantages, returns);
-    return hipGetLastError() == hipSuccess ? 0 : -1;
+    return launch_status("grip_rollout_gae");
 }

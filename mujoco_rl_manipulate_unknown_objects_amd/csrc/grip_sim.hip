@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -24,6 +25,7 @@
 static thread_local std::string g_err;
 extern "C" const char *grip_last_error(void) { return g_err.c_str(); }
 static int fail(const std::string &s) { g_err = s; return -1; }
+int grip_fail(const char *msg) { return fail(msg); }      // for the other translation units of the library
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 // ------------------------------------------------------------------------------------------------
@@ -35,16 +37,20 @@ struct Blob {
     bool load(const char *path) {
         FILE *f = fopen(path, "rb"); if (!f) return false;
         fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+        if (n < 12) { fclose(f); return false; }
         buf.resize(n); bool ok = fread(buf.data(), 1, n, f) == (size_t)n; fclose(f);
-        if (!ok || n < 12 || memcmp(buf.data(), "GRPM", 4) != 0) return false;
+        if (!ok || memcmp(buf.data(), "GRPM", 4) != 0) return false;
         unsigned cnt; memcpy(&cnt, buf.data() + 8, 4);
         size_t off = 12;
         for (unsigned i = 0; i < cnt; i++) {
             if (off + 48 > buf.size()) return false;
             Entry e; char nm[25] = {0}; memcpy(nm, buf.data() + off, 24); e.name = nm;
             memcpy(&e.dtype, buf.data() + off + 24, 4); memcpy(&e.ndim, buf.data() + off + 28, 4); memcpy(e.dims, buf.data() + off + 32, 16);
+            if (e.ndim > 4 || e.dtype > 1) return false;
             off += 48; e.off = off; e.count = 1; for (unsigned k = 0; k < e.ndim; k++) e.count *= e.dims[k];
-            size_t nb = e.count * (e.dtype == 0 ? 8 : 4); off += nb + ((8 - nb % 8) % 8);
+            size_t nb = e.count * (e.dtype == 0 ? 8 : 4);
+            if (nb > buf.size() - off) return false;                     // truncated or corrupt entry
+            off += nb + ((8 - nb % 8) % 8);
             entries.push_back(e);
         }
         return true;
@@ -766,27 +772,38 @@ static StepOutDev to_dev(const GripStepOut *o) {
 static MacroCtx macro_ctx(GripBatch *b) { MacroCtx c; c.ints = b->mc_ints; c.flts = b->mc_flts; c.astate = b->mc_astate; c.slot = b->mc_slot; c.heavy = b->mc_heavy; c.tick = b->mc_tick; c.gen = b->mc_gen; c.t0 = b->mc_t0; return c; }
 static int grid_of(const GripBatch *b) { return (b->n + EPB - 1) / EPB; }
 
-static int ensure_lds_attr() {
-    static bool done = false;
-    if (done) return 0;
+static int ensure_lds_attr(int device) {      // function attributes are per device
+    static std::mutex mu; static std::vector<char> set_on;
+    std::lock_guard<std::mutex> lock(mu);
+    if (device >= 0 && (size_t)device < set_on.size() && set_on[device]) return 0;
     HIPCHK(hipFuncSetAttribute((const void *)k_reset, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)k_macro_step, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)k_substep, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)k_debug_forward, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES));
     HIPCHK(hipFuncSetAttribute((const void *)k_target_pose, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES));
-    done = true;
+    if (device >= 0) { if (set_on.size() <= (size_t)device) set_on.resize(device + 1, 0); set_on[device] = 1; }
     return 0;
 }
 
+static int batch_build(GripBatch *b, const GripModel *m);
 extern "C" int grip_batch_create(const GripModel *m, int n_envs, int device_id, GripBatch **out) {
     if (!m || n_envs <= 0 || !out) return fail("grip_batch_create: bad arguments");
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (ndev <= 0) return fail("grip_batch_create: no HIP device (this library has no CPU fallback)");
+    if (device_id < 0 || device_id >= ndev) return fail("grip_batch_create: device_id out of range");
     HIPCHK(hipSetDevice(device_id));
-    if (ensure_lds_attr()) return -1;
+    if (ensure_lds_attr(device_id)) return -1;
     GripBatch *b = new GripBatch(); b->n = n_envs; b->device = device_id;
-    size_t N = (size_t)n_envs;
+    if (batch_build(b, m) || grip_batch_reset(b, nullptr, nullptr, nullptr)) {      // g_err is set; release what was allocated
+        std::string why = g_err; grip_batch_destroy(b); g_err = why; return -1;
+    }
+    *out = b;
+    return 0;
+}
+
+static int batch_build(GripBatch *b, const GripModel *m) {
+    size_t N = (size_t)b->n;
     HIPCHK(hipMalloc(&b->d_hull, m->hull_blob.size() * sizeof(unsigned)));
     HIPCHK(hipMemcpy(b->d_hull, m->hull_blob.data(), m->hull_blob.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     b->lds_bytes = ((size_t)LDS_ENV_BASE(m->hull_blob.size()) + (size_t)EPB * ENV_FLOATS) * sizeof(float);
@@ -820,10 +837,9 @@ extern "C" int grip_batch_create(const GripModel *m, int n_envs, int device_id, 
     b->cfg.auto_reset = 0; b->cfg.max_translation = 0.05f; b->cfg.max_rotation = 0.15f; b->cfg.pos_tolerance = 0.002f;
     b->cfg.grasp_tolerance = 0.03f; b->cfg.dir_x = 1.f; b->cfg.dir_y = 0.f;
     b->xfrc_z = -(0.438f * m->host.gravity_z);      // robot_env.py:64-65, constant verbatim
-    b->ev0.resize(EV_RING); b->ev1.resize(EV_RING);
+    b->ev0.assign(EV_RING, nullptr); b->ev1.assign(EV_RING, nullptr);
     for (int i = 0; i < EV_RING; i++) { HIPCHK(hipEventCreate(&b->ev0[i])); HIPCHK(hipEventCreate(&b->ev1[i])); }
-    *out = b;
-    return grip_batch_reset(b, nullptr, nullptr, nullptr);
+    return 0;
 }
 
 extern "C" void grip_batch_destroy(GripBatch *b) {
@@ -834,8 +850,8 @@ extern "C" void grip_batch_destroy(GripBatch *b) {
                     b->gripper_open, b->pad_grasp, b->pad_pher, b->reset_info, b->scratch, b->mc_ints, b->mc_flts, b->mc_astate,
                     b->mc_slot, b->mc_order, b->mc_heavy, b->mc_tick, b->mc_gen, b->mc_t0};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    for (auto &e : b->ev0) (void)hipEventDestroy(e);
-    for (auto &e : b->ev1) (void)hipEventDestroy(e);
+    for (auto &e : b->ev0) if (e) (void)hipEventDestroy(e);
+    for (auto &e : b->ev1) if (e) (void)hipEventDestroy(e);
     delete b;
 }
 
@@ -927,6 +943,13 @@ extern "C" int grip_batch_substep(GripBatch *b, int k, void *stream) {
     return 0;
 }
 
+struct DevBuf {      // device allocation released on every return path
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+    template <class T> T *as() const { return (T *)p; }
+};
+
 static int xfer_field(GripBatch *b, float *soa, float *user, int width, bool to_user, int host_or_dev, hipStream_t s) {
     if (!user) return 0;
     size_t cnt = (size_t)width * b->n;
@@ -988,10 +1011,12 @@ extern "C" int grip_batch_debug_forward(GripBatch *b, int32_t *ncon, float *con,
     if (!b || !ncon || !con || !xpos || !qacc || !qacc_smooth || !M || !bias) return fail("grip_batch_debug_forward: null argument");
     HIPCHK(hipSetDevice(b->device));
     hipStream_t s = (hipStream_t)stream; size_t N = (size_t)b->n;
-    int *d_ncon; float *d_con, *d_xpos, *d_qacc, *d_qs, *d_M, *d_bias;
-    HIPCHK(hipMalloc(&d_ncon, N * sizeof(int))); HIPCHK(hipMalloc(&d_con, N * G_MAXC * 10 * sizeof(float))); HIPCHK(hipMalloc(&d_xpos, N * 24 * sizeof(float)));
-    HIPCHK(hipMalloc(&d_qacc, N * 13 * sizeof(float))); HIPCHK(hipMalloc(&d_qs, N * 13 * sizeof(float))); HIPCHK(hipMalloc(&d_M, N * 169 * sizeof(float)));
-    HIPCHK(hipMalloc(&d_bias, N * 13 * sizeof(float)));
+    DevBuf b_ncon, b_con, b_xpos, b_qacc, b_qs, b_M, b_bias;
+    HIPCHK(b_ncon.alloc(N * sizeof(int))); HIPCHK(b_con.alloc(N * G_MAXC * 10 * sizeof(float))); HIPCHK(b_xpos.alloc(N * 24 * sizeof(float)));
+    HIPCHK(b_qacc.alloc(N * 13 * sizeof(float))); HIPCHK(b_qs.alloc(N * 13 * sizeof(float))); HIPCHK(b_M.alloc(N * 169 * sizeof(float)));
+    HIPCHK(b_bias.alloc(N * 13 * sizeof(float)));
+    int *d_ncon = b_ncon.as<int>(); float *d_con = b_con.as<float>(), *d_xpos = b_xpos.as<float>(), *d_qacc = b_qacc.as<float>(),
+          *d_qs = b_qs.as<float>(), *d_M = b_M.as<float>(), *d_bias = b_bias.as<float>();
     hipLaunchKernelGGL(k_debug_forward, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, s, b->hmodel, state_ptrs(b), b->xfrc_z, getenv("GRIP_DEBUG_H") ? 1 : 0, d_ncon, d_con, d_xpos, d_qacc, d_qs, d_M, d_bias);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(ncon, d_ncon, N * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1002,7 +1027,6 @@ extern "C" int grip_batch_debug_forward(GripBatch *b, int32_t *ncon, float *con,
     HIPCHK(hipMemcpyAsync(M, d_M, N * 169 * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(bias, d_bias, N * 13 * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    (void)hipFree(d_ncon); (void)hipFree(d_con); (void)hipFree(d_xpos); (void)hipFree(d_qacc); (void)hipFree(d_qs); (void)hipFree(d_M); (void)hipFree(d_bias);
     return 0;
 }
 
@@ -1010,12 +1034,11 @@ extern "C" int grip_batch_target_pose(GripBatch *b, const float *actions_dev, fl
     if (!b || !actions_dev || !target_qpos_host) return fail("grip_batch_target_pose: null argument");
     HIPCHK(hipSetDevice(b->device));
     hipStream_t s = (hipStream_t)stream; size_t N = (size_t)b->n;
-    float *d_t; HIPCHK(hipMalloc(&d_t, N * 5 * sizeof(float)));
+    DevBuf b_t; HIPCHK(b_t.alloc(N * 5 * sizeof(float))); float *d_t = b_t.as<float>();
     hipLaunchKernelGGL(k_target_pose, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, s, b->hmodel, b->cfg, state_ptrs(b), actions_dev, d_t);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(target_qpos_host, d_t, N * 5 * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    (void)hipFree(d_t);
     return 0;
 }
 

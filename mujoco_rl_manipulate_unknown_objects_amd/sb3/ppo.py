@@ -93,7 +93,10 @@ class PPO:
         # on a GPU the minibatch update is captured into hipGraphs (forward+backward | gradient all-reduce | clip+Adam), which
         # needs the optimiser's step counter on the device
         self.graph_update = self.device.type == "cuda"
-        self.optimizer = th.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5, capturable=self.graph_update)
+        # on a GPU: the fused multi-tensor Adam (one kernel per step; the foreach form spends ~45 small launches per step on
+        # dividing every parameter-shaped tensor by 0-dim bias corrections), capturable so that it can sit in the update graph
+        self.optimizer = th.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5, capturable=self.graph_update,
+                                       fused=True if self.graph_update else None)
         self._upd = None
         obs_shape = env.observation_space["observation"].shape
         self.rollout_buffer = None if (async_slice and async_slice > 0) else RolloutBuffer(n_steps, self.n_envs, obs_shape, self.policy.action_dim, self.device)
