@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ppo", action="store_true", help="diagnostic: rollout only (INVALID as a headline number)")
     ap.add_argument("--lockstep", action="store_true", help="classic vector-env schedule instead of asynchronous time slices")
+    ap.add_argument("--mixed", action="store_true", help="BASELINE.json configs[3]: {acorn, sand_ball, sugar_cube, bread_crumb} x direction {0, 45}, "
+                                                         "--envs / 8 each, sorted by group (lock-step; not the headline workload)")
     ap.add_argument("--slice", type=int, default=96, help="physics.step() calls per env per tick (async schedule)")
     ap.add_argument("--capacity", type=int, default=1024, help="finished envs decided per tick (async schedule)")
     ap.add_argument("--policy-dtype", choices=["f32", "bf16"], default="f32", help="autocast dtype of the policy / PPO update (physics is always f32)")
@@ -80,6 +82,11 @@ def main():
     ap.add_argument("--pipeline", action="store_true", help="decide for tick t on a side stream while tick t+1 advances (lag 2)")
     ap.add_argument("--budget-us", type=int, default=2000, help="wall-clock cap of a wavefront's slice in microseconds (async schedule; 0 = none)")
     a = ap.parse_args()
+    if a.mixed:
+        a.lockstep = True; a.no_cpu_baseline = True
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # one hardware queue per group (read when the HIP runtime starts; default 4)
+        if a.envs % 8:
+            raise SystemExit("--mixed needs --envs divisible by 8")
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus:
@@ -97,12 +104,15 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import BatchedRobotEnv, default_config
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import BatchedRobotEnv, MixedBatchedRobotEnv, default_config
     from mujoco_rl_manipulate_unknown_objects_amd.sb3 import PPO, GpuVecEnv
     from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
 
     cfg = default_config(sim_env=f"/xmls/{a.object}_env.xml", direction=a.direction)
-    env = GpuVecEnv(BatchedRobotEnv(cfg, n_envs=a.envs, device_index=local, auto_reset=True))
+    if a.mixed:
+        env = GpuVecEnv(MixedBatchedRobotEnv(cfg, envs_per_group=a.envs // 8, device_index=local, auto_reset=True))
+    else:
+        env = GpuVecEnv(BatchedRobotEnv(cfg, n_envs=a.envs, device_index=local, auto_reset=True))
     model = PPO("MultiInputPolicy", env, n_steps=a.rollout, batch_size=a.minibatch, n_epochs=a.epochs, seed=1234 + rank,
                 policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]),
                 async_slice=0 if a.lockstep else a.slice, async_capacity=min(a.capacity, a.envs), async_budget_us=a.budget_us,
@@ -206,11 +216,12 @@ def main():
                  f"asynchronous time slices (<= {a.slice} physics steps and <= {a.budget_us} us per wavefront and tick, {min(a.capacity, a.envs)} decisions/tick)" + ("; PPO update overlapped with the next rollout (policy lag 1)" if a.overlap_update else ""))
         achieved = macro_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
-            "metric": "env-steps/sec (whole node), acorn_env 4096 envs/GPU", "value": value, "unit": "env-steps/s",
+            "metric": "env-steps/sec (whole node), " + ("mixed objects" if a.mixed else f"{a.object}_env") + f" {a.envs} envs/GPU", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.policy_dtype == "f32" else "f32 physics / bf16 policy",
             "data": "synthetic (deterministic reset state, actions sampled from the randomly initialised PPO policy)",
-            "config": {"workload": f"{a.object}_env ({'stand-in hull; ' if a.object == 'acorn' else ''}direction {a.direction}), "
+            "config": {"workload": ("mixed {acorn (stand-in hull), sand_ball, sugar_cube, bread_crumb} x direction {0, 45}, " if a.mixed else
+                                    f"{a.object}_env ({'stand-in hull; ' if a.object == 'acorn' else ''}direction {a.direction}), ") +
                                    f"{a.envs} envs/GPU, macro-step + observation + PPO actor-critic fwd each step, "
                                    f"PPO update every {a.rollout} steps ({a.epochs} epochs, minibatch {a.minibatch})",
                        "envs_per_gpu": a.envs, "parallelism": f"dp{world}", "ppo_in_timed_region": not a.no_ppo, "schedule": sched,

@@ -48,19 +48,7 @@ class BatchedRobotEnv:
         self.im_reward = bool(getattr(config, "im_reward", False))          # robot_env.py:39-42
         if config.width_capture != 64 or config.height_capture != 64:
             raise ValueError("the observation kernel renders 64x64 (config/base_config.py:18-19 defaults)")
-        if config.direction == 0:                      # robot_env.py:30-33
-            self.target_direction = np.array([1, 0])
-        elif config.direction == 45:
-            self.target_direction = np.array([1, 1])
-        else:
-            raise ValueError("direction must be 0 or 45 (robot_env.py:30-33)")
-        self.batch = engine.Batch(_object_name(config.sim_env), self.n_envs, device_index,
-                                  max_steps=config.max_steps, time_horizon=config.time_horizon,
-                                  include_roll=int(bool(config.include_roll)), full_observation=int(bool(config.full_observation)),
-                                  her_buffer=int(bool(config.her_buffer)), auto_reset=int(bool(auto_reset)),
-                                  max_translation=config.max_translation, max_rotation=config.max_rotation,
-                                  pos_tolerance=config.pos_tolerance, grasp_tolerance=config.grasp_tolerance,
-                                  target_dir=self.target_direction)
+        self.batch = self._make_batch(config, device_index, auto_reset)
         self.device = self.batch.device
         self._sensor = RGBDSensor(config=config)
         self._actuator = Actuator(config=config)
@@ -68,6 +56,27 @@ class BatchedRobotEnv:
         self.setup_spaces()
         self._obs = self.batch.torch.empty((self.n_envs, self.batch.obs_channels, 64, 64), dtype=self.batch.torch.uint8, device=self.device)
         self._obs_prev = self.batch.torch.empty_like(self._obs) if self.im_reward else None
+
+    @staticmethod
+    def _direction_vector(direction):
+        if direction == 0:                             # robot_env.py:30-33
+            return np.array([1, 0])
+        if direction == 45:
+            return np.array([1, 1])                    # unnormalised, as the reference has it
+        raise ValueError("direction must be 0 or 45 (robot_env.py:30-33)")
+
+    @staticmethod
+    def _engine_flags(config, auto_reset):
+        return dict(max_steps=config.max_steps, time_horizon=config.time_horizon,
+                    include_roll=int(bool(config.include_roll)), full_observation=int(bool(config.full_observation)),
+                    her_buffer=int(bool(config.her_buffer)), auto_reset=int(bool(auto_reset)),
+                    max_translation=config.max_translation, max_rotation=config.max_rotation,
+                    pos_tolerance=config.pos_tolerance, grasp_tolerance=config.grasp_tolerance)
+
+    def _make_batch(self, config, device_index, auto_reset):
+        self.target_direction = self._direction_vector(config.direction)
+        return engine.Batch(_object_name(config.sim_env), self.n_envs, device_index, target_dir=self.target_direction,
+                            **self._engine_flags(config, auto_reset))
 
     def setup_spaces(self):
         self.action_space = self._actuator.setup_action_space()
@@ -117,6 +126,23 @@ class BatchedRobotEnv:
 
     def close(self):
         self.batch.close()
+
+
+class MixedBatchedRobotEnv(BatchedRobotEnv):
+    """Groups of envs with different objects and target directions on one GPU (BASELINE.json configs[3]), sorted by
+    (object, direction) so that every wavefront is homogeneous. `config.sim_env` / `config.direction` are ignored in favour
+    of `objects` x `directions`; env e belongs to group e // envs_per_group, groups ordered object-major. Lock-step only."""
+
+    def __init__(self, config, objects=("acorn", "sand_ball", "sugar_cube", "bread_crumb"), directions=(0, 45), envs_per_group=512,
+                 device_index=0, auto_reset=False):
+        self.group_specs = [(o, int(envs_per_group), d) for o in objects for d in directions]
+        super().__init__(config, n_envs=len(self.group_specs) * int(envs_per_group), device_index=device_index, auto_reset=auto_reset)
+
+    def _make_batch(self, config, device_index, auto_reset):
+        groups = [(_object_name(o), n, self._direction_vector(d)) for o, n, d in self.group_specs]
+        b = engine.MixedBatch(groups, device_index, **self._engine_flags(config, auto_reset))
+        self.target_direction = b.target_dirs.cpu().numpy()                 # [n_envs, 2]
+        return b
 
 
 class RobotEnv(BatchedRobotEnv):
