@@ -73,15 +73,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ppo", action="store_true", help="diagnostic: rollout only (INVALID as a headline number)")
     ap.add_argument("--lockstep", action="store_true", help="classic vector-env schedule instead of asynchronous time slices")
+    ap.add_argument("--state-dtype", choices=["f32", "f16"], default="f32", help="HBM storage of qpos / qvel / ctrl (BASELINE.json configs[4]: f16; arithmetic is always f32)")
     ap.add_argument("--mixed", action="store_true", help="BASELINE.json configs[3]: {acorn, sand_ball, sugar_cube, bread_crumb} x direction {0, 45}, "
                                                          "--envs / 8 each, sorted by group (lock-step; not the headline workload)")
     ap.add_argument("--slice", type=int, default=96, help="physics.step() calls per env per tick (async schedule)")
-    ap.add_argument("--capacity", type=int, default=1024, help="finished envs decided per tick (async schedule)")
+    ap.add_argument("--capacity", type=int, default=0, help="finished envs decided per tick (async schedule); default envs / 4")
     ap.add_argument("--policy-dtype", choices=["f32", "bf16"], default="f32", help="autocast dtype of the policy / PPO update (physics is always f32)")
     ap.add_argument("--overlap-update", action="store_true", help="PPO update of rollout i on a second stream while rollout i+1 is collected (one update of policy lag)")
     ap.add_argument("--pipeline", action="store_true", help="decide for tick t on a side stream while tick t+1 advances (lag 2)")
     ap.add_argument("--budget-us", type=int, default=2000, help="wall-clock cap of a wavefront's slice in microseconds (async schedule; 0 = none)")
     a = ap.parse_args()
+    if a.capacity <= 0:
+        a.capacity = max(1, a.envs // 4)
     if a.mixed:
         a.lockstep = True; a.no_cpu_baseline = True
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # one hardware queue per group (read when the HIP runtime starts; default 4)
@@ -118,6 +121,8 @@ def main():
                 async_slice=0 if a.lockstep else a.slice, async_capacity=min(a.capacity, a.envs), async_budget_us=a.budget_us,
                 autocast_dtype=torch.bfloat16 if a.policy_dtype == "bf16" else None, overlap_update=a.overlap_update and not a.lockstep)
     batch = env.env.batch
+    if a.state_dtype == "f16":
+        batch.set_state_storage("f16")
     ar = model._async
     if ar is not None and a.pipeline:
         ar.enable_pipeline()
@@ -210,15 +215,15 @@ def main():
         value = total_env_steps / dt
         # async: one launch = one time slice = state + suspended macro-step context in and out (21 words each way) per env
         macro_bytes = (MACRO_BYTES_PER_ENV if ar is None else (47 + 40 + 2 * 21) * 4 + 8) * a.envs
-        if ar is not None and a.overlap_update:
-            pass
+        if a.state_dtype == "f16":      # 34 of the 47 words read and 27 of the 40 written (qpos, qvel, ctrl) are 2 bytes
+            macro_bytes -= (34 + 27) * 2 * a.envs
         sched = ("lock-step vector env" if ar is None else
                  f"asynchronous time slices (<= {a.slice} physics steps and <= {a.budget_us} us per wavefront and tick, {min(a.capacity, a.envs)} decisions/tick)" + ("; PPO update overlapped with the next rollout (policy lag 1)" if a.overlap_update else ""))
         achieved = macro_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
             "metric": "env-steps/sec (whole node), " + ("mixed objects" if a.mixed else f"{a.object}_env") + f" {a.envs} envs/GPU", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.policy_dtype == "f32" else "f32 physics / bf16 policy",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("f32" if a.policy_dtype == "f32" else "f32 physics / bf16 policy") + (" (physics state stored as f16)" if a.state_dtype == "f16" else ""),
             "data": "synthetic (deterministic reset state, actions sampled from the randomly initialised PPO policy)",
             "config": {"workload": ("mixed {acorn (stand-in hull), sand_ball, sugar_cube, bread_crumb} x direction {0, 45}, " if a.mixed else
                                     f"{a.object}_env ({'stand-in hull; ' if a.object == 'acorn' else ''}direction {a.direction}), ") +

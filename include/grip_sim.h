@@ -190,6 +190,13 @@ int grip_batch_target_pose(GripBatch *b, const float *actions_dev, float *target
  * x = A^-1 b for n SPD systems, A float32 [n,13,13], b and x float32 [n,13], device pointers. */
 int grip_selftest_cholesky(const float *A_dev, const float *b_dev, float *x_dev, int n, void *stream);
 
+/* BASELINE.json configs[4] ("fp16 physics state"): keep qpos / qvel / ctrl of every env as IEEE half in HBM (half != 0) or as
+ * fp32 (0, the default). Arithmetic stays fp32: values are rounded to nearest even when a kernel stores the state -- once per
+ * grip_batch_step, once per time slice of grip_batch_advance -- and every reader (observation, state hooks) converts on load.
+ * qacc_warmstart and the suspended macro-step context stay fp32. Converts the current contents; synchronises the stream.
+ * This trades accuracy (positions to 2^-11 relative) for 94 B of the 348 B of state per env; it is off unless asked for. */
+int grip_batch_set_state_storage(GripBatch *b, int half, void *stream);
+
 /* timing of the macro-step kernel on its own stream: average ms per launch since the last call with reset != 0 */
 int grip_batch_kernel_time(GripBatch *b, int reset, float *ms_avg, int *launches);
 

@@ -1,12 +1,13 @@
 // grip_device.h -- device-side model layout and small fp32 vector algebra for the gfx950 kernels.
 //
-// One environment lives in one wavefront lane (64 envs per wave). The articulated system of
+// One environment is worked on by 16 lanes (4 envs per wavefront). The articulated system of
 // xmls/<object>_env.xml (reference robot xml :58-99) is folded, at model-load time on the host,
 // into FOUR rigid groups -- G = ee + welded base, L = left knuckle + welded finger, R = right
 // knuckle + finger, O = object -- because welded bodies never move relative to each other.
 // This is a restructuring of the same mechanics the reference gets from MuJoCo, not a port.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 
 #define GN_GEOM 7          // 0 floor, 1 base, 2 lk, 3 lf, 4 rk, 5 rf, 6 object
@@ -65,7 +66,17 @@ struct DevConfig {
     int max_steps, time_horizon, include_roll, full_observation, her_buffer, auto_reset;
     float max_translation, max_rotation, pos_tolerance, grasp_tolerance;
     float dir_x, dir_y;
+    int state_half;      // qpos / qvel / ctrl are stored as IEEE half in HBM (grip_batch_set_state_storage); arithmetic stays fp32
 };
+
+// one word of the SoA state arrays: fp32, or IEEE half (round to nearest even on store) when the batch keeps qpos / qvel /
+// ctrl in half precision (BASELINE.json configs[4]); `half` is uniform over the launch
+__device__ __forceinline__ float ld_word(const float *base, size_t idx, int half) {
+    return half ? __half2float(reinterpret_cast<const __half *>(base)[idx]) : base[idx];
+}
+__device__ __forceinline__ void st_word(float *base, size_t idx, float v, int half) {
+    if (half) reinterpret_cast<__half *>(base)[idx] = __float2half_rn(v); else base[idx] = v;
+}
 
 // ---------------------------------------------------------------- fp32 helpers
 struct V3 { float x, y, z; };

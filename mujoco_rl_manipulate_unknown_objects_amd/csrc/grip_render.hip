@@ -28,9 +28,9 @@ static int launch_status(const char *what) {
 
 struct Frames { float p[6][3]; float R[6][9]; float cam_o[3]; float cam_R[9]; };
 
-__device__ static void compute_frames(const DevModel &m, const float *qpos, int n, int e, Frames &f) {
+__device__ static void compute_frames(const DevModel &m, const float *qpos, int n, int e, int half, Frames &f) {
     float q[14];
-    for (int i = 0; i < 14; i++) q[i] = qpos[(size_t)i * n + e];
+    for (int i = 0; i < 14; i++) q[i] = ld_word(qpos, (size_t)i * n + e, half);
     V3 pe = v3(m.ee_pos0[0] + q[0], m.ee_pos0[1] + q[1], m.ee_pos0[2] + q[2]);
     float sr = sinf(q[3]), cr = cosf(q[3]), sy = sinf(q[4]), cy = cosf(q[4]);
     M3 Re;
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
     __shared__ int redi[RTHREADS];
     const int e = list ? list[blockIdx.x] : blockIdx.x, tid = threadIdx.x;
     if (tid == 0) {
-        compute_frames(m, qpos, n, e, fr);
+        compute_frames(m, qpos, n, e, cfg.state_half, fr);
         V3 co = ldv(fr.cam_o); M3 Rc = ldm(fr.cam_R);
         int adr = 0;
         for (int g = 1; g < GN_GEOM; g++) {

@@ -257,7 +257,7 @@ static constexpr int EV_RING = 1024;
 static constexpr int LDS_MAX_BYTES = 160 * 1024;
 
 // ---- state load / store (SoA; the 16 lanes of an env read the same words)
-struct StatePtrs { float *qpos, *qvel, *ctrl, *warm; int *episode_step, *status, *gripper_open, *pad_grasp, *pad_pher; int n; };
+struct StatePtrs { float *qpos, *qvel, *ctrl, *warm; int *episode_step, *status, *gripper_open, *pad_grasp, *pad_pher; int n; int half; };
 
 // A macro step suspended between two time slices (grip_batch_advance): everything k_macro_step keeps in registers across
 // its physics.step() loop, SoA [field][N]. astate: 0 = macro step in flight, 1 = finished, waiting for an action;
@@ -270,21 +270,21 @@ enum { MC_TARGET = 0, MC_INITQ = 5, MC_OPENCLOSE = 10, MC_TQ = 11, MC_INITOBJ = 
 
 DEVI void ld_state(const StatePtrs &p, int e, LaneState &s) {
 #pragma unroll
-    for (int i = 0; i < 14; i++) s.qpos[i] = p.qpos[(size_t)i * p.n + e];
+    for (int i = 0; i < 14; i++) s.qpos[i] = ld_word(p.qpos, (size_t)i * p.n + e, p.half);
 #pragma unroll
-    for (int i = 0; i < 13; i++) s.qvel[i] = p.qvel[(size_t)i * p.n + e];
+    for (int i = 0; i < 13; i++) s.qvel[i] = ld_word(p.qvel, (size_t)i * p.n + e, p.half);
 #pragma unroll
-    for (int i = 0; i < 7; i++) s.ctrl[i] = p.ctrl[(size_t)i * p.n + e];
+    for (int i = 0; i < 7; i++) s.ctrl[i] = ld_word(p.ctrl, (size_t)i * p.n + e, p.half);
 #pragma unroll
     for (int i = 0; i < 13; i++) s.warm[i] = p.warm[(size_t)i * p.n + e];
 }
 DEVI void st_state(const StatePtrs &p, int e, const LaneState &s) {
 #pragma unroll
-    for (int i = 0; i < 14; i++) p.qpos[(size_t)i * p.n + e] = s.qpos[i];
+    for (int i = 0; i < 14; i++) st_word(p.qpos, (size_t)i * p.n + e, s.qpos[i], p.half);
 #pragma unroll
-    for (int i = 0; i < 13; i++) p.qvel[(size_t)i * p.n + e] = s.qvel[i];
+    for (int i = 0; i < 13; i++) st_word(p.qvel, (size_t)i * p.n + e, s.qvel[i], p.half);
 #pragma unroll
-    for (int i = 0; i < 7; i++) p.ctrl[(size_t)i * p.n + e] = s.ctrl[i];
+    for (int i = 0; i < 7; i++) st_word(p.ctrl, (size_t)i * p.n + e, s.ctrl[i], p.half);
 #pragma unroll
     for (int i = 0; i < 13; i++) p.warm[(size_t)i * p.n + e] = s.warm[i];
 }
@@ -744,11 +744,16 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_target_pose(const DevModel m,
 }
 
 // [rows][cols] -> [cols][rows]; used by the env-major <-> SoA state hooks
-__global__ void k_transpose(const float *src, float *dst, int rows, int cols) {
+__global__ void k_transpose(const float *src, float *dst, int rows, int cols, int src_half, int dst_half) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * cols) return;
     int r = i / cols, c = i % cols;
-    dst[(size_t)c * rows + r] = src[i];
+    st_word(dst, (size_t)c * rows + r, ld_word(src, i, src_half), dst_half);
+}
+// elementwise fp32 <-> half change of a state array's storage (src and dst are different buffers)
+__global__ void k_restore(const float *src, float *dst, size_t cnt, int src_half, int dst_half) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) st_word(dst, i, ld_word(src, i, src_half), dst_half);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -757,6 +762,7 @@ __global__ void k_transpose(const float *src, float *dst, int rows, int cols) {
 static StatePtrs state_ptrs(GripBatch *b) {
     StatePtrs p; p.qpos = b->qpos; p.qvel = b->qvel; p.ctrl = b->ctrl; p.warm = b->warm; p.episode_step = b->episode_step;
     p.status = b->status; p.gripper_open = b->gripper_open; p.pad_grasp = b->pad_grasp; p.pad_pher = b->pad_pher; p.n = b->n;
+    p.half = b->cfg.state_half;
     return p;
 }
 static StepOutDev to_dev(const GripStepOut *o) {
@@ -835,7 +841,7 @@ static int batch_build(GripBatch *b, const GripModel *m) {
     // config defaults (config/base_config.py:12-54)
     b->cfg.max_steps = 400; b->cfg.time_horizon = 400; b->cfg.include_roll = 1; b->cfg.full_observation = 1; b->cfg.her_buffer = 0;
     b->cfg.auto_reset = 0; b->cfg.max_translation = 0.05f; b->cfg.max_rotation = 0.15f; b->cfg.pos_tolerance = 0.002f;
-    b->cfg.grasp_tolerance = 0.03f; b->cfg.dir_x = 1.f; b->cfg.dir_y = 0.f;
+    b->cfg.grasp_tolerance = 0.03f; b->cfg.dir_x = 1.f; b->cfg.dir_y = 0.f; b->cfg.state_half = 0;
     b->xfrc_z = -(0.438f * m->host.gravity_z);      // robot_env.py:64-65, constant verbatim
     b->ev0.assign(EV_RING, nullptr); b->ev1.assign(EV_RING, nullptr);
     for (int i = 0; i < EV_RING; i++) { HIPCHK(hipEventCreate(&b->ev0[i])); HIPCHK(hipEventCreate(&b->ev1[i])); }
@@ -950,20 +956,20 @@ struct DevBuf {      // device allocation released on every return path
     template <class T> T *as() const { return (T *)p; }
 };
 
-static int xfer_field(GripBatch *b, float *soa, float *user, int width, bool to_user, int host_or_dev, hipStream_t s) {
+static int xfer_field(GripBatch *b, float *soa, float *user, int width, bool to_user, int host_or_dev, hipStream_t s, int half = 0) {
     if (!user) return 0;
     size_t cnt = (size_t)width * b->n;
     int threads = 256, blocks = (int)((cnt + threads - 1) / threads);
     if (cnt * sizeof(float) > b->scratch_bytes) return fail("state scratch too small");
     if (to_user) {
         float *dst = host_or_dev ? user : b->scratch;
-        hipLaunchKernelGGL(k_transpose, dim3(blocks), dim3(threads), 0, s, soa, dst, width, b->n);       // [width][N] -> [N][width]
+        hipLaunchKernelGGL(k_transpose, dim3(blocks), dim3(threads), 0, s, soa, dst, width, b->n, half, 0);       // [width][N] -> [N][width]
         HIPCHK(hipGetLastError());
         if (!host_or_dev) { HIPCHK(hipMemcpyAsync(user, b->scratch, cnt * sizeof(float), hipMemcpyDeviceToHost, s)); HIPCHK(hipStreamSynchronize(s)); }
     } else {
         const float *src = user;
         if (!host_or_dev) { HIPCHK(hipMemcpyAsync(b->scratch, user, cnt * sizeof(float), hipMemcpyHostToDevice, s)); src = b->scratch; }
-        hipLaunchKernelGGL(k_transpose, dim3(blocks), dim3(threads), 0, s, src, soa, b->n, width);        // [N][width] -> [width][N]
+        hipLaunchKernelGGL(k_transpose, dim3(blocks), dim3(threads), 0, s, src, soa, b->n, width, 0, half);        // [N][width] -> [width][N]
         HIPCHK(hipGetLastError());
         if (!host_or_dev) HIPCHK(hipStreamSynchronize(s));
     }
@@ -974,18 +980,38 @@ extern "C" int grip_batch_get_state(GripBatch *b, float *qpos, float *qvel, floa
     if (!b) return fail("grip_batch_get_state: null batch");
     HIPCHK(hipSetDevice(b->device));
     hipStream_t s = (hipStream_t)stream;
-    if (xfer_field(b, b->qpos, qpos, 14, true, host_or_dev, s) || xfer_field(b, b->qvel, qvel, 13, true, host_or_dev, s) ||
-        xfer_field(b, b->ctrl, ctrl, 7, true, host_or_dev, s) || xfer_field(b, b->warm, warm, 13, true, host_or_dev, s)) return -1;
+    const int h = b->cfg.state_half;
+    if (xfer_field(b, b->qpos, qpos, 14, true, host_or_dev, s, h) || xfer_field(b, b->qvel, qvel, 13, true, host_or_dev, s, h) ||
+        xfer_field(b, b->ctrl, ctrl, 7, true, host_or_dev, s, h) || xfer_field(b, b->warm, warm, 13, true, host_or_dev, s)) return -1;
     return 0;
 }
 extern "C" int grip_batch_set_state(GripBatch *b, const float *qpos, const float *qvel, const float *ctrl, const float *warm, int host_or_dev, void *stream) {
     if (!b) return fail("grip_batch_set_state: null batch");
     HIPCHK(hipSetDevice(b->device));
     hipStream_t s = (hipStream_t)stream;
-    if (xfer_field(b, b->qpos, (float *)qpos, 14, false, host_or_dev, s) || xfer_field(b, b->qvel, (float *)qvel, 13, false, host_or_dev, s) ||
-        xfer_field(b, b->ctrl, (float *)ctrl, 7, false, host_or_dev, s) || xfer_field(b, b->warm, (float *)warm, 13, false, host_or_dev, s)) return -1;
+    const int h = b->cfg.state_half;
+    if (xfer_field(b, b->qpos, (float *)qpos, 14, false, host_or_dev, s, h) || xfer_field(b, b->qvel, (float *)qvel, 13, false, host_or_dev, s, h) ||
+        xfer_field(b, b->ctrl, (float *)ctrl, 7, false, host_or_dev, s, h) || xfer_field(b, b->warm, (float *)warm, 13, false, host_or_dev, s)) return -1;
     return 0;
 }
+extern "C" int grip_batch_set_state_storage(GripBatch *b, int half, void *stream) {
+    if (!b || (half != 0 && half != 1)) return fail("grip_batch_set_state_storage: need a batch and half in {0, 1}");
+    HIPCHK(hipSetDevice(b->device));
+    if (b->cfg.state_half == half) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    float *arr[3] = {b->qpos, b->qvel, b->ctrl}; const int width[3] = {14, 13, 7};
+    for (int k = 0; k < 3; k++) {       // through the scratch buffer: the two layouts of one array overlap
+        size_t cnt = (size_t)width[k] * b->n;
+        if (cnt * sizeof(float) > b->scratch_bytes) return fail("state scratch too small");
+        HIPCHK(hipMemcpyAsync(b->scratch, arr[k], cnt * (b->cfg.state_half ? sizeof(__half) : sizeof(float)), hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_restore, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s, (const float *)b->scratch, arr[k], cnt, b->cfg.state_half, half);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    b->cfg.state_half = half;
+    return 0;
+}
+
 extern "C" int grip_batch_get_flags(GripBatch *b, int32_t *episode_step, int32_t *status, int32_t *gripper_open, void *stream) {
     if (!b) return fail("grip_batch_get_flags: null batch");
     HIPCHK(hipSetDevice(b->device));

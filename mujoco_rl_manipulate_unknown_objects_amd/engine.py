@@ -75,7 +75,8 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_destroy", "grip_batch_set_config", "grip_batch_num_envs", "grip_batch_reset", "grip_batch_step",
            "grip_batch_observe", "grip_batch_get_state", "grip_batch_set_state", "grip_batch_get_flags",
            "grip_batch_set_flags", "grip_batch_substep", "grip_batch_debug_forward", "grip_batch_target_pose",
-           "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward", "grip_obs_preprocess"]
+           "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward", "grip_obs_preprocess",
+           "grip_batch_set_state_storage"]
 
 
 def lib():
@@ -103,6 +104,7 @@ def lib():
     L.grip_batch_get_flags.argtypes = [vp, vp, vp, vp, vp]
     L.grip_batch_set_flags.argtypes = [vp, vp, vp, vp, vp]
     L.grip_batch_substep.argtypes = [vp, C.c_int, vp]
+    L.grip_batch_set_state_storage.argtypes = [vp, C.c_int, vp]
     L.grip_batch_debug_forward.argtypes = [vp] + [vp] * 7 + [vp]
     L.grip_batch_target_pose.argtypes = [vp, vp, vp, vp]
     L.grip_batch_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
@@ -292,6 +294,13 @@ class Batch:
                 keep.append(arr); ptrs.append(p)
         _chk(lib().grip_batch_set_state(self.ptr, *ptrs, 0, self._stream()))
 
+    def set_state_storage(self, dtype):
+        """'f16': keep qpos / qvel / ctrl as IEEE half in HBM (BASELINE.json configs[4]; fp32 arithmetic, rounded on every
+        state store); 'f32': the default."""
+        if dtype not in ("f16", "f32"):
+            raise GripError("state storage is 'f32' or 'f16'")
+        _chk(lib().grip_batch_set_state_storage(self.ptr, int(dtype == "f16"), self._stream()))
+
     def get_flags(self):
         es = np.zeros(self.n, np.int32); st = np.zeros(self.n, np.int32); go = np.zeros(self.n, np.int32)
         _chk(lib().grip_batch_get_flags(self.ptr, es.ctypes.data, st.ctypes.data, go.ctypes.data, self._stream()))
@@ -442,6 +451,10 @@ class MixedBatch:
         for g, p in enumerate(self.parts):
             lo, hi = self.offsets[g], self.offsets[g + 1]
             p.set_state(*[None if x is None else np.asarray(x)[lo:hi] for x in (qpos, qvel, ctrl, warm)])
+
+    def set_state_storage(self, dtype):
+        for p in self.parts:
+            p.set_state_storage(dtype)
 
     def get_flags(self):
         parts = [p.get_flags() for p in self.parts]
