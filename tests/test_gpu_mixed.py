@@ -116,3 +116,45 @@ def test_mixed_env_trains_with_ppo(torch):
     assert any(not torch.equal(a, b) for a, b in zip(before, model.policy.parameters()))
     assert all(torch.isfinite(p).all() for p in model.policy.parameters())
     env.close()
+
+
+def test_random_episodes_resemble_the_reference_training_logs(engine, torch):
+    """The one piece of physics-level data the reference holds: the Monitor CSVs of its published runs. The episodes before
+    the first evaluation (training step 2000) are played by a freshly initialised SAC actor (near-random actions) in the real
+    MuJoCo simulation (tests/golden/reference_monitor_early_episodes.json, tools/make_monitor_fixture.py). First episodes of
+    this engine under uniformly random actions, same four objects and two directions, must show the same statistics: how
+    often an episode survives to the 400-step time limit instead of ending in Status.FAIL, how long episodes last, how much
+    progress reward random pushing collects. A statistical band (about three standard errors of the 51 reference episodes
+    plus the policy mismatch), not a bit-level pin: reference 43 % at the limit / mean length 301 / mean return 1.24; this
+    engine measured 37 % / 271 / 1.16 over 1024 episodes (profiles/r01_episode_stats_uniform.json)."""
+    import json
+    import os
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_monitor_early_episodes.json")))["runs"]
+    ref_len = np.array([l for r in ref.values() for l in r["lengths"]]); ref_ret = np.array([x for r in ref.values() for x in r["returns"]])
+    assert len(ref_len) == 51 and ref_len.max() == 400          # time_horizon 400 (base_config.py) is what ends the longest ones
+
+    per = 48
+    groups = [(k.rsplit("_dir", 1)[0], per, (1.0, 0.0) if k.endswith("dir0") else (1.0, 1.0)) for k in ref]
+    mb = engine.MixedBatch(groups, auto_reset=1)
+    mb.reset()
+    n = mb.n
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    ret = torch.zeros(n, device="cuda"); first_ret = torch.zeros(n, device="cuda")
+    first_len = torch.zeros(n, dtype=torch.int32, device="cuda"); open_ = torch.ones(n, dtype=torch.bool, device="cuda")
+    for t in range(1, 401):
+        out = mb.step(torch.rand(n, 6, device="cuda", generator=g) * 2 - 1)
+        ret += out["reward"]
+        d = out["done"].bool() & open_
+        first_ret[d] = ret[d]; first_len[d] = t
+        open_ &= ~d
+    torch.cuda.synchronize()
+    assert not open_.any()                                       # every env ended its first episode by the time limit
+    ln = first_len.cpu().numpy(); rt = first_ret.cpu().numpy()
+    assert ln.max() == 400 and ln.min() >= 1
+    frac_ref, frac = (ref_len == 400).mean(), (ln == 400).mean()
+    assert abs(frac - frac_ref) < 0.2, (frac, frac_ref)
+    assert abs(ln.mean() - ref_len.mean()) < 60, (ln.mean(), ref_len.mean())
+    assert abs(np.median(ln) - np.median(ref_len)) < 90, (np.median(ln), np.median(ref_len))
+    assert 0.5 * ref_ret.mean() < rt.mean() < 2.0 * ref_ret.mean(), (rt.mean(), ref_ret.mean())
+    assert rt.min() >= 0.0 and rt.max() < 60.0                   # progress reward is never negative (reward.py:18-41)
+    mb.close()
