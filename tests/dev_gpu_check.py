@@ -1,4 +1,5 @@
-"""Quick GPU-vs-oracle comparison used while developing (the real tests live in tests/)."""
+"""Quick GPU-vs-oracle comparison used while developing (not collected by pytest; it lives under tests/ because only
+tests may load the oracle). usage: python tests/dev_gpu_check.py [object]"""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np
