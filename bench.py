@@ -25,6 +25,9 @@ import os
 import sys
 import time
 
+if "--mixed" in sys.argv:       # a hardware queue per group stream; the HIP runtime reads this when it is loaded (default 4)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -75,7 +78,7 @@ def main():
     ap.add_argument("--lockstep", action="store_true", help="classic vector-env schedule instead of asynchronous time slices")
     ap.add_argument("--state-dtype", choices=["f32", "f16"], default="f32", help="HBM storage of qpos / qvel / ctrl (BASELINE.json configs[4]: f16; arithmetic is always f32)")
     ap.add_argument("--mixed", action="store_true", help="BASELINE.json configs[3]: {acorn, sand_ball, sugar_cube, bread_crumb} x direction {0, 45}, "
-                                                         "--envs / 8 each, sorted by group (lock-step; not the headline workload)")
+                                                         "--envs / 8 each, sorted by group (not the headline workload)")
     ap.add_argument("--slice", type=int, default=96, help="physics.step() calls per env per tick (async schedule)")
     ap.add_argument("--capacity", type=int, default=0, help="finished envs decided per tick (async schedule); default envs / 4")
     ap.add_argument("--policy-dtype", choices=["f32", "bf16"], default="f32", help="autocast dtype of the policy / PPO update (physics is always f32)")
@@ -86,10 +89,9 @@ def main():
     if a.capacity <= 0:
         a.capacity = max(1, a.envs // 4)
     if a.mixed:
-        a.lockstep = True; a.no_cpu_baseline = True
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # one hardware queue per group (read when the HIP runtime starts; default 4)
-        if a.envs % 8:
-            raise SystemExit("--mixed needs --envs divisible by 8")
+        a.no_cpu_baseline = True
+        if a.envs % 8 or a.capacity % 8:
+            raise SystemExit("--mixed needs --envs and --capacity divisible by 8")
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus:

@@ -134,7 +134,8 @@ int grip_batch_observe_list(GripBatch *b, const int32_t *list_dev, const int32_t
  *   the reference trains through stable_baselines3, train_agent.py:82-92). */
 typedef struct {
     int32_t n_envs, capacity, action_dim; int64_t n_records;
-    const int32_t *ready_list, *ready_count;      /* from grip_batch_advance */
+    const int32_t *ready_list, *ready_count;      /* from grip_batch_advance; rows >= *ready_count and negative entries are skipped
+                                                   * (lists of several batches laid side by side leave holes) */
     const int64_t *base;                          /* [1] first record row of this tick */
     const float *reward; const uint8_t *done; const int32_t *n_substeps;   /* GripStepOut arrays [n_envs] (n_substeps may be NULL) */
     const float *actions, *values, *log_probs;    /* policy outputs [capacity, action_dim], [capacity], [capacity] */

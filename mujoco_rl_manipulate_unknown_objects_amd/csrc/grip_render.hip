@@ -249,6 +249,7 @@ __global__ void __launch_bounds__(256) k_intrinsic_reward(const uint8_t *old_obs
                                                           const int *list, const int *count, int channels, int full_observation, float *reward) {
     const int r = blockIdx.x, tid = threadIdx.x;
     if (count && r >= *count) return;
+    if (list && list[r] < 0) return;                        // a hole of a merged list
     const long long orow = old_rows ? old_rows[r] : (long long)r;
     if (orow < 0) return;                                   // no previous observation (first decision of this env)
     __shared__ int h[4][256];

@@ -23,7 +23,7 @@ __global__ void k_rollout_tick(GripRolloutTick a) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.capacity) return;
     const int N = a.n_envs; const long long R = a.n_records;
-    const bool valid = r < a.ready_count[0];
+    const bool valid = r < a.ready_count[0] && a.ready_list[r] >= 0;      // a negative entry is a hole (lists merged from several batches)
     const long long row = a.base[0] + r;
     const int env = valid ? a.ready_list[r] : N;                     // row N / record R: dump rows for masked writes
     // close the previous decision of this env

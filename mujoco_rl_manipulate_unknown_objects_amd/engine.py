@@ -360,8 +360,8 @@ class MixedBatch:
     into, the caller's stream, so that the small per-group grids share the chip (the HIP runtime maps streams onto
     GPU_MAX_HW_QUEUES hardware queues, 4 by default: with more groups than that export GPU_MAX_HW_QUEUES=<groups> before
     the first GPU call -- measured 83 ms -> 52 ms per step for 8 groups x 512 envs, the time of the slowest group alone).
-    Lock-step stepping only: the time-sliced schedule (advance / observe_list) keeps one decision list per GripBatch and
-    is not offered here.
+    The time-sliced schedule works the same way: every group keeps its own decision list and owns a fixed segment of the
+    caller's ready list / action / observation rows (advance, observe_list below).
     """
 
     def __init__(self, groups, device_index=0, **cfg):
@@ -435,10 +435,50 @@ class MixedBatch:
         self._fan_out(lambda g, p: p.observe(obs[self.offsets[g]:self.offsets[g + 1]]))
         return obs
 
-    def advance(self, *a, **k):
-        raise GripError("MixedBatch steps in lock-step; the time-sliced schedule needs one GripBatch")
+    # -- asynchronous stepping: every group keeps its own decision list; the caller sees them side by side ------------------
+    def _async_buffers(self, cap):
+        """Group g owns rows [g * cap / G, (g + 1) * cap / G) of the caller's ready list, action and observation arrays. Its
+        GripBatch fills a local list (local env ids, -1 beyond its count); the caller's list gets the global ids with the
+        unused rows of every segment left at -1: a list with holes, which grip_rollout_tick / AsyncRollout skip by sign."""
+        t, G = self.torch, len(self.parts)
+        if cap % G:
+            raise GripError(f"the ready-list capacity ({cap}) must be a multiple of the number of groups ({G})")
+        if getattr(self, "_acap", None) != cap:
+            self._acap = cap
+            self._llst = t.full((G, cap // G), -1, dtype=t.int32, device=self.device)
+            self._lcnt = t.zeros(G, dtype=t.int32, device=self.device)
+            self._goff = t.tensor(self.offsets[:-1], dtype=t.int32, device=self.device).unsqueeze(1)
+            self._rows = t.zeros(G, dtype=t.int64, device=self.device)
+            self._rowoff = t.arange(G, dtype=t.int64, device=self.device) * (cap // G)
+        return cap // G
 
-    observe_list = advance
+    def advance(self, slot_actions, slice_len, ready_list, ready_count, budget_us=0, lag=1):
+        """Batch.advance for every group on its own stream. slot_actions [capacity, action_dim]: row r of segment g is the
+        action of the env the previous call listed there. ready_list receives global env ids or -1 (holes), ready_count the
+        capacity (validity is the sign of the entry)."""
+        t = self.torch
+        cap = int(ready_list.numel())
+        cg = self._async_buffers(cap)
+        if slot_actions.dtype != t.float32 or not slot_actions.is_contiguous() or tuple(slot_actions.shape) != (cap, self.action_dim):
+            raise GripError(f"slot_actions must be contiguous float32 [{cap},{self.action_dim}]")
+        if ready_list.dtype != t.int32 or ready_count.dtype != t.int32:
+            raise GripError("ready_list / ready_count must be int32")
+        self._fan_out(lambda g, p: p.advance(slot_actions[g * cg:(g + 1) * cg], slice_len, self._llst[g], self._lcnt[g:g + 1], budget_us, lag))
+        ready_list.view(len(self.parts), cg).copy_(t.where(self._llst >= 0, self._llst + self._goff, self._llst))
+        ready_count.fill_(cap)
+        return self.out
+
+    def observe_list(self, ready_list, ready_count, obs, records=None, record_row=None):
+        """Render the envs listed by the last advance(): segment g of `obs` (and of the record rows from record_row on)."""
+        cap = int(ready_list.numel())
+        cg = self._async_buffers(cap)
+        if obs.dtype != self.torch.uint8 or not obs.is_contiguous() or obs.shape[0] < cap:
+            raise GripError("obs must be contiguous uint8 [capacity, C, 64, 64]")
+        if records is not None:
+            self.torch.add(self._rowoff, record_row, out=self._rows)           # first record row of every segment
+        self._fan_out(lambda g, p: p.observe_list(self._llst[g], self._lcnt[g:g + 1], obs[g * cg:(g + 1) * cg], records,
+                                                  None if records is None else self._rows[g:g + 1]))
+        return obs
 
     def add_intrinsic_reward(self, *a, **k):
         return self.parts[0].add_intrinsic_reward(*a, **k)      # pairs of observation rows only; no group state involved

@@ -135,7 +135,7 @@ class AsyncRollout:
         else:
             self.eng.observe_list(lst, cnt, obs_stage)
         if getattr(self.eng, "im_reward", False):
-            env = th.where(self.ar_c < cnt, lst, self.N).long()
+            env = th.where((self.ar_c < cnt) & (lst >= 0), lst, self.N).long()
             self.eng.add_intrinsic_reward(self.obs, self.rec_of_env[env], obs_stage, lst, cnt, out["reward"])
         noise = log_std = None
         if self.fused and self.policy_parts_fn is not None:
@@ -176,7 +176,7 @@ class AsyncRollout:
 
     def _torch_tick(self, out, lst, cnt, slot_act, rows, actions, values, log_probs):
         N, C, R = self.N, self.C, self.R
-        valid = self.ar_c < cnt                                        # [C]
+        valid = (self.ar_c < cnt) & (lst >= 0)                         # [C]; negative entries are holes (lists merged from several batches)
         env = th.where(valid, lst, N).long()                           # dump env N for empty rows
         env_c = env.clamp(max=N - 1)
         slot_act.copy_(th.max(th.min(actions, self.high), self.low))

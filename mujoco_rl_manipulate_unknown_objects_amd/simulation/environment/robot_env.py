@@ -131,7 +131,9 @@ class BatchedRobotEnv:
 class MixedBatchedRobotEnv(BatchedRobotEnv):
     """Groups of envs with different objects and target directions on one GPU (BASELINE.json configs[3]), sorted by
     (object, direction) so that every wavefront is homogeneous. `config.sim_env` / `config.direction` are ignored in favour
-    of `objects` x `directions`; env e belongs to group e // envs_per_group, groups ordered object-major. Lock-step only."""
+    of `objects` x `directions`; env e belongs to group e // envs_per_group, groups ordered object-major.
+    Steps lock-step (reset / step) or time-sliced (PPO(async_slice=...): the ready-list capacity must be a multiple of the
+    number of groups)."""
 
     def __init__(self, config, objects=("acorn", "sand_ball", "sugar_cube", "bread_crumb"), directions=(0, 45), envs_per_group=512,
                  device_index=0, auto_reset=False):

@@ -26,8 +26,10 @@ class ScriptedEngine:
     """N envs; env e's k-th macro step lasts duration(e, k) ticks, pays reward_of(e, k), ends an episode every HORIZON steps.
     Observations encode (env, k) so that the fake policy can answer value_of(env, k)."""
 
-    def __init__(self, n, capacity, slow=1):
-        self.slow = slow
+    def __init__(self, n, capacity, slow=1, segments=1):
+        """segments > 1 mimics engine.MixedBatch: the envs are split into `segments` contiguous groups, group g lists its
+        waiting envs in rows [g * capacity / segments, ...) only, so the list has holes (-1) and the count is the capacity."""
+        self.slow = slow; self.segments = segments
         self.num_envs, self.action_dim, self.obs_shape, self.device = n, 6, (5, 64, 64), th.device("cpu")
         self.cap = capacity
         self.k = np.zeros(n, int)                 # macro steps finished so far
@@ -53,17 +55,30 @@ class ScriptedEngine:
                     self.k[e] += 1
         waiting = [(e - self.rot) % n for e in range(n)]
         waiting = sorted(v for v in waiting if self.left[(v + self.rot) % n] == 0)
-        ids = [(v + self.rot) % n for v in waiting][:self.cap]
+        ids = [(v + self.rot) % n for v in waiting]
         lst.fill_(-1)
-        for r, e in enumerate(ids):
-            lst[r] = e; self.slot[e] = r
-        cnt[0] = len(ids)
+        if self.segments == 1:
+            for r, e in enumerate(ids[:self.cap]):
+                lst[r] = e; self.slot[e] = r
+            cnt[0] = min(len(ids), self.cap)
+        else:
+            cg, per = self.cap // self.segments, -(-n // self.segments)
+            used = [0] * self.segments
+            for e in ids:
+                g = e // per
+                if used[g] < cg:
+                    r = g * cg + used[g]; used[g] += 1
+                    lst[r] = e; self.slot[e] = r
+            cnt[0] = self.cap
         self.rot = (self.rot + self.cap) % n
         return {"reward": self.reward, "done": self.done}
 
     def observe_list(self, lst, cnt, rows):
         for r in range(int(cnt[0])):
-            e = int(lst[r]); rows[r].zero_(); rows[r, 0, 0, 0] = e; rows[r, 0, 0, 1] = self.k[e] % 256; rows[r, 0, 0, 2] = self.k[e] // 256
+            e = int(lst[r])
+            if e < 0:
+                continue
+            rows[r].zero_(); rows[r, 0, 0, 0] = e; rows[r, 0, 0, 1] = self.k[e] % 256; rows[r, 0, 0, 2] = self.k[e] // 256
 
 
 def fake_policy(rows):
@@ -84,9 +99,13 @@ def reference_gae(n_first, n_done, env, gamma, lam):
     return adv
 
 
-def test_records_chain_rewards_and_gae_over_two_rollouts():
+import pytest
+
+
+@pytest.mark.parametrize("segments", [1, 2])
+def test_records_chain_rewards_and_gae_over_two_rollouts(segments):
     n, cap, gamma, lam = 13, 4, 0.97, 0.9
-    eng = ScriptedEngine(n, cap)
+    eng = ScriptedEngine(n, cap, segments=segments)
     ro = AsyncRollout(eng, fake_policy, target=40, capacity=cap, slice_len=8, gamma=gamma, gae_lambda=lam, poll_every=1)
     first = np.zeros(n, int)
     for rollout in range(3):

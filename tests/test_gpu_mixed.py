@@ -59,8 +59,6 @@ def test_mixed_batch_equals_its_groups_run_alone(engine, torch):
     assert list(changed) == [30]
     es = mb.get_flags()[0]
     assert es[30] == 0 and (np.delete(es, 30) == 3).all()
-    with pytest.raises(engine.GripError):
-        mb.advance(None, 1, None, None)
     mb.close()
     for b in solo:
         b.close()
@@ -98,6 +96,98 @@ def test_mixed_batch_against_the_oracle(engine, orc, torch):
             assert np.abs(np.array(o.desired_goal) - o_np["desired_goal"][i]).max() < tolo
             assert abs(o.reward - o_np["reward"][i]) < (1e-3 if t == 0 else 30 * tolo)
     mb.close()
+
+
+FIELDS = ["reward", "done", "achieved_goal", "desired_goal", "status", "episode_step", "gripper_open", "object_grasped",
+          "position_reached", "total_distance", "line_distance", "gripper_position", "object_position", "init_obj_pos",
+          "n_substeps", "fault"]
+
+
+def test_mixed_time_sliced_equals_lockstep(engine, torch):
+    """The time-sliced schedule over a mixed batch: every group lists its finished envs in its own segment of the ready list
+    (holes are -1, the count is the capacity). Each env plays its own action sequence; every macro step's outputs and the
+    final state are bit-identical to the lock-step mixed batch."""
+    groups = [("sand_ball", 20, (1.0, 0.0)), ("sugar_cube", 17, (1.0, 1.0)), ("bread_crumb", 12, (1.0, 0.0))]
+    steps, cap, slice_len = 3, 24, 37
+    ref_b = engine.MixedBatch(groups)
+    n = ref_b.n
+    rng = np.random.default_rng(13)
+    actions = rng.uniform(-1, 1, (steps, n, 6)).astype(np.float32); actions[:, :, 0] = np.abs(actions[:, :, 0])
+    ref = []
+    for t in range(steps):
+        o = ref_b.step(torch.from_numpy(actions[t]).cuda()); torch.cuda.synchronize()
+        ref.append({k: o[k].cpu().numpy().copy() for k in FIELDS})
+    ref_state = ref_b.get_state(); ref_b.close()
+
+    mb = engine.MixedBatch(groups)
+    lst = torch.full((cap,), -1, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    slot_act = torch.zeros(cap, 6, device="cuda")
+    obs = torch.zeros(cap, 5, 64, 64, dtype=torch.uint8, device="cuda")
+    given = np.zeros(n, int); got = [[None] * steps for _ in range(n)]; final_state = [None] * n
+    seg = cap // len(groups)
+    for tick in range(20000):
+        out = mb.advance(slot_act, slice_len, lst, cnt)
+        mb.observe_list(lst, cnt, obs)
+        torch.cuda.synchronize()
+        assert int(cnt.item()) == cap
+        ids = lst.cpu().numpy()
+        listed = ids[ids >= 0]
+        assert len(set(listed.tolist())) == len(listed)
+        for g in range(len(groups)):                                   # a segment lists only envs of its group, packed to the front
+            s_ = ids[g * seg:(g + 1) * seg]; k = int((s_ >= 0).sum())
+            assert (s_[:k] >= mb.offsets[g]).all() and (s_[:k] < mb.offsets[g + 1]).all() and (s_[k:] == -1).all()
+        o_host = {k: out[k].cpu().numpy() for k in FIELDS}
+        st = mb.get_state() if len(listed) else None
+        full = mb.observe() if len(listed) else None
+        new_act = np.zeros((cap, 6), np.float32)
+        for r in range(cap):
+            e = int(ids[r])
+            if e < 0:
+                continue
+            assert torch.equal(obs[r], full[e])                         # the listed env's observation sits in its row
+            if given[e] > 0 and got[e][given[e] - 1] is None:
+                got[e][given[e] - 1] = {k: o_host[k][e].copy() for k in FIELDS}
+                if given[e] == steps:
+                    final_state[e] = [a[e].copy() for a in st]
+            if given[e] < steps:
+                new_act[r] = actions[given[e], e]; given[e] += 1
+        slot_act.copy_(torch.from_numpy(new_act))
+        if all(g_[steps - 1] is not None for g_ in got):
+            break
+    else:
+        raise AssertionError("envs did not finish")
+    for e in range(n):
+        for t in range(steps):
+            for k in FIELDS:
+                assert np.array_equal(got[e][t][k], ref[t][k][e]), (e, t, k)
+        for a, b_ in zip(final_state[e], ref_state):
+            assert np.array_equal(a, b_[e]), e
+    mb.close()
+
+
+def test_mixed_env_trains_time_sliced(torch):
+    """PPO over the time-sliced schedule of a mixed batch (tick graph with the groups' forked streams captured inside)."""
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import MixedBatchedRobotEnv, default_config
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3 import PPO, GpuVecEnv
+    from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
+    env = MixedBatchedRobotEnv(default_config(), envs_per_group=16, auto_reset=True)
+    model = PPO("MultiInputPolicy", GpuVecEnv(env), n_steps=2, batch_size=128, n_epochs=1, seed=3, async_slice=64, async_capacity=32,
+                async_budget_us=2000, policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]))
+    ar = model._async
+    assert ar is not None and ar.C == 32
+    before = [p.detach().clone() for p in model.policy.parameters()]
+    for _ in range(3):
+        assert model.collect_rollouts()
+        stats = model.train()
+    torch.cuda.synchronize()
+    assert ar._graph is not None                                        # the tick ran as a captured graph
+    assert np.isfinite(float(stats["loss"])) and model.num_timesteps >= 3 * 2 * 128
+    rows = ar.window_rows()
+    rec = rows[ar.is_rec[rows]]
+    envs = ar.rec_env[rec]
+    assert envs.min().item() >= 0 and envs.max().item() < 128 and len(set((envs // 16).tolist())) == 8     # every group decides
+    assert any(not torch.equal(a, b) for a, b in zip(before, model.policy.parameters()))
+    env.close()
 
 
 def test_mixed_env_trains_with_ppo(torch):
