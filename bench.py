@@ -25,9 +25,6 @@ import os
 import sys
 import time
 
-if "--mixed" in sys.argv:       # a hardware queue per group stream; the HIP runtime reads this when it is loaded (default 4)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-
 import numpy as np
 import torch
 import torch.distributed as dist

@@ -169,6 +169,30 @@ int grip_intrinsic_reward(const uint8_t *old_obs_dev, const int64_t *old_rows_de
  * of the last channel / 255 ([n, 2]). */
 int grip_obs_preprocess(const uint8_t *obs_dev, int n, int channels, float *img_nhwc_dev, float *other_dev, void *stream);
 
+/* ---- batch sets: several batches -- other object models, other target directions -- stepped by ONE launch per phase
+ * (BASELINE.json configs[3]: {acorn, sand_ball, sugar_cube, bread_crumb} x direction {0, 45} in one process). Env ids are
+ * global: batch g owns ids [sum of the sizes before it, ... + its size). `out` (may be NULL) holds result arrays over all
+ * envs of the set; it is bound at creation. The batches stay usable on their own (reset, state hooks); after
+ * grip_batch_set_config / grip_batch_set_state_storage on a member call grip_batchset_refresh. A single batch runs the same
+ * kernels as a set of one, so a set is bit-identical to its batches stepped alone. */
+typedef struct GripBatchSet GripBatchSet;
+int  grip_batchset_create(GripBatch *const *batches, int n, const GripStepOut *out, GripBatchSet **out_set);
+void grip_batchset_destroy(GripBatchSet *s);                 /* the member batches are not destroyed */
+int  grip_batchset_refresh(GripBatchSet *s);
+int  grip_batchset_num_envs(const GripBatchSet *s);
+/* grip_batch_step over the set: actions_dev float32 [total envs, 6 or 5]. */
+int  grip_batchset_step(GripBatchSet *s, const float *actions_dev, void *stream);
+/* grip_batch_advance over the set. Batch g owns rows [g * capacity / n, (g + 1) * capacity / n) of slot_actions_dev and
+ * ready_list_dev; its segment lists its waiting envs (global ids) packed to the front, -1 behind them, so the list has holes
+ * and *ready_count_dev is set to capacity: consumers test the sign of an entry (grip_rollout_tick does). */
+int  grip_batchset_advance(GripBatchSet *s, const float *slot_actions_dev, int slice, int budget_us, int lag, int capacity,
+                           int32_t *ready_list_dev, int32_t *ready_count_dev, void *stream);
+/* get_observation of every env of the set, obs_dev uint8 [total envs, 5 or 4, 64, 64]. */
+int  grip_batchset_observe(GripBatchSet *s, uint8_t *obs_dev, void *stream);
+/* row r of obs_dev (and of records_dev from row record_row_dev[0] on) = observation of env list_dev[r]; negative entries are skipped. */
+int  grip_batchset_observe_list(GripBatchSet *s, const int32_t *list_dev, int capacity, uint8_t *obs_dev, uint8_t *records_dev,
+                                const int64_t *record_row_dev, void *stream);
+
 /* ---- low-level hooks (the dm_control Physics surface the reference touches; used by tests) ---- */
 /* physics.data.qpos / qvel / ctrl / qacc_warmstart, env-major float32 [N,14],[N,13],[N,7],[N,13];
  * host_or_dev = 0: host pointers (synchronous copy), 1: device pointers. NULL skips a field. */

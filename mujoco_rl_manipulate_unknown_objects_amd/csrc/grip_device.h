@@ -69,6 +69,10 @@ struct DevConfig {
     int state_half;      // qpos / qvel / ctrl are stored as IEEE half in HBM (grip_batch_set_state_storage); arithmetic stays fp32
 };
 
+// per-batch arguments of the observation kernel (one record per batch of a set; a single batch is a set of one)
+struct DevModel;
+struct RenderGroup { const DevModel *model; DevConfig cfg; const float *qpos; const int *pad_grasp, *pad_pher; int n, env0; };
+
 // one word of the SoA state arrays: fp32, or IEEE half (round to nearest even on store) when the batch keeps qpos / qvel /
 // ctrl in half precision (BASELINE.json configs[4]); `half` is uniform over the launch
 __device__ __forceinline__ float ld_word(const float *base, size_t idx, int half) {

@@ -65,19 +65,17 @@ __device__ static uint8_t to_u8(float v) { v *= 255.f; v = fminf(fmaxf(v, 0.f), 
 #define TW 2                // tile width: every thread owns a TW x TW pixel tile
 #define TPX (TW * TW)
 
-__global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevConfig cfg, const float *qpos, const int *pad_grasp, const int *pad_pher,
-                                                      int n, const int *list, const int *count, uint8_t *obs, uint8_t *obs2, const long long *row2) {
-    // list != NULL: block b renders env list[b] into row b of obs, for b < *count (grip_batch_observe_list); obs2 != NULL: the
-    // same bytes also go to row row2[0] + b of obs2 (the trainer's record buffer), saving a 20 KB-per-env copy kernel
-    if (list && (int)blockIdx.x >= *count) return;
-    const DevModel &m = *mp;
+// Renders env e of one batch into row blockIdx.x of obs (and, when obs2 != NULL, into row row2[0] + blockIdx.x of obs2: the
+// trainer's record buffer, saving a 20 KB-per-env copy kernel).
+__device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig &cfg, const float *qpos, const int *pad_grasp, const int *pad_pher,
+                                             int n, int e, uint8_t *obs, uint8_t *obs2, const long long *row2) {
     __shared__ Frames fr;
     __shared__ float gsph[GN_GEOM][4];          // bounding sphere centre in camera coordinates, radius^2
     extern __shared__ float4 spl[];             // camera-space plane table of this env (sized by the launcher: planes x 16 B)
     __shared__ int gadr[GN_GEOM], gnum[GN_GEOM];
     __shared__ float red[RTHREADS];
     __shared__ int redi[RTHREADS];
-    const int e = list ? list[blockIdx.x] : blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     if (tid == 0) {
         compute_frames(m, qpos, n, e, cfg.state_half, fr);
         V3 co = ldv(fr.cam_o); M3 Rc = ldm(fr.cam_R);
@@ -233,9 +231,23 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const DevModel *mp, DevCon
     }
 }
 
-extern "C" int grip_render_launch(const DevModel *d_model, DevConfig cfg, const float *qpos, const int *pad_grasp, const int *pad_pher, int n,
-                                  const int *list, const int *count, int nblocks, int nplanes, uint8_t *obs, uint8_t *obs2, const long long *row2, hipStream_t s) {
-    hipLaunchKernelGGL(k_observe, dim3(nblocks), dim3(RTHREADS), (size_t)nplanes * sizeof(float4), s, d_model, cfg, qpos, pad_grasp, pad_pher, n, list, count, obs, obs2, row2);
+// One kernel for a batch and for a set of batches: per-batch arguments in device memory behind a const __restrict__ pointer
+// (workgroup-uniform index -> scalar loads). list != NULL: row b shows env list[b] (global id over the set; a negative entry is a
+// hole, rows >= *count -- when count is given -- are skipped too: their rows are left alone); list == NULL: row b = env b.
+__global__ void __launch_bounds__(RTHREADS) k_observe(const RenderGroup *__restrict__ groups, int ngroups, const int *list, const int *count,
+                                                      uint8_t *obs, uint8_t *obs2, const long long *row2) {
+    if (list && count && (int)blockIdx.x >= *count) return;
+    const int ge = list ? list[blockIdx.x] : (int)blockIdx.x;
+    if (ge < 0) return;
+    int g = 0;
+    for (int i = 1; i < ngroups; i++) g = ge >= groups[i].env0 ? i : g;
+    const RenderGroup &rg = groups[g];
+    observe_body(*rg.model, rg.cfg, rg.qpos, rg.pad_grasp, rg.pad_pher, rg.n, ge - rg.env0, obs, obs2, row2);
+}
+
+extern "C" int grip_render_launch(const RenderGroup *groups_dev, int ngroups, const int *list, const int *count, int nblocks, int nplanes_max,
+                                  uint8_t *obs, uint8_t *obs2, const long long *row2, hipStream_t s) {
+    hipLaunchKernelGGL(k_observe, dim3(nblocks), dim3(RTHREADS), (size_t)nplanes_max * sizeof(float4), s, groups_dev, ngroups, list, count, obs, obs2, row2);
     return launch_status("grip_render_launch");
 }
 

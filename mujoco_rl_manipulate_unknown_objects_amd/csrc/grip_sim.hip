@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -251,6 +252,7 @@ struct GripBatch {
     float xfrc_z = 0.f;
     std::vector<hipEvent_t> ev0, ev1; int ev_used = 0;
     bool reset_info_valid = false;
+    void *d_self = nullptr, *d_rself = nullptr;    // this batch as a set of one: GroupArgs / RenderGroup records in device memory
 };
 
 static constexpr int EV_RING = 1024;
@@ -418,11 +420,12 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_reset(const DevModel m, DevCo
 // slice  > 0: time slice of grip_batch_advance -- an env in flight resumes from its MacroCtx, a waiting env that holds a
 // slot starts a macro step with actions[slot], both run at most `slice` calls of physics.step(); envs that finish write
 // their outputs and wait, the others are suspended. The arithmetic per env is the same in both modes.
-__global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, DevConfig cfg, StatePtrs st, const float *actions, StepOutDev out,
-                                                              const float *reset_info, float xfrc_z, MacroCtx mc, int slice, const int *order, long long budget_ticks, int lag) {
+// `block`: index of the workgroup within its batch (blockIdx.x for a single batch; a set of batches shares one launch)
+DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePtrs &st, const float *actions, const StepOutDev &out,
+                          const float *reset_info, float xfrc_z, const MacroCtx &mc, int slice, const int *order, long long budget_ticks, int lag, int block) {
     const Ctx cx = stage_tables(m, lds_dyn);
     STAMPS_DECL
-    int e = blockIdx.x * EPB + threadIdx.x / KL;
+    int e = block * EPB + threadIdx.x / KL;
     const bool valid = e < st.n;
     if (!valid) e = st.n - 1;
     if (order) e = order[e];
@@ -628,13 +631,44 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const DevModel m, 
     }
 }
 
+// ---- ONE kernel for a batch and for a SET of batches (different object models / target directions): the per-batch arguments
+// (model constants, config, array pointers) are GroupArgs records in device memory, read through a const __restrict__ pointer
+// with a workgroup-uniform index -> scalar loads, exactly what kernel arguments cost. Workgroup b belongs to the group whose
+// [wg0, wg0 + workgroups) range holds it. A single batch is a set of one, so both run the same machine code and a mixed batch
+// is bit-identical to its groups run alone; mixed-object training (BASELINE.json configs[3]) fills the chip with ONE grid.
+struct GroupArgs {
+    DevModel m; DevConfig cfg; StatePtrs st; StepOutDev out; const float *reset_info; float xfrc_z; MacroCtx mc; int *order;
+    int wg0, env0;                 // first workgroup / first global env id of the group
+};
+
+DEVI int group_of_block(const GroupArgs *__restrict__ groups, int ngroups, int block) {
+    int g = 0;
+    for (int i = 1; i < ngroups; i++) g = block >= groups[i].wg0 ? i : g;
+    return g;
+}
+
+// out1 (use_out1 != 0): result arrays given with the call (grip_batch_step / _advance of a single batch) instead of the ones
+// bound to the set. slice <= 0: actions float32 [total envs, adim] (lock-step); slice > 0: [ngroups * seg_rows, adim].
+__global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const GroupArgs *__restrict__ groups, int ngroups, StepOutDev out1, int use_out1, const float *actions,
+                                                              int seg_rows, int slice, long long budget_ticks, int lag) {
+    const int g = group_of_block(groups, ngroups, (int)blockIdx.x);
+    const GroupArgs &ga = groups[g];
+    const int adim = ga.cfg.include_roll ? 6 : 5;
+    const float *act = actions + (slice > 0 ? (size_t)g * seg_rows : (size_t)ga.env0) * adim;
+    StepOutDev out = ga.out;
+    if (use_out1) out = out1;
+    macro_step_body(ga.m, ga.cfg, ga.st, act, out, ga.reset_info, ga.xfrc_z, ga.mc, slice, slice > 0 ? ga.order : nullptr, budget_ticks, lag,
+                    (int)blockIdx.x - ga.wg0);
+}
+
 // Deterministic compaction after a time slice (one 1024-thread block): the waiting envs that hold no slot yet, scanned from env `rot` on so that
 // nobody starves when more wait than `capacity`, get slots 0..count-1 (list[slot] = env, -1 beyond count). order[] is the
 // work order of the next slice: envs that will run (in flight, or holding a slot) sorted by cost class -- no hull contact,
 // one or two, more -- so that the 4 envs of a wave and the 16 of a workgroup cost about the same per physics.step(), then
 // the idle envs, whose workgroups retire at once.
 #define CP_THREADS 1024
-__global__ void __launch_bounds__(CP_THREADS) k_compact(MacroCtx mc, int n, int capacity, int *list, int *count, int *order) {
+// id_offset: added to the env ids written to `list` (0 for a single batch, the group's first global env id in a set)
+DEVI void compact_body(const MacroCtx &mc, int n, int capacity, int *list, int *count, int *order, int id_offset) {
     // the rotation advances with a device-side tick counter, so that a captured (hipGraph) tick keeps rotating
     const int rot = (int)(((long long)mc.tick[0] * capacity) % n);
     __shared__ int sa[CP_THREADS];
@@ -652,7 +686,7 @@ __global__ void __launch_bounds__(CP_THREADS) k_compact(MacroCtx mc, int n, int 
         int v = t * chunk + i;
         if (v < n) {
             int e = v + rot; if (e >= n) e -= n;
-            if (mc.astate[e] != 0 && mc.slot[e] < 0) { int p = base++; if (p < capacity) { mc.slot[e] = p; mc.gen[e] = tick; list[p] = e; } }
+            if (mc.astate[e] != 0 && mc.slot[e] < 0) { int p = base++; if (p < capacity) { mc.slot[e] = p; mc.gen[e] = tick; list[p] = e + id_offset; } }
         }
     }
     int cnt = total < capacity ? total : capacity;
@@ -675,6 +709,13 @@ __global__ void __launch_bounds__(CP_THREADS) k_compact(MacroCtx mc, int n, int 
     for (int k = 0; k < CP_CLASSES; k++) { before[k] += start; start += cls_total[k]; }
     for (int i = 0; i < chunk; i++) { int e = t * chunk + i; if (e < n) order[before[cls_of(e)]++] = e; }
     if (t == 0) { mc.tick[0] = mc.tick[0] + 1; mc.t0[0] = 0ULL; }     // every thread read the old tick before the first barrier
+}
+// one block per group: segment g of the list gets the group's waiting envs (global ids), -1 beyond its count (counts[g]);
+// total != NULL receives the number of rows (the merged list of a set has holes: validity is the sign of an entry)
+__global__ void __launch_bounds__(CP_THREADS) k_compact(const GroupArgs *__restrict__ groups, int seg_rows, int *list, int *counts, int *total) {
+    const GroupArgs &ga = groups[blockIdx.x];
+    compact_body(ga.mc, ga.st.n, seg_rows, list + (size_t)blockIdx.x * seg_rows, counts + blockIdx.x, ga.order, ga.env0);
+    if (total && blockIdx.x == 0 && threadIdx.x == 0) *total = (int)gridDim.x * seg_rows;
 }
 
 // k calls of physics.step() with the stored ctrl (test hook / micro-benchmark)
@@ -778,6 +819,37 @@ static StepOutDev to_dev(const GripStepOut *o) {
 static MacroCtx macro_ctx(GripBatch *b) { MacroCtx c; c.ints = b->mc_ints; c.flts = b->mc_flts; c.astate = b->mc_astate; c.slot = b->mc_slot; c.heavy = b->mc_heavy; c.tick = b->mc_tick; c.gen = b->mc_gen; c.t0 = b->mc_t0; return c; }
 static int grid_of(const GripBatch *b) { return (b->n + EPB - 1) / EPB; }
 
+// observation kernel (grip_render.hip)
+extern "C" int grip_render_launch(const RenderGroup *groups_dev, int ngroups, const int *list, const int *count, int nblocks, int nplanes_max,
+                                  uint8_t *obs, uint8_t *obs2, const long long *row2, hipStream_t s);
+
+template <class T> static T *off(T *p, size_t n) { return p ? p + n : nullptr; }
+
+// the GroupArgs / RenderGroup records of batch b as member of a set: first workgroup wg0, first global env id env0, result arrays
+// `out` over all envs of the set (NULL: none bound)
+static void fill_group(GripBatch *b, int wg0, int env0, const GripStepOut *out, GroupArgs &ga, RenderGroup &rg) {
+    memset(&ga, 0, sizeof ga);
+    ga.m = b->hmodel; ga.cfg = b->cfg; ga.st = state_ptrs(b); ga.reset_info = b->reset_info; ga.xfrc_z = b->xfrc_z;
+    ga.mc = macro_ctx(b); ga.order = b->mc_order; ga.wg0 = wg0; ga.env0 = env0;
+    if (out) {
+        const GripStepOut &o = *out; StepOutDev &d = ga.out; const size_t e0 = (size_t)env0;
+        d.reward = off(o.reward, e0); d.done = off(o.done, e0); d.achieved_goal = off(o.achieved_goal, 2 * e0); d.desired_goal = off(o.desired_goal, 2 * e0);
+        d.status = off(o.status, e0); d.episode_step = off(o.episode_step, e0); d.gripper_open = off(o.gripper_open, e0);
+        d.object_grasped = off(o.object_grasped, e0); d.position_reached = off(o.position_reached, e0); d.total_distance = off(o.total_distance, e0);
+        d.line_distance = off(o.line_distance, e0); d.gripper_position = off(o.gripper_position, 3 * e0); d.object_position = off(o.object_position, 3 * e0);
+        d.init_obj_pos = off(o.init_obj_pos, 3 * e0); d.n_substeps = off(o.n_substeps, e0); d.fault = off(o.fault, e0);
+    }
+    rg.model = b->d_model; rg.cfg = b->cfg; rg.qpos = b->qpos; rg.pad_grasp = b->pad_grasp; rg.pad_pher = b->pad_pher; rg.n = b->n; rg.env0 = env0;
+}
+// (re)write the batch's own records; synchronous -- callers are creation and the configuration setters, which synchronise anyway
+static int upload_self(GripBatch *b) {
+    GroupArgs ga; RenderGroup rg;
+    fill_group(b, 0, 0, nullptr, ga, rg);
+    HIPCHK(hipMemcpy(b->d_self, &ga, sizeof ga, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(b->d_rself, &rg, sizeof rg, hipMemcpyHostToDevice));
+    return 0;
+}
+
 static int ensure_lds_attr(int device) {      // function attributes are per device
     static std::mutex mu; static std::vector<char> set_on;
     std::lock_guard<std::mutex> lock(mu);
@@ -845,7 +917,8 @@ static int batch_build(GripBatch *b, const GripModel *m) {
     b->xfrc_z = -(0.438f * m->host.gravity_z);      // robot_env.py:64-65, constant verbatim
     b->ev0.assign(EV_RING, nullptr); b->ev1.assign(EV_RING, nullptr);
     for (int i = 0; i < EV_RING; i++) { HIPCHK(hipEventCreate(&b->ev0[i])); HIPCHK(hipEventCreate(&b->ev1[i])); }
-    return 0;
+    HIPCHK(hipMalloc(&b->d_self, sizeof(GroupArgs))); HIPCHK(hipMalloc(&b->d_rself, sizeof(RenderGroup)));
+    return upload_self(b);
 }
 
 extern "C" void grip_batch_destroy(GripBatch *b) {
@@ -854,7 +927,7 @@ extern "C" void grip_batch_destroy(GripBatch *b) {
     (void)hipDeviceSynchronize();
     void *ptrs[] = {b->d_model, b->d_hull, b->d_planes, b->qpos, b->qvel, b->ctrl, b->warm, b->episode_step, b->status,
                     b->gripper_open, b->pad_grasp, b->pad_pher, b->reset_info, b->scratch, b->mc_ints, b->mc_flts, b->mc_astate,
-                    b->mc_slot, b->mc_order, b->mc_heavy, b->mc_tick, b->mc_gen, b->mc_t0};
+                    b->mc_slot, b->mc_order, b->mc_heavy, b->mc_tick, b->mc_gen, b->mc_t0, b->d_self, b->d_rself};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : b->ev0) if (e) (void)hipEventDestroy(e);
     for (auto &e : b->ev1) if (e) (void)hipEventDestroy(e);
@@ -878,7 +951,7 @@ extern "C" int grip_batch_set_config(GripBatch *b, const GripEnvConfig *c) {
     hipLaunchKernelGGL(k_reset, dim3(1), dim3(WG_THREADS), b->lds_bytes, nullptr, b->hmodel, b->cfg, state_ptrs(b), zero_mask, none, b->reset_info, macro_ctx(b));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(nullptr));
-    return 0;
+    return upload_self(b);
 }
 
 extern "C" int grip_batch_reset(GripBatch *b, const uint8_t *mask_dev, const GripStepOut *out, void *stream) {
@@ -896,8 +969,7 @@ extern "C" int grip_batch_step(GripBatch *b, const float *actions_dev, const Gri
     hipStream_t s = (hipStream_t)stream;
     int slot = b->ev_used % EV_RING;
     HIPCHK(hipEventRecord(b->ev0[slot], s));
-    hipLaunchKernelGGL(k_macro_step, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, s, b->hmodel, b->cfg, state_ptrs(b), actions_dev, to_dev(out),
-                       b->reset_info, b->xfrc_z, macro_ctx(b), 0, (const int *)nullptr, 0LL, 1);
+    hipLaunchKernelGGL(k_macro_step, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, s, (const GroupArgs *)b->d_self, 1, to_dev(out), 1, actions_dev, 0, 0, 0LL, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(b->ev1[slot], s));
     b->ev_used++;
@@ -917,11 +989,11 @@ extern "C" int grip_batch_advance(GripBatch *b, const float *slot_actions_dev, i
     const bool timed = cap == hipStreamCaptureStatusNone;
     int slot = b->ev_used % EV_RING;
     if (timed) HIPCHK(hipEventRecord(b->ev0[slot], s));
-    hipLaunchKernelGGL(k_macro_step, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, s, b->hmodel, b->cfg, state_ptrs(b), slot_actions_dev, to_dev(out),
-                       b->reset_info, b->xfrc_z, macro_ctx(b), slice, (const int *)b->mc_order, (long long)(budget_us > 0 ? budget_us : 0) * 100LL, lag);
+    hipLaunchKernelGGL(k_macro_step, dim3(grid_of(b)), dim3(WG_THREADS), b->lds_bytes, s, (const GroupArgs *)b->d_self, 1, to_dev(out), 1, slot_actions_dev, capacity, slice,
+                       (long long)(budget_us > 0 ? budget_us : 0) * 100LL, lag);
     HIPCHK(hipGetLastError());
     if (timed) { HIPCHK(hipEventRecord(b->ev1[slot], s)); b->ev_used++; }
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(CP_THREADS), 0, s, macro_ctx(b), b->n, capacity, ready_list_dev, ready_count_dev, b->mc_order);
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(CP_THREADS), 0, s, (const GroupArgs *)b->d_self, capacity, ready_list_dev, ready_count_dev, (int *)nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1009,7 +1081,7 @@ extern "C" int grip_batch_set_state_storage(GripBatch *b, int half, void *stream
     }
     HIPCHK(hipStreamSynchronize(s));
     b->cfg.state_half = half;
-    return 0;
+    return upload_self(b);
 }
 
 extern "C" int grip_batch_get_flags(GripBatch *b, int32_t *episode_step, int32_t *status, int32_t *gripper_open, void *stream) {
@@ -1068,23 +1140,131 @@ extern "C" int grip_batch_target_pose(GripBatch *b, const float *actions_dev, fl
     return 0;
 }
 
-// observation kernels live in grip_render.hip
-extern "C" int grip_render_launch(const DevModel *d_model, DevConfig cfg, const float *qpos, const int *pad_grasp, const int *pad_pher, int n,
-                                  const int *list, const int *count, int nblocks, int nplanes, uint8_t *obs, uint8_t *obs2, const long long *row2, hipStream_t s);
 extern "C" int grip_batch_observe(GripBatch *b, uint8_t *obs_dev, void *stream) {
     if (!b || !obs_dev) return fail("grip_batch_observe: null argument");
     HIPCHK(hipSetDevice(b->device));
-    if (grip_render_launch(b->d_model, b->cfg, b->qpos, b->pad_grasp, b->pad_pher, b->n, nullptr, nullptr, b->n, b->nplanes, obs_dev, nullptr, nullptr, (hipStream_t)stream))
-        return fail("render launch failed");
+    if (grip_render_launch((const RenderGroup *)b->d_rself, 1, nullptr, nullptr, b->n, b->nplanes, obs_dev, nullptr, nullptr, (hipStream_t)stream)) return -1;
     return 0;
 }
 extern "C" int grip_batch_observe_list(GripBatch *b, const int32_t *list_dev, const int32_t *count_dev, int capacity, uint8_t *obs_dev,
                                        uint8_t *records_dev, const int64_t *record_row_dev, void *stream) {
     if (!b || !obs_dev || !list_dev || !count_dev || capacity <= 0 || (records_dev && !record_row_dev)) return fail("grip_batch_observe_list: bad argument");
     HIPCHK(hipSetDevice(b->device));
-    if (grip_render_launch(b->d_model, b->cfg, b->qpos, b->pad_grasp, b->pad_pher, b->n, list_dev, count_dev, capacity, b->nplanes, obs_dev, records_dev, (const long long *)record_row_dev, (hipStream_t)stream))
-        return fail("render launch failed");
+    if (grip_render_launch((const RenderGroup *)b->d_rself, 1, list_dev, count_dev, capacity, b->nplanes, obs_dev, records_dev, (const long long *)record_row_dev, (hipStream_t)stream)) return -1;
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batch sets: several batches (object models / target directions) behind one launch per phase
+// ------------------------------------------------------------------------------------------------
+struct GripBatchSet {
+    std::vector<GripBatch *> b; int device = 0, total_envs = 0, total_wgs = 0, nplanes_max = 0; size_t lds_max = 0;
+    std::vector<int> env0, wg0;
+    GripStepOut out; bool has_out = false;
+    GroupArgs *d_groups = nullptr; RenderGroup *d_rgroups = nullptr;
+    int *counts = nullptr;                 // per-group ready counts of the last advance (device)
+};
+
+static int set_upload(GripBatchSet *s) {
+    const int G = (int)s->b.size();
+    std::vector<GroupArgs> ga(G); std::vector<RenderGroup> rg(G);
+    for (int g = 0; g < G; g++) fill_group(s->b[g], s->wg0[g], s->env0[g], s->has_out ? &s->out : nullptr, ga[g], rg[g]);
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipMemcpy(s->d_groups, ga.data(), sizeof(GroupArgs) * G, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(s->d_rgroups, rg.data(), sizeof(RenderGroup) * G, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int grip_batchset_create(GripBatch *const *batches, int n, const GripStepOut *out, GripBatchSet **out_set) {
+    if (!batches || n <= 0 || n > 64 || !out_set) return fail("grip_batchset_create: need 1..64 batches");
+    for (int g = 0; g < n; g++) {
+        if (!batches[g]) return fail("grip_batchset_create: null batch");
+        if (batches[g]->device != batches[0]->device) return fail("grip_batchset_create: the batches of a set live on one device");
+        if (batches[g]->cfg.include_roll != batches[0]->cfg.include_roll || batches[g]->cfg.full_observation != batches[0]->cfg.full_observation)
+            return fail("grip_batchset_create: the batches of a set share the action and observation layout (include_roll, full_observation)");
+    }
+    GripBatchSet *s = new GripBatchSet(); s->device = batches[0]->device;
+    for (int g = 0; g < n; g++) {
+        GripBatch *b = batches[g];
+        s->b.push_back(b); s->env0.push_back(s->total_envs); s->wg0.push_back(s->total_wgs);
+        s->total_envs += b->n; s->total_wgs += grid_of(b);
+        s->lds_max = std::max(s->lds_max, b->lds_bytes); s->nplanes_max = std::max(s->nplanes_max, b->nplanes);
+    }
+    if (out) { s->out = *out; s->has_out = true; }
+    if (hipSetDevice(s->device) != hipSuccess || hipMalloc(&s->counts, n * sizeof(int)) != hipSuccess || hipMemset(s->counts, 0, n * sizeof(int)) != hipSuccess ||
+        hipMalloc(&s->d_groups, n * sizeof(GroupArgs)) != hipSuccess || hipMalloc(&s->d_rgroups, n * sizeof(RenderGroup)) != hipSuccess || set_upload(s)) {
+        std::string why = g_err.empty() ? std::string("grip_batchset_create: device setup failed") : g_err;
+        grip_batchset_destroy(s); g_err = why; return -1;
+    }
+    *out_set = s;
+    return 0;
+}
+
+extern "C" void grip_batchset_destroy(GripBatchSet *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device); (void)hipDeviceSynchronize();
+    if (s->counts) (void)hipFree(s->counts);
+    if (s->d_groups) (void)hipFree(s->d_groups);
+    if (s->d_rgroups) (void)hipFree(s->d_rgroups);
+    delete s;
+}
+
+extern "C" int grip_batchset_refresh(GripBatchSet *s) {
+    if (!s) return fail("grip_batchset_refresh: null set");
+    HIPCHK(hipSetDevice(s->device)); HIPCHK(hipDeviceSynchronize());
+    return set_upload(s);
+}
+
+extern "C" int grip_batchset_num_envs(const GripBatchSet *s) { return s ? s->total_envs : -1; }
+
+static int set_launch(GripBatchSet *s, const float *actions, int seg_rows, int slice, int budget_us, int lag, hipStream_t st) {
+    GripBatch *b0 = s->b[0];                         // launch timing goes to the first batch's event ring (grip_batch_kernel_time)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st) HIPCHK(hipStreamIsCapturing(st, &cap));
+    const bool timed = cap == hipStreamCaptureStatusNone;
+    int slot = b0->ev_used % EV_RING;
+    if (timed) HIPCHK(hipEventRecord(b0->ev0[slot], st));
+    StepOutDev none; memset(&none, 0, sizeof none);
+    hipLaunchKernelGGL(k_macro_step, dim3(s->total_wgs), dim3(WG_THREADS), s->lds_max, st, (const GroupArgs *)s->d_groups, (int)s->b.size(), none, 0, actions, seg_rows, slice,
+                       (long long)(budget_us > 0 ? budget_us : 0) * 100LL, lag);
+    HIPCHK(hipGetLastError());
+    if (timed) { HIPCHK(hipEventRecord(b0->ev1[slot], st)); b0->ev_used++; }
+    return 0;
+}
+
+extern "C" int grip_batchset_step(GripBatchSet *s, const float *actions_dev, void *stream) {
+    if (!s || !actions_dev) return fail("grip_batchset_step: null argument");
+    HIPCHK(hipSetDevice(s->device));
+    return set_launch(s, actions_dev, 0, 0, 0, 1, (hipStream_t)stream);
+}
+
+extern "C" int grip_batchset_advance(GripBatchSet *s, const float *slot_actions_dev, int slice, int budget_us, int lag, int capacity,
+                                     int32_t *ready_list_dev, int32_t *ready_count_dev, void *stream) {
+    if (!s || !slot_actions_dev || !ready_list_dev || !ready_count_dev) return fail("grip_batchset_advance: null argument");
+    const int G = (int)s->b.size();
+    if (slice <= 0 || capacity <= 0 || capacity % G) return fail("grip_batchset_advance: need slice > 0 and a capacity that is a multiple of the number of batches");
+    const int seg = capacity / G;
+    for (GripBatch *b : s->b) if (seg > b->n) return fail("grip_batchset_advance: capacity / batches exceeds a batch's env count");
+    if (lag != 1 && lag != 2) return fail("grip_batchset_advance: lag must be 1 or 2");
+    HIPCHK(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (set_launch(s, slot_actions_dev, seg, slice, budget_us, lag, st)) return -1;
+    hipLaunchKernelGGL(k_compact, dim3(G), dim3(CP_THREADS), 0, st, (const GroupArgs *)s->d_groups, seg, ready_list_dev, s->counts, ready_count_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int grip_batchset_observe(GripBatchSet *s, uint8_t *obs_dev, void *stream) {
+    if (!s || !obs_dev) return fail("grip_batchset_observe: null argument");
+    HIPCHK(hipSetDevice(s->device));
+    return grip_render_launch(s->d_rgroups, (int)s->b.size(), nullptr, nullptr, s->total_envs, s->nplanes_max, obs_dev, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int grip_batchset_observe_list(GripBatchSet *s, const int32_t *list_dev, int capacity, uint8_t *obs_dev, uint8_t *records_dev,
+                                          const int64_t *record_row_dev, void *stream) {
+    if (!s || !list_dev || !obs_dev || capacity <= 0 || (records_dev && !record_row_dev)) return fail("grip_batchset_observe_list: bad argument");
+    HIPCHK(hipSetDevice(s->device));
+    return grip_render_launch(s->d_rgroups, (int)s->b.size(), list_dev, nullptr, capacity, s->nplanes_max, obs_dev, records_dev, (const long long *)record_row_dev, (hipStream_t)stream);
 }
 
 #ifdef GRIP_STAMPS

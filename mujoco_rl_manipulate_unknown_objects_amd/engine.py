@@ -76,7 +76,8 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_observe", "grip_batch_get_state", "grip_batch_set_state", "grip_batch_get_flags",
            "grip_batch_set_flags", "grip_batch_substep", "grip_batch_debug_forward", "grip_batch_target_pose",
            "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward", "grip_obs_preprocess",
-           "grip_batch_set_state_storage"]
+           "grip_batch_set_state_storage", "grip_batchset_create", "grip_batchset_destroy", "grip_batchset_refresh", "grip_batchset_num_envs",
+           "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list"]
 
 
 def lib():
@@ -113,6 +114,14 @@ def lib():
     L.grip_batch_observe_list.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
     L.grip_intrinsic_reward.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.grip_obs_preprocess.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+    L.grip_batchset_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(StepOutC), C.POINTER(vp)]
+    L.grip_batchset_destroy.argtypes = [vp]
+    L.grip_batchset_refresh.argtypes = [vp]
+    L.grip_batchset_num_envs.argtypes = [vp]
+    L.grip_batchset_step.argtypes = [vp, vp, vp]
+    L.grip_batchset_advance.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    L.grip_batchset_observe.argtypes = [vp, vp, vp]
+    L.grip_batchset_observe_list.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
     L.grip_rollout_tick.argtypes = [vp, vp]
     L.grip_rollout_gae.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
     _lib = L
@@ -356,12 +365,10 @@ class MixedBatch:
 
     Envs are sorted by group, so every wavefront is homogeneous: group g owns the contiguous env range
     [offsets[g], offsets[g + 1]). Each group is a GripBatch of its own that writes straight into its slice of the shared
-    result / observation tensors; the groups' kernels are enqueued on separate HIP streams forked from, and joined back
-    into, the caller's stream, so that the small per-group grids share the chip (the HIP runtime maps streams onto
-    GPU_MAX_HW_QUEUES hardware queues, 4 by default: with more groups than that export GPU_MAX_HW_QUEUES=<groups> before
-    the first GPU call -- measured 83 ms -> 52 ms per step for 8 groups x 512 envs, the time of the slowest group alone).
-    The time-sliced schedule works the same way: every group keeps its own decision list and owns a fixed segment of the
-    caller's ready list / action / observation rows (advance, observe_list below).
+    result / observation tensors; the groups form a GripBatchSet (include/grip_sim.h), i.e. ONE launch per phase covers all
+    of them -- the per-group kernel arguments sit in constant memory and a workgroup picks its group from its index -- so the
+    chip is filled by one grid on one stream. In the time-sliced schedule every group keeps its own decision list and owns a
+    fixed segment of the caller's ready list / action / observation rows (advance, observe_list below).
     """
 
     def __init__(self, groups, device_index=0, **cfg):
@@ -381,6 +388,7 @@ class MixedBatch:
             self.offsets.append(self.offsets[-1] + n)
         self.n = self.offsets[-1]
         self.out = {name: torch.zeros((self.n,) + shp, dtype=getattr(torch, dt), device=self.device) for name, dt, shp in _OUT_FIELDS}
+        self._outc = StepOutC(**{n: self.out[n].data_ptr() for n, _, _ in _OUT_FIELDS})
         cfg.pop("target_dir", None)
         models = {}
         self.parts = []
@@ -390,41 +398,40 @@ class MixedBatch:
             self.parts.append(Batch(model, n, device_index, out={k: v[lo:hi] for k, v in self.out.items()}, target_dir=d, **cfg))
         self.cfg = self.parts[0].cfg                       # the flags every group shares (action / observation layout)
         self.target_dirs = torch.tensor([d for _, n, d in self.groups for _ in range(n)], dtype=torch.float32, device=self.device)
-        self._streams = [torch.cuda.Stream(self.device) for _ in self.parts]
+        self.ptr = C.c_void_p()
+        arr = (C.c_void_p * len(self.parts))(*[p.ptr for p in self.parts])
+        _chk(lib().grip_batchset_create(arr, len(self.parts), C.byref(self._outc), C.byref(self.ptr)))
 
     action_dim = Batch.action_dim
     obs_channels = Batch.obs_channels
+    _stream = Batch._stream
 
     def set_config(self, **kw):
         if "target_dir" in kw:
             raise GripError("target directions of a MixedBatch are fixed per group")
         for p in self.parts:
             p.set_config(**kw)
+        _chk(lib().grip_batchset_refresh(self.ptr))
 
-    def _fan_out(self, fn):
-        """Run fn(group index, part) for every group on the group's stream, between a fork from and a join into the current stream."""
-        t = self.torch
-        cur = t.cuda.current_stream(self.device)
-        for g, (p, s) in enumerate(zip(self.parts, self._streams)):
-            s.wait_stream(cur)
-            with t.cuda.stream(s):
-                fn(g, p)
-        for s in self._streams:
-            cur.wait_stream(s)
+    def set_state_storage(self, dtype):
+        for p in self.parts:
+            p.set_state_storage(dtype)
+        _chk(lib().grip_batchset_refresh(self.ptr))
 
     def reset(self, mask=None):
         if mask is not None:
             mask = mask.to(device=self.device, dtype=self.torch.uint8).contiguous()
             if mask.numel() != self.n:
                 raise GripError(f"mask must have {self.n} entries")
-        self._fan_out(lambda g, p: p.reset(None if mask is None else mask[self.offsets[g]:self.offsets[g + 1]]))
+        for g, p in enumerate(self.parts):
+            p.reset(None if mask is None else mask[self.offsets[g]:self.offsets[g + 1]])
         return self.out
 
     def step(self, actions):
         a = actions.to(device=self.device, dtype=self.torch.float32).contiguous()
         if a.shape != (self.n, self.action_dim):
             raise GripError(f"actions must be [{self.n},{self.action_dim}], got {tuple(a.shape)}")
-        self._fan_out(lambda g, p: p.step(a[self.offsets[g]:self.offsets[g + 1]]))     # joined before returning: `a` may be freed
+        _chk(lib().grip_batchset_step(self.ptr, C.c_void_p(a.data_ptr()), self._stream()))
         return self.out
 
     def observe(self, obs=None):
@@ -432,52 +439,34 @@ class MixedBatch:
             obs = self.torch.empty((self.n, self.obs_channels, 64, 64), dtype=self.torch.uint8, device=self.device)
         if obs.dtype != self.torch.uint8 or not obs.is_contiguous() or obs.shape[0] != self.n:
             raise GripError(f"obs must be contiguous uint8 [{self.n}, C, 64, 64]")
-        self._fan_out(lambda g, p: p.observe(obs[self.offsets[g]:self.offsets[g + 1]]))
+        _chk(lib().grip_batchset_observe(self.ptr, C.c_void_p(obs.data_ptr()), self._stream()))
         return obs
 
     # -- asynchronous stepping: every group keeps its own decision list; the caller sees them side by side ------------------
-    def _async_buffers(self, cap):
-        """Group g owns rows [g * cap / G, (g + 1) * cap / G) of the caller's ready list, action and observation arrays. Its
-        GripBatch fills a local list (local env ids, -1 beyond its count); the caller's list gets the global ids with the
-        unused rows of every segment left at -1: a list with holes, which grip_rollout_tick / AsyncRollout skip by sign."""
-        t, G = self.torch, len(self.parts)
-        if cap % G:
-            raise GripError(f"the ready-list capacity ({cap}) must be a multiple of the number of groups ({G})")
-        if getattr(self, "_acap", None) != cap:
-            self._acap = cap
-            self._llst = t.full((G, cap // G), -1, dtype=t.int32, device=self.device)
-            self._lcnt = t.zeros(G, dtype=t.int32, device=self.device)
-            self._goff = t.tensor(self.offsets[:-1], dtype=t.int32, device=self.device).unsqueeze(1)
-            self._rows = t.zeros(G, dtype=t.int64, device=self.device)
-            self._rowoff = t.arange(G, dtype=t.int64, device=self.device) * (cap // G)
-        return cap // G
-
     def advance(self, slot_actions, slice_len, ready_list, ready_count, budget_us=0, lag=1):
-        """Batch.advance for every group on its own stream. slot_actions [capacity, action_dim]: row r of segment g is the
-        action of the env the previous call listed there. ready_list receives global env ids or -1 (holes), ready_count the
-        capacity (validity is the sign of the entry)."""
+        """Batch.advance for every group in one launch. Group g owns rows [g * cap / G, (g + 1) * cap / G) of slot_actions and
+        ready_list: row r of its segment is the action of the env the previous call listed there. ready_list receives global
+        env ids, -1 behind the listed envs of every segment (holes); ready_count the capacity (validity = sign of the entry)."""
         t = self.torch
         cap = int(ready_list.numel())
-        cg = self._async_buffers(cap)
+        if cap % len(self.parts):
+            raise GripError(f"the ready-list capacity ({cap}) must be a multiple of the number of groups ({len(self.parts)})")
         if slot_actions.dtype != t.float32 or not slot_actions.is_contiguous() or tuple(slot_actions.shape) != (cap, self.action_dim):
             raise GripError(f"slot_actions must be contiguous float32 [{cap},{self.action_dim}]")
         if ready_list.dtype != t.int32 or ready_count.dtype != t.int32:
             raise GripError("ready_list / ready_count must be int32")
-        self._fan_out(lambda g, p: p.advance(slot_actions[g * cg:(g + 1) * cg], slice_len, self._llst[g], self._lcnt[g:g + 1], budget_us, lag))
-        ready_list.view(len(self.parts), cg).copy_(t.where(self._llst >= 0, self._llst + self._goff, self._llst))
-        ready_count.fill_(cap)
+        _chk(lib().grip_batchset_advance(self.ptr, C.c_void_p(slot_actions.data_ptr()), int(slice_len), int(budget_us), int(lag), cap,
+                                         C.c_void_p(ready_list.data_ptr()), C.c_void_p(ready_count.data_ptr()), self._stream()))
         return self.out
 
     def observe_list(self, ready_list, ready_count, obs, records=None, record_row=None):
-        """Render the envs listed by the last advance(): segment g of `obs` (and of the record rows from record_row on)."""
+        """Row r of obs (and of records from row record_row on) = observation of env ready_list[r]; holes are skipped."""
         cap = int(ready_list.numel())
-        cg = self._async_buffers(cap)
         if obs.dtype != self.torch.uint8 or not obs.is_contiguous() or obs.shape[0] < cap:
             raise GripError("obs must be contiguous uint8 [capacity, C, 64, 64]")
-        if records is not None:
-            self.torch.add(self._rowoff, record_row, out=self._rows)           # first record row of every segment
-        self._fan_out(lambda g, p: p.observe_list(self._llst[g], self._lcnt[g:g + 1], obs[g * cg:(g + 1) * cg], records,
-                                                  None if records is None else self._rows[g:g + 1]))
+        rp = None if records is None else C.c_void_p(records.data_ptr())
+        rr = None if record_row is None else C.c_void_p(record_row.data_ptr())
+        _chk(lib().grip_batchset_observe_list(self.ptr, C.c_void_p(ready_list.data_ptr()), cap, C.c_void_p(obs.data_ptr()), rp, rr, self._stream()))
         return obs
 
     def add_intrinsic_reward(self, *a, **k):
@@ -492,23 +481,18 @@ class MixedBatch:
             lo, hi = self.offsets[g], self.offsets[g + 1]
             p.set_state(*[None if x is None else np.asarray(x)[lo:hi] for x in (qpos, qvel, ctrl, warm)])
 
-    def set_state_storage(self, dtype):
-        for p in self.parts:
-            p.set_state_storage(dtype)
-
     def get_flags(self):
         parts = [p.get_flags() for p in self.parts]
         return tuple(np.concatenate([q[i] for q in parts]) for i in range(3))
 
     def kernel_time(self, reset=True):
-        """(mean launch duration in ms over all groups' macro-step launches, number of launches)."""
-        tot, cnt = 0.0, 0
-        for p in self.parts:
-            ms, n = p.kernel_time(reset)
-            tot += ms * n; cnt += n
-        return (tot / cnt if cnt else 0.0), cnt
+        """(mean duration in ms of the set's macro-step launches, number of launches): timed on the first group's event ring."""
+        return self.parts[0].kernel_time(reset)
 
     def close(self):
+        if getattr(self, "ptr", None) and _lib is not None:
+            _lib.grip_batchset_destroy(self.ptr)
+            self.ptr = None
         for p in getattr(self, "parts", []):
             p.close()
 

@@ -3,10 +3,6 @@ import sys
 
 import pytest
 
-# read when the HIP runtime starts (first GPU call): one hardware queue per group of the mixed-object batches of
-# tests/test_gpu_mixed.py (default 4), so that their eight lock-step groups run side by side
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
