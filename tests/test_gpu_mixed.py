@@ -166,7 +166,7 @@ def test_mixed_time_sliced_equals_lockstep(engine, torch):
 
 
 def test_mixed_env_trains_time_sliced(torch):
-    """PPO over the time-sliced schedule of a mixed batch (tick graph with the groups' forked streams captured inside)."""
+    """PPO over the time-sliced schedule of a mixed batch (the tick, one launch per phase over the eight groups, captured as a hipGraph)."""
     from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import MixedBatchedRobotEnv, default_config
     from mujoco_rl_manipulate_unknown_objects_amd.sb3 import PPO, GpuVecEnv
     from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN

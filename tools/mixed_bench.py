@@ -19,7 +19,7 @@ def timed(fn, n):
 
 for i in range(4):
     mb.step(acts[i])
-print(f"mixed step ({len(groups)} groups x {per} envs, forked streams): {timed(lambda i: mb.step(acts[4 + i]), 8):.2f} ms")
+print(f"mixed step ({len(groups)} groups x {per} envs, one launch): {timed(lambda i: mb.step(acts[4 + i]), 8):.2f} ms")
 print(f"mixed observe: {timed(lambda i: mb.observe(), 4):.2f} ms")
 for g, p in enumerate(mb.parts):
     lo, hi = mb.offsets[g], mb.offsets[g + 1]
