@@ -1,13 +1,17 @@
 """Sanity probe: PPO over the time-sliced engine for a minute; prints episode return / length and losses per rollout."""
 import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import BatchedRobotEnv, default_config
+from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import BatchedRobotEnv, MixedBatchedRobotEnv, default_config
 from mujoco_rl_manipulate_unknown_objects_amd.sb3 import PPO, GpuVecEnv
 from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
 obj = sys.argv[1] if len(sys.argv) > 1 else "sand_ball"
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 60
 overlap = len(sys.argv) > 3 and sys.argv[3] == "overlap"
-cfg = default_config(sim_env=f"/xmls/{obj}_env.xml", time_horizon=50)
-env = GpuVecEnv(BatchedRobotEnv(cfg, n_envs=4096, device_index=0, auto_reset=True))
+if obj == "mixed":          # four objects x two directions, 512 envs each, one batch set
+    cfg = default_config(time_horizon=50)
+    env = GpuVecEnv(MixedBatchedRobotEnv(cfg, envs_per_group=512, device_index=0, auto_reset=True))
+else:
+    cfg = default_config(sim_env=f"/xmls/{obj}_env.xml", time_horizon=50)
+    env = GpuVecEnv(BatchedRobotEnv(cfg, n_envs=4096, device_index=0, auto_reset=True))
 model = PPO("MultiInputPolicy", env, n_steps=8, batch_size=4096, n_epochs=2, seed=0, async_slice=96, async_capacity=1024, async_budget_us=2000, ent_coef=0.0, overlap_update=overlap,
             policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]))
 ar = model._async
