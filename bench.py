@@ -54,8 +54,17 @@ def cpu_baseline(obj, seconds_target=15.0):
     while time.time() - t0 < seconds_target and steps < 64:
         sub += b.step(np.clip(rng.normal(size=(n, 6)), -1, 1), obs=obs); steps += 1
     dt = time.time() - t0
+    # one env on one thread (the analogue of BASELINE.json configs[0], the reference's own single-env run)
+    e = orc.EnvOracle(m); e.reset(); e.step(np.zeros(6, np.float32)); e.observation()
+    t1 = time.time(); k1 = 0
+    while time.time() - t1 < 3.0 and k1 < 200:
+        o = e.step(np.clip(rng.normal(size=6), -1, 1).astype(np.float32)); e.observation(); k1 += 1
+        if o.done:
+            e.reset()
+    dt1 = time.time() - t1
     return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": f"{n} envs x {steps} macro steps incl. observation render, no policy; {sub / dt:.0f} mj-substeps/s",
+            "single_env_single_thread": {"value": k1 / dt1, "unit": "env-steps/s", "sample": f"1 env x {k1} macro steps incl. observation render"},
             "note": "reference dm_control+SB3 stack cannot be installed here; its recorded whole-training rate is 3.95-12.97 env-steps/s (BASELINE.md)"}
 
 
