@@ -54,6 +54,24 @@ def test_model_load_rejects_truncated_blobs(lib, tmp_path):
         engine.Model(str(f))
 
 
+def test_entry_points_validate_arguments_without_a_gpu(lib):
+    """Bad arguments are refused with a message before anything touches a device."""
+    vp = C.c_void_p
+    out = vp()
+    assert lib.grip_batchset_create(None, 0, None, C.byref(out)) != 0 and b"grip_batchset_create" in lib.grip_last_error()
+    arr = (vp * 1)(None)
+    assert lib.grip_batchset_create(arr, 1, None, C.byref(out)) != 0 and b"null batch" in lib.grip_last_error()
+    assert lib.grip_batchset_step(None, None, None) != 0 and b"grip_batchset_step" in lib.grip_last_error()
+    assert lib.grip_batchset_advance(None, None, 1, 0, 1, 8, None, None, None) != 0
+    assert lib.grip_batchset_observe(None, None, None) != 0 and lib.grip_batchset_observe_list(None, None, 8, None, None, None, None) != 0
+    assert lib.grip_batchset_num_envs(None) == -1 and lib.grip_batch_num_envs(None) == -1
+    assert lib.grip_batch_set_state_storage(None, 1, None) != 0 and b"grip_batch_set_state_storage" in lib.grip_last_error()
+    assert lib.grip_batch_step(None, None, None, None) != 0 and lib.grip_batch_advance(None, None, 1, 0, 1, 8, None, None, None, None) != 0
+    assert lib.grip_rollout_tick(None, None) != 0 and b"grip_rollout_tick" in lib.grip_last_error()
+    assert lib.grip_obs_preprocess(None, 0, 5, None, None, None) != 0 and b"grip_obs_preprocess" in lib.grip_last_error()
+    lib.grip_batchset_destroy(None); lib.grip_batch_destroy(None)          # no-ops
+
+
 def test_no_cpu_fallback():
     import torch
     from mujoco_rl_manipulate_unknown_objects_amd import engine

@@ -98,6 +98,29 @@ def test_mixed_batch_against_the_oracle(engine, orc, torch):
     mb.close()
 
 
+def test_batch_set_rules(engine, torch):
+    """A set needs one action / observation layout; the capacity of a merged ready list is a multiple of the group count; a set
+    of one batch is that batch."""
+    import ctypes as C
+    a = engine.Batch("sand_ball", 8); b = engine.Batch("sugar_cube", 8, include_roll=0)
+    ptr = C.c_void_p(); arr = (C.c_void_p * 2)(a.ptr, b.ptr)
+    assert engine.lib().grip_batchset_create(arr, 2, None, C.byref(ptr)) != 0
+    assert b"include_roll" in engine.lib().grip_last_error()
+    a.close(); b.close()
+    mb = engine.MixedBatch([("sand_ball", 8, (1, 0)), ("sugar_cube", 8, (1, 1)), ("acorn", 8, (1, 0))])
+    lst = torch.full((8,), -1, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    with pytest.raises(engine.GripError):
+        mb.advance(torch.zeros(8, 6, device="cuda"), 16, lst, cnt)          # 8 rows for 3 groups
+    mb.close()
+    one = engine.MixedBatch([("sand_ball", 9, (1, 0))]); solo = engine.Batch("sand_ball", 9)
+    acts = torch.rand(9, 6, device="cuda") * 2 - 1
+    o1 = one.step(acts); o2 = solo.step(acts); torch.cuda.synchronize()
+    for k in o1:
+        assert torch.equal(o1[k], o2[k]), k
+    assert torch.equal(one.observe(), solo.observe())
+    one.close(); solo.close()
+
+
 FIELDS = ["reward", "done", "achieved_goal", "desired_goal", "status", "episode_step", "gripper_open", "object_grasped",
           "position_reached", "total_distance", "line_distance", "gripper_position", "object_position", "init_obj_pos",
           "n_substeps", "fault"]
