@@ -32,7 +32,8 @@ def build_library(force=False, verbose=False):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-fno-strict-aliasing", "-shared", "-fPIC", "-o", LIB_PATH + f".tmp{os.getpid()}",
-           os.path.join(CSRC, "grip_sim.hip"), os.path.join(CSRC, "grip_render.hip"), os.path.join(CSRC, "grip_rollout.hip")]
+           os.path.join(CSRC, "grip_sim.hip"), os.path.join(CSRC, "grip_render.hip"), os.path.join(CSRC, "grip_rollout.hip"),
+           os.path.join(CSRC, "grip_policy.hip")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or r.returncode:
         print(r.stdout, r.stderr)
@@ -77,7 +78,7 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_set_flags", "grip_batch_substep", "grip_batch_debug_forward", "grip_batch_target_pose",
            "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward", "grip_obs_preprocess",
            "grip_batch_set_state_storage", "grip_batchset_create", "grip_batchset_destroy", "grip_batchset_refresh", "grip_batchset_num_envs",
-           "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list"]
+           "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list", "grip_conv1_u8"]
 
 
 def lib():
@@ -122,6 +123,7 @@ def lib():
     L.grip_batchset_advance.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.grip_batchset_observe.argtypes = [vp, vp, vp]
     L.grip_batchset_observe_list.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
+    L.grip_conv1_u8.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int64), vp, vp, vp, vp, vp]
     L.grip_rollout_tick.argtypes = [vp, vp]
     L.grip_rollout_gae.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
     _lib = L
@@ -153,6 +155,24 @@ def obs_preprocess(obs):
     if lib().grip_obs_preprocess(C.c_void_p(obs.data_ptr()), n, ch, C.c_void_p(img.data_ptr()), C.c_void_p(other.data_ptr()), stream) != 0:
         raise GripError("grip_obs_preprocess failed")
     return img, other
+
+
+def conv1_u8(obs, weight, bias):
+    """First layer of AugmentedNatureCNN for rollouts (grip_conv1_u8, csrc/grip_policy.hip): uint8 CUDA observations
+    [n, 5, 64, 64] -> (relu(conv2d(obs[:, :4] / 255, weight, bias, stride 4)) as a channels-last float32 [n, 32, 15, 15]
+    tensor, the two sensor-pad scalars / 255 as [n, 2]) in one launch on the matrix cores (f32 MFMA). No autograd."""
+    import torch
+    assert obs.is_cuda and obs.dtype == torch.uint8 and obs.is_contiguous() and tuple(obs.shape[1:]) == (5, 64, 64)
+    assert weight.dtype == torch.float32 and tuple(weight.shape) == (32, 4, 8, 8) and bias.dtype == torch.float32 and bias.is_contiguous()
+    n = int(obs.shape[0])
+    out = torch.empty((n, 32, 15, 15), dtype=torch.float32, device=obs.device, memory_format=torch.channels_last)
+    other = torch.empty((n, 2), dtype=torch.float32, device=obs.device)
+    scratch = torch.empty(8192, dtype=torch.float32, device=obs.device)
+    strides = (C.c_int64 * 4)(*weight.stride())
+    stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
+    _chk(lib().grip_conv1_u8(C.c_void_p(obs.data_ptr()), n, 5, C.c_void_p(weight.data_ptr()), strides, C.c_void_p(bias.data_ptr()),
+                             C.c_void_p(scratch.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(other.data_ptr()), stream))
+    return out, other
 
 
 class Model:

@@ -30,6 +30,15 @@ class AugmentedNatureCNN(BaseFeaturesExtractor):
 
     def forward(self, observations, num_direct_features: int = 2) -> th.Tensor:
         obs = observations["observation"]
+        c0 = self.cnn[0]
+        if (obs.dtype == th.uint8 and obs.is_cuda and not th.is_grad_enabled() and num_direct_features == 2 and tuple(obs.shape[1:]) == (5, 64, 64)
+                and tuple(c0.weight.shape) == (32, 4, 8, 8) and c0.stride == (4, 4) and c0.padding == (0, 0) and c0.weight.dtype == th.float32):
+            # rollouts (no autograd): normalisation, first convolution, bias and ReLU in one f32-MFMA launch (csrc/grip_policy.hip)
+            from ..engine import conv1_u8
+            x, other = conv1_u8(obs.contiguous(), c0.weight, c0.bias)
+            for layer in list(self.cnn)[2:]:
+                x = layer(x)
+            return th.cat((self.linear(x), other.to(x.dtype)), dim=1)
         if obs.dtype == th.uint8 and obs.is_cuda and num_direct_features == 2 and obs.shape[2:] == (64, 64):
             # raw uint8 observation on the GPU (the policies pass it through un-normalised): cast, / 255 and the NHWC layout
             # in one kernel instead of three passes (csrc/grip_render.hip: k_obs_preprocess)

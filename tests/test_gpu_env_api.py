@@ -87,6 +87,45 @@ def test_fused_observation_preprocessing_matches_tensor_ops(torch):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
 
 
+def test_fused_first_layer_matches_the_tensor_library(torch):
+    """grip_conv1_u8 (uint8 rows -> /255 -> Conv2d(4, 32, 8, 4) -> bias -> ReLU on f32 MFMA, plus the two pad scalars) against
+    torch.nn.functional on the same weights, for contiguous and channels-last weight layouts and ragged batch sizes; and the
+    extractor's no-grad path (which uses it) against its autograd path (which does not). fp32 both ways: 2e-5 absolute on
+    activations of order 1 (summation order differs)."""
+    import torch.nn.functional as F
+    from mujoco_rl_manipulate_unknown_objects_amd.engine import conv1_u8
+    from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.controller.sensor import RGBDSensor
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import default_config
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    for n in (1, 7, 130):
+        obs = torch.randint(0, 256, (n, 5, 64, 64), dtype=torch.uint8, device="cuda", generator=g)
+        w = torch.randn(32, 4, 8, 8, device="cuda", generator=g) * 0.1; b = torch.randn(32, device="cuda", generator=g)
+        ref = F.relu(F.conv2d(obs[:, :4].float() / 255.0, w, b, stride=4))
+        for wl in (w, w.contiguous(memory_format=torch.channels_last)):
+            y, other = conv1_u8(obs, wl, b)
+            assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+            assert (y - ref).abs().max().item() < 2e-5
+            assert torch.equal(other, obs[:, 4, 0, :2].float() / 255.0)
+    # exact-integer check of the operand / accumulator lane maps: weights = one-hot taps, so every output is one pixel / 255
+    obs = torch.randint(0, 256, (3, 5, 64, 64), dtype=torch.uint8, device="cuda", generator=g)
+    w = torch.zeros(32, 4, 8, 8, device="cuda")
+    taps = [(n_, n_ % 4, (3 * n_) % 8, (5 * n_ + 1) % 8) for n_ in range(32)]
+    for n_, ci, ky, kx in taps:
+        w[n_, ci, ky, kx] = 255.0
+    y, _ = conv1_u8(obs, w, torch.zeros(32, device="cuda"))
+    for n_, ci, ky, kx in taps:
+        want = obs[:, ci, ky:ky + 57:4, kx:kx + 57:4].float()
+        assert (y[:, n_] - want).abs().max().item() < 1e-3, n_
+    fe = AugmentedNatureCNN(RGBDSensor(config=default_config()).setup_observation_space()).cuda().to(memory_format=torch.channels_last)
+    obs = torch.randint(0, 256, (33, 5, 64, 64), dtype=torch.uint8, device="cuda", generator=g)
+    with torch.no_grad():
+        fast = fe({"observation": obs})
+    slow = fe({"observation": obs})                       # autograd on: tensor-library path
+    assert slow.requires_grad and not fast.requires_grad
+    assert (fast - slow.detach()).abs().max().item() < 2e-5
+
+
 def test_overlapped_update_keeps_one_update_of_lag(torch):
     """overlap_update: rollout i + 1 is collected with the parameters after update i - 1 while update i runs on a second
     stream; the rollout copy only ever holds complete parameter sets."""
