@@ -1,3 +1,4 @@
+"""fwd+bwd time of the NatureCNN under layouts / dtypes (MIOpen NCHW vs channels-last vs unfold+GEMM, fp32 vs bf16)."""
 import torch, time, torch.nn as nn, torch.nn.functional as F
 B=4096
 def run(name, net, x, n=5):
