@@ -69,17 +69,22 @@ struct DevConfig {
     int state_half;      // qpos / qvel / ctrl are stored as IEEE half in HBM (grip_batch_set_state_storage); arithmetic stays fp32
 };
 
-// per-batch arguments of the observation kernel (one record per batch of a set; a single batch is a set of one)
-struct DevModel;
-struct RenderGroup { const DevModel *model; DevConfig cfg; const float *qpos; const int *pad_grasp, *pad_pher; int n, env0; };
+// per-batch arguments of the observation kernel (one record per batch of a set; a single batch is a set of one). The model is
+// held BY VALUE: its constants are then read through the kernel's const __restrict__ record pointer with a uniform index,
+// i.e. by scalar loads (through a pointer stored in the record they would be per-lane flat loads and double the VGPR count).
+struct RenderGroup { DevModel m; DevConfig cfg; const float *qpos; const int *pad_grasp, *pad_pher; int n, env0; };
+
+// A pointer read from a record in memory has no known address space, and every access through it becomes a flat_* instruction
+// with a 64-bit VGPR address. The state arrays are global memory: GPTR(T, p) says so at the point of use.
+#define GPTR(T, p) ((__attribute__((address_space(1))) T *)(p))
 
 // one word of the SoA state arrays: fp32, or IEEE half (round to nearest even on store) when the batch keeps qpos / qvel /
 // ctrl in half precision (BASELINE.json configs[4]); `half` is uniform over the launch
 __device__ __forceinline__ float ld_word(const float *base, size_t idx, int half) {
-    return half ? __half2float(reinterpret_cast<const __half *>(base)[idx]) : base[idx];
+    return half ? __half2float(__ushort_as_half(GPTR(const unsigned short, base)[idx])) : GPTR(const float, base)[idx];
 }
 __device__ __forceinline__ void st_word(float *base, size_t idx, float v, int half) {
-    if (half) reinterpret_cast<__half *>(base)[idx] = __float2half_rn(v); else base[idx] = v;
+    if (half) GPTR(unsigned short, base)[idx] = __half_as_ushort(__float2half_rn(v)); else GPTR(float, base)[idx] = v;
 }
 
 // ---------------------------------------------------------------- fp32 helpers

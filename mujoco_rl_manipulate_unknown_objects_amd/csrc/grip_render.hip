@@ -226,15 +226,16 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
     }
     __syncthreads();
     if (tid == 0) {
-        o[(nch - 1) * RPIX] = (uint8_t)pad_grasp[e]; o[(nch - 1) * RPIX + 1] = (uint8_t)pad_pher[e];
-        if (o2) { o2[(nch - 1) * RPIX] = (uint8_t)pad_grasp[e]; o2[(nch - 1) * RPIX + 1] = (uint8_t)pad_pher[e]; }
+        const int pg_ = GPTR(const int, pad_grasp)[e], pp_ = GPTR(const int, pad_pher)[e];
+        o[(nch - 1) * RPIX] = (uint8_t)pg_; o[(nch - 1) * RPIX + 1] = (uint8_t)pp_;
+        if (o2) { o2[(nch - 1) * RPIX] = (uint8_t)pg_; o2[(nch - 1) * RPIX + 1] = (uint8_t)pp_; }
     }
 }
 
 // One kernel for a batch and for a set of batches: per-batch arguments in device memory behind a const __restrict__ pointer
 // (workgroup-uniform index -> scalar loads). list != NULL: row b shows env list[b] (global id over the set; a negative entry is a
 // hole, rows >= *count -- when count is given -- are skipped too: their rows are left alone); list == NULL: row b = env b.
-__global__ void __launch_bounds__(RTHREADS) k_observe(const RenderGroup *__restrict__ groups, int ngroups, const int *list, const int *count,
+__global__ void __launch_bounds__(RTHREADS, 8) k_observe(const RenderGroup *__restrict__ groups, int ngroups, const int *list, const int *count,
                                                       uint8_t *obs, uint8_t *obs2, const long long *row2) {
     if (list && count && (int)blockIdx.x >= *count) return;
     const int ge = list ? list[blockIdx.x] : (int)blockIdx.x;
@@ -242,7 +243,8 @@ __global__ void __launch_bounds__(RTHREADS) k_observe(const RenderGroup *__restr
     int g = 0;
     for (int i = 1; i < ngroups; i++) g = ge >= groups[i].env0 ? i : g;
     const RenderGroup &rg = groups[g];
-    observe_body(*rg.model, rg.cfg, rg.qpos, rg.pad_grasp, rg.pad_pher, rg.n, ge - rg.env0, obs, obs2, row2);
+    const DevConfig cfg = rg.cfg;
+    observe_body(rg.m, cfg, rg.qpos, rg.pad_grasp, rg.pad_pher, rg.n, ge - rg.env0, obs, obs2, row2);
 }
 
 extern "C" int grip_render_launch(const RenderGroup *groups_dev, int ngroups, const int *list, const int *count, int nblocks, int nplanes_max,

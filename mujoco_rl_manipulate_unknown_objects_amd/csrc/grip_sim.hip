@@ -839,7 +839,7 @@ static void fill_group(GripBatch *b, int wg0, int env0, const GripStepOut *out, 
         d.line_distance = off(o.line_distance, e0); d.gripper_position = off(o.gripper_position, 3 * e0); d.object_position = off(o.object_position, 3 * e0);
         d.init_obj_pos = off(o.init_obj_pos, 3 * e0); d.n_substeps = off(o.n_substeps, e0); d.fault = off(o.fault, e0);
     }
-    rg.model = b->d_model; rg.cfg = b->cfg; rg.qpos = b->qpos; rg.pad_grasp = b->pad_grasp; rg.pad_pher = b->pad_pher; rg.n = b->n; rg.env0 = env0;
+    rg.m = b->hmodel; rg.cfg = b->cfg; rg.qpos = b->qpos; rg.pad_grasp = b->pad_grasp; rg.pad_pher = b->pad_pher; rg.n = b->n; rg.env0 = env0;
 }
 // (re)write the batch's own records; synchronous -- callers are creation and the configuration setters, which synchronise anyway
 static int upload_self(GripBatch *b) {
