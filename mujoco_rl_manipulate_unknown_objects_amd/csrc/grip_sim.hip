@@ -240,7 +240,7 @@ struct StepOutDev {     // device copy of GripStepOut (kernel argument)
 
 struct GripBatch {
     int n = 0, device = 0;
-    DevModel hmodel; DevModel *d_model = nullptr; unsigned *d_hull = nullptr; float *d_planes = nullptr; size_t lds_bytes = 0;
+    DevModel hmodel; unsigned *d_hull = nullptr; float *d_planes = nullptr; size_t lds_bytes = 0;
     DevConfig cfg;
     float *qpos = nullptr, *qvel = nullptr, *ctrl = nullptr, *warm = nullptr;     // SoA [field][N]
     int *episode_step = nullptr, *status = nullptr, *gripper_open = nullptr;
@@ -893,8 +893,6 @@ static int batch_build(GripBatch *b, const GripModel *m) {
     HIPCHK(hipMemcpy(b->d_planes, m->planes.data(), m->planes.size() * sizeof(float), hipMemcpyHostToDevice));
     DevModel hm_ = m->host; hm_.hull_blob = b->d_hull; hm_.hull_planes = b->d_planes;
     b->hmodel = hm_;
-    HIPCHK(hipMalloc(&b->d_model, sizeof(DevModel)));
-    HIPCHK(hipMemcpy(b->d_model, &hm_, sizeof(DevModel), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&b->qpos, 14 * N * sizeof(float))); HIPCHK(hipMalloc(&b->qvel, 13 * N * sizeof(float)));
     HIPCHK(hipMalloc(&b->ctrl, 7 * N * sizeof(float))); HIPCHK(hipMalloc(&b->warm, 13 * N * sizeof(float)));
     HIPCHK(hipMalloc(&b->episode_step, N * sizeof(int))); HIPCHK(hipMalloc(&b->status, N * sizeof(int)));
@@ -925,7 +923,7 @@ extern "C" void grip_batch_destroy(GripBatch *b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {b->d_model, b->d_hull, b->d_planes, b->qpos, b->qvel, b->ctrl, b->warm, b->episode_step, b->status,
+    void *ptrs[] = {b->d_hull, b->d_planes, b->qpos, b->qvel, b->ctrl, b->warm, b->episode_step, b->status,
                     b->gripper_open, b->pad_grasp, b->pad_pher, b->reset_info, b->scratch, b->mc_ints, b->mc_flts, b->mc_astate,
                     b->mc_slot, b->mc_order, b->mc_heavy, b->mc_tick, b->mc_gen, b->mc_t0, b->d_self, b->d_rself};
     for (void *p : ptrs) if (p) (void)hipFree(p);
