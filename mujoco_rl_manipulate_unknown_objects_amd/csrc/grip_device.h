@@ -59,6 +59,7 @@ struct DevModel {
     float floor_rgb[6], sky_rgb[6];
     float light_dir[2][3];
     int hull_padr[GN_HULL], hull_pnum[GN_HULL];
+    float hull_aabb[GN_HULL][6];                // min xyz, max xyz of the hull's vertices in its geom frame (observation kernel: ray cull)
     const float *hull_planes;                   // [nplane][4] n.x <= d, body frame
 };
 

@@ -64,6 +64,7 @@ __device__ static uint8_t to_u8(float v) { v *= 255.f; v = fminf(fmaxf(v, 0.f), 
 // read from LDS once per 16 rays and costs one FMA + rcp + a few selects per ray; depth never leaves registers.
 #define TW 2                // tile width: every thread owns a TW x TW pixel tile
 #define TPX (TW * TW)
+#define NBOX 6              // bounding-box planes in front of every hull's plane list
 
 // Renders env e of one batch into row blockIdx.x of obs (and, when obs2 != NULL, into row row2[0] + blockIdx.x of obs2: the
 // trainer's record buffer, saving a 20 KB-per-env copy kernel).
@@ -87,13 +88,15 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
             gsph[g][0] = c.x; gsph[g][1] = c.y; gsph[g][2] = c.z; gsph[g][3] = r * r;
             bool vis = c.z - r < 0.f;                                   // some of the sphere is in front of the camera
             gadr[g] = adr; gnum[g] = vis ? m.hull_pnum[g - 1] : 0;
-            if (vis) adr += m.hull_pnum[g - 1];
+            if (vis) adr += NBOX + m.hull_pnum[g - 1];
         }
     }
     __syncthreads();
     const V3 co = ldv(fr.cam_o); const M3 Rc = ldm(fr.cam_R);
     // plane n.x <= d of a hull (body frame), rewritten for rays from the camera origin in camera coordinates dc = (x, y, -1):
-    // t (A.dc) <= B with A = (Rg^T Rc)^T n, B = d - n.(Rg^T (co - pg)); one float4 per plane of the visible hulls in LDS
+    // t (A.dc) <= B with A = (Rg^T Rc)^T n, B = d - n.(Rg^T (co - pg)); one float4 per plane of the visible hulls in LDS.
+    // Each hull's table starts with the six planes of its vertices' bounding box (same form): a ray that misses the box misses
+    // the hull, and a wave whose 256 rays all miss it skips the hull's whole plane list.
     for (int g = 1; g < GN_GEOM; g++) {
         const int np = gnum[g];
         if (np == 0) continue;
@@ -101,10 +104,19 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
         M3 Mx = mulm(M3{{R.m[0], R.m[3], R.m[6], R.m[1], R.m[4], R.m[7], R.m[2], R.m[5], R.m[8]}}, Rc);      // Rg^T Rc
         V3 ol = multv(R, co - p);
         const float *pl = m.hull_planes + 4 * m.hull_padr[g - 1];
-        for (int i = tid; i < np; i += RTHREADS) {
-            V3 nn = v3(pl[4 * i], pl[4 * i + 1], pl[4 * i + 2]);
+        for (int i = tid; i < np + NBOX; i += RTHREADS) {
+            V3 nn; float d;
+            if (i < NBOX) {
+                const int ax = i >> 1; const bool hi = i & 1;
+                nn = v3(ax == 0 ? 1.f : 0.f, ax == 1 ? 1.f : 0.f, ax == 2 ? 1.f : 0.f);
+                if (!hi) nn = -nn;
+                d = (hi ? m.hull_aabb[g - 1][3 + ax] : -m.hull_aabb[g - 1][ax]) + 1e-6f;
+            } else {
+                const int j = i - NBOX;
+                nn = v3(pl[4 * j], pl[4 * j + 1], pl[4 * j + 2]); d = pl[4 * j + 3];
+            }
             V3 A = multv(Mx, nn);
-            spl[gadr[g] + i] = make_float4(A.x, A.y, A.z, pl[4 * i + 3] - dot(nn, ol));
+            spl[gadr[g] + i] = make_float4(A.x, A.y, A.z, d - dot(nn, ol));
         }
     }
     __syncthreads();
@@ -145,7 +157,28 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
             mask |= pass ? (1u << q) : 0u;
         }
         if (mask == 0u) continue;
-        const float4 *sp = spl + gadr[g];
+        {   // bounding box first: six planes, no entering-plane bookkeeping
+            const float4 *sb = spl + gadr[g];
+            float bin[TPX], bout[TPX];
+#pragma unroll
+            for (int q = 0; q < TPX; q++) { bin[q] = -3.0e38f; bout[q] = 3.0e38f; }
+#pragma unroll
+            for (int pi = 0; pi < NBOX; pi++) {
+                const float4 P = sb[pi];
+#pragma unroll
+                for (int q = 0; q < TPX; q++) {
+                    float den = fmaf(P.y, ys[q / TW], fmaf(P.x, xs[q % TW], -P.z));
+                    float u = P.w * rcp(fabsf(den));
+                    bool in = den < 0.f;
+                    bin[q] = (in && -u > bin[q]) ? -u : bin[q];
+                    bout[q] = (!in && u < bout[q]) ? u : bout[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < TPX; q++) if (bin[q] > bout[q] || bout[q] < 0.f) mask &= ~(1u << q);
+        }
+        if (mask == 0u) continue;
+        const float4 *sp = spl + gadr[g] + NBOX;
         float tin[TPX], tout[TPX]; int ent[TPX];
 #pragma unroll
         for (int q = 0; q < TPX; q++) { tin[q] = -3.0e38f; tout[q] = 3.0e38f; ent[q] = -1; }
@@ -249,7 +282,7 @@ __global__ void __launch_bounds__(RTHREADS, 8) k_observe(const RenderGroup *__re
 
 extern "C" int grip_render_launch(const RenderGroup *groups_dev, int ngroups, const int *list, const int *count, int nblocks, int nplanes_max,
                                   uint8_t *obs, uint8_t *obs2, const long long *row2, hipStream_t s) {
-    hipLaunchKernelGGL(k_observe, dim3(nblocks), dim3(RTHREADS), (size_t)nplanes_max * sizeof(float4), s, groups_dev, ngroups, list, count, obs, obs2, row2);
+    hipLaunchKernelGGL(k_observe, dim3(nblocks), dim3(RTHREADS), (size_t)(nplanes_max + NBOX * GN_HULL) * sizeof(float4), s, groups_dev, ngroups, list, count, obs, obs2, row2);
     return launch_status("grip_render_launch");
 }
 

@@ -191,6 +191,15 @@ extern "C" int grip_model_load(const char *blob_path, GripModel **out) {
         for (int k = 0; k < 4; k++) m.geom_rgba[g][k] = (float)grgba[4*g+k];
     }
     for (int h = 0; h < 6; h++) { m.hull_vadr[h] = hvadr[h]; m.hull_vnum[h] = hvnum[h]; m.hull_padr[h] = hpadr[h]; m.hull_pnum[h] = hpnum[h]; }
+    for (int h = 0; h < 6; h++) {
+        if (hvadr[h] < 0 || hvnum[h] <= 0 || (size_t)(hvadr[h] + hvnum[h]) * 3 > hverts.size()) { delete gm; return fail("hull vertex ranges do not fit hull_verts"); }
+        for (int k = 0; k < 3; k++) { m.hull_aabb[h][k] = 3.0e38f; m.hull_aabb[h][3 + k] = -3.0e38f; }
+        for (int v = hvadr[h]; v < hvadr[h] + hvnum[h]; v++)
+            for (int k = 0; k < 3; k++) {
+                m.hull_aabb[h][k] = std::min(m.hull_aabb[h][k], (float)hverts[3 * v + k]);
+                m.hull_aabb[h][3 + k] = std::max(m.hull_aabb[h][3 + k], (float)hverts[3 * v + k]);
+            }
+    }
     m.npair = (int)pairs.size() / 2;
     if (m.npair > GN_PAIR_MAX) { delete gm; return fail("too many collision pairs"); }
     for (int q = 0; q < m.npair; q++) { m.pairs[q][0] = pairs[2*q]; m.pairs[q][1] = pairs[2*q+1]; }
