@@ -71,8 +71,8 @@ def cpu_baseline(obj, seconds_target=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (SURVEY.md 8d: >= 200 macro steps after 20 warm-up steps)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=4096, help="environments per GPU")
     ap.add_argument("--object", default="acorn")
     ap.add_argument("--direction", type=int, default=0)
@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--overlap-update", action="store_true", help="PPO update of rollout i on a second stream while rollout i+1 is collected (one update of policy lag)")
     ap.add_argument("--pipeline", action="store_true", help="decide for tick t on a side stream while tick t+1 advances (lag 2)")
     ap.add_argument("--budget-us", type=int, default=2000, help="wall-clock cap of a wavefront's slice in microseconds (async schedule; 0 = none)")
+    ap.add_argument("--fixed-slice", action="store_true", help="keep --slice / --budget-us for the whole run (default: they follow the measured length of the macro steps)")
     a = ap.parse_args()
     if a.capacity <= 0:
         a.capacity = max(1, a.envs // 4)
@@ -127,7 +128,8 @@ def main():
     model = PPO("MultiInputPolicy", env, n_steps=a.rollout, batch_size=a.minibatch, n_epochs=a.epochs, seed=1234 + rank,
                 policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]),
                 async_slice=0 if a.lockstep else a.slice, async_capacity=min(a.capacity, a.envs), async_budget_us=a.budget_us,
-                autocast_dtype=torch.bfloat16 if a.policy_dtype == "bf16" else None, overlap_update=a.overlap_update and not a.lockstep)
+                autocast_dtype=torch.bfloat16 if a.policy_dtype == "bf16" else None, overlap_update=a.overlap_update and not a.lockstep,
+                async_auto_slice=not a.fixed_slice and not a.lockstep and a.slice == 96 and a.budget_us == 2000)
     batch = env.env.batch
     if a.state_dtype == "f16":
         batch.set_state_storage("f16")
@@ -136,16 +138,17 @@ def main():
         ar.enable_pipeline()
 
     def run_async(nsteps):
-        """nsteps x envs completed transitions, a PPO update after every `rollout` x envs of them."""
+        """nsteps x envs completed transitions, a PPO update after every `rollout` x envs of them (a shorter last rollout is
+        trained on as well: every timed step carries its share of the update, whatever K is)."""
         done_steps = 0
         while done_steps < nsteps:
             chunk = min(a.rollout, nsteps - done_steps)
-            ar.target = chunk * a.envs
+            ar.target = chunk * a.envs; model.n_steps = chunk
             model.collect_rollouts()
-            if not a.no_ppo and chunk == a.rollout:
+            if not a.no_ppo:
                 model.train()
             done_steps += chunk
-        ar.target = a.rollout * a.envs
+        ar.target = a.rollout * a.envs; model.n_steps = a.rollout
 
     def run(nsteps):
         """nsteps vec-env steps with a PPO update after every `rollout` of them."""
@@ -157,7 +160,7 @@ def main():
             chunk = min(a.rollout, nsteps - done_steps)
             model.n_steps = chunk; model.rollout_buffer.n_steps = chunk
             model.collect_rollouts()
-            if not a.no_ppo and chunk == a.rollout:
+            if not a.no_ppo:
                 model.train()
             done_steps += chunk
         model.n_steps = a.rollout; model.rollout_buffer.n_steps = a.rollout
@@ -226,7 +229,9 @@ def main():
         if a.state_dtype == "f16":      # 34 of the 47 words read and 27 of the 40 written (qpos, qvel, ctrl) are 2 bytes
             macro_bytes -= (34 + 27) * 2 * a.envs
         sched = ("lock-step vector env" if ar is None else
-                 f"asynchronous time slices (<= {a.slice} physics steps and <= {a.budget_us} us per wavefront and tick, {min(a.capacity, a.envs)} decisions/tick)" + ("; PPO update overlapped with the next rollout (policy lag 1)" if a.overlap_update else ""))
+                 f"asynchronous time slices (<= {ar.S} physics steps and <= {ar.eng.budget_us} us per wavefront and tick"
+                 + (f" at the end of the run: slice / budget follow the measured macro-step length, {ar.ladder}" if ar.ladder else "")
+                 + f", {min(a.capacity, a.envs)} decisions/tick)" + ("; PPO update overlapped with the next rollout (policy lag 1)" if a.overlap_update else ""))
         achieved = macro_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
             "metric": "env-steps/sec (whole node), " + ("mixed objects" if a.mixed else f"{a.object}_env") + f" {a.envs} envs/GPU", "value": value, "unit": "env-steps/s",

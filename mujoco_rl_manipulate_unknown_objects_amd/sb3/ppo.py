@@ -63,11 +63,13 @@ class RolloutBuffer:
 class PPO:
     def __init__(self, policy, env, learning_rate=3e-4, n_steps=16, batch_size=4096, n_epochs=4, gamma=0.99, gae_lambda=0.95,
                  clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, policy_kwargs=None, verbose=0, tensorboard_log=None,
-                 device=None, seed=None, autocast_dtype=None, async_slice=0, async_capacity=None, async_budget_us=0, overlap_update=False):
+                 device=None, seed=None, autocast_dtype=None, async_slice=0, async_capacity=None, async_budget_us=0, overlap_update=False,
+                 async_auto_slice=False):
         """async_slice > 0 switches rollout collection to the time-sliced engine (sb3/async_rollout.py): every tick gives
         each env at most `async_slice` calls of physics.step(), at most `async_capacity` finished envs (default N/4) are
         rendered and decided per tick, and a rollout is n_steps * N completed transitions whichever envs they come from.
-        async_budget_us > 0 also caps a wavefront's slice by wall-clock time (include/grip_sim.h).
+        async_budget_us > 0 also caps a wavefront's slice by wall-clock time (include/grip_sim.h); async_auto_slice lets slice
+        and budget follow the measured length of the macro steps (AsyncRollout.set_slice_ladder).
         overlap_update (async, GPU only): the update of rollout i runs on a second stream WHILE rollout i + 1 is collected,
         with a frozen copy of the policy (the parameters after update i - 1: one update of policy lag, as in asynchronous
         PPO variants); the records of the two rollouts live in AsyncRollout's two windows."""
@@ -123,6 +125,8 @@ class PPO:
             self._async = AsyncRollout(eng, policy_fn, policy_parts_fn=parts, target=n_steps * self.n_envs, capacity=min(cap, self.n_envs), slice_len=async_slice,
                                        gamma=gamma, gae_lambda=gae_lambda, action_low=env.action_space.low, action_high=env.action_space.high)
             self.rollout_buffer = None
+            if async_auto_slice:
+                self._async.set_slice_ladder()
         self.num_timesteps = 0
         self._last_obs = None
         self._last_dones = None
@@ -263,8 +267,9 @@ class PPO:
             sel = buf.training_indices()
         else:
             buf = self.rollout_buffer
-            src = (buf.obs.view((total,) + buf.obs.shape[2:]), buf.actions.view(total, -1), buf.log_probs.view(-1),
-                   buf.advantages.view(-1), buf.returns.view(-1))
+            T = self.n_steps                      # may be shorter than the buffer (a caller trimming its last rollout)
+            src = (buf.obs[:T].view((total,) + buf.obs.shape[2:]), buf.actions[:T].view(total, -1), buf.log_probs[:T].view(-1),
+                   buf.advantages[:T].view(-1), buf.returns[:T].view(-1))
             sel = None
         if not self.overlap_update:
             return self._train_on(src, sel, total)
