@@ -14,7 +14,8 @@ out = (C.c_ulonglong * 20)()
 def ticks(k):
     for _ in range(k):
         b.advance(torch.randn(cap, 6, device="cuda", generator=g).clamp(-1, 1), 96, lst, cnt, 2000)
-ticks(150); engine.lib().grip_debug_stamps(out)
+warm = int(sys.argv[2]) if len(sys.argv) > 2 else 150        # 150 ticks: fresh episodes (free motion); ~3000: envs at mixed episode phases
+ticks(warm); engine.lib().grip_debug_stamps(out)
 ticks(100); engine.lib().grip_debug_stamps(out)
 names = ["kinematics", "collide", "mass+bias+qs", "make_constraints", "solve: other (bookkeeping)", "integrate", "solve: constraint pass", "solve: tri-solves+gather", "solve: assemble rows", "solve: cholesky", "solve: line search"]
 names2 = {14: "solve: prologue (mrow, jar of both starts)", 15: "solve: stage logic after pricing", 16: "solve: hessian_vectors + sync",
