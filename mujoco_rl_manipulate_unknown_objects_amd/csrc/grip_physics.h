@@ -63,7 +63,13 @@ __device__ unsigned long long g_stamp_acc[NSTAMP];
 struct Stamps { unsigned long long t; unsigned long long acc[NSTAMP]; };
 DEVI unsigned long long stamp_now() { __builtin_amdgcn_sched_barrier(0); unsigned long long t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); return t; }
 #define STAMP(st, i) do { unsigned long long n_ = stamp_now(); (st).acc[i] += n_ - (st).t; (st).t = n_; } while (0)
+// event counters of collide(): 0 calls (per env), 1 loop trips with per-lane supports, 2 loop trips in cooperative refinement,
+// 3 hull-pair items past the sphere test, 4 of them ended by the remembered direction, 5 contacts from hull pairs,
+// 6 hill-climb hops (all lanes), 7 support_vertex calls (all lanes)
+__device__ unsigned long long g_dbg_cnt[8];
+#define DBG_COUNT(i, n) atomicAdd(&g_dbg_cnt[i], (unsigned long long)(n))
 #else
+#define DBG_COUNT(i, n) do { } while (0)
 struct Stamps { int dummy; };
 #define STAMP(st, i) do { } while (0)
 #endif
@@ -522,8 +528,10 @@ DEVI int support_vertex(const Tables &T, int h, int base, V3 dl, V3 &vout, int h
             if (cand == cur) break;
             cur = cand; bx = cx; by = cy; bz = cz;
             e = T.nadr[base + cur]; eend = T.nadr[base + cur + 1];
+            DBG_COUNT(6, 1);
         }
     }
+    DBG_COUNT(7, 1);
     vout = v3(bx, by, bz);
     return cur;
 }
@@ -663,6 +671,7 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
             float bound = t1[3] + t2[3] + m.margin;
             phase = dot(dc, dc) > bound * bound ? -1 : 0;
             if (phase < 0) sep = v3(0, 0, 0);
+            if (phase == 0) DBG_COUNT(3, 1);
             s0.v1 = c1; s0.v2 = c2; s0.v = c1 - c2;
             if (dot(s0.v, s0.v) < EPS2) s0.v.x += 1e-5f;
             dir = normalized(-s0.v);
@@ -678,10 +687,12 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
         // serve them one at a time: the lowest-numbered refining lane (the "owner") publishes its two local directions and
         // hull ranges, everybody scans a sixteenth of the vertices, the owner takes the arg-max and advances its portal.
         const int nv2 = __float_as_int(t2[9]), nv1 = __float_as_int(t1[9]);
+        if (round == 0 && cx.sub == 0) DBG_COUNT(0, 1);
         while (__any(phase >= 0)) {
             const unsigned actm = group_bits(__ballot(phase >= 0), cx.lane);
             const unsigned early = group_bits(__ballot(phase >= 0 && phase != 3 && phase != 4), cx.lane);
             const bool coop = actm != 0u && early == 0u;
+            if (cx.sub == 0 && actm != 0u) DBG_COUNT(coop ? 2 : 1, 1);
             const int owner = coop ? (__ffs((int)actm) - 1) : -1;
             const bool mine = coop ? owner == cx.sub : phase >= 0;
             V3 vl = v3(0, 0, 0), vl1 = v3(0, 0, 0); int vi2 = 0;
@@ -736,7 +747,7 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
                     cnt++;
                     bool hit = false; float depth = 0.f; V3 nrm = v3(0, 0, 0), pos = v3(0, 0, 0);
                     if (phase == 6) {
-                        if (dot(s.v, dir) <= 0.f) { phase = -1; memo.h1 = vi1; memo.h2 = vi2; }     // still apart along the remembered direction
+                        if (dot(s.v, dir) <= 0.f) { phase = -1; memo.h1 = vi1; memo.h2 = vi2; DBG_COUNT(4, 1); }     // still apart along the remembered direction
                         else { sep = v3(0, 0, 0); dir = normalized(-s0.v); phase = 0; cnt = 0; }
                     } else if (phase == 0) {
                         sup_set(s1, s);
@@ -788,7 +799,7 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
                         float dist = m.margin - depth;
                         if (dist < m.margin) {
                             if (dot(nrm, nrm) < 0.5f) nrm = normalized(s0.v2 - s0.v1);
-                            rp0 = pos; rd0 = dist; rn = nrm; rc = 1;
+                            rp0 = pos; rd0 = dist; rn = nrm; rc = 1; DBG_COUNT(5, 1);
                         }
                         phase = -1;
                     }

@@ -11,7 +11,19 @@ b = engine.Batch(obj, n); b.reset(); b.substep(300); torch.cuda.synchronize()
 if mode == "push":
     q, v, c, w = b.get_state(); q[:, 0] = 0.2; q[:, 2] = 0.05; b.set_state(qpos=q)
     c[:, 0] = 1.0; b.set_state(ctrl=c); b.substep(60); torch.cuda.synchronize()
+if mode == "mixed":                                      # states of a random policy at mixed episode phases
+    b.set_config(auto_reset=1); b.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    for t in range(int(sys.argv[3]) if len(sys.argv) > 3 else 150):
+        b.step(torch.rand(n, 6, device="cuda", generator=g) * 2 - 1)
+    torch.cuda.synchronize()
+cnt = (C.c_ulonglong * 8)(); engine.lib().grip_debug_counters(cnt)            # drop what the set-up accumulated
 b.substep(k); torch.cuda.synchronize()
+engine.lib().grip_debug_counters(cnt)
+calls = max(1, cnt[0])
+print(f"collide() per env and call: {cnt[1] / calls:.2f} trips with per-lane supports, {cnt[2] / calls:.2f} cooperative refinement trips, "
+      f"{cnt[3] / calls:.2f} hull pairs past the sphere test ({cnt[4] / calls:.2f} ended by the remembered direction), "
+      f"{cnt[5] / calls:.3f} hull contacts, {cnt[7] / calls:.1f} hill climbs with {cnt[6] / max(1, cnt[7]):.2f} hops each")
 out = (C.c_ulonglong * 20)()
 assert engine.lib().grip_debug_stamps(out) == 0
 names = ["kinematics", "collide", "mass+bias+qs", "make_constraints", "solve: other (LS, bookkeeping)", "integrate", "solve: constraint pass", "solve: tri-solves+gather", "solve: assemble rows", "solve: cholesky", "solve: line search", "-", "-", "-", "solve: prologue", "solve: stage logic", "solve: hessian_vectors", "solve: p readback, Mp, Jp", "solve: loop exit", "solve: final gathers"]

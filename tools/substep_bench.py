@@ -3,6 +3,8 @@ import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np, torch
 from mujoco_rl_manipulate_unknown_objects_amd import engine
+if os.environ.get("GRIP_LIB"):                           # an alternative build of the library (experiments)
+    engine.LIB_PATH = os.environ["GRIP_LIB"]
 obj = sys.argv[1] if len(sys.argv) > 1 else "acorn"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 100
@@ -13,6 +15,13 @@ if mode == "push":                                       # gripper tip touching 
     q, v, c, w = b.get_state()
     q[:, 0] = 0.235 + 0.01 * np.random.default_rng(0).random(n); q[:, 2] = 0.05
     b.set_state(qpos=q); b.substep(20); torch.cuda.synchronize()
+if mode == "mixed":                                      # states of a random policy at mixed episode phases (what training sees)
+    b.set_config(auto_reset=1); b.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    steps = int(sys.argv[5]) if len(sys.argv) > 5 else 150
+    for t in range(steps):
+        b.step(torch.rand(n, 6, device="cuda", generator=g) * 2 - 1)
+    torch.cuda.synchronize()
 for rep in range(3):
     t0 = time.perf_counter(); b.substep(k); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"{obj} n={n} mode={mode}: {k} substeps in {dt*1e3:.2f} ms -> {dt/k*1e6:.1f} us/substep/launch, {n*k/dt:.3e} env-substeps/s")
