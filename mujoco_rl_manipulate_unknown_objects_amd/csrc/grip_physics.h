@@ -66,7 +66,7 @@ DEVI unsigned long long stamp_now() { __builtin_amdgcn_sched_barrier(0); unsigne
 // event counters of collide(): 0 calls (per env), 1 loop trips with per-lane supports, 2 loop trips in cooperative refinement,
 // 3 hull-pair items past the sphere test, 4 of them ended by the remembered direction, 5 contacts from hull pairs,
 // 6 hill-climb hops (all lanes), 7 support_vertex calls (all lanes)
-__device__ unsigned long long g_dbg_cnt[8];
+__device__ unsigned long long g_dbg_cnt[16];   // 8..11: wave-level (first wave of a workgroup): cycles / trips with per-lane supports, cycles / trips of pure cooperative refinement; 12: cycles of collide() outside the loop
 #define DBG_COUNT(i, n) atomicAdd(&g_dbg_cnt[i], (unsigned long long)(n))
 #else
 #define DBG_COUNT(i, n) do { } while (0)
@@ -536,32 +536,36 @@ DEVI int support_vertex(const Tables &T, int h, int base, V3 dl, V3 &vout, int h
     return cur;
 }
 
-// Support vertex of a hull by all 16 lanes of the env: lane j scans vertices j, j + 16, ... of the LDS vertex table, then a
-// 16-lane arg-max (ties: lowest index, as an exhaustive scan would give). ~n/16 LDS reads per lane with no dependent chain,
-// against ~3 dependent neighbour hops per step of the per-lane hill climb it replaces in collide().
+// Support vertices of two hulls by all 16 lanes of the env (portal refinement asks for one on each): lane j scans vertices j,
+// j + 16, ... of both LDS vertex tables, then two interleaved 16-lane arg-max reductions (ties: lowest index, as an exhaustive
+// scan would give). ~n/16 LDS reads per lane and hull with no dependent chain, against ~3 dependent neighbour hops per step
+// of the per-lane hill climb it replaces in collide().
 template <int CTRL> DEVI int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, false); }
-DEVI int coop_support(const Tables &T, int base, int n, V3 dl, int sub) {
-    float bv = -3.0e38f; int bi = 0x7fffffff;
-    const float4 *v4 = reinterpret_cast<const float4 *>(T.v) + base;
-    // four independent LDS reads in flight per iteration (indices past the end are clamped: a duplicate of the last vertex
-    // cannot win a tie against itself)
-    for (int i = sub; i < n; i += 4 * KL) {
-        int j[4]; float4 v[4];
+DEVI void coop_support2(const Tables &T, int baseA, int nA, V3 dA, int baseB, int nB, V3 dB, int sub, int &ia, int &ib) {
+    float av = -3.0e38f, bv = -3.0e38f; int ai = 0x7fffffff, bi = 0x7fffffff;
+    const float4 *vA = reinterpret_cast<const float4 *>(T.v) + baseA, *vB = reinterpret_cast<const float4 *>(T.v) + baseB;
+    const int nmax = max(nA, nB);
+    for (int i = sub; i < nmax; i += 2 * KL) {
+        int ja[2], jb[2]; float4 a[2], b[2];
 #pragma unroll
-        for (int q = 0; q < 4; q++) j[q] = min(i + q * KL, n - 1);
+        for (int q = 0; q < 2; q++) { ja[q] = min(i + q * KL, nA - 1); jb[q] = min(i + q * KL, nB - 1); }
 #pragma unroll
-        for (int q = 0; q < 4; q++) v[q] = v4[j[q]];
+        for (int q = 0; q < 2; q++) { a[q] = vA[ja[q]]; b[q] = vB[jb[q]]; }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float s = fmaf(v[q].x, dl.x, fmaf(v[q].y, dl.y, v[q].z * dl.z));
-            const bool t = s > bv || (s == bv && j[q] < bi);
-            bv = t ? s : bv; bi = t ? j[q] : bi;
+        for (int q = 0; q < 2; q++) {
+            const float sa = fmaf(a[q].x, dA.x, fmaf(a[q].y, dA.y, a[q].z * dA.z));
+            const bool ta = sa > av || (sa == av && ja[q] < ai);
+            av = ta ? sa : av; ai = ta ? ja[q] : ai;
+            const float sb = fmaf(b[q].x, dB.x, fmaf(b[q].y, dB.y, b[q].z * dB.z));
+            const bool tb = sb > bv || (sb == bv && jb[q] < bi);
+            bv = tb ? sb : bv; bi = tb ? jb[q] : bi;
         }
     }
-#define COOP_STEP(R) { float ov = dpp_f<DPP_ROW_ROR(R)>(bv); int oi = dpp_i<DPP_ROW_ROR(R)>(bi); bool t = ov > bv || (ov == bv && oi < bi); bv = t ? ov : bv; bi = t ? oi : bi; }
-    COOP_STEP(8) COOP_STEP(4) COOP_STEP(2) COOP_STEP(1)
-#undef COOP_STEP
-    return bi;
+#define COOP_STEP2(R) { float oa = dpp_f<DPP_ROW_ROR(R)>(av); int oia = dpp_i<DPP_ROW_ROR(R)>(ai); float ob = dpp_f<DPP_ROW_ROR(R)>(bv); int oib = dpp_i<DPP_ROW_ROR(R)>(bi); \
+        bool ta = oa > av || (oa == av && oia < ai); av = ta ? oa : av; ai = ta ? oia : ai; bool tb = ob > bv || (ob == bv && oib < bi); bv = tb ? ob : bv; bi = tb ? oib : bi; }
+    COOP_STEP2(8) COOP_STEP2(4) COOP_STEP2(2) COOP_STEP2(1)
+#undef COOP_STEP2
+    ia = ai; ib = bi;
 }
 
 struct Sup { V3 v, v1, v2; };
@@ -688,32 +692,37 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
         // hull ranges, everybody scans a sixteenth of the vertices, the owner takes the arg-max and advances its portal.
         const int nv2 = __float_as_int(t2[9]), nv1 = __float_as_int(t1[9]);
         if (round == 0 && cx.sub == 0) DBG_COUNT(0, 1);
+#ifdef GRIP_STAMPS
+        unsigned long long tw_ = stamp_now();
+#endif
         while (__any(phase >= 0)) {
             const unsigned actm = group_bits(__ballot(phase >= 0), cx.lane);
             const unsigned early = group_bits(__ballot(phase >= 0 && phase != 3 && phase != 4), cx.lane);
             const bool coop = actm != 0u && early == 0u;
             if (cx.sub == 0 && actm != 0u) DBG_COUNT(coop ? 2 : 1, 1);
+#ifdef GRIP_STAMPS
+            const bool phase_was_early_ = phase >= 0 && !coop;
+#endif
             const int owner = coop ? (__ffs((int)actm) - 1) : -1;
             const bool mine = coop ? owner == cx.sub : phase >= 0;
             V3 vl = v3(0, 0, 0), vl1 = v3(0, 0, 0); int vi2 = 0;
             if (__any(coop)) {
-                float *qs = cx.envl + EF_M;                 // query slot: the mass-matrix area is not in use yet
-                if (coop && mine) {
-                    V3 d2 = multv(R2, -dir), d1 = multv(R1, dir);
-                    qs[0] = d2.x; qs[1] = d2.y; qs[2] = d2.z; qs[3] = __int_as_float(base2); qs[4] = __int_as_float(nv2);
-                    qs[5] = d1.x; qs[6] = d1.y; qs[7] = d1.z; qs[8] = __int_as_float(base1); qs[9] = __int_as_float(nv1);
-                }
-                wave_sync();
+                // the owner's query (two local directions, hull ranges) goes to its 15 helpers by lane shuffles (ds_bpermute: no LDS
+                // store, no barrier); every lane reads from the owner lane of ITS env
+                const int src = 4 * ((cx.lane & 48) + max(owner, 0));
+                V3 d2o = multv(R2, -dir), d1o = multv(R1, dir);
+                auto bc = [&](float x) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(x))); };
+                auto bci = [&](int x) { return __builtin_amdgcn_ds_bpermute(src, x); };
+                V3 d2 = v3(bc(d2o.x), bc(d2o.y), bc(d2o.z)), d1 = v3(bc(d1o.x), bc(d1o.y), bc(d1o.z));
+                const int qb2 = bci(base2), qn2 = bci(nv2), qb1 = bci(base1), qn1 = bci(nv1);
                 if (coop) {
-                    V3 d2 = v3(qs[0], qs[1], qs[2]), d1 = v3(qs[5], qs[6], qs[7]);
-                    const int qb2 = __float_as_int(qs[3]), qn2 = __float_as_int(qs[4]), qb1 = __float_as_int(qs[8]), qn1 = __float_as_int(qs[9]);
-                    int b2i = coop_support(T, qb2, qn2, d2, cx.sub), b1i = coop_support(T, qb1, qn1, d1, cx.sub);
+                    int b2i, b1i;
+                    coop_support2(T, qb2, qn2, d2, qb1, qn1, d1, cx.sub, b2i, b1i);
                     if (mine) {
                         const float *vp2 = T.v + 4 * (base2 + b2i), *vp1 = T.v + 4 * (base1 + b1i);
                         vl = v3(vp2[0], vp2[1], vp2[2]); vl1 = v3(vp1[0], vp1[1], vp1[2]); vi2 = b2i;
                     }
                 }
-                wave_sync();
             }
             int vi1 = 0;
             if (!coop && mine) {
@@ -805,6 +814,12 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
                     }
                 }
             }
+#ifdef GRIP_STAMPS
+            {   const bool any_early = __any(phase_was_early_);
+                unsigned long long tn_ = stamp_now();
+                if (threadIdx.x == 0) { DBG_COUNT(any_early ? 8 : 10, tn_ - tw_); DBG_COUNT(any_early ? 9 : 11, 1); }
+                tw_ = tn_; }
+#endif
         }
         // ---- compaction: exclusive prefix of rc over the env's 16 lanes (rc <= 4: three ballots)
         unsigned b0 = group_bits(__ballot(rc & 1), cx.lane), b1 = group_bits(__ballot(rc & 2), cx.lane), b2 = group_bits(__ballot(rc & 4), cx.lane);

@@ -1281,10 +1281,10 @@ extern "C" int grip_debug_stamps(unsigned long long *out8) {   // NSTAMP entries
     unsigned long long zero[NSTAMP] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_acc), zero, sizeof zero) == hipSuccess ? 0 : -1;
 }
-extern "C" int grip_debug_counters(unsigned long long *out8) {   // collide() event counters (grip_physics.h), reset on read
+extern "C" int grip_debug_counters(unsigned long long *out8) {   // 16 collide() event counters (grip_physics.h), reset on read
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dbg_cnt), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-    unsigned long long zero[8] = {0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dbg_cnt), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    unsigned long long zero[16] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_cnt), zero, sizeof zero) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -17,13 +17,14 @@ if mode == "mixed":                                      # states of a random po
     for t in range(int(sys.argv[3]) if len(sys.argv) > 3 else 150):
         b.step(torch.rand(n, 6, device="cuda", generator=g) * 2 - 1)
     torch.cuda.synchronize()
-cnt = (C.c_ulonglong * 8)(); engine.lib().grip_debug_counters(cnt)            # drop what the set-up accumulated
+cnt = (C.c_ulonglong * 16)(); engine.lib().grip_debug_counters(cnt)            # drop what the set-up accumulated
 b.substep(k); torch.cuda.synchronize()
 engine.lib().grip_debug_counters(cnt)
 calls = max(1, cnt[0])
 print(f"collide() per env and call: {cnt[1] / calls:.2f} trips with per-lane supports, {cnt[2] / calls:.2f} cooperative refinement trips, "
       f"{cnt[3] / calls:.2f} hull pairs past the sphere test ({cnt[4] / calls:.2f} ended by the remembered direction), "
       f"{cnt[5] / calls:.3f} hull contacts, {cnt[7] / calls:.1f} hill climbs with {cnt[6] / max(1, cnt[7]):.2f} hops each")
+print(f"first wave of each workgroup: {cnt[9]} trips with per-lane supports at {cnt[8] / max(1, cnt[9]):.0f} cycles, {cnt[11]} pure refinement trips at {cnt[10] / max(1, cnt[11]):.0f} cycles")
 out = (C.c_ulonglong * 20)()
 assert engine.lib().grip_debug_stamps(out) == 0
 names = ["kinematics", "collide", "mass+bias+qs", "make_constraints", "solve: other (LS, bookkeeping)", "integrate", "solve: constraint pass", "solve: tri-solves+gather", "solve: assemble rows", "solve: cholesky", "solve: line search", "-", "-", "-", "solve: prologue", "solve: stage logic", "solve: hessian_vectors", "solve: p readback, Mp, Jp", "solve: loop exit", "solve: final gathers"]
