@@ -505,9 +505,10 @@ DEVI int support_vertex(const Tables &T, int h, int base, V3 dl, V3 &vout, int h
     int iu = min(LUT_RES - 1, max(0, (int)((u * im + 1.f) * (0.5f * LUT_RES))));
     int iv = min(LUT_RES - 1, max(0, (int)((v * im + 1.f) * (0.5f * LUT_RES))));
     int cell = (2 * axis + (mj < 0.f ? 1 : 0)) * (LUT_RES * LUT_RES) + iu * LUT_RES + iv;
-    const float *vb = T.v + 4 * base;
+    const float4 *vb = reinterpret_cast<const float4 *>(T.v) + base;      // vertices are padded to 16 bytes: one ds_read_b128 each
     int cur = hint >= 0 ? hint : T.lut[h * LUT_CELLS + cell];       // any start climbs to the same maximum on a convex hull
-    float bx = vb[4 * cur], by = vb[4 * cur + 1], bz = vb[4 * cur + 2];
+    const float4 v0 = vb[cur];
+    float bx = v0.x, by = v0.y, bz = v0.z;
     float bv = fmaf(bx, dl.x, fmaf(by, dl.y, bz * dl.z));
     int e = T.nadr[base + cur], eend = T.nadr[base + cur + 1];
     int cand = cur; float cv = bv, cx = bx, cy = by, cz = bz;
@@ -517,7 +518,7 @@ DEVI int support_vertex(const Tables &T, int h, int base, V3 dl, V3 &vout, int h
 #pragma unroll
             for (int q = 0; q < 4; q++) j[q] = T.nbr[min(e + q, eend - 1)];
 #pragma unroll
-            for (int q = 0; q < 4; q++) { x[q] = vb[4 * j[q]]; y[q] = vb[4 * j[q] + 1]; z[q] = vb[4 * j[q] + 2]; }
+            for (int q = 0; q < 4; q++) { const float4 vq = vb[j[q]]; x[q] = vq.x; y[q] = vq.y; z[q] = vq.z; }
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 float s = fmaf(x[q], dl.x, fmaf(y[q], dl.y, z[q] * dl.z));
