@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--overlap-update", action="store_true", help="PPO update of rollout i on a second stream while rollout i+1 is collected (one update of policy lag)")
     ap.add_argument("--pipeline", action="store_true", help="decide for tick t on a side stream while tick t+1 advances (lag 2)")
     ap.add_argument("--budget-us", type=int, default=2000, help="wall-clock cap of a wavefront's slice in microseconds (async schedule; 0 = none)")
+    ap.add_argument("--cold-portal", action="store_true", help="diagnostic: the comparison build whose narrow phase starts every portal refinement from scratch (engine.select_library)")
     ap.add_argument("--fixed-slice", action="store_true", help="keep --slice / --budget-us for the whole run (default: they follow the measured length of the macro steps)")
     a = ap.parse_args()
     if a.capacity <= 0:
@@ -116,6 +117,9 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
+    if a.cold_portal:
+        from mujoco_rl_manipulate_unknown_objects_amd import engine as _engine
+        _engine.select_library(cold_portal=True)
     from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import BatchedRobotEnv, MixedBatchedRobotEnv, default_config
     from mujoco_rl_manipulate_unknown_objects_amd.sb3 import PPO, GpuVecEnv
     from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
@@ -231,7 +235,7 @@ def main():
         sched = ("lock-step vector env" if ar is None else
                  f"asynchronous time slices (<= {ar.S} physics steps and <= {ar.eng.budget_us} us per wavefront and tick"
                  + (f" at the end of the run: slice / budget follow the measured macro-step length, {ar.ladder}" if ar.ladder else "")
-                 + f", {min(a.capacity, a.envs)} decisions/tick)" + ("; PPO update overlapped with the next rollout (policy lag 1)" if a.overlap_update else ""))
+                 + f", {min(a.capacity, a.envs)} decisions/tick)" + ("; comparison build: cold-started portal refinement" if a.cold_portal else "") + ("; PPO update overlapped with the next rollout (policy lag 1)" if a.overlap_update else ""))
         achieved = macro_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
             "metric": "env-steps/sec (whole node), " + ("mixed objects" if a.mixed else f"{a.object}_env") + f" {a.envs} envs/GPU", "value": value, "unit": "env-steps/s",

@@ -569,17 +569,27 @@ DEVI void coop_support2(const Tables &T, int baseA, int nA, V3 dA, int baseB, in
     ia = ai; ib = bi;
 }
 
+#ifndef GRIP_COLD_PORTAL      // support records also carry what is needed to rebuild them one physics.step() later (-DGRIP_COLD_PORTAL: the comparison build without the portal memory)
+struct Sup { V3 v, v1, v2; int id; V3 qd; };
+#define SUP_EXTRA_SET(d, s) (d).id = (s).id; (d).qd.x = (s).qd.x; (d).qd.y = (s).qd.y; (d).qd.z = (s).qd.z;
+#define SUP_EXTRA_SEL(d, c, s) (d).id = (c) ? (s).id : (d).id; (d).qd.x = (c) ? (s).qd.x : (d).qd.x; (d).qd.y = (c) ? (s).qd.y : (d).qd.y; (d).qd.z = (c) ? (s).qd.z : (d).qd.z;
+#else
 struct Sup { V3 v, v1, v2; };
+#define SUP_EXTRA_SET(d, s)
+#define SUP_EXTRA_SEL(d, c, s)
+#endif
 // field-by-field copy: a whole-struct assignment becomes llvm.memcpy between stack slots, which SROA then leaves in scratch
 // memory -- and the MPR loop pays a scratch round trip per portal update
 DEVI void sup_set(Sup &d, const Sup &s) {
     d.v.x = s.v.x; d.v.y = s.v.y; d.v.z = s.v.z; d.v1.x = s.v1.x; d.v1.y = s.v1.y; d.v1.z = s.v1.z; d.v2.x = s.v2.x; d.v2.y = s.v2.y; d.v2.z = s.v2.z;
+    SUP_EXTRA_SET(d, s)
 }
 
 DEVI void sup_sel(Sup &d, bool c, const Sup &s) {
     d.v.x = c ? s.v.x : d.v.x; d.v.y = c ? s.v.y : d.v.y; d.v.z = c ? s.v.z : d.v.z;
     d.v1.x = c ? s.v1.x : d.v1.x; d.v1.y = c ? s.v1.y : d.v1.y; d.v1.z = c ? s.v1.z : d.v1.z;
     d.v2.x = c ? s.v2.x : d.v2.x; d.v2.y = c ? s.v2.y : d.v2.y; d.v2.z = c ? s.v2.z : d.v2.z;
+    SUP_EXTRA_SEL(d, c, s)
 }
 DEVI V3 portal_dir(const Sup &a, const Sup &b, const Sup &c) { return normalized(cross(b.v - a.v, c.v - a.v)); }
 DEVI void expand_portal(const Sup &p0, Sup &p1, Sup &p2, Sup &p3, const Sup &p4) {
@@ -627,8 +637,16 @@ DEVI V3 find_pos(const Sup &p0, const Sup &p1, const Sup &p2, const Sup &p3) {
 
 // a contact owned by one lane
 // what a pair lane of collide() remembers between calls: the direction that last separated its pair and the two support
-// vertices that proved it (the hill climbs of the next check start there: same direction, bodies moved by one 2 ms step)
+// vertices that proved it (the hill climbs of the next check start there: same direction, bodies moved by one 2 ms step); and,
+// for a pair in contact, the portal its refinement converged to -- three (vertex of hull 1, vertex of hull 2, query direction)
+// records. The next call rebuilds that portal at the new poses and, if it still holds the origin ray, refines from there:
+// 1-3 trips instead of 3 discovery + ~8 refinement trips. The converged facet is the same to the 1e-6 tolerance; the path is
+// not, so results differ from a cold start at the 1e-6 m level over tens of steps (tests/test_gpu_parity.py).
+#ifndef GRIP_COLD_PORTAL
+struct PairMemo { V3 sep; int h1, h2; int has; int pi[3]; V3 pd[3]; };      // + the last converged portal: vertex pairs and query directions
+#else
 struct PairMemo { V3 sep; int h1, h2; };
+#endif
 
 struct Contact {
     V3 p, n; float dist; int g1, g2, gA, gB; float fs, ft, tran, D0;
@@ -681,6 +699,29 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
             if (dot(s0.v, s0.v) < EPS2) s0.v.x += 1e-5f;
             dir = normalized(-s0.v);
             if (phase == 0 && dot(sep, sep) > 0.5f) { dir = sep; phase = 6; }
+#ifndef GRIP_COLD_PORTAL
+            if (phase < 0) memo.has = 0;
+            if (phase == 0 && memo.has) {           // rebuild the portal the last step converged to at the new poses; use it if it still holds the origin ray
+                Sup w[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const int i1 = memo.pi[k] & 0xffff, i2 = memo.pi[k] >> 16;
+                    const float *a1 = T.v + 4 * (base1 + i1), *a2 = T.v + 4 * (base2 + i2);
+                    w[k].v1 = p1 + mulv(R1, v3(a1[0], a1[1], a1[2])) + memo.pd[k] * infl;
+                    w[k].v2 = p2 + mulv(R2, v3(a2[0], a2[1], a2[2])) - memo.pd[k] * infl;
+                    w[k].v = w[k].v1 - w[k].v2; w[k].id = memo.pi[k]; w[k].qd = memo.pd[k];
+                }
+                V3 nn = cross(w[1].v - w[0].v, w[2].v - w[0].v);
+                const float n2 = dot(nn, nn);
+                bool ok = n2 > 1e-20f;
+                V3 nd = nn * rsqrtf(fmaxf(n2, 1e-30f));
+                const bool flip = dot(nd, s0.v) > 0.f;
+                sup_set(s1, flip ? w[1] : w[0]); sup_set(s2, flip ? w[0] : w[1]); sup_set(s3, w[2]);
+                if (flip) nd = -nd;
+                ok = ok && dot(cross(s1.v, s3.v), s0.v) >= -EPSD && dot(cross(s3.v, s2.v), s0.v) >= -EPSD && dot(cross(s2.v, s1.v), s0.v) >= -EPSD;
+                if (ok) { dir = nd; phase = dot(dir, s1.v) >= -EPSD ? 4 : 3; DBG_COUNT(13, 1); }
+            }
+#endif
         }
         // results of this lane's item: up to 4 contacts
         V3 rp0 = v3(0, 0, 0), rp1 = rp0, rp2 = rp0, rp3 = rp0; float rd0 = 0.f, rd1 = 0.f, rd2 = 0.f, rd3 = 0.f;
@@ -706,7 +747,7 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
 #endif
             const int owner = coop ? (__ffs((int)actm) - 1) : -1;
             const bool mine = coop ? owner == cx.sub : phase >= 0;
-            V3 vl = v3(0, 0, 0), vl1 = v3(0, 0, 0); int vi2 = 0;
+            V3 vl = v3(0, 0, 0), vl1 = v3(0, 0, 0); int vi2 = 0, vi1w = 0;
             if (__any(coop)) {
                 // the owner's query (two local directions, hull ranges) goes to its 15 helpers by lane shuffles (ds_bpermute: no LDS
                 // store, no barrier); every lane reads from the owner lane of ITS env
@@ -721,11 +762,11 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
                     coop_support2(T, qb2, qn2, d2, qb1, qn1, d1, cx.sub, b2i, b1i);
                     if (mine) {
                         const float *vp2 = T.v + 4 * (base2 + b2i), *vp1 = T.v + 4 * (base1 + b1i);
-                        vl = v3(vp2[0], vp2[1], vp2[2]); vl1 = v3(vp1[0], vp1[1], vp1[2]); vi2 = b2i;
+                        vl = v3(vp2[0], vp2[1], vp2[2]); vl1 = v3(vp1[0], vp1[1], vp1[2]); vi2 = b2i; vi1w = b1i;
                     }
                 }
             }
-            int vi1 = 0;
+            int vi1 = vi1w;
             if (!coop && mine) {
                 const bool rem = phase == 6;
                 vi2 = support_vertex(T, g2 - 1, base2, multv(R2, plane ? dir : -dir), vl, rem ? memo.h2 : -1);
@@ -754,6 +795,9 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
                     s.v2 = s.v2 - dir * infl;
                     s.v1 = p1 + mulv(R1, vl1) + dir * infl;
                     s.v = s.v1 - s.v2;
+#ifndef GRIP_COLD_PORTAL
+                    s.id = vi1 | (vi2 << 16); s.qd = dir;
+#endif
                     cnt++;
                     bool hit = false; float depth = 0.f; V3 nrm = v3(0, 0, 0), pos = v3(0, 0, 0);
                     if (phase == 6) {
@@ -800,6 +844,9 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
                             V3 w; float d2 = origin_tri_dist2(s1.v, s2.v, s3.v, w);
                             depth = sqrtf(d2); nrm = depth < 1e-9f ? v3(0, 0, 0) : normalized(w);
                             pos = find_pos(s0, s1, s2, s3); hit = true;
+#ifndef GRIP_COLD_PORTAL
+                            memo.has = 1; memo.pi[0] = s1.id; memo.pi[1] = s2.id; memo.pi[2] = s3.id; memo.pd[0] = s1.qd; memo.pd[1] = s2.qd; memo.pd[2] = s3.qd;
+#endif
                         } else {
                             expand_portal(s0, s1, s2, s3, s);
                             dir = portal_dir(s1, s2, s3);

@@ -255,7 +255,7 @@ struct GripBatch {
     int *episode_step = nullptr, *status = nullptr, *gripper_open = nullptr;
     int *pad_grasp = nullptr, *pad_pher = nullptr;                              // sensor-pad scalars of the current state
     int nplanes = 0;
-    int *mc_ints = nullptr, *mc_astate = nullptr, *mc_slot = nullptr, *mc_order = nullptr, *mc_heavy = nullptr, *mc_tick = nullptr, *mc_gen = nullptr; unsigned long long *mc_t0 = nullptr; float *mc_flts = nullptr;   // suspended macro steps
+    int *mc_ints = nullptr, *mc_astate = nullptr, *mc_slot = nullptr, *mc_order = nullptr, *mc_heavy = nullptr, *mc_tick = nullptr, *mc_gen = nullptr; unsigned long long *mc_t0 = nullptr; float *mc_flts = nullptr, *mc_memo = nullptr;   // suspended macro steps
     float *reset_info = nullptr;                                                // grasp0, pher0, objx0, objy0 of the reset state
     float *scratch = nullptr; size_t scratch_bytes = 0;
     float xfrc_z = 0.f;
@@ -275,7 +275,8 @@ struct StatePtrs { float *qpos, *qvel, *ctrl, *warm; int *episode_step, *status,
 // slot: row of the compact action / observation arrays this waiting env was given by the last k_compact (-1 = none yet);
 // heavy: hull-hull contacts the env had at its last physics.step() -- the cost class k_compact sorts the work order by;
 // gen: number of the compaction that gave the slot (tick[0] counts compactions): a slot-holder starts `lag` launches later.
-struct MacroCtx { int *ints; float *flts; int *astate; int *slot; int *heavy; int *tick; int *gen; unsigned long long *t0; };
+struct MacroCtx { int *ints; float *flts; int *astate; int *slot; int *heavy; int *tick; int *gen; unsigned long long *t0; float *memo; };
+#define MC_MEMO_WORDS 13       // per lane: has, 3 vertex-pair ids, 3 query directions (the narrow phase's portal memory)
 enum { MC_PHASE = 0, MC_CNT, MC_NSUB, MC_GRASPED, MC_FLAGS, MC_FAULT, MC_NINT };
 enum { MC_TARGET = 0, MC_INITQ = 5, MC_OPENCLOSE = 10, MC_TQ = 11, MC_INITOBJ = 12, MC_NFLT = 15 };
 
@@ -387,6 +388,11 @@ enum { PH_MOVE = 0, PH_RETURN, PH_OPEN, PH_CLOSE, PH_FINAL, PH_DONE };
 // kernels: 256-thread workgroups = 16 environments x 16 cooperating lanes (grip_physics.h)
 // ------------------------------------------------------------------------------------------------
 extern __shared__ float lds_dyn[];
+#ifndef GRIP_COLD_PORTAL
+#define PAIRMEMO_EXTRA_INIT(m) (m).has = 0; for (int k_ = 0; k_ < 3; k_++) { (m).pi[k_] = 0; (m).pd[k_] = v3(0, 0, 1); }
+#else
+#define PAIRMEMO_EXTRA_INIT(m)
+#endif
 
 #define STAMPS_DECL Stamps stm; STAMPS_INIT
 #ifdef GRIP_STAMPS
@@ -404,7 +410,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_reset(const DevModel m, DevCo
     bool doit = valid && (mask == nullptr || mask[e] != 0);
     LaneState s; reset_lane(m, s);
     Kin k; Contact con; int ncon = 0, fault = 0;
-    PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1;
+    PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1; PAIRMEMO_EXTRA_INIT(sep)
     forward_pos(m, cx, s, k, con, ncon, fault, stm, sep);
     int grasp = check_grasp(cx, con, ncon), pher = pheromone_level(k.pe, cfg);
     if (blockIdx.x == 0 && threadIdx.x == 0 && reset_info) { reset_info[0] = (float)grasp; reset_info[1] = (float)pher; reset_info[2] = k.po.x; reset_info[3] = k.po.y; }
@@ -472,7 +478,20 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
         for (int i = 0; i < 6; i++) act[i] = i < adim ? actions[arow * adim + i] : 0.f;
     }
     int budget = sliced ? slice : 0x7fffffff, last_iters = 0, sum_iters = 0, nsub_slice = 0;
-    PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1;   // collide()'s per-lane memory of its pair's separating direction
+    PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1; PAIRMEMO_EXTRA_INIT(sep)   // collide()'s per-lane memory of its pair's separating direction
+#ifndef GRIP_COLD_PORTAL
+    // the portal memory lives as long as the macro step: a resumed env gets it back, so that the result does not depend on where
+    // the time slices end (lock-step keeps it in registers for the whole macro step)
+    if (sliced && valid && !first) {
+        const float *mm = mc.memo + ((size_t)cx.sub * N + e);
+        sep.has = __float_as_int(mm[0]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            sep.pi[k] = __float_as_int(mm[(size_t)(1 + k) * 16 * N]);
+            sep.pd[k] = v3(mm[(size_t)(4 + 3 * k) * 16 * N], mm[(size_t)(5 + 3 * k) * 16 * N], mm[(size_t)(6 + 3 * k) * 16 * N]);
+        }
+    }
+#endif
     // the wall-clock budget runs from the moment the FIRST workgroup of the launch started (k_compact clears the stamp), so
     // that a workgroup that was placed late -- other streams' kernels were using its CU -- does not stretch the launch
     unsigned long long t0v = 0ULL;
@@ -626,6 +645,17 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
         // (twice the mean Newton iteration count of this slice: single steps alternate between 1 and 2 iterations)
         if (writer && nsub_slice > 0) mc.heavy[e] = min(CP_CLASSES - 2, (2 * sum_iters + nsub_slice / 2) / nsub_slice + 3 * min(hv, 3));
     }
+#ifndef GRIP_COLD_PORTAL
+    if (sliced && valid && phase != PH_DONE) {              // every lane parks its pair's portal memory
+        float *mm = mc.memo + ((size_t)cx.sub * N + e);
+        mm[0] = __int_as_float(sep.has);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            mm[(size_t)(1 + k) * 16 * N] = __int_as_float(sep.pi[k]);
+            mm[(size_t)(4 + 3 * k) * 16 * N] = sep.pd[k].x; mm[(size_t)(5 + 3 * k) * 16 * N] = sep.pd[k].y; mm[(size_t)(6 + 3 * k) * 16 * N] = sep.pd[k].z;
+        }
+    }
+#endif
     if (sliced && writer && phase != PH_DONE) {             // out of budget mid-step: suspend
         st_state(st, e, s);
         st.status[e] = status; st.gripper_open[e] = gripper_open;
@@ -736,7 +766,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_substep(const DevModel m, Sta
     if (!valid) e = st.n - 1;
     LaneState s; ld_state(st, e, s);
     Kin k; Contact con; int ncon = 0, fault = 0;
-    PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1;
+    PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1; PAIRMEMO_EXTRA_INIT(sep)
     for (int i = 0; i < nsteps; i++) {
         forward_pos(m, cx, s, k, con, ncon, fault, stm, sep);
         physics_advance(m, cx, s, xfrc_z, k, con, ncon, fault, stm);
@@ -756,7 +786,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_debug_forward(const DevModel 
     if (!valid) e = st.n - 1;
     LaneState s; ld_state(st, e, s);
     Kin k; Contact con; int ncon = 0, fault = 0, iters = 0;
-    PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1;
+    PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1; PAIRMEMO_EXTRA_INIT(sep)
     forward_pos(m, cx, s, k, con, ncon, fault, stm, sep);
     float qfs[13], qacc[13], jtf[13], qs[13], bias[13];
     forward_acc(m, cx, s, xfrc_z, k, con, ncon, fault, qfs, qacc, jtf, iters, qs, bias, stm, getenv_dbgH ? M_out + (size_t)e * 169 : nullptr);
@@ -825,7 +855,7 @@ static StepOutDev to_dev(const GripStepOut *o) {
     d.n_substeps = o->n_substeps; d.fault = o->fault;
     return d;
 }
-static MacroCtx macro_ctx(GripBatch *b) { MacroCtx c; c.ints = b->mc_ints; c.flts = b->mc_flts; c.astate = b->mc_astate; c.slot = b->mc_slot; c.heavy = b->mc_heavy; c.tick = b->mc_tick; c.gen = b->mc_gen; c.t0 = b->mc_t0; return c; }
+static MacroCtx macro_ctx(GripBatch *b) { MacroCtx c; c.ints = b->mc_ints; c.flts = b->mc_flts; c.astate = b->mc_astate; c.slot = b->mc_slot; c.heavy = b->mc_heavy; c.tick = b->mc_tick; c.gen = b->mc_gen; c.t0 = b->mc_t0; c.memo = b->mc_memo; return c; }
 static int grid_of(const GripBatch *b) { return (b->n + EPB - 1) / EPB; }
 
 // observation kernel (grip_render.hip)
@@ -913,6 +943,7 @@ static int batch_build(GripBatch *b, const GripModel *m) {
     HIPCHK(hipMalloc(&b->mc_tick, sizeof(int))); HIPCHK(hipMemset(b->mc_tick, 0, sizeof(int)));
     HIPCHK(hipMalloc(&b->mc_gen, N * sizeof(int))); HIPCHK(hipMemset(b->mc_gen, 0, N * sizeof(int)));
     HIPCHK(hipMalloc(&b->mc_t0, sizeof(unsigned long long))); HIPCHK(hipMemset(b->mc_t0, 0, sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&b->mc_memo, (size_t)MC_MEMO_WORDS * 16 * N * sizeof(float))); HIPCHK(hipMemset(b->mc_memo, 0, (size_t)MC_MEMO_WORDS * 16 * N * sizeof(float)));
     {   std::vector<int> ident(N); for (size_t i = 0; i < N; i++) ident[i] = (int)i;          // work order: identity until the first compaction
         HIPCHK(hipMemcpy(b->mc_order, ident.data(), N * sizeof(int), hipMemcpyHostToDevice)); }
     b->scratch_bytes = 169 * N * sizeof(float) + 1024;
@@ -934,7 +965,7 @@ extern "C" void grip_batch_destroy(GripBatch *b) {
     (void)hipDeviceSynchronize();
     void *ptrs[] = {b->d_hull, b->d_planes, b->qpos, b->qvel, b->ctrl, b->warm, b->episode_step, b->status,
                     b->gripper_open, b->pad_grasp, b->pad_pher, b->reset_info, b->scratch, b->mc_ints, b->mc_flts, b->mc_astate,
-                    b->mc_slot, b->mc_order, b->mc_heavy, b->mc_tick, b->mc_gen, b->mc_t0, b->d_self, b->d_rself};
+                    b->mc_slot, b->mc_order, b->mc_heavy, b->mc_tick, b->mc_gen, b->mc_t0, b->mc_memo, b->d_self, b->d_rself};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &e : b->ev0) if (e) (void)hipEventDestroy(e);
     for (auto &e : b->ev1) if (e) (void)hipEventDestroy(e);
