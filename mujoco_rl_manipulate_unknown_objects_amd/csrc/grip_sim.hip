@@ -485,10 +485,12 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
     if (sliced && valid && !first) {
         const float *mm = mc.memo + ((size_t)cx.sub * N + e);
         sep.has = __float_as_int(mm[0]);
+        if (sep.has) {                                      // only lanes whose pair was in contact carry more than the flag
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            sep.pi[k] = __float_as_int(mm[(size_t)(1 + k) * 16 * N]);
-            sep.pd[k] = v3(mm[(size_t)(4 + 3 * k) * 16 * N], mm[(size_t)(5 + 3 * k) * 16 * N], mm[(size_t)(6 + 3 * k) * 16 * N]);
+            for (int k = 0; k < 3; k++) {
+                sep.pi[k] = __float_as_int(mm[(size_t)(1 + k) * 16 * N]);
+                sep.pd[k] = v3(mm[(size_t)(4 + 3 * k) * 16 * N], mm[(size_t)(5 + 3 * k) * 16 * N], mm[(size_t)(6 + 3 * k) * 16 * N]);
+            }
         }
     }
 #endif
@@ -646,13 +648,15 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
         if (writer && nsub_slice > 0) mc.heavy[e] = min(CP_CLASSES - 2, (2 * sum_iters + nsub_slice / 2) / nsub_slice + 3 * min(hv, 3));
     }
 #ifndef GRIP_COLD_PORTAL
-    if (sliced && valid && phase != PH_DONE) {              // every lane parks its pair's portal memory
+    if (sliced && valid && phase != PH_DONE) {              // every lane parks its pair's portal memory (the flag; the portal if there is one)
         float *mm = mc.memo + ((size_t)cx.sub * N + e);
         mm[0] = __int_as_float(sep.has);
+        if (sep.has) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            mm[(size_t)(1 + k) * 16 * N] = __int_as_float(sep.pi[k]);
-            mm[(size_t)(4 + 3 * k) * 16 * N] = sep.pd[k].x; mm[(size_t)(5 + 3 * k) * 16 * N] = sep.pd[k].y; mm[(size_t)(6 + 3 * k) * 16 * N] = sep.pd[k].z;
+            for (int k = 0; k < 3; k++) {
+                mm[(size_t)(1 + k) * 16 * N] = __int_as_float(sep.pi[k]);
+                mm[(size_t)(4 + 3 * k) * 16 * N] = sep.pd[k].x; mm[(size_t)(5 + 3 * k) * 16 * N] = sep.pd[k].y; mm[(size_t)(6 + 3 * k) * 16 * N] = sep.pd[k].z;
+            }
         }
     }
 #endif

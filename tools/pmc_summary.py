@@ -9,7 +9,7 @@ def load(pat):
 
 def main(prefix, out_path):
     out = {"source": "rocprofv3 --pmc, three separate passes (SQ counters | FETCH_SIZE | WRITE_SIZE), --kernel-include-regex 'k_macro_step|k_observe|k_conv1_u8', "
-                     "command: python3 bench.py --no-cpu-baseline --steps 8 --warmup 8 (time-sliced schedule, bench defaults)",
+                     "command: python3 bench.py --no-cpu-baseline --steps 40 --warmup 20 (time-sliced schedule, bench defaults otherwise)",
            "notes": ["SQ_* counters in quad-cycles summed over all waves, averaged per launch",
                      "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of wide "
                      "(16 B/lane) streaming reads and is uncalibrated for other widths -- these kernels read 4 B per lane, so both the raw and the "
