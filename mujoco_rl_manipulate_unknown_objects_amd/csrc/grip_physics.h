@@ -67,7 +67,7 @@ DEVI unsigned long long stamp_now() { __builtin_amdgcn_sched_barrier(0); unsigne
 // 3 hull-pair items past the sphere test, 4 of them ended by the remembered direction, 5 contacts from hull pairs,
 // 6 hill-climb hops (all lanes), 7 support_vertex calls (all lanes)
 __device__ unsigned long long g_dbg_cnt[16];   // 8..11: wave-level (first wave of a workgroup): cycles / trips with per-lane supports, cycles / trips of pure cooperative refinement; 12: cycles of collide() outside the loop
-#define DBG_COUNT(i, n) atomicAdd(&g_dbg_cnt[i], (unsigned long long)(n))
+#define DBG_COUNT(i, n) do { if (blockIdx.x == 0) atomicAdd(&g_dbg_cnt[i], (unsigned long long)(n)); } while (0)      // first workgroup only: thousands of lanes on 16 counters would distort the timings
 #else
 #define DBG_COUNT(i, n) do { } while (0)
 struct Stamps { int dummy; };
