@@ -210,3 +210,28 @@ def test_gloo_world2_async_rollouts_keep_replicas_identical():
     assert np.array_equal(res[0][0], res[1][0])                 # same parameters after two distributed updates
     assert res[0][1] != res[1][1]                               # although the ranks' rollouts took different numbers of ticks
     assert res[0][2] >= 2 * 18 and res[1][2] >= 2 * 18
+
+
+def test_slice_ladder_follows_the_macro_step_length():
+    """AsyncRollout.set_slice_ladder: the rung is chosen from the measured mean number of physics.step() calls per macro step,
+    with 10 % hysteresis around a threshold, and a change drops the captured tick graph."""
+    eng = ScriptedEngine(8, 4)
+    eng.budget_us = 2000
+    ro = AsyncRollout(eng, fake_policy, target=8, capacity=4, slice_len=96, gamma=0.99, gae_lambda=0.95)
+    ro.set_slice_ladder()
+    assert ro.ladder == ((0, 96, 2000), (215, 144, 3000), (270, 192, 4000))
+
+    def feed(mean, n=100):
+        ro._graph = "captured"
+        ro.substeps_total += int(mean * n)
+        ro._retune(n)
+        return ro.S, eng.budget_us, ro._graph
+
+    assert feed(180) == (96, 2000, "captured")                 # stays on the first rung, graph kept
+    assert feed(225) == (96, 2000, "captured")                 # within 10 % of the 215 threshold: no move
+    assert feed(250) == (144, 3000, None)                      # clearly above: second rung, graph dropped
+    assert feed(262) == (144, 3000, "captured")                # within 10 % of 270
+    assert feed(320) == (192, 4000, None)
+    assert feed(255) == (192, 4000, "captured")                # hysteresis on the way down too
+    assert feed(150) == (96, 2000, None)
+    assert abs(ro.mean_substeps - 150) < 1e-9
