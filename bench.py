@@ -18,6 +18,9 @@ vector-env schedule (all envs step together, the launch waits for the slowest) f
 Workload = BASELINE.json configs[1]: acorn_env (labelled stand-in hull: the reference checkout has no
 acorn.stl), 4096 envs per GPU, direction 0, default flags; synthetic = deterministic reset state,
 actions from the randomly initialised policy. Weak scaling: per-GPU work is fixed as N grows.
+Defaults: 20 warm-up + 200 timed steps. The value depends on K and W -- fresh episodes are free motion, later
+steps push and grasp and cost more physics.step() calls each (DESIGN.md section 6 has the table); a shorter last rollout is
+trained on too, so every timed step carries its share of the PPO update whatever K is.
 """
 import argparse
 import json
