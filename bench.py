@@ -1,26 +1,32 @@
 #!/usr/bin/env python3
 """Headline benchmark: env-steps/s of the batched rollout engine + PPO on N MI355X GPUs.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch = `--envs` completed env transitions per GPU: the
-PPO actor-critic forward (AugmentedNatureCNN + heads) samples an action, the engine runs RobotEnv.step
-(controller + all physics.step() sub-steps + reward/done), the observation kernel renders the 5x64x64
-uint8 observation, the transition is stored in the HBM rollout buffer; every `--rollout` steps a full
-PPO update (GAE, `--epochs` epochs of minibatch forward/backward/Adam, one flattened-gradient all-reduce
-per minibatch when N > 1) runs inside the timed region.
+N > 1: run as one rank per GPU under torch.distributed.run (the driver does that); when WORLD_SIZE is not set, this process
+spawns `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same args>` as a CHILD
+before anything touches a GPU, relays rank 0's JSON line and exits with the child's code.
 
-Default schedule: asynchronous time slices (grip_batch_advance; sb3/async_rollout.py) -- every env runs on
-its own clock, finished envs are re-decided every tick, and a step is counted when `--envs` transitions
-have completed, whichever envs they came from. Only the transitions PPO trains on are counted (the few
-that complete between the last poll and the end of a rollout are not). `--lockstep` runs the classic
-vector-env schedule (all envs step together, the launch waits for the slowest) for comparison.
-Workload = BASELINE.json configs[1]: acorn_env (labelled stand-in hull: the reference checkout has no
-acorn.stl), 4096 envs per GPU, direction 0, default flags; synthetic = deterministic reset state,
-actions from the randomly initialised policy. Weak scaling: per-GPU work is fixed as N grows.
-Defaults: 20 warm-up + 200 timed steps. The value depends on K and W -- fresh episodes are free motion, later
-steps push and grasp and cost more physics.step() calls each (DESIGN.md section 6 has the table); a shorter last rollout is
-trained on too, so every timed step carries its share of the PPO update whatever K is.
+One "step" = one pass of the hot path over one batch = `--envs` completed env transitions per GPU: the PPO actor-critic forward
+(AugmentedNatureCNN + heads) runs on every finished env, the engine runs RobotEnv.step (controller + all physics.step()
+sub-steps + reward/done), the observation kernel renders the 5x64x64 uint8 observation, the transition is stored in the HBM
+rollout buffer; every `--rollout` steps a full PPO update (GAE, `--epochs` epochs of minibatch forward/backward/Adam, one
+flattened-gradient all-reduce per minibatch when N > 1) runs inside the timed region.
+
+Synthetic input: every env starts from the deterministic reset state; actions are a ~ U(-1, 1)^6 from a
+counter-based generator keyed by (seed, rank, env, t) (`--actions rng`, the default) -- the policy still runs on every decision
+and the update trains on the log-probabilities of those actions, so the arithmetic is that of training, but the physics workload
+does not drift as the policy learns. `--actions policy` samples from the (randomly initialised, learning) policy instead.
+Before the W warm-up steps an UNTIMED pre-roll of `--preroll` rollout-only steps takes the envs from the common reset state to
+desynchronised, mixed episode phases (fresh episodes are free motion: 160 physics.step() calls per macro step; the stationary mix
+of pushing / grasping / failing episodes needs ~290), so that the value does not depend on K and W.
+
+Default schedule: asynchronous time slices (grip_batch_advance; sb3/async_rollout.py) -- every env runs on its own clock, finished
+envs are re-decided every tick, and a step is counted when `--envs` transitions have completed, whichever envs they came from. Only
+transitions PPO trains on are counted, as completed (a rollout that ran out of ticks counts what it finished and is reported in
+`short_rollouts`). `--lockstep` runs the classic vector-env schedule for comparison.
+Workload = BASELINE.json configs[1]: acorn_env (labelled stand-in hull: the reference checkout has no acorn.stl), 4096 envs per GPU,
+direction 0, default flags. Weak scaling: per-GPU work is fixed as N grows. Defaults: 20 warm-up + 200 timed steps.
 """
 import argparse
 import json
@@ -36,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md)
+VALU_PEAK_LANE_OPS = 157.3e12 / 2   # fp32 vector peak 157.3 TFLOP/s (MI355X_MICROARCH.md) = 7.9e13 lane-instructions/s (an FMA is 2 flops): 1024 SIMDs x 32 lanes/clk x 2.4 GHz
 # algorithmic bytes per env per macro-step launch of k_macro_step: state in 47 x 4 + action 24,
 # state out 40 x 4, reward 4 + done 1 + goals 16 + info 64
 MACRO_BYTES_PER_ENV = 47 * 4 + 24 + 40 * 4 + 4 + 1 + 16 + 64
@@ -96,6 +103,10 @@ def main():
     ap.add_argument("--budget-us", type=int, default=2000, help="wall-clock cap of a wavefront's slice in microseconds (async schedule; 0 = none)")
     ap.add_argument("--cold-portal", action="store_true", help="diagnostic: the comparison build whose narrow phase starts every portal refinement from scratch (engine.select_library)")
     ap.add_argument("--fixed-slice", action="store_true", help="keep --slice / --budget-us for the whole run (default: they follow the measured length of the macro steps)")
+    ap.add_argument("--actions", choices=["rng", "policy"], default="rng", help="rng: synthetic U(-1,1) action stream keyed by (seed, rank, env, t) (SURVEY.md 8d); "
+                                                                                 "policy: samples of the learning policy")
+    ap.add_argument("--preroll", type=int, default=300, help="untimed rollout-only steps before the warm-up: desynchronised, mixed episode phases")
+    ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
     if a.capacity <= 0:
         a.capacity = max(1, a.envs // 4)
@@ -104,10 +115,26 @@ def main():
         if a.envs % 8 or a.capacity % 8:
             raise SystemExit("--mixed needs --envs and --capacity divisible by 8")
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: become one. Nothing in this process has touched a GPU yet (torch is imported, no HIP call made), and
+        # the ranks are CHILD processes -- never an exec of a process that initialised the GPU.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+        if lines:
+            print(lines[-1], flush=True)
+        else:
+            sys.stderr.write(child.stdout[-4000:])
+        raise SystemExit(child.returncode if child.returncode or lines else 1)
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or run without a launcher: bench.py spawns one)")
     # rehearsal of the N > 1 code path on a one-GPU box: every rank on device 0, gloo instead of RCCL (never a headline number)
     rehearsal = os.environ.get("GRIP_BENCH_REHEARSAL") == "1"
     if rehearsal:
@@ -143,31 +170,40 @@ def main():
     ar = model._async
     if ar is not None and a.pipeline:
         ar.enable_pipeline()
+    if a.actions == "rng":
+        if ar is None:
+            raise SystemExit("--actions rng needs the time-sliced schedule (the fused recorder draws the stream); use --actions policy with --lockstep")
+        ar.set_synthetic_actions(a.seed, rank)
+    counted = {"done": 0, "short": 0}
 
-    def run_async(nsteps):
+    def run_async(nsteps, train=True):
         """nsteps x envs completed transitions, a PPO update after every `rollout` x envs of them (a shorter last rollout is
         trained on as well: every timed step carries its share of the update, whatever K is)."""
         done_steps = 0
         while done_steps < nsteps:
             chunk = min(a.rollout, nsteps - done_steps)
-            ar.target = chunk * a.envs; model.n_steps = chunk
+            ar.set_target(chunk * a.envs); model.n_steps = chunk
+            before = model.num_timesteps
             model.collect_rollouts()
-            if not a.no_ppo:
+            got = model.num_timesteps - before                  # transitions that really completed (polled on the device counter)
+            counted["done"] += min(got, ar.target); counted["short"] += int(got < ar.target)
+            if train and not a.no_ppo:
                 model.train()
             done_steps += chunk
-        ar.target = a.rollout * a.envs; model.n_steps = a.rollout
+        ar.set_target(a.rollout * a.envs); model.n_steps = a.rollout
 
-    def run(nsteps):
+    def run(nsteps, train=True):
         """nsteps vec-env steps with a PPO update after every `rollout` of them."""
         if ar is not None:
-            return run_async(nsteps)
+            return run_async(nsteps, train)
         done_steps = 0; subs = 0
         while done_steps < nsteps:
             # collect_rollouts always does n_steps steps; trim the last chunk
             chunk = min(a.rollout, nsteps - done_steps)
             model.n_steps = chunk; model.rollout_buffer.n_steps = chunk
             model.collect_rollouts()
-            if not a.no_ppo:
+            counted["done"] += chunk * a.envs
+            if train and not a.no_ppo:
                 model.train()
             done_steps += chunk
         model.n_steps = a.rollout; model.rollout_buffer.n_steps = a.rollout
@@ -198,6 +234,9 @@ def main():
             for p, q in zip(model.policy_rollout.parameters(), snap_p):
                 p.copy_(q)
     del snap_p
+    # untimed pre-roll, rollout only: from the common reset state to desynchronised, mixed episode phases (module docstring)
+    if a.preroll > 0:
+        run(a.preroll, train=False)
     run(a.warmup)
     if hasattr(model, "finish_updates"):
         model.finish_updates()
@@ -214,7 +253,8 @@ def main():
         return r
     env.step = counted_step
     if ar is not None:
-        ar.substeps_total.zero_(); ticks0 = ar.total_ticks; ar.done_total = 0
+        ar.reset_counters(); ticks0 = ar.total_ticks
+    counted["done"] = 0; counted["short"] = 0
     sync()
     t0 = time.perf_counter()
     run(a.steps)
@@ -223,14 +263,22 @@ def main():
     env.step = orig_step
     tmax = torch.tensor([dt], dtype=torch.float64, device=env.device)
     subs = (sub_acc if ar is None else ar.substeps_total).double().reshape(1)
+    cnt = torch.tensor([float(counted["done"]), float(counted["short"])], dtype=torch.float64, device=env.device)
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dist.all_reduce(subs, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dist.all_reduce(subs, op=dist.ReduceOp.SUM); dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
     dt = float(tmax.item()); total_sub = float(subs.item())
+    total_env_steps = float(cnt[0].item()); short_rollouts = int(cnt[1].item())
+    replicas_identical = None
+    if world > 1:           # data parallelism keeps the replicas bit-identical: compare a checksum of every parameter across the ranks
+        with torch.no_grad():
+            cs = torch.stack([p.detach().double().sum() for p in model.policy.parameters()] + [p.detach().double().abs().sum() for p in model.policy.parameters()])
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(torch.equal(lo, hi))
     k_ms, k_n = batch.kernel_time(reset=True)
 
     if rank == 0:
-        total_env_steps = a.envs * world * a.steps
-        value = total_env_steps / dt
+        value = total_env_steps / dt            # transitions that completed and were trained on, all ranks / max-over-ranks time
         # async: one launch = one time slice = state + suspended macro-step context in and out (21 words each way) per env, plus the
         # narrow phase's portal memory: a flag per lane each way, and 12 more words each way for the ~0.5 pairs in contact per env
         macro_bytes = (MACRO_BYTES_PER_ENV if ar is None else (47 + 40 + 2 * 21) * 4 + 8 + 2 * 16 * 4 + 2 * 12 * 4 // 2) * a.envs
@@ -245,14 +293,17 @@ def main():
             "metric": "env-steps/sec (whole node), " + ("mixed objects" if a.mixed else f"{a.object}_env") + f" {a.envs} envs/GPU", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("f32" if a.policy_dtype == "f32" else "f32 physics / bf16 policy") + (" (physics state stored as f16)" if a.state_dtype == "f16" else ""),
-            "data": "synthetic (deterministic reset state, actions sampled from the randomly initialised PPO policy)",
+            "data": "synthetic (deterministic reset state; " + (f"actions U(-1,1)^6 from a counter-based generator keyed by (seed={a.seed}, rank, env, t)" if a.actions == "rng"
+                                                                else "actions sampled from the randomly initialised, learning PPO policy") +
+                    f"; {a.preroll} untimed rollout-only pre-roll steps to mixed episode phases)",
             "config": {"workload": ("mixed {acorn (stand-in hull), sand_ball, sugar_cube, bread_crumb} x direction {0, 45}, " if a.mixed else
                                     f"{a.object}_env ({'stand-in hull; ' if a.object == 'acorn' else ''}direction {a.direction}), ") +
                                    f"{a.envs} envs/GPU, macro-step + observation + PPO actor-critic fwd each step, "
                                    f"PPO update every {a.rollout} steps ({a.epochs} epochs, minibatch {a.minibatch})",
                        "envs_per_gpu": a.envs, "parallelism": f"dp{world}", "ppo_in_timed_region": not a.no_ppo, "schedule": sched,
                        "step": f"{a.envs} completed env transitions per GPU"},
-            "mj_substeps_per_s": total_sub / dt, "mean_substeps_per_env_step": total_sub / total_env_steps,
+            "mj_substeps_per_s": total_sub / dt, "mean_substeps_per_env_step": total_sub / max(total_env_steps, 1.0),
+            "replicas_identical": replicas_identical, "env_steps_counted": total_env_steps, "env_steps_nominal": a.envs * world * a.steps, "short_rollouts": short_rollouts,
             "roofline": {"bound": "hbm", "kernel": "k_macro_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms_avg": k_ms, "launches": k_n,
                          "algorithmic_bytes_per_launch": macro_bytes,
@@ -260,15 +311,24 @@ def main():
         }
         if ar is not None:
             out["ticks"] = ar.total_ticks - ticks0
-            # HBM traffic and issue statistics cannot be read from inside the process: they come from the committed rocprofv3
-            # --pmc passes of this same command (profiles/r01_pmc_summary.json; separate passes, gfx950 FETCH_SIZE correction)
+            # HBM traffic and instruction counts cannot be read from inside the process: they come from the committed rocprofv3 --pmc
+            # passes of THIS command at THIS configuration (profiles/r02_pmc_summary.json: separate passes, gfx950 FETCH_SIZE
+            # correction) and are attached only when the run is that configuration; otherwise traffic stays null.
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))["kernels"]["k_macro_step"]
-                out["roofline"]["traffic"] = pm["hbm_bytes_per_launch_fetch_doubled"]
-                out["roofline"]["traffic_source"] = ("profiles/r01_pmc_summary.json: (2 x FETCH_SIZE + WRITE_SIZE) per launch; raw "
-                                                     f"{pm['hbm_bytes_per_launch_raw']:.0f} B")
-                out["roofline"]["valu_active_frac"] = pm["active_inst_valu_frac"]
-                out["roofline"]["wait_frac"] = pm["wait_any_frac"]
+                pmj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+                same_cfg = (pmj.get("config") == {"object": a.object, "envs": a.envs, "state_dtype": a.state_dtype, "mixed": bool(a.mixed)})
+                pm = pmj["kernels"]["k_macro_step"]
+                if same_cfg and not a.lockstep:
+                    rf = out["roofline"]
+                    rf["traffic"] = pm["hbm_bytes_per_launch_fetch_doubled"]
+                    rf["traffic_source"] = ("profiles/r02_pmc_summary.json, same command and configuration: (2 x FETCH_SIZE + WRITE_SIZE) per launch; raw "
+                                            f"{pm['hbm_bytes_per_launch_raw']:.0f} B")
+                    # the bound that really binds this kernel: VALU issue. lane-operations per physics.step() of one env from the PMC
+                    # pass (SQ_INSTS_VALU x 64 lanes / env-substeps of the launch) x the LIVE physics.step() rate of this run
+                    lane_ops = pm["valu_lane_ops_per_env_substep"] * (total_sub / dt) / world
+                    rf["valu"] = {"achieved": lane_ops, "peak": VALU_PEAK_LANE_OPS, "unit": "fp32 lane-ops/s", "frac": lane_ops / VALU_PEAK_LANE_OPS,
+                                  "lane_ops_per_env_substep": pm["valu_lane_ops_per_env_substep"], "valu_active_frac": pm["active_inst_valu_frac"],
+                                  "wait_frac": pm["wait_any_frac"], "source": "profiles/r02_pmc_summary.json (SQ_INSTS_VALU, SQ_WAVE_CYCLES) x live physics.step() rate"}
             except Exception:
                 pass
         if not a.no_cpu_baseline and world == 1:

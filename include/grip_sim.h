@@ -151,6 +151,12 @@ typedef struct {
      * N(0,1) of the same shape and log_std [action_dim] the policy's state-independent log standard deviation; the kernel
      * forms action = mean + exp(log_std) * noise and its log-probability itself (`log_probs` is then ignored) */
     const float *noise, *log_std;
+    /* optional synthetic action stream (a ~ U(-1, 1)^action_dim from a counter-based generator keyed by (seed, rank,
+     * env, t)): when rng_count != NULL (and noise != NULL: the fused head supplies mean and log_std) the action of a listed env is
+     * u(rng_seed, env, rng_count[env], i) instead of a sample of the policy, its log-probability is that of u under the policy's
+     * Gaussian (what PPO's ratio needs), and rng_count[env] -- [n_envs + 1], the env's decision counter t -- is incremented.
+     * rng_seed carries seed and rank. The stream of an env does not depend on the order in which envs finish. */
+    int64_t *rng_count; uint64_t rng_seed;
 } GripRolloutTick;
 int grip_rollout_tick(const GripRolloutTick *args, void *stream);
 /* GAE over every env's record chain, backwards from its open record (whose value bootstraps) along prev_rec. */

@@ -19,6 +19,13 @@ static int launch_status(const char *what) {
     return grip_fail(buf);
 }
 
+// counter-based uniform in (-1, 1): splitmix64 finaliser over (seed, env, t, component); 24 random bits -> float
+__device__ __forceinline__ float synth_action(unsigned long long seed, int env, long long t, int i) {
+    unsigned long long x = seed + 0x9E3779B97F4A7C15ULL * ((unsigned long long)env + 1ULL) + 0xBF58476D1CE4E5B9ULL * (unsigned long long)t + 0x94D049BB133111EBULL * ((unsigned long long)i + 1ULL);
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 27; x *= 0x94D049BB133111EBULL; x ^= x >> 31;
+    return ((float)(unsigned)(x >> 40) + 0.5f) * (2.0f / 16777216.0f) - 1.0f;
+}
+
 __global__ void k_rollout_tick(GripRolloutTick a) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.capacity) return;
@@ -43,8 +50,11 @@ __global__ void k_rollout_tick(GripRolloutTick a) {
     for (int i = 0; i < a.action_dim; i++) {
         float v = a.actions[(size_t)r * a.action_dim + i];
         if (a.noise) {
-            const float z = a.noise[(size_t)r * a.action_dim + i], ls = a.log_std[i];
-            v = fmaf(expf(ls), z, v);
+            float z = a.noise[(size_t)r * a.action_dim + i]; const float ls = a.log_std[i];
+            if (a.rng_count) {                                             // synthetic stream: the action is given, z follows from it
+                const float u = synth_action(a.rng_seed, env, a.rng_count[env], i);
+                z = (u - v) * expf(-ls); v = u;
+            } else v = fmaf(expf(ls), z, v);
             logp += -0.5f * z * z - ls - 0.91893853320467274178f;          // 0.5 log(2 pi)
         }
         a.actions_buf[(size_t)row * a.action_dim + i] = v;
@@ -55,6 +65,7 @@ __global__ void k_rollout_tick(GripRolloutTick a) {
     a.prev_rec[row] = had ? prev : -1;
     a.rec_env[row] = valid ? env : -1;
     if (valid) a.rec_of_env[env] = row;
+    if (valid && a.noise && a.rng_count) a.rng_count[env] += 1;
 }
 
 extern "C" int grip_rollout_tick(const GripRolloutTick *args, void *stream) {

@@ -70,7 +70,8 @@ class RolloutTickC(C.Structure):
                 [(n, C.c_void_p) for n in ("ready_list", "ready_count", "base", "reward", "done", "n_substeps", "actions", "values", "log_probs",
                                            "low", "high", "slot_actions", "rec_of_env", "rewards", "dones", "next_rec", "prev_rec", "rec_env",
                                            "completed", "is_rec", "actions_buf", "log_probs_buf", "values_buf", "n_completed", "substeps_total",
-                                           "ep_ret", "ep_len", "ep_ret_sum", "ep_len_sum", "ep_count", "noise", "log_std")])
+                                           "ep_ret", "ep_len", "ep_ret_sum", "ep_len_sum", "ep_count", "noise", "log_std", "rng_count")] +
+                [("rng_seed", C.c_uint64)])
 
 
 class EnvConfigC(C.Structure):

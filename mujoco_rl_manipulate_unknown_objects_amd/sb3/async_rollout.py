@@ -116,6 +116,32 @@ class AsyncRollout:
         self.ladder = None
         self._sub_seen = 0
         self.mean_substeps = None
+        # synthetic action stream (set_synthetic_actions): per-env decision counters t of the counter-based generator
+        self.rng_seed = None
+        self.rng_count = th.zeros(self.N + 1, dtype=th.int64, device=dev)
+
+    def set_synthetic_actions(self, seed, rank=0):
+        """actions a ~ U(-1, 1)^A from a counter-based generator keyed by (seed, rank, env, t) instead of samples of
+        the policy -- the benchmark's synthetic input: the physics workload then does not drift as the policy trains. The policy
+        still runs on every listed env and the records hold the log-probability of the given action under it, so the PPO update does
+        the same arithmetic. GPU fused recorder only. seed=None switches back to policy samples."""
+        if seed is not None and not (self.fused and self.policy_parts_fn is not None):
+            raise RuntimeError("synthetic actions need the fused recorder (GPU) and a policy with forward_parts")
+        self.rng_seed = None if seed is None else ((int(seed) * 1000003 + int(rank)) * 0x9E3779B97F4A7C15 + 0x1234567) % (1 << 64)
+        self.rng_count.zero_()
+        self._graph = None
+        self._targs = [None, None]
+
+    def set_target(self, target):
+        """Completed transitions per rollout; the tick budget follows (it was sized for the constructor's target)."""
+        self.target = int(target)
+        need = max(64, 4 * (self.target + self.C - 1) // self.C)
+        if need > self.max_ticks:
+            raise ValueError(f"target {target} needs {need} ticks of record rows, the rollout was built for {self.max_ticks}")
+
+    def reset_counters(self):
+        """Zero the statistics a benchmark reads over a timed region (keeps the slice ladder's bookkeeping consistent with them)."""
+        self.substeps_total.zero_(); self._sub_seen = 0
 
     def set_slice_ladder(self, ladder=((0, 96, 2000), (215, 144, 3000), (270, 192, 4000))):
         """Let the slice length / wall-clock budget follow the measured mean number of physics.step() calls per macro step: after
@@ -255,6 +281,10 @@ class AsyncRollout:
             a.noise, a.log_std = noise.data_ptr(), log_std.data_ptr()
         else:
             a.noise, a.log_std = None, None
+        if self.rng_seed is not None and noise is not None:
+            a.rng_count, a.rng_seed = self.rng_count.data_ptr(), self.rng_seed
+        else:
+            a.rng_count, a.rng_seed = None, 0
         stream = C.c_void_p(th.cuda.current_stream(self.dev).cuda_stream)
         if E.lib().grip_rollout_tick(C.byref(a), stream) != 0:
             raise E.GripError("grip_rollout_tick failed")

@@ -40,9 +40,16 @@ class RolloutBuffer:
         self.rewards, self.values, self.log_probs, self.dones, self.advantages, self.returns = z(), z(), z(), z(), z(), z()
         self.pos = 0
 
+    def stage_obs(self, obs):
+        """Row `pos` of the observation storage, written BEFORE the env steps: an env may hand out its own scratch buffer and
+        rewrite it in place (the reference's RobotEnv mutates self.obs, robot_env.py:35,223; SB3 copies for the same reason)."""
+        self.obs[self.pos].copy_(obs)
+
     def add(self, obs, actions, rewards, dones_before, values, log_probs):
         t = self.pos
-        self.obs[t].copy_(obs); self.actions[t].copy_(actions); self.rewards[t].copy_(rewards)
+        if obs is not None:
+            self.obs[t].copy_(obs)
+        self.actions[t].copy_(actions); self.rewards[t].copy_(rewards)
         self.dones[t].copy_(dones_before); self.values[t].copy_(values); self.log_probs[t].copy_(log_probs)
         self.pos += 1
 
@@ -169,8 +176,9 @@ class PPO:
                 actions, values, log_probs = self.policy(self._last_obs)
             clipped = th.max(th.min(actions, high), low)
             env_actions = clipped if isinstance(self._last_obs["observation"], th.Tensor) and hasattr(self.env, "device") else clipped.cpu().numpy()
+            buf.stage_obs(self._last_obs["observation"])            # obs_t goes into the buffer before the env may rewrite its tensors
             new_obs, rewards, dones, infos = self.env.step(env_actions)
-            buf.add(self._last_obs["observation"], actions, _to_t(rewards, self.device).float(), self._last_dones, values, log_probs)
+            buf.add(None, actions, _to_t(rewards, self.device).float(), self._last_dones, values, log_probs)
             self._last_obs = self._obs_t(new_obs)
             self._last_dones = _to_t(dones, self.device).float()
             self.num_timesteps += self.n_envs
@@ -182,14 +190,44 @@ class PPO:
         return True
 
     # ------------------------------------------------------------------ update
-    def _allreduce_grads(self):
-        params = [p for p in self.policy.parameters() if p.grad is not None]
-        flat = th.cat([p.grad.reshape(-1) for p in params])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat /= dist.get_world_size()
+    def _bind_flat_grads(self):
+        """One flat fp32 bucket IS the gradient storage: every parameter's .grad is a view into it (layout = parameter order), so the
+        all-reduce of a minibatch is one collective on memory the backward pass wrote in place -- no concatenation before it, no
+        copy-back after it, and the addresses the captured update graphs hold never change."""
+        params = list(self.policy.parameters())
+        n = sum(p.numel() for p in params)
+        if self._flat_grad is None or self._flat_grad.numel() != n:
+            self._flat_grad = th.zeros(n, dtype=th.float32, device=self.device)
         off = 0
         for p in params:
-            n = p.numel(); p.grad.copy_(flat[off:off + n].view_as(p.grad)); off += n
+            k = p.numel()
+            view = self._flat_grad[off:off + k].view(p.shape)
+            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                p.grad = view
+            off += k
+
+    def _zero_grads(self):
+        if self.distributed:
+            self._bind_flat_grads(); self._flat_grad.zero_()
+        else:
+            self.optimizer.zero_grad(set_to_none=False)
+
+    def _allreduce_grads(self):
+        """Sum the ranks' minibatch gradients (about 4 MB of fp32: one collective per optimiser step, latency-bound on xGMI) and
+        average. The clip + Adam step needs the reduced gradient and the next minibatch's forward needs the stepped parameters, so
+        there is nothing of this replica's own to overlap the collective with short of applying stale gradients."""
+        if self._flat_grad is None or any(p.grad is None or p.grad.untyped_storage().data_ptr() != self._flat_grad.untyped_storage().data_ptr()
+                                          for p in self.policy.parameters()):
+            # gradients produced outside the bucket (a caller ran backward before the first update): move them in once
+            old = [None if p.grad is None else p.grad.detach().clone() for p in self.policy.parameters()]
+            for p in self.policy.parameters():
+                p.grad = None
+            self._bind_flat_grads(); self._flat_grad.zero_()
+            for p, g in zip(self.policy.parameters(), old):
+                if g is not None:
+                    p.grad.copy_(g)
+        dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
+        self._flat_grad.mul_(1.0 / dist.get_world_size())
 
     def _loss_backward(self, src, idx):
         """Forward + PPO loss + backward of one minibatch `idx` (record / sample ids into the rollout storage `src`)."""
@@ -213,7 +251,7 @@ class PPO:
     def _minibatch_update(self, src, idx):
         """One optimiser step. Eager on CPU; on a GPU two captured graphs with the (eager) gradient all-reduce between them."""
         if not self.graph_update:
-            self.optimizer.zero_grad(set_to_none=False)
+            self._zero_grads()
             out = self._loss_backward(src, idx)
             if self.distributed:
                 self._allreduce_grads()
@@ -227,7 +265,10 @@ class PPO:
         if u["warm"] < 2:                           # two eager steps on a side stream before capturing (PyTorch's capture recipe)
             cur = th.cuda.current_stream(self.device); side = th.cuda.Stream(self.device); side.wait_stream(cur)
             with th.cuda.stream(side):
-                self.optimizer.zero_grad(set_to_none=True)
+                if self.distributed:
+                    self._zero_grads()
+                else:
+                    self.optimizer.zero_grad(set_to_none=True)
                 out = self._loss_backward(src, u["idx"])
                 if self.distributed:
                     self._allreduce_grads()
@@ -238,14 +279,20 @@ class PPO:
         if u["fwd"] is None:
             th.cuda.synchronize(self.device)
             try:
-                self.optimizer.zero_grad(set_to_none=True)      # the captured backward allocates .grad from the graph's pool
+                if self.distributed:
+                    self._zero_grads()                          # .grad = views of the flat bucket: the captured backward accumulates in place
+                else:
+                    self.optimizer.zero_grad(set_to_none=True)  # the captured backward allocates .grad from the graph's pool
                 g1 = th.cuda.CUDAGraph()
                 with th.cuda.graph(g1, capture_error_mode="thread_local"):
                     u["out"] = self._loss_backward(src, u["idx"])
                 g2 = th.cuda.CUDAGraph()
                 with th.cuda.graph(g2, capture_error_mode="thread_local"):
                     self._apply()
-                    self.optimizer.zero_grad(set_to_none=False)
+                    if self.distributed:
+                        self._flat_grad.zero_()
+                    else:
+                        self.optimizer.zero_grad(set_to_none=False)
                 u["fwd"], u["apply"] = g1, g2
             except Exception as ex:                               # noqa: BLE001 -- fall back to the eager update
                 import warnings
@@ -318,10 +365,20 @@ class PPO:
             self.num_timesteps = 0
         it, t0 = 0, time.time()
         while self.num_timesteps < total_timesteps:
-            if not self.collect_rollouts(callback):
+            ok = self.collect_rollouts(callback)
+            # every rank must leave this loop after the same iteration: train() holds one all-reduce per minibatch, and a rank that
+            # went on alone would wait in it for ever. The time-sliced rollout counts polled completions, which overshoot the target
+            # by a rank-dependent amount, and a callback may stop one rank only: agree on both flags (MAX) once per iteration.
+            stop = th.tensor([0.0 if ok else 1.0, 1.0 if self.num_timesteps >= total_timesteps else 0.0], device=self.device)
+            if self.distributed:
+                dist.all_reduce(stop, op=dist.ReduceOp.MAX)
+            stop_now, last = bool(stop[0] > 0), bool(stop[1] > 0)
+            if stop_now:
                 break
             self.train()
             it += 1
+            if last:
+                self.num_timesteps = max(self.num_timesteps, total_timesteps)
             if self.verbose and it % log_interval == 0:
                 fps = self.num_timesteps / max(1e-9, time.time() - t0)
                 print(f"[ppo] iter {it} timesteps {self.num_timesteps} fps {fps:.0f} loss {float(self.logger.get('loss', 0)):.4f}")

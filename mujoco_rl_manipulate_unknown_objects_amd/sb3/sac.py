@@ -135,19 +135,28 @@ class ReplayBuffer:
         z = lambda *s, dt=th.float32: th.zeros((self.T, n_envs) + s, dtype=dt, device=device)
         self.obs, self.next_obs = z(*shp, dt=th.uint8), z(*shp, dt=th.uint8)
         self.actions, self.rewards, self.dones = z(A), z(), z()
-        self.achieved, self.desired, self.next_achieved = z(2), z(2), z(2)
+        self.achieved, self.desired, self.next_achieved, self.next_desired = z(2), z(2), z(2), z(2)
         self.pos, self.full = 0, False
 
     def size(self):
         return (self.T if self.full else self.pos) * self.n_envs
 
-    def add(self, obs, next_obs, action, reward, done, infos=None):
+    def stage_obs(self, obs):
+        """The pre-step half of add(), written BEFORE the env steps (an env may hand out scratch tensors it rewrites in place:
+        robot_env.py:35,223 does, SB3 copies for the same reason); add(None, ...) then completes the row."""
         t = self.pos
-        self.obs[t].copy_(obs["observation"]); self.next_obs[t].copy_(next_obs["observation"])
-        self.actions[t].copy_(action); self.rewards[t].copy_(reward); self.dones[t].copy_(done)
+        self.obs[t].copy_(obs["observation"])
         if "achieved_goal" in obs:
             self.achieved[t].copy_(obs["achieved_goal"]); self.desired[t].copy_(obs["desired_goal"])
-            self.next_achieved[t].copy_(next_obs["achieved_goal"])
+
+    def add(self, obs, next_obs, action, reward, done, infos=None):
+        t = self.pos
+        if obs is not None:
+            self.stage_obs(obs)
+        self.next_obs[t].copy_(next_obs["observation"])
+        self.actions[t].copy_(action); self.rewards[t].copy_(reward); self.dones[t].copy_(done)
+        if "achieved_goal" in next_obs:
+            self.next_achieved[t].copy_(next_obs["achieved_goal"]); self.next_desired[t].copy_(next_obs["desired_goal"])
         self.pos += 1
         if self.pos == self.T:
             self.pos, self.full = 0, True
@@ -207,7 +216,8 @@ class HerReplayBuffer(ReplayBuffer):
         off = (th.rand(batch_size, device=self.device, generator=generator) * (span + 1).float()).long().clamp(max=self.T - 1)
         ft = (t + th.minimum(off, span)) % self.T
         new_goal = self.next_achieved[ft, e]
-        old = self.her_term(self.desired[t, e], self.next_achieved[t, e]); new = self.her_term(new_goal, self.next_achieved[t, e])
+        # the stored reward holds e^-|dg - ag| of the POST-step goals (robot_env.py:176-178, 268-271): take exactly that term out
+        old = self.her_term(self.next_desired[t, e], self.next_achieved[t, e]); new = self.her_term(new_goal, self.next_achieved[t, e])
         rewards = th.where(relabel, rewards - old + new, rewards)
         desired = th.where(relabel[:, None], new_goal, self.desired[t, e])
         return dict(obs={"observation": self.obs[t, e], "achieved_goal": self.achieved[t, e], "desired_goal": desired},
@@ -256,6 +266,18 @@ class SAC:
     def _scale(self, a):            # policy space [-1, 1] -> env action space
         low = th.as_tensor(self.env.action_space.low, device=self.device); high = th.as_tensor(self.env.action_space.high, device=self.device)
         return low + 0.5 * (a + 1.0) * (high - low)
+
+    def _true_next(self, new_obs, infos):
+        """next_obs as the replay buffer should see it. An auto-resetting engine returns the RESET goals for a finished env; the goals
+        the reward of that step was computed with (robot_env.py:175-178) are the final object position and its projection on the
+        target direction, which the engine reports in info['object_position']: use those for every env (identical for unfinished ones)."""
+        if not (self._tensor_env and isinstance(infos, dict) and "object_position" in infos and "achieved_goal" in new_obs):
+            return new_obs
+        benv = getattr(self.env, "env", self.env)
+        d = th.as_tensor(np.asarray(benv.target_direction, dtype=np.float32), device=self.device)
+        ag = infos["object_position"][:, :2].to(self.device, th.float32)
+        p = (ag * d).sum(-1, keepdim=True) / (d * d).sum(-1, keepdim=True)
+        return {"observation": new_obs["observation"], "achieved_goal": ag, "desired_goal": p * d}
 
     def _allreduce(self, params):
         grads = [p.grad for p in params if p.grad is not None]
@@ -321,9 +343,10 @@ class SAC:
                 with th.no_grad():
                     a, _ = self.policy.action_log_prob(self._last_obs)
             env_a = self._scale(a)
+            self.replay_buffer.stage_obs(self._last_obs)            # obs_t is stored before the env may rewrite its tensors
             new_obs, rew, done, infos = self.env.step(env_a if self._tensor_env else env_a.cpu().numpy())
             new_obs = self._obs_t(new_obs)
-            self.replay_buffer.add(self._last_obs, new_obs, a, _to_t(rew, self.device, th.float32), _to_t(done, self.device, th.float32), infos)
+            self.replay_buffer.add(None, self._true_next(new_obs, infos), a, _to_t(rew, self.device, th.float32), _to_t(done, self.device, th.float32), infos)
             self._last_obs = new_obs
             self.num_timesteps += self.n_envs; step += 1
             if callback is not None and not callback.on_step():

@@ -54,8 +54,10 @@ class BatchedRobotEnv:
         self._actuator = Actuator(config=config)
         self._reward_fn = IntrinsicReward(config=config) if self.im_reward else Reward(config=config)
         self.setup_spaces()
+        # TWO observation buffers, used in turn: the dict a reset / step returns stays valid until the step after the next one, so a
+        # caller may hold the previous observation across a step (rollout / replay buffers do) without copying 20 KB per env first
         self._obs = self.batch.torch.empty((self.n_envs, self.batch.obs_channels, 64, 64), dtype=self.batch.torch.uint8, device=self.device)
-        self._obs_prev = self.batch.torch.empty_like(self._obs) if self.im_reward else None
+        self._obs_prev = self.batch.torch.empty_like(self._obs)
 
     @staticmethod
     def _direction_vector(direction):
@@ -83,8 +85,10 @@ class BatchedRobotEnv:
         self.observation_space = self._sensor.setup_observation_space()
 
     def _obs_dict(self, out):
+        self._obs, self._obs_prev = self._obs_prev, self._obs          # the buffer handed out last time is left alone for one more call
         self.batch.observe(self._obs)
-        return {"observation": self._obs, "achieved_goal": out["achieved_goal"], "desired_goal": out["desired_goal"]}
+        # the goals are the engine's result arrays, rewritten in place by the next step: hand out copies (16 B per env)
+        return {"observation": self._obs, "achieved_goal": out["achieved_goal"].clone(), "desired_goal": out["desired_goal"].clone()}
 
     def reset(self, mask=None):
         """robot_env.py:56-75 for every env (or the masked ones)."""
@@ -93,9 +97,7 @@ class BatchedRobotEnv:
     def step(self, actions):
         """robot_env.py:77-241 for every env. Returns (obs, reward[N], done[N] bool, info dict of tensors)."""
         out = self.batch.step(actions)
-        if self.im_reward:                                   # robot_env.py:186-197: old_obs = the observation before this step
-            self._obs, self._obs_prev = self._obs_prev, self._obs
-        obs = self._obs_dict(out)
+        obs = self._obs_dict(out)                            # robot_env.py:186-197: _obs_prev = old_obs, the observation before this step
         if self.im_reward:
             # with auto-reset the new observation of a finished env is its reset state, as DummyVecEnv would return it
             self.batch.add_intrinsic_reward(self._obs_prev, self._obs, out["reward"])
@@ -115,7 +117,7 @@ class BatchedRobotEnv:
     def render(self, mode='rgb_array', env_index=0):
         """Gripper-camera image of one env (robot_env.py:302-340 renders three cameras at a zoomed size;
         only the observation camera exists here: SURVEY.md §8(f) n4)."""
-        o = self.batch.observe(self._obs)[env_index].cpu().numpy()
+        o = self.batch.observe(self.batch.torch.empty_like(self._obs))[env_index].cpu().numpy()
         if mode == 'depth_array':
             return o[3]
         return o[:3].transpose(1, 2, 0)
@@ -199,4 +201,4 @@ class RobotEnv(BatchedRobotEnv):
         return self.obs, reward, done, info
 
     def get_observation(self):
-        return self.batch.observe(self._obs)[0].cpu().numpy()
+        return self.batch.observe(self.batch.torch.empty_like(self._obs))[0].cpu().numpy()

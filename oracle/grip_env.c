@@ -59,6 +59,28 @@ static void euler_matrix_sxyz(double ai, double aj, double ak, double M[9]) {
     M[6] = -sj;     M[7] = cj * si;      M[8] = cj * ci;
 }
 
+/* actuator.py:266-293 (_enforce_constraints), in place */
+void orc_enforce_constraints(int include_roll, double position[3], double orientation[3]) {
+    if (!include_roll) orientation[0] = 0.0;
+    else {
+        if (orientation[0] > M_PI / 4) orientation[0] = M_PI / 4;
+        if (orientation[0] < -M_PI / 4) orientation[0] = -M_PI / 4;
+    }
+    orientation[1] = 0.0;
+    if (position[2] < 0.1) position[2] = 0.1;
+    if (position[2] > 0.5) position[2] = 0.5;
+}
+
+/* test hooks for the transformations.py rows (a16): the static helpers above, exported one to one */
+void orc_euler_matrix_sxyz(double ai, double aj, double ak, double M[9]) { euler_matrix_sxyz(ai, aj, ak, M); }
+void orc_euler_sxyz_from_matrix(const double M[9], double e[3]) { euler_sxyz_from_matrix(M, e); }
+/* transformations.euler_from_quaternion(q_wxyz, axes=(0, 0, 0, 1)) as actuator.py:53-54 calls it: returns (yaw, pitch, roll) */
+void orc_euler_rzyx_from_quat_wxyz(const double q[4], double e[3]) {
+    double R[9], s[3];
+    quaternion_matrix_wxyz(q, R); euler_sxyz_from_matrix(R, s);
+    e[0] = s[2]; e[1] = s[1]; e[2] = s[0];
+}
+
 /* actuator.py:58-102 (with :21-44, :249-264, :266-293 and Appendix B's closed-form pinv) */
 void orc_target_pose(const OrcModel *m, const OrcEnvConfig *c, const OrcData *d, const double action[6], double target_qpos[5]) {
     (void)m;
@@ -100,15 +122,7 @@ void orc_target_pose(const OrcModel *m, const OrcEnvConfig *c, const OrcData *d,
     mulmm3(Rnew, Rold, Rrel);
     mulmv3(t, Rold, translation); add3(position, cur_pos, t);
     euler_sxyz_from_matrix(Rnew, orientation);
-    /* _enforce_constraints */
-    if (!c->include_roll) orientation[0] = 0.0;
-    else {
-        if (orientation[0] > M_PI / 4) orientation[0] = M_PI / 4;
-        if (orientation[0] < -M_PI / 4) orientation[0] = -M_PI / 4;
-    }
-    orientation[1] = 0.0;
-    if (position[2] < 0.1) position[2] = 0.1;
-    if (position[2] > 0.5) position[2] = 0.5;
+    orc_enforce_constraints(c->include_roll, position, orientation);
     double err_pos[3], err_ori[3];
     sub3(err_pos, position, cur_pos); sub3(err_ori, orientation, cur_ori);
     /* J = [jacp[:, :5]; jacr[:, :5]] of body ee at its origin has orthonormal columns: pinv = J^T */

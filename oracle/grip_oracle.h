@@ -121,6 +121,8 @@ void orc_reset_data(const OrcModel *m, OrcData *d);              /* mj_resetData
 void orc_fwd_position(const OrcModel *m, OrcData *d);            /* kinematics, M, collision */
 void orc_forward(const OrcModel *m, OrcData *d);                 /* everything up to qacc */
 void orc_step(const OrcModel *m, OrcData *d);                    /* dm_control Physics.step() */
+void orc_set_step_noise(double amp, unsigned seed);               /* conditioning probe, see grip_physics.c; 0 = off (default) */
+void orc_set_step_noise2(double amp_qpos, double amp_qvel, unsigned seed);
 void orc_jac_body(const OrcModel *m, const OrcData *d, int body, const double point[3],
                   double jacp[3][ORC_NV], double jacr[3][ORC_NV]);
 int orc_hull_hull(const OrcModel *m, OrcData *d, int g1, int g2, OrcContact *out);
@@ -135,6 +137,10 @@ int orc_check_grasp(const OrcData *d);
 int orc_pheromone_level(const OrcData *d, const double dir[2]);
 void orc_target_pose(const OrcModel *m, const OrcEnvConfig *c, const OrcData *d, const double action[6],
                      double target_qpos[5]);
+void orc_enforce_constraints(int include_roll, double position[3], double orientation[3]);   /* actuator.py:266-293 */
+void orc_euler_matrix_sxyz(double ai, double aj, double ak, double M[9]);                    /* transformations.py:972-1032 */
+void orc_euler_sxyz_from_matrix(const double M[9], double e[3]);                             /* transformations.py:1035-1090 */
+void orc_euler_rzyx_from_quat_wxyz(const double q[4], double e[3]);                          /* transformations.py:1093-1102 via :1179 */
 double orc_agent_reward(const double init_obj[3], const double final_obj[3], const double dir[2],
                         int gripper_open, const double controls[2], int object_grasped);
 

@@ -733,10 +733,31 @@ static void euler_advance(const OrcModel *m, OrcData *d) {
     d->time += h;
 }
 
+/* Conditioning probe (tests / fixture generation only; off by default). An fp32 implementation injects ~1e-7 relative rounding
+ * noise into the state at EVERY physics.step(); whether a macro step's integer outputs survive that is a property of the state, not of
+ * the implementation. With amp > 0 every orc_step() ends by perturbing qpos / qvel by amp * (1 + |x|) * u, u uniform in [-1, 1] from a
+ * counter hash of (seed, step time, index): deterministic and thread safe. */
+static double g_step_noise_amp = 0.0, g_step_noise_vamp = 0.0;
+static unsigned g_step_noise_seed = 0;
+void orc_set_step_noise(double amp, unsigned seed) { g_step_noise_amp = amp; g_step_noise_vamp = amp; g_step_noise_seed = seed; }
+/* separate amplitudes for positions and velocities: an fp32 solver's acceleration error (Newton stopped at the fp32 noise floor of
+ * its gradient) shows up in qvel first */
+void orc_set_step_noise2(double amp_qpos, double amp_qvel, unsigned seed) { g_step_noise_amp = amp_qpos; g_step_noise_vamp = amp_qvel; g_step_noise_seed = seed; }
+static double noise_u(unsigned a, unsigned b, unsigned c) {
+    unsigned long long x = ((unsigned long long)a << 32) ^ ((unsigned long long)b * 0x9E3779B97F4A7C15ULL) ^ ((unsigned long long)c << 17);
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return (double)(x >> 11) / 4503599627370496.0 - 1.0;      /* 53 bits -> [-1, 1) */
+}
+
 void orc_step(const OrcModel *m, OrcData *d) {
     /* mj_step2 on the state whose position stage is already current, then mj_step1 */
     fwd_velocity_to_acc(m, d);
     euler_advance(m, d);
+    if (g_step_noise_amp > 0.0 || g_step_noise_vamp > 0.0) {
+        unsigned t = (unsigned)(d->time / m->timestep + 0.5);
+        for (int i = 0; i < ORC_NQ; i++) d->qpos[i] += g_step_noise_amp * (1.0 + fabs(d->qpos[i])) * noise_u(g_step_noise_seed, t, (unsigned)i);
+        for (int i = 0; i < ORC_NV; i++) d->qvel[i] += g_step_noise_vamp * (1.0 + fabs(d->qvel[i])) * noise_u(g_step_noise_seed, t, 100u + (unsigned)i);
+    }
     orc_fwd_position(m, d);
 }
 

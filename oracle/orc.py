@@ -78,8 +78,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    build()
-    L = C.CDLL(_LIB_PATH)
+    alt = os.environ.get("GRIP_ORACLE_LIB")          # tests: the -fsanitize build (make -C oracle asan)
+    if not alt:
+        build()
+    L = C.CDLL(alt or _LIB_PATH)
     vp, dp = C.c_void_p, C.POINTER(C.c_double)
     L.orc_model_load.restype = vp; L.orc_model_load.argtypes = [C.c_char_p]
     L.orc_model_free.argtypes = [vp]
