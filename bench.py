@@ -103,13 +103,15 @@ def main():
     ap.add_argument("--budget-us", type=int, default=2000, help="wall-clock cap of a wavefront's slice in microseconds (async schedule; 0 = none)")
     ap.add_argument("--cold-portal", action="store_true", help="diagnostic: the comparison build whose narrow phase starts every portal refinement from scratch (engine.select_library)")
     ap.add_argument("--fixed-slice", action="store_true", help="keep --slice / --budget-us for the whole run (default: they follow the measured length of the macro steps)")
-    ap.add_argument("--actions", choices=["rng", "policy"], default="rng", help="rng: synthetic U(-1,1) action stream keyed by (seed, rank, env, t) (SURVEY.md 8d); "
+    ap.add_argument("--actions", choices=["rng", "policy"], default=None, help="default: rng with the time-sliced schedule, policy with --lockstep. ""rng: synthetic U(-1,1) action stream keyed by (seed, rank, env, t) (SURVEY.md 8d); "
                                                                                  "policy: samples of the learning policy")
     ap.add_argument("--preroll", type=int, default=300, help="untimed rollout-only steps before the warm-up: desynchronised, mixed episode phases")
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
     if a.capacity <= 0:
         a.capacity = max(1, a.envs // 4)
+    if a.actions is None:
+        a.actions = "policy" if a.lockstep else "rng"
     if a.mixed:
         a.no_cpu_baseline = True
         if a.envs % 8 or a.capacity % 8:

@@ -1,0 +1,32 @@
+"""Physics-only rate of the time-sliced engine at mixed episode phases: the working metric of kernel optimisation.
+    python tools/physics_rate.py [variant-name|-] [object] [slice] [budget_us]
+4096 envs, actions U(-1,1) (torch generator, fixed seed), `pre` ticks of pre-roll, then 400 timed ticks; no render, no policy.
+Prints env-steps/s, physics.step() calls/s and the mean slice-kernel time; `variant-name` picks csrc/libgrip_sim_<name>.so."""
+import sys, os, time, json; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mujoco_rl_manipulate_unknown_objects_amd import engine
+var = sys.argv[1] if len(sys.argv) > 1 else "-"
+if var != "-":
+    engine.LIB_PATH = os.path.join(engine.CSRC, f"libgrip_sim_{var}.so")
+obj = sys.argv[2] if len(sys.argv) > 2 else "acorn"
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 144
+bud = int(sys.argv[4]) if len(sys.argv) > 4 else 3000
+pre = int(sys.argv[5]) if len(sys.argv) > 5 else 1500
+n, cap = 4096, 1024
+b = engine.Batch(obj, n, auto_reset=1)
+lst = torch.full((cap,), -1, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+g = torch.Generator(device="cuda"); g.manual_seed(0)
+total = torch.zeros(1, dtype=torch.int64, device="cuda"); subs = torch.zeros(1, dtype=torch.int64, device="cuda")
+ar = torch.arange(cap, device="cuda")
+def tick():
+    act = torch.rand(cap, 6, device="cuda", generator=g) * 2 - 1
+    out = b.advance(act, S, lst, cnt, bud)
+    valid = (ar < cnt) & (lst >= 0)
+    total.add_(valid.sum()); subs.add_((out["n_substeps"][lst.clamp(min=0).long()] * valid).sum())
+for _ in range(pre): tick()
+torch.cuda.synchronize(); b.kernel_time(True); c0, s0 = int(total.item()), int(subs.item()); T = 400; t0 = time.time()
+for _ in range(T): tick()
+torch.cuda.synchronize(); dt = time.time() - t0; c1, s1 = int(total.item()), int(subs.item())
+kms, kn = b.kernel_time(True)
+print(json.dumps({"lib": var, "object": obj, "slice": S, "budget_us": bud, "env_steps_per_s": (c1 - c0) / dt, "substeps_per_s": (s1 - s0) / dt,
+                  "substeps_per_env_step": (s1 - s0) / max(1, c1 - c0), "ms_per_tick": dt / T * 1e3, "slice_kernel_ms": kms, "fault_max": int(b.out["fault"].max())}))
