@@ -35,6 +35,12 @@
 #define EF_U ((EF_M + 169 + 3) & ~3)     // per-contact Hessian vectors (16-byte aligned): G_MAXC x 6 slots x U_STRIDE (13 entries + weight)
 #define U_STRIDE 16                    // 13 entries + weight, padded to 64 B so a slot is four ds_read_b128
 #define ENV_FLOATS (EF_U + G_MAXC * 6 * U_STRIDE)
+// The Newton step's linear system, gathered so that EVERY lane holds all of it: row r of H at EF_H + 16 r (13 entries), the negative
+// gradient at EF_HG. It reuses the geom frames and the staging area (226 floats, dead between collide() and the next kinematics()) and
+// overwrites EF_FORCE / EF_P, which the next pricing rewrites before anybody reads them.
+#define EF_H EF_FRAMES
+#define EF_HG (EF_FRAMES + 208)
+static_assert(EF_HG + 13 <= EF_M, "the gathered Hessian must fit the frames + staging area");
 // per-workgroup geom table (floats per geom): centre3, rbound, fs, ft, invweight, group, hull_vadr
 #define GT_STRIDE 10
 #define GT_FLOATS (GN_GEOM * GT_STRIDE)
@@ -68,6 +74,12 @@ DEVI unsigned long long stamp_now() { __builtin_amdgcn_sched_barrier(0); unsigne
 // 6 hill-climb hops (all lanes), 7 support_vertex calls (all lanes)
 __device__ unsigned long long g_dbg_cnt[16];   // 8..11: wave-level (first wave of a workgroup): cycles / trips with per-lane supports, cycles / trips of pure cooperative refinement; 12: cycles of collide() outside the loop
 #define DBG_COUNT(i, n) do { if (blockIdx.x == 0) atomicAdd(&g_dbg_cnt[i], (unsigned long long)(n)); } while (0)      // first workgroup only: thousands of lanes on 16 counters would distort the timings
+#elif defined(GRIP_MARKS)      // listing build only (hipcc -S -DGRIP_MARKS): phase boundaries as comments in the ISA, to count instructions per phase
+#define DBG_COUNT(i, n) do { } while (0)
+struct Stamps { int dummy; };
+#define STAMP_STR2(x) #x
+#define STAMP_STR(x) STAMP_STR2(x)
+#define STAMP(st, i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; ==MARK " STAMP_STR(i) " line " STAMP_STR(__LINE__) ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define DBG_COUNT(i, n) do { } while (0)
 struct Stamps { int dummy; };
@@ -473,6 +485,39 @@ DEVI float chol_solve_rows_obj(const float (&row)[13], float b, int sub) {
     bwd_step<8>(row, sub, y, x); bwd_step<7>(row, sub, y, x);
     return sub >= 7 ? x : 0.f;
 }
+// Newton direction by a REDUNDANT factorisation. The row-distributed Cholesky above pays one ds_swizzle round trip per column and per
+// substitution step (39 dependent LDS-crossbar trips per solve) and a wave that is alone on its SIMD waits every one of them out. Here
+// each lane publishes its row of H and its gradient component once, every lane reads the whole (lower triangle of the) system back
+// -- one round trip -- and factorises it in registers, all 16 lanes bit-identically: about the same number of VALU instructions, no
+// communication, and the direction comes out as a full vector in every lane (no second trip through EF_P).
+// LO = 7: only the trailing 6 x 6 (object) block, the leading components of p are 0.
+template <int LO>
+DEVI void gathered_solve(const Ctx &cx, const float (&row)[13], float gi, float (&p)[13]) {
+    constexpr int N = 13 - LO;
+    float *H = cx.envl + EF_H;
+    if (cx.sub < 13) {
+        float *hr = H + cx.sub * 16;
+#pragma unroll
+        for (int j = LO; j < 13; j++) hr[j] = row[j];
+        cx.envl[EF_HG + cx.sub] = -gi;
+    }
+    wave_sync();
+    float A[N * (N + 1) / 2], x[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+#pragma unroll
+        for (int j = 0; j <= i; j++) A[pidx(i, j)] = H[(LO + i) * 16 + LO + j];
+        x[i] = cx.envl[EF_HG + LO + i];
+    }
+    wave_sync();                                        // the area is rewritten by the next pricing: reads first (one wave, in order)
+    chol_packed<N>(A);
+    chol_solve_packed<N>(A, x);
+#pragma unroll
+    for (int i = 0; i < 13; i++) p[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; i++) p[LO + i] = x[i];
+}
+
 // this lane's row of the env's mass matrix (zero in lanes 13..15)
 DEVI void load_mrow(const Ctx &cx, float (&mrow)[13]) {
     const float *M = cx.envl + EF_M + min(cx.sub, 12) * 13;
@@ -1036,6 +1081,7 @@ DEVI void make_constraints(const DevModel &m, const Kin &k, const float (&qpos)[
 // (J^T f)_i directly -- a reduce-scatter through LDS instead of 13 sixteen-lane all-reduces. Lane j < 7 adds its joint limit.
 #define EF_FORCE EF_STAGE               // [G_MAXC][4] contact forces; the staging area is free once collide() is done
 #define EF_P (EF_STAGE + 64)            // [16] search direction, one component per dof lane
+
 DEVI float price_constraints(const DevModel &m, const Ctx &cx, float lsgn, float lD, float laref, float xi, int ncon,
                              const Contact &c, bool live, Cone &cn, float &jtfi, float &hdiag) {
 #pragma unroll
@@ -1231,6 +1277,7 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
 #pragma unroll
                         for (int j = 0; j < 13; j++) dbgH[cx.sub * 13 + j] = row[j];
                     }
+#ifdef GRIP_DISTRIBUTED_CHOL                           // the row-distributed factorisation (comparison build; kept for grip_selftest_cholesky)
                     if (cx.sub >= 13) row[12] = 1.f;        // harmless: those lanes never take part (sub > 12 masked everywhere)
                     if (full) chol_rows(row, cx.sub); else chol_rows_obj(row, cx.sub);
                     STAMP(st, 9);
@@ -1242,6 +1289,12 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
                         float4 a = p4[0], b = p4[1], c4 = p4[2]; float d = cx.envl[EF_P + 12];
                         p[0] = a.x; p[1] = a.y; p[2] = a.z; p[3] = a.w; p[4] = b.x; p[5] = b.y; p[6] = b.z; p[7] = b.w;
                         p[8] = c4.x; p[9] = c4.y; p[10] = c4.z; p[11] = c4.w; p[12] = d; }
+#else
+                    float p[13];
+                    if (full) gathered_solve<0>(cx, row, gi, p); else gathered_solve<7>(cx, row, gi, p);
+                    STAMP(st, 9);
+                    const float pi = cx.sub < 13 ? pick13(p, cx.sub) : 0.f;
+#endif
                     STAMP(st, 7);
                     float Mpi = row_dot(mrow, p);
                     float g0 = sum16(Mpi * (xi - qsi)), g1 = sum16(Mpi * pi);
