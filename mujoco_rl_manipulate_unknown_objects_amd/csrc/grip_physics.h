@@ -64,7 +64,7 @@ static_assert(EF_HG + 13 <= EF_M, "the gathered Hessian must fit the frames + st
 
 // diagnostic build only (-DGRIP_STAMPS): per-phase cycle accounting with s_memtime, never in the shipped library
 #ifdef GRIP_STAMPS
-#define NSTAMP 20
+#define NSTAMP 32
 __device__ unsigned long long g_stamp_acc[NSTAMP];
 struct Stamps { unsigned long long t; unsigned long long acc[NSTAMP]; };
 DEVI unsigned long long stamp_now() { __builtin_amdgcn_sched_barrier(0); unsigned long long t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); return t; }
@@ -541,7 +541,11 @@ DEVI void make_tangents(V3 n, V3 &t1, V3 &t2) {
 // Support vertex of the hull starting at vertex offset `base` (cube-map table `h`) for the LOCAL direction dl:
 // start at the table entry and hill-climb the edge graph to the best neighbour until none improves. Four
 // neighbour tests per iteration so that their dependent index -> vertex LDS hops overlap.
-DEVI int support_vertex(const Tables &T, int h, int base, V3 dl, V3 &vout, int hint = -1) {
+#ifndef SUP_NB
+#define SUP_NB 4                // neighbours tested per pass of the hill climb
+#endif
+// `adj` (out): the support vertex's adjacency range as packed in its 4th word (CSR offset | degree << 16).
+DEVI int support_vertex(const Tables &T, int h, int base, V3 dl, V3 &vout, int hint, unsigned &adj) {
     float ax = fabsf(dl.x), ay = fabsf(dl.y), az = fabsf(dl.z);
     int axis = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
     float mj = axis == 0 ? dl.x : axis == 1 ? dl.y : dl.z;
@@ -555,31 +559,36 @@ DEVI int support_vertex(const Tables &T, int h, int base, V3 dl, V3 &vout, int h
     const float4 v0 = vb[cur];
     float bx = v0.x, by = v0.y, bz = v0.z;
     float bv = fmaf(bx, dl.x, fmaf(by, dl.y, bz * dl.z));
-    int e = T.nadr[base + cur], eend = T.nadr[base + cur + 1];
+    // the vertex's own 4th word holds its adjacency range: moving to a neighbour needs no trip through the CSR offset table
+    unsigned aw = __float_as_uint(v0.w), caw = aw;
+    int e = (int)(aw & 0xffffu), eend = e + (int)(aw >> 16);
     int cand = cur; float cv = bv, cx = bx, cy = by, cz = bz;
     for (int guard = 0; guard < 2048; guard++) {
-        if (e < eend) {
-            int j[4]; float x[4], y[4], z[4];
+        int j[SUP_NB]; float x[SUP_NB], y[SUP_NB], z[SUP_NB]; unsigned w[SUP_NB];
 #pragma unroll
-            for (int q = 0; q < 4; q++) j[q] = T.nbr[min(e + q, eend - 1)];
+        for (int q = 0; q < SUP_NB; q++) j[q] = T.nbr[min(e + q, eend - 1)];
 #pragma unroll
-            for (int q = 0; q < 4; q++) { const float4 vq = vb[j[q]]; x[q] = vq.x; y[q] = vq.y; z[q] = vq.z; }
+        for (int q = 0; q < SUP_NB; q++) { const float4 vq = vb[j[q]]; x[q] = vq.x; y[q] = vq.y; z[q] = vq.z; w[q] = __float_as_uint(vq.w); }
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                float s = fmaf(x[q], dl.x, fmaf(y[q], dl.y, z[q] * dl.z));
-                if (s > cv) { cv = s; cand = j[q]; cx = x[q]; cy = y[q]; cz = z[q]; }
-            }
-            e += 4;
-        } else {
+        for (int q = 0; q < SUP_NB; q++) {
+            float s = fmaf(x[q], dl.x, fmaf(y[q], dl.y, z[q] * dl.z));
+            if (s > cv) { cv = s; cand = j[q]; cx = x[q]; cy = y[q]; cz = z[q]; caw = w[q]; }
+        }
+        e += SUP_NB;
+        if (e >= eend) {                                   // this vertex's neighbours are all seen
             if (cand == cur) break;
-            cur = cand; bx = cx; by = cy; bz = cz;
-            e = T.nadr[base + cur]; eend = T.nadr[base + cur + 1];
+            cur = cand; bx = cx; by = cy; bz = cz; aw = caw;
+            e = (int)(aw & 0xffffu); eend = e + (int)(aw >> 16);
             DBG_COUNT(6, 1);
         }
     }
     DBG_COUNT(7, 1);
-    vout = v3(bx, by, bz);
+    vout = v3(bx, by, bz); adj = aw;
     return cur;
+}
+DEVI int support_vertex(const Tables &T, int h, int base, V3 dl, V3 &vout, int hint = -1) {
+    unsigned adj;
+    return support_vertex(T, h, base, dl, vout, hint, adj);
 }
 
 // Support vertices of two hulls by all 16 lanes of the env (portal refinement asks for one on each): lane j scans vertices j,
@@ -715,7 +724,7 @@ struct Contact {
 // support <= 0). Bodies move little in 2 ms, so the next call first tests that one direction (phase 6, one support pair) and
 // usually is done -- the exact separating-axis argument MPR itself ends with, so no result changes; only when it fails does
 // the portal search start from scratch.
-DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, PairMemo &memo) {
+DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, PairMemo &memo, Stamps &st) {
     V3 &sep = memo.sep;
     const float EPS2 = 1e-12f, EPSD = 1e-10f;
     const float infl = 0.5f * m.margin;
@@ -789,6 +798,7 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
 #ifdef GRIP_STAMPS
         unsigned long long tw_ = stamp_now();
 #endif
+        STAMP(st, 20);
         while (__any(phase >= 0)) {
             const unsigned actm = group_bits(__ballot(phase >= 0), cx.lane);
             const unsigned early = group_bits(__ballot(phase >= 0 && phase != 3 && phase != 4), cx.lane);
@@ -818,19 +828,22 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
                     }
                 }
             }
-            int vi1 = vi1w;
+            int vi1 = vi1w; unsigned adj2 = 0u;
+            STAMP(st, 21);
             if (!coop && mine) {
                 const bool rem = phase == 6;
-                vi2 = support_vertex(T, g2 - 1, base2, multv(R2, plane ? dir : -dir), vl, rem ? memo.h2 : -1);
+                vi2 = support_vertex(T, g2 - 1, base2, multv(R2, plane ? dir : -dir), vl, rem ? memo.h2 : -1, adj2);
+                STAMP(st, 22);
                 if (!plane) vi1 = support_vertex(T, g1 - 1, base1, multv(R1, dir), vl1, rem ? memo.h1 : -1);
             }
+            STAMP(st, 23);
             if (mine) {
                 Sup s;
                 s.v2 = p2 + mulv(R2, vl);
                 if (plane) {
                     if (s.v2.z <= m.margin) {
                         rp0 = v3(s.v2.x, s.v2.y, 0.5f * s.v2.z); rd0 = s.v2.z; rc = 1;
-                        int e0 = T.nadr[base2 + vi2], e1 = T.nadr[base2 + vi2 + 1];
+                        const int e0 = (int)(adj2 & 0xffffu), e1 = e0 + (int)(adj2 >> 16);       // floor items always take the per-lane path: adj2 is set
                         for (int e = e0; e < e1 && rc < 4; e++) {
                             int j = T.nbr[e];
                             const float *vp = T.v + 4 * (base2 + j);
@@ -843,6 +856,7 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
                         }
                     }
                     phase = -1;
+                    STAMP(st, 24);
                 } else {
                     s.v2 = s.v2 - dir * infl;
                     s.v1 = p1 + mulv(R1, vl1) + dir * infl;
@@ -914,6 +928,7 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
                     }
                 }
             }
+            STAMP(st, 25);
 #ifdef GRIP_STAMPS
             {   const bool any_early = __any(phase_was_early_);
                 unsigned long long tn_ = stamp_now();
@@ -921,6 +936,7 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
                 tw_ = tn_; }
 #endif
         }
+        STAMP(st, 26);
         // ---- compaction: exclusive prefix of rc over the env's 16 lanes (rc <= 4: three ballots)
         unsigned b0 = group_bits(__ballot(rc & 1), cx.lane), b1 = group_bits(__ballot(rc & 2), cx.lane), b2 = group_bits(__ballot(rc & 4), cx.lane);
         unsigned below = (1u << cx.sub) - 1u;
@@ -1187,14 +1203,54 @@ DEVI void line_eval(const DevModel &m, float lsgn, float lD, float laref, float 
     dphi = sum16(dp) + g0 + alpha * g1; ddphi = sum16(hp) + g1;
 }
 
+// Pricing of BOTH candidate starts of the Newton solve in one pass (qacc_smooth: x = a_s, M (x - a_s) = 0; qacc_warmstart): two cone
+// evaluations per contact lane, two force sets through LDS, one exchange. Same arithmetic per point as price_constraints.
+#define EF_FORCE2 (EF_STAGE + 80)       // [G_MAXC][4] forces of the second point
+static_assert(EF_FORCE2 + 4 * G_MAXC <= EF_M, "second force set must fit the staging area");
+DEVI void price_two_starts(const DevModel &m, const Ctx &cx, float lsgn, float lD, float laref, float xs, float xw, int ncon, const Contact &c, bool live,
+                           const float (&jar_s)[4], const float (&jar_w)[4], Cone &cn_s, Cone &cn_w, float &lc_s, float &lc_w,
+                           float &jt_s, float &jt_w, float &hd_s, float &hd_w) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) { cn_s.grad[i] = cn_s.w[i] = cn_s.a[i] = cn_s.b[i] = 0.f; cn_w.grad[i] = cn_w.w[i] = cn_w.a[i] = cn_w.b[i] = 0.f; }
+    cn_s.cost = cn_s.ka = cn_s.kb = 0.f; cn_w.cost = cn_w.ka = cn_w.kb = 0.f;
+    if (live) {
+        cone_eval(jar_s, c.D0, m.impratio, c.fs, c.ft, cn_s);
+        cone_eval(jar_w, c.D0, m.impratio, c.fs, c.ft, cn_w);
+        *reinterpret_cast<float4 *>(cx.envl + EF_FORCE + 4 * cx.sub) = make_float4(-cn_s.grad[0], -cn_s.grad[1], -cn_s.grad[2], -cn_s.grad[3]);
+        *reinterpret_cast<float4 *>(cx.envl + EF_FORCE2 + 4 * cx.sub) = make_float4(-cn_w.grad[0], -cn_w.grad[1], -cn_w.grad[2], -cn_w.grad[3]);
+    }
+    lc_s = cn_s.cost; lc_w = cn_w.cost;
+    {   float lj = lsgn * xs - laref; bool la = lsgn != 0.f && lj < 0.f;
+        jt_s = la ? -lD * lj * lsgn : 0.f; lc_s += la ? 0.5f * lD * lj * lj : 0.f; hd_s = la ? lD : 0.f; }
+    {   float lj = lsgn * xw - laref; bool la = lsgn != 0.f && lj < 0.f;
+        jt_w = la ? -lD * lj * lsgn : 0.f; lc_w += la ? 0.5f * lD * lj * lj : 0.f; hd_w = la ? lD : 0.f; }
+    wave_sync();
+    const int isub = min(cx.sub, 12);
+    for (int k = 0; k < ncon; k++) {
+        const float4 f = *reinterpret_cast<const float4 *>(cx.envl + EF_FORCE + 4 * k);
+        const float4 g = *reinterpret_cast<const float4 *>(cx.envl + EF_FORCE2 + 4 * k);
+        const float *u = cx.envl + EF_U + k * 6 * U_STRIDE + isub;
+        const float u0 = u[0], u1 = u[U_STRIDE], u2 = u[2 * U_STRIDE], u3 = u[3 * U_STRIDE];
+        jt_s = fmaf(u0, f.x, jt_s); jt_s = fmaf(u1, f.y, jt_s); jt_s = fmaf(u2, f.z, jt_s); jt_s = fmaf(u3, f.w, jt_s);
+        jt_w = fmaf(u0, g.x, jt_w); jt_w = fmaf(u1, g.y, jt_w); jt_w = fmaf(u2, g.z, jt_w); jt_w = fmaf(u3, g.w, jt_w);
+    }
+    if (cx.sub >= 13) { jt_s = 0.f; jt_w = 0.f; }
+}
+DEVI void cone_sel(Cone &d, bool take, const Cone &s) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) { d.grad[i] = take ? s.grad[i] : d.grad[i]; d.w[i] = take ? s.w[i] : d.w[i]; d.a[i] = take ? s.a[i] : d.a[i]; d.b[i] = take ? s.b[i] : d.b[i]; }
+    d.cost = take ? s.cost : d.cost; d.ka = take ? s.ka : d.ka; d.kb = take ? s.kb : d.kb;
+}
+
 // Primal Newton solve of  min 1/2 (a - a_s)^T M (a - a_s) + s(J a - aref)   (mj_solNewton's problem), cooperatively and
-// row-distributed: dof lane i carries x_i, (M (x - a_s))_i and its gradient component, contact lane c carries jar_c; full
-// 13-vectors exist only transiently (the search direction, read back from LDS for J p and M p). Staged loop with ONE
-// pricing site: stage 0 prices qacc_smooth, stage 1 prices qacc_warmstart (the better one is the start, as MuJoCo does)
-// and stops right there when the start already satisfies the gradient tolerance; stages >= 2 are Newton iterations: every
-// lane assembles and factorises its own row of the Hessian, the direction comes from the lane-distributed triangular
-// solves, the exact line search all-reduces two scalars per evaluation. All control flow depends only on all-reduced
-// values, so the 16 lanes of an env always agree.
+// row-distributed: dof lane i carries x_i, (M (x - a_s))_i and its gradient component, contact lane c carries jar_c; the search
+// direction is a full vector in every lane (gathered_solve). Both candidate starts -- qacc_smooth and qacc_warmstart -- are priced
+// in ONE pass (price_two_starts): qacc_smooth wins when it already satisfies the gradient tolerance (constraints inactive),
+// otherwise the cheaper of the two is the start, as MuJoCo chooses it, and the solve ends right there when that start is converged.
+// A Newton iteration: every lane assembles its own row of the Hessian, the system is gathered and factorised redundantly in
+// registers, the exact line search all-reduces two scalars per evaluation (its first evaluation, at alpha = 0, reuses the cone the
+// pricing just evaluated), then the new point is priced: one pricing per iteration, none repeated. All control flow depends only on
+// all-reduced values, so the 16 lanes of an env always agree.
 DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, float laref,
                        const float (&qs)[13], float qsi, const float (&warm)[13], Contact &c, bool live, int ncon,
                        float (&qacc)[13], float (&jtf)[13], int &fault, int &iters, Stamps &st, bool objonly, float *dbgH = nullptr) {
@@ -1219,129 +1275,118 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
         }
     }
     STAMP(st, 14);
-    float xi = qsi, Mdi = 0.f, jtfi = 0.f;                  // current point, row-distributed
+    // ---- both starts priced at once
+    float xi, Mdi, jtfi, hdiag, cost; Cone cn; bool gconv;
+    {   Cone cn_w; float lc_s, lc_w, jt_s, jt_w, hd_s, hd_w;
+        price_two_starts(m, cx, lsgn, lD, laref, qsi, warmi, ncon, c, live, jar_s, jar_w, cn, cn_w, lc_s, lc_w, jt_s, jt_w, hd_s, hd_w);
+        const float cost_s = sum16(lc_s);                                   // M (x - a_s) = 0 at x = a_s
+        const float cost_w = sum16(0.5f * Md_w * (warmi - qsi) + lc_w);
+        // converged when the scaled gradient is below the model's tolerance -- or below what fp32 can resolve: g = M(x - a_s) - J^T f
+        // is a difference of two O(force) vectors, each carrying ~1e-6 relative rounding error
+        const float gs = -jt_s, gw = Md_w - jt_w;
+        const float g2s = sum16(gs * gs), t2s = sum16(jt_s * jt_s);
+        const float g2w = sum16(gw * gw), t2w = sum16(Md_w * Md_w + jt_w * jt_w);
+        const bool conv_s = scale * sqrtf(g2s) < tol || g2s < NEWTON_GRAD_NOISE * NEWTON_GRAD_NOISE * t2s;
+        const bool conv_w = scale * sqrtf(g2w) < tol || g2w < NEWTON_GRAD_NOISE * NEWTON_GRAD_NOISE * t2w;
+        const bool take_w = !conv_s && cost_w < cost_s;                     // qacc_smooth already optimal: keep it (constraints inactive)
+        xi = take_w ? warmi : qsi; Mdi = take_w ? Md_w : 0.f; jtfi = take_w ? jt_w : jt_s; hdiag = take_w ? hd_w : hd_s;
+        cost = take_w ? cost_w : cost_s; gconv = take_w ? conv_w : conv_s;
+        cone_sel(cn, take_w, cn_w);
 #pragma unroll
-    for (int r = 0; r < 4; r++) c.jar[r] = jar_s[r];
-    float cost = 0.f, cs = 0.f;
-    int stage = 0; bool done = false;
+        for (int r = 0; r < 4; r++) c.jar[r] = take_w ? jar_w[r] : jar_s[r];
+    }
+    STAMP(st, 6);
+    bool done = gconv;
     iters = 0;
     while (__any(!done)) {
         if (!done) {
-            float hdiag; Cone cn;
-            STAMP(st, 4);
-            float lc = price_constraints(m, cx, lsgn, lD, laref, xi, ncon, c, live, cn, jtfi, hdiag);
-            float newcost = sum16(0.5f * Mdi * (xi - qsi) + lc);
-            float gi = Mdi - jtfi;                                          // gradient component of this lane
-            // converged when the scaled gradient is below the model's tolerance -- or below what fp32 can resolve: g = M(x - a_s) - J^T f
-            // is a difference of two O(force) vectors, each carrying ~1e-6 relative rounding error
-            const float g2 = sum16(gi * gi), t2 = sum16(Mdi * Mdi + jtfi * jtfi);
-            const bool gconv = scale * sqrtf(g2) < tol || g2 < NEWTON_GRAD_NOISE * NEWTON_GRAD_NOISE * t2;
-            STAMP(st, 6);
-            if (stage == 0) {
-                cs = newcost;
-                if (gconv) done = true;                     // qacc_smooth already optimal (constraints inactive)
-                else {
-                    xi = warmi; Mdi = Md_w;
+            // ---- one Newton iteration from the priced point (xi, Mdi, jtfi, cn, hdiag, cost)
+            const float gi = Mdi - jtfi;                                    // gradient component of this lane
+            STAMP(st, 15);
+            hessian_vectors(cx, c, live, cn);
+            wave_sync();                                    // the contact lanes' Hessian vectors are in LDS
+            float row[13];
+            STAMP(st, 16);
+            // no limit and only floor-object contacts in every env of the wave that is still iterating: H is block
+            // diagonal and the gripper block's gradient is exactly zero, so only the object's 6 x 6 block is needed
+            const bool full = __any(!objonly);
+            assemble_rows(cx, ncon, mrow, hdiag, row, full);
+            STAMP(st, 8);
+            if (dbgH && iters == 0 && cx.sub < 13) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) c.jar[r] = jar_w[r];
+                for (int j = 0; j < 13; j++) dbgH[cx.sub * 13 + j] = row[j];
+            }
+            float p[13];
+            if (full) gathered_solve<0>(cx, row, gi, p); else gathered_solve<7>(cx, row, gi, p);
+            STAMP(st, 9);
+            const float pi = cx.sub < 13 ? pick13(p, cx.sub) : 0.f;
+            STAMP(st, 7);
+            float Mpi = row_dot(mrow, p);
+            float g0 = sum16(Mpi * (xi - qsi)), g1 = sum16(Mpi * pi);
+            if (live) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 13; i++) v = fmaf(c.J[r][i], p[i], v);
+                    c.jv[r] = v;
                 }
             }
-            bool newton = stage >= 2;
-            if (stage == 1) {
-                stage = 2;
-                if (newcost < cs) { if (gconv) done = true; else newton = true; }   // the warm start is priced: iterate from it right away
-                else {                                                              // back to qacc_smooth, priced again next pass
-                    xi = qsi; Mdi = 0.f;
+            STAMP(st, 17);
+            // exact line search: safeguarded 1-D Newton on phi'(alpha); one evaluation site
+            float lo = 0.f, hi = -1.f, alpha = 0.f, gtol = 0.f;
+            bool lsdone = false, descent = true;
+            {   // alpha = 0: the cone of the current point is the one the pricing evaluated (cn)
+                float dp = 0.f, hp = 0.f;
+                if (live) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) c.jar[r] = jar_s[r];
+                    for (int r = 0; r < 4; r++) dp = fmaf(cn.grad[r], c.jv[r], dp);
+                    hp = cone_quad(cn, c.jv);
                 }
-            } else if (stage == 0) stage = 1;
-            if (newton && !done) {
-                bool stop = gconv;
-                if (stage > 2 && scale * (cost - newcost) < tol) stop = true;
+                {   float jv = lsgn * pi, xx = lsgn * xi - laref;
+                    bool act = lsgn != 0.f && xx < 0.f;
+                    dp += act ? lD * xx * jv : 0.f; hp += act ? lD * jv * jv : 0.f; }
+                dp = sum16(dp) + g0; hp = sum16(hp) + g1;
+                if (dp >= 0.f) { descent = false; lsdone = true; }
+                gtol = LS_GTOL * fabsf(dp) + 1e-30f;
+                if (!lsdone) alpha = -dp * rcp(fmaxf(hp, 1e-30f));
+            }
+            for (int ls = 1; ls <= LS_MAXIT; ls++) {
+                if (!__any(!lsdone)) break;
+                if (!lsdone) {
+                    float dp, hp;
+                    line_eval(m, lsgn, lD, laref, xi, pi, c, live, alpha, g0, g1, dp, hp);
+                    if (fabsf(dp) < gtol) lsdone = true;
+                    else {
+                        if (dp < 0.f) lo = alpha; else hi = alpha;
+                        if (hi > 0.f && (hi - lo) < 1e-6f * hi) lsdone = true;
+                    }
+                    if (!lsdone && ls < LS_MAXIT) {
+                        float an = alpha - dp * rcp(fmaxf(hp, 1e-30f));
+                        if (hi > 0.f && (an <= lo || an >= hi)) an = 0.5f * (lo + hi);
+                        alpha = an;
+                    }
+                }
+            }
+            STAMP(st, 10);
+            if (!descent) done = true;
+            else {
+                xi = fmaf(alpha, pi, xi); Mdi = fmaf(alpha, Mpi, Mdi);
+#pragma unroll
+                for (int r = 0; r < 4; r++) c.jar[r] = fmaf(alpha, c.jv[r], c.jar[r]);
+                iters++;
+                // ---- price the new point; stop on the gradient, on a stalled cost, or at the iteration limit
+                STAMP(st, 4);
+                float lc = price_constraints(m, cx, lsgn, lD, laref, xi, ncon, c, live, cn, jtfi, hdiag);
+                const float newcost = sum16(0.5f * Mdi * (xi - qsi) + lc);
+                const float gn = Mdi - jtfi;
+                const float g2 = sum16(gn * gn), t2 = sum16(Mdi * Mdi + jtfi * jtfi);
+                bool stop = scale * sqrtf(g2) < tol || g2 < NEWTON_GRAD_NOISE * NEWTON_GRAD_NOISE * t2;
+                if (scale * (cost - newcost) < tol) stop = true;
                 cost = newcost;
                 if (!stop && iters >= NEWTON_MAXIT) { stop = true; fault |= 4; }
-                if (stop) done = true;
-                else {
-                    STAMP(st, 15);
-                    hessian_vectors(cx, c, live, cn);
-                    wave_sync();                            // the contact lanes' Hessian vectors are in LDS
-                    float row[13];
-                    STAMP(st, 16);
-                    // no limit and only floor-object contacts in every env of the wave that is still iterating: H is block
-                    // diagonal and the gripper block's gradient is exactly zero, so only the object's 6 x 6 block is needed
-                    const bool full = __any(!objonly);
-                    assemble_rows(cx, ncon, mrow, hdiag, row, full);
-                    STAMP(st, 8);
-                    if (dbgH && iters == 0 && cx.sub < 13) {
-#pragma unroll
-                        for (int j = 0; j < 13; j++) dbgH[cx.sub * 13 + j] = row[j];
-                    }
-#ifdef GRIP_DISTRIBUTED_CHOL                           // the row-distributed factorisation (comparison build; kept for grip_selftest_cholesky)
-                    if (cx.sub >= 13) row[12] = 1.f;        // harmless: those lanes never take part (sub > 12 masked everywhere)
-                    if (full) chol_rows(row, cx.sub); else chol_rows_obj(row, cx.sub);
-                    STAMP(st, 9);
-                    float pi = full ? chol_solve_rows(row, -gi, cx.sub) : chol_solve_rows_obj(row, -gi, cx.sub);
-                    cx.envl[EF_P + cx.sub] = pi;            // lanes 13..15 publish 0
-                    wave_sync();
-                    float p[13];
-                    {   const float4 *p4 = reinterpret_cast<const float4 *>(cx.envl + EF_P);
-                        float4 a = p4[0], b = p4[1], c4 = p4[2]; float d = cx.envl[EF_P + 12];
-                        p[0] = a.x; p[1] = a.y; p[2] = a.z; p[3] = a.w; p[4] = b.x; p[5] = b.y; p[6] = b.z; p[7] = b.w;
-                        p[8] = c4.x; p[9] = c4.y; p[10] = c4.z; p[11] = c4.w; p[12] = d; }
-#else
-                    float p[13];
-                    if (full) gathered_solve<0>(cx, row, gi, p); else gathered_solve<7>(cx, row, gi, p);
-                    STAMP(st, 9);
-                    const float pi = cx.sub < 13 ? pick13(p, cx.sub) : 0.f;
-#endif
-                    STAMP(st, 7);
-                    float Mpi = row_dot(mrow, p);
-                    float g0 = sum16(Mpi * (xi - qsi)), g1 = sum16(Mpi * pi);
-                    if (live) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            float v = 0.f;
-#pragma unroll
-                            for (int i = 0; i < 13; i++) v = fmaf(c.J[r][i], p[i], v);
-                            c.jv[r] = v;
-                        }
-                    }
-                    STAMP(st, 17);
-                    // exact line search: safeguarded 1-D Newton on phi'(alpha); one evaluation site
-                    float lo = 0.f, hi = -1.f, alpha = 0.f, gtol = 0.f;
-                    bool lsdone = false, descent = true;
-                    for (int ls = 0; ls <= LS_MAXIT; ls++) {
-                        if (!__any(!lsdone)) break;
-                        if (!lsdone) {
-                            float dp, hp;
-                            line_eval(m, lsgn, lD, laref, xi, pi, c, live, alpha, g0, g1, dp, hp);
-                            if (ls == 0) {
-                                if (dp >= 0.f) { descent = false; lsdone = true; }
-                                gtol = LS_GTOL * fabsf(dp) + 1e-30f;
-                            } else {
-                                if (fabsf(dp) < gtol) lsdone = true;
-                                else {
-                                    if (dp < 0.f) lo = alpha; else hi = alpha;
-                                    if (hi > 0.f && (hi - lo) < 1e-6f * hi) lsdone = true;
-                                }
-                            }
-                            if (!lsdone && ls < LS_MAXIT) {
-                                float an = alpha - dp * rcp(fmaxf(hp, 1e-30f));
-                                if (hi > 0.f && (an <= lo || an >= hi)) an = 0.5f * (lo + hi);
-                                alpha = an;
-                            }
-                        }
-                    }
-                    STAMP(st, 10);
-                    if (!descent) done = true;
-                    else {
-                        xi = fmaf(alpha, pi, xi); Mdi = fmaf(alpha, Mpi, Mdi);
-#pragma unroll
-                        for (int r = 0; r < 4; r++) c.jar[r] = fmaf(alpha, c.jv[r], c.jar[r]);
-                        iters++; stage++;
-                    }
-                }
+                done = stop;
+                STAMP(st, 6);
             }
         }
     }
@@ -1359,7 +1404,7 @@ DEVI void forward_pos(const DevModel &m, const Ctx &cx, LaneState &s, Kin &k, Co
     kinematics(m, s.qpos, k, cx, true);
     wave_sync();
     STAMP(st, 0);
-    ncon = collide(m, cx, con, fault, sep);
+    ncon = collide(m, cx, con, fault, sep, st);
     STAMP(st, 1);
 }
 

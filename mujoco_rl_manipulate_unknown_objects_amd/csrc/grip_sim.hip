@@ -221,7 +221,16 @@ extern "C" int grip_model_load(const char *blob_path, GripModel **out) {
         std::vector<unsigned> &hb = gm->hull_blob;
         hb.resize(4 * (size_t)gm->nvert);
         float *vf = reinterpret_cast<float *>(hb.data());
-        for (int i = 0; i < gm->nvert; i++) { for (int k = 0; k < 3; k++) vf[4*i+k] = (float)hverts[3*i+k]; vf[4*i+3] = 0.f; }
+        if ((int)nadr.size() != gm->nvert + 1) { delete gm; return fail("hull_nadr must hold one CSR offset per hull vertex plus the end"); }
+        // the 4th word of a vertex carries its own adjacency range (CSR offset | degree << 16): a hill climb that moves to a neighbour
+        // has that neighbour's range from the vertex read it already made -- no dependent trip through the offset table
+        for (int i = 0; i < gm->nvert; i++) {
+            for (int k = 0; k < 3; k++) vf[4*i+k] = (float)hverts[3*i+k];
+            const int deg = nadr[i + 1] - nadr[i];
+            if (deg < 0 || deg > 65535) { delete gm; return fail("hull vertex degree does not fit 16 bits"); }
+            const unsigned packed = (unsigned)nadr[i] | ((unsigned)deg << 16);
+            memcpy(&vf[4*i+3], &packed, 4);
+        }
         m.hull_off_nadr = (int)hb.size(); pack16(hb, nadr);
         m.hull_off_nbr = (int)hb.size(); pack16(hb, nbr);
         m.hull_off_lut = (int)hb.size(); pack16(hb, lut);
@@ -792,6 +801,9 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_debug_forward(const DevModel 
     Kin k; Contact con; int ncon = 0, fault = 0, iters = 0;
     PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1; PAIRMEMO_EXTRA_INIT(sep)
     forward_pos(m, cx, s, k, con, ncon, fault, stm, sep);
+    float gpos[18];                             // geom frame origins, read now: the solver reuses the frames' LDS area (EF_H)
+    for (int g = 1; g <= 6; g++) { V3 p; M3 R; load_frame(cx.envl, g, p, R); gpos[3 * (g - 1)] = p.x; gpos[3 * (g - 1) + 1] = p.y; gpos[3 * (g - 1) + 2] = p.z; }
+    wave_sync();
     float qfs[13], qacc[13], jtf[13], qs[13], bias[13];
     forward_acc(m, cx, s, xfrc_z, k, con, ncon, fault, qfs, qacc, jtf, iters, qs, bias, stm, getenv_dbgH ? M_out + (size_t)e * 169 : nullptr);
     if (!valid) return;
@@ -808,7 +820,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_debug_forward(const DevModel 
     float *xp = getenv_dbgH ? xp_dummy : xpos_out + (size_t)e * 24;
     xp[0] = xp[1] = xp[2] = 0.f;
     xp[3] = k.pe.x; xp[4] = k.pe.y; xp[5] = k.pe.z;
-    for (int g = 1; g <= 6; g++) { V3 p; M3 R; load_frame(cx.envl, g, p, R); xp[3 * (g + 1)] = p.x; xp[3 * (g + 1) + 1] = p.y; xp[3 * (g + 1) + 2] = p.z; }
+    for (int g = 1; g <= 6; g++) { xp[3 * (g + 1)] = gpos[3 * (g - 1)]; xp[3 * (g + 1) + 1] = gpos[3 * (g - 1) + 1]; xp[3 * (g + 1) + 2] = gpos[3 * (g - 1) + 2]; }
     for (int i = 0; i < 13; i++) { qacc_out[(size_t)e * 13 + i] = qacc[i]; qs_out[(size_t)e * 13 + i] = qs[i]; if (!getenv_dbgH) bias_out[(size_t)e * 13 + i] = bias[i]; }
     if (!getenv_dbgH) for (int i = 0; i < 169; i++) M_out[(size_t)e * 169 + i] = cx.envl[EF_M + i];
 }

@@ -38,7 +38,11 @@ def build_library(force=False, verbose=False):
         if not force and os.path.exists(path) and os.path.getmtime(path) >= newest:
             continue
         tmp = path + f".tmp{os.getpid()}"
-        cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-fno-strict-aliasing", "-shared", "-fPIC"] + extra + ["-o", tmp,
+        # -fno-hip-fp32-correctly-rounded-divide-sqrt: `/` and sqrtf as v_rcp / v_sqrt + one Newton step (<= 2.5 ulp) instead of the
+        # ~10-instruction correctly rounded sequences; -fgpu-flush-denormals-to-zero: no denormal fix-ups. Together +2.6 % physics rate
+        # (tools/physics_rate.py); every oracle-parity tolerance holds unchanged.
+        cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-fno-strict-aliasing", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
+               "-fgpu-flush-denormals-to-zero", "-shared", "-fPIC"] + extra + ["-o", tmp,
                os.path.join(CSRC, "grip_sim.hip"), os.path.join(CSRC, "grip_render.hip"), os.path.join(CSRC, "grip_rollout.hip"),
                os.path.join(CSRC, "grip_policy.hip")]
         procs.append((path, tmp, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))

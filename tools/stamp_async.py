@@ -10,7 +10,7 @@ n, cap = 4096, 1024
 b = engine.Batch(obj, n, auto_reset=1)
 lst = torch.full((cap,), -1, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
 g = torch.Generator(device="cuda"); g.manual_seed(0)
-out = (C.c_ulonglong * 20)()
+out = (C.c_ulonglong * 32)()
 def ticks(k):
     for _ in range(k):
         b.advance(torch.randn(cap, 6, device="cuda", generator=g).clamp(-1, 1), 96, lst, cnt, 2000)
@@ -21,6 +21,10 @@ names = ["kinematics", "collide", "mass+bias+qs", "make_constraints", "solve: ot
 names2 = {14: "solve: prologue (mrow, jar of both starts)", 15: "solve: stage logic after pricing", 16: "solve: hessian_vectors + sync",
           17: "solve: p readback, M p, J p, g0/g1", 18: "solve: loop exit", 19: "solve: final gathers"}
 tot = sum(out[:11]) + sum(out[14:20])
+names3 = {20: "collide: prologue (frames, sphere tests, portal rebuild)", 21: "collide: votes + cooperative support", 22: "collide: per-lane support of geom 2",
+          23: "collide: per-lane support of geom 1", 24: "collide: floor branch (neighbours inside the margin)", 25: "collide: portal phase logic", 26: "collide: loop exit"}
+for i, nm in names3.items():
+    print(f"   {nm:58s} {100 * out[i] / tot:5.1f} %   (inside `collide`, whose own slot then holds only compaction + contact load)")
 for nm, v in zip(names, out):
     print(f"{nm:34s} {100 * v / tot:5.1f} %")
 for i, nm in names2.items():
