@@ -563,7 +563,16 @@ DEVI int support_vertex(const Tables &T, int h, int base, V3 dl, V3 &vout, int h
     unsigned aw = __float_as_uint(v0.w), caw = aw;
     int e = (int)(aw & 0xffffu), eend = e + (int)(aw >> 16);
     int cand = cur; float cv = bv, cx = bx, cy = by, cz = bz;
+#ifdef GRIP_STAMPS
+    const unsigned long long act_ = __ballot(1);
+    const bool first_ = (__ffsll((long long)act_) - 1) == (int)(threadIdx.x & 63);
+    const int nact_ = __popcll(act_);
+    if (first_) { DBG_COUNT(15, 1); DBG_COUNT(12, nact_); }
+#endif
     for (int guard = 0; guard < 2048; guard++) {
+#ifdef GRIP_STAMPS
+        if ((__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) DBG_COUNT(14, 1);
+#endif
         int j[SUP_NB]; float x[SUP_NB], y[SUP_NB], z[SUP_NB]; unsigned w[SUP_NB];
 #pragma unroll
         for (int q = 0; q < SUP_NB; q++) j[q] = T.nbr[min(e + q, eend - 1)];

@@ -146,7 +146,10 @@ class PPO:
 
     def _ac(self):
         if self.autocast_dtype is not None and self.device.type == "cuda":
-            return th.autocast("cuda", dtype=self.autocast_dtype)
+            # cache_enabled=False: the rollout tick and the minibatch update are captured into hipGraphs, and autocast's weight-cast
+            # cache must not outlive a capture (the cached bf16 copies live in the graph's private pool: replays then read stale or
+            # recycled memory -- NaN losses within a few updates)
+            return th.autocast("cuda", dtype=self.autocast_dtype, cache_enabled=False)
         return th.autocast("cpu", enabled=False)
 
     def collect_rollouts(self, callback=None):
@@ -236,7 +239,9 @@ class PPO:
         adv = (adv - adv.mean()) / (adv.std() + 1e-8)
         with self._ac():
             values, logp, entropy = self.policy.evaluate_actions({"observation": obs[idx]}, actions[idx])
-        ratio = th.exp(logp - old_logp[idx])
+        # the log-ratio is clamped before exp(): beyond +-20 the clipped surrogate is flat anyway, and an overflowing ratio times a zero
+        # advantage is the NaN that ends a run (seen with the bf16 policy, whose rollout and update forwards round differently)
+        ratio = th.exp(th.clamp(logp - old_logp[idx], -20.0, 20.0))
         pl = -th.min(adv * ratio, adv * th.clamp(ratio, 1 - self.clip_range, 1 + self.clip_range)).mean()
         vl = th.nn.functional.mse_loss(ret_all[idx], values)
         el = -entropy.mean()

@@ -23,12 +23,17 @@ def engine(torch):
     return e
 
 
-def oracle_states(orc, m, n, seed):
-    """n interesting states: random macro steps with a forward bias, then a few raw sub-steps with random ctrl."""
+def oracle_states(orc, m, n, seed, preroll=0):
+    """n interesting states: random macro steps with a forward bias, then a few raw sub-steps with random ctrl.
+    preroll: macro steps played before the first state is taken (mixed episode phases: the gripper has reached the object)."""
     rng = np.random.default_rng(seed)
     e = orc.EnvOracle(m); e.reset()
     out = []
     import ctypes as C
+    for _ in range(preroll):
+        a = rng.uniform(-1, 1, 6).astype(np.float32); a[0] = abs(a[0])
+        if e.step(a).done:
+            e.reset()
     for i in range(n):
         a = rng.uniform(-1, 1, 6).astype(np.float32); a[0] = abs(a[0])
         o = e.step(a)
@@ -52,11 +57,16 @@ def oracle_sim(orc, m, qpos, qvel, ctrl, warm):
 
 
 @pytest.mark.parametrize("obj", OBJECTS)
-def test_forward_dynamics_parity(engine, orc, torch, obj):
-    """kinematics, mass matrix, bias, unconstrained and constrained accelerations of one forward pass."""
-    n = 64
+@pytest.mark.parametrize("phase", ["fresh", "mixed"])
+def test_forward_dynamics_parity(engine, orc, torch, obj, phase):
+    """kinematics, mass matrix, bias, unconstrained and constrained accelerations of one forward pass. `fresh`: states of the first
+    64 macro steps of an episode; `mixed`: 96 states taken after 150 macro steps (the gripper is at the object: hull contacts in
+    most states). Floors, with the achieved values printed: the constrained acceleration is compared on >= 60 % of the states (the
+    rest have a tie between equally deep floor vertices or a hull contact on a neighbouring facet), <= 10 % of the hull contacts
+    on another facet than the oracle's."""
+    n = 64 if phase == "fresh" else 96
     m = orc.Model(obj); b = engine.Batch(obj, n)
-    qpos, qvel, ctrl, warm = oracle_states(orc, m, n, seed=11)
+    qpos, qvel, ctrl, warm = oracle_states(orc, m, n, seed=11, preroll=0 if phase == "fresh" else 150)
     b.set_state(qpos, qvel, ctrl, warm)
     dbg = b.debug_forward()
     compared = tie_states = hull_total = hull_mismatch = 0
@@ -97,12 +107,14 @@ def test_forward_dynamics_parity(engine, orc, torch, obj):
         if same:
             compared += 1
             assert np.abs(s.qacc - dbg["qacc"][i]).max() < 5e-3 * (1 + np.abs(s.qacc).max())
-    assert compared >= n // 3, (compared, tie_states, hull_mismatch, hull_total)
-    assert hull_mismatch <= max(2, hull_total // 4), (hull_mismatch, hull_total)
+    print(f"\n[forward parity] {obj} {phase}: qacc compared on {compared}/{n} states ({tie_states} floor-vertex ties), hull contacts on another facet "
+          f"{hull_mismatch}/{hull_total}")
+    assert compared >= 0.6 * n, (compared, tie_states, hull_mismatch, hull_total)
+    assert hull_mismatch <= max(2, hull_total // 10), (hull_mismatch, hull_total)
     b.close()
 
 
-@pytest.mark.parametrize("obj", ["sand_ball", "sugar_cube"])
+@pytest.mark.parametrize("obj", OBJECTS)
 def test_substep_parity(engine, orc, torch, obj):
     """20 calls of physics.step() from identical states: positions within 1e-4 m / rad for all but a few lanes whose
     contact set changes inside the window (fp32 vs fp64 takes a different branch there)."""

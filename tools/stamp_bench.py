@@ -25,7 +25,8 @@ print(f"collide() per env and call: {cnt[1] / calls:.2f} trips with per-lane sup
       f"{cnt[3] / calls:.2f} hull pairs past the sphere test ({cnt[4] / calls:.2f} ended by the remembered direction), "
       f"{cnt[5] / calls:.3f} hull contacts, {cnt[7] / calls:.1f} hill climbs with {cnt[6] / max(1, cnt[7]):.2f} hops each")
 print(f"first wave of each workgroup: {cnt[9]} trips with per-lane supports at {cnt[8] / max(1, cnt[9]):.0f} cycles, {cnt[11]} pure refinement trips at {cnt[10] / max(1, cnt[11]):.0f} cycles")
-out = (C.c_ulonglong * 20)()
+print(f"support_vertex at wave level (workgroup 0): {cnt[15]} calls, {cnt[14] / max(1, cnt[15]):.2f} passes per call (the slowest lane's), {cnt[12] / max(1, cnt[15]):.1f} lanes active at entry")
+out = (C.c_ulonglong * 32)()
 assert engine.lib().grip_debug_stamps(out) == 0
 names = ["kinematics", "collide", "mass+bias+qs", "make_constraints", "solve: other (LS, bookkeeping)", "integrate", "solve: constraint pass", "solve: tri-solves+gather", "solve: assemble rows", "solve: cholesky", "solve: line search", "-", "-", "-", "solve: prologue", "solve: stage logic", "solve: hessian_vectors", "solve: p readback, Mp, Jp", "solve: loop exit", "solve: final gathers"]
 tot = sum(out[:11]) + sum(out[14:20])

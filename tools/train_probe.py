@@ -1,22 +1,28 @@
-"""Sanity probe: PPO over the time-sliced engine for a minute; prints episode return / length and losses per rollout."""
+"""Sanity probe: PPO over the time-sliced engine for a minute; prints episode return / length and losses per rollout.
+    python tools/train_probe.py <object|mixed> <seconds> [overlap] [--seed S] [--dtype f32|bf16] [--steps N]
+--steps N: stop after N env transitions instead of after <seconds> (learning curves of variants compared at equal samples)."""
 import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import BatchedRobotEnv, MixedBatchedRobotEnv, default_config
 from mujoco_rl_manipulate_unknown_objects_amd.sb3 import PPO, GpuVecEnv
 from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
 obj = sys.argv[1] if len(sys.argv) > 1 else "sand_ball"
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 60
-overlap = len(sys.argv) > 3 and sys.argv[3] == "overlap"
+overlap = "overlap" in sys.argv[3:]
+def _opt(name, default, cast):
+    return cast(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else default
+seed = _opt("--seed", 0, int); dtype = _opt("--dtype", "f32", str); max_steps = _opt("--steps", 0, int)
+import torch
 if obj == "mixed":          # four objects x two directions, 512 envs each, one batch set
     cfg = default_config(time_horizon=50)
     env = GpuVecEnv(MixedBatchedRobotEnv(cfg, envs_per_group=512, device_index=0, auto_reset=True))
 else:
     cfg = default_config(sim_env=f"/xmls/{obj}_env.xml", time_horizon=50)
     env = GpuVecEnv(BatchedRobotEnv(cfg, n_envs=4096, device_index=0, auto_reset=True))
-model = PPO("MultiInputPolicy", env, n_steps=8, batch_size=4096, n_epochs=2, seed=0, async_slice=96, async_capacity=1024, async_budget_us=2000, ent_coef=0.0, overlap_update=overlap,
+model = PPO("MultiInputPolicy", env, n_steps=8, batch_size=4096, n_epochs=2, seed=seed, autocast_dtype=torch.bfloat16 if dtype == "bf16" else None, async_slice=96, async_capacity=1024, async_budget_us=2000, ent_coef=0.0, overlap_update=overlap,
             policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]))
 ar = model._async
 t0 = time.time(); it = 0; last = (0.0, 0.0, 0.0)
-while time.time() - t0 < secs:
+while (model.num_timesteps < max_steps) if max_steps else (time.time() - t0 < secs):
     model.collect_rollouts(); st = model.train(); it += 1
     if it % 5 == 0:
         c, r, l = float(ar.ep_count.item()), float(ar.ep_ret_sum.item()), float(ar.ep_len_sum.item())
@@ -27,4 +33,4 @@ while time.time() - t0 < secs:
               f"ep_len {(l - last[2]) / dc:6.1f} loss {float(st['loss']):9.4f} value_loss {float(st['value_loss']):9.4f}", flush=True)
         last = (c, r, l)
 model.finish_updates()
-print("fps", model.num_timesteps / (time.time() - t0), "overlap_update", overlap)
+print("fps", model.num_timesteps / (time.time() - t0), "overlap_update", overlap, "seed", seed, "policy dtype", dtype)
