@@ -125,6 +125,14 @@ int grip_batch_advance(GripBatch *b, const float *slot_actions_dev, int slice, i
 int grip_batch_observe_list(GripBatch *b, const int32_t *list_dev, const int32_t *count_dev, int capacity, uint8_t *obs_dev,
                             uint8_t *records_dev, const int64_t *record_row_dev, void *stream);
 
+/* RobotEnv.render (robot_env.py:302-340; sensor.py:56-77 with w_zoom / h_zoom): env `env` seen from any camera at any size -- the
+ * reference's workbench / upper / gripper views for videos, GIFs and the human window (not on the training path). cam_pose_dev: 12 floats
+ * on the device, optical centre (3) then rotation (9, row-major; columns = camera x, y, z axes in world coordinates, the camera looks
+ * along -z), or NULL for the model's gripper camera of that env. fovy in degrees. rgb_dev uint8 [height, width, 3] and / or depth_dev
+ * float32 [height, width] (metres along the optical axis), either may be NULL. */
+int grip_batch_render_camera(GripBatch *b, int env, const float *cam_pose_dev, float fovy_deg, int width, int height, uint8_t *rgb_dev,
+                             float *depth_dev, void *stream);
+
 /* ---- rollout recorder: the trainer-side bookkeeping of asynchronous stepping, fused (csrc/grip_rollout.hip) ---------
  * Decision records live in caller-owned device arrays of n_records + 1 rows (row n_records is a dump row); per-env arrays
  * have n_envs + 1 rows (row n_envs: dump). One call per tick, after the policy ran on the listed envs:

@@ -174,8 +174,9 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
                     bout[q] = (!in && u < bout[q]) ? u : bout[q];
                 }
             }
+            // ... and a box that starts behind what the ray has already hit (floor, nearer hull) cannot give a nearer hit
 #pragma unroll
-            for (int q = 0; q < TPX; q++) if (bin[q] > bout[q] || bout[q] < 0.f) mask &= ~(1u << q);
+            for (int q = 0; q < TPX; q++) if (bin[q] > bout[q] || bout[q] < 0.f || bin[q] > best[q]) mask &= ~(1u << q);
         }
         if (mask == 0u) continue;
         const float4 *sp = spl + gadr[g] + NBOX;
@@ -185,6 +186,14 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
         // Cyrus-Beck: u = B / |A.dc| by v_rcp_f32 (1 ulp). Entering planes (A.dc < 0) raise t_in = -u, the others lower
         // t_out = u; a parallel plane with the origin outside gives u = -inf and so t_in > t_out: a miss, as it must be.
         for (int pi = 0; pi < np; pi++) {
+            // every 16 planes: rays that are already clipped away (t_in > t_out) stay missed; when that holds for every ray of the
+            // wave the rest of the list is skipped (tiles next to a hull's silhouette pass its box but miss the hull)
+            if ((pi & 15) == 0 && pi > 0) {
+                bool alive = false;
+#pragma unroll
+                for (int q = 0; q < TPX; q++) alive |= ((mask >> q) & 1u) && !(tin[q] > tout[q]);
+                if (!__any(alive)) break;
+            }
             const float4 P = sp[pi];
             float cxa[TW];
 #pragma unroll
@@ -284,6 +293,78 @@ extern "C" int grip_render_launch(const RenderGroup *groups_dev, int ngroups, co
                                   uint8_t *obs, uint8_t *obs2, const long long *row2, hipStream_t s) {
     hipLaunchKernelGGL(k_observe, dim3(nblocks), dim3(RTHREADS), (size_t)(nplanes_max + NBOX * GN_HULL) * sizeof(float4), s, groups_dev, ngroups, list, count, obs, obs2, row2);
     return launch_status("grip_render_launch");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// RobotEnv.render (robot_env.py:302-340): any camera, any size -- the workbench / upper / gripper views of the reference at their
+// zoomed size (64 * rendering_zoom_width x 64 * rendering_zoom_height), for videos, GIFs and the human window. Not on the training path:
+// one thread per pixel, the hull planes are read from global memory in the hull's own frame (the ray is taken there), the same
+// scene, materials and shading as the observation kernel. camera = optical centre cam_o and rotation cam_R (columns: camera x, y, z in
+// world coordinates, looking along -z) -- NULL: the model's gripper camera of env e; fovy in degrees (vertical).
+// Output: rgb uint8 [h, w, 3] (HWC, as dm_control's physics.render returns it) and/or depth float32 [h, w], metres along the optical
+// axis (zfar where nothing is hit).
+__global__ void __launch_bounds__(256) k_render_camera(const RenderGroup *__restrict__ groups, int e, const float *cam, float fovy_deg, int w, int h,
+                                                       uint8_t *rgb, float *depth) {
+    __shared__ Frames fr;
+    const RenderGroup &rg = groups[0];
+    const DevModel &m = rg.m;
+    if (threadIdx.x == 0) {
+        compute_frames(m, rg.qpos, rg.n, e, rg.cfg.state_half, fr);
+        if (cam) { for (int i = 0; i < 3; i++) fr.cam_o[i] = cam[i]; for (int i = 0; i < 9; i++) fr.cam_R[i] = cam[3 + i]; }
+    }
+    __syncthreads();
+    const int px = blockIdx.x * blockDim.x + threadIdx.x;
+    if (px >= w * h) return;
+    const int i = px / w, j = px % w;
+    const V3 co = ldv(fr.cam_o); const M3 Rc = ldm(fr.cam_R);
+    const float th = tanf(0.5f * fovy_deg * 0.017453292519943295f), tw = th * (float)w / (float)h;
+    const float x = (2.0f * (j + 0.5f) / w - 1.0f) * tw, y = (1.0f - 2.0f * (i + 0.5f) / h) * th;
+    const V3 dir = mulv(Rc, v3(x, y, -1.f));                       // parameter t = distance along the optical axis
+    float best = m.zfar; int hit = -1; V3 nrm = v3(0, 0, 1);
+    if (dir.z < 0.f) { float t = -co.z / dir.z; if (t > m.znear && t < best) { best = t; hit = 0; } }
+    for (int g = 1; g < GN_GEOM; g++) {
+        const V3 p = ldv(fr.p[g - 1]); const M3 R = ldm(fr.R[g - 1]);
+        const V3 ol = multv(R, co - p), dl = multv(R, dir);
+        const float *pl = m.hull_planes + 4 * m.hull_padr[g - 1];
+        float tin = -3.0e38f, tout = 3.0e38f; int ent = -1;
+        for (int k = 0; k < m.hull_pnum[g - 1]; k++) {
+            const V3 nn = v3(pl[4 * k], pl[4 * k + 1], pl[4 * k + 2]);
+            const float den = dot(nn, dl), num = pl[4 * k + 3] - dot(nn, ol);
+            if (den < 0.f) { const float t = num / den; if (t > tin) { tin = t; ent = k; } }
+            else if (den > 0.f) tout = fminf(tout, num / den);
+            else if (num < 0.f) { tin = 3.0e38f; }                 // parallel, origin outside: miss
+            if (tin > tout) break;
+        }
+        if (ent >= 0 && !(tin > tout) && tin > m.znear && tin < best) {
+            best = tin; hit = g; nrm = mulv(R, v3(pl[4 * ent], pl[4 * ent + 1], pl[4 * ent + 2]));
+        }
+    }
+    if (depth) depth[px] = best;
+    if (!rgb) return;
+    const V3 L = normalized(v3(-m.light_dir[0][0], -m.light_dir[0][1], -m.light_dir[0][2]));
+    float c0, c1, c2;
+    if (hit < 0) {
+        V3 dn = normalized(dir); float f = 0.5f * (dn.z + 1.0f);
+        c0 = m.sky_rgb[3] + f * (m.sky_rgb[0] - m.sky_rgb[3]); c1 = m.sky_rgb[4] + f * (m.sky_rgb[1] - m.sky_rgb[4]); c2 = m.sky_rgb[5] + f * (m.sky_rgb[2] - m.sky_rgb[5]);
+    } else {
+        float b0, b1, b2;
+        if (hit == 0) {
+            float pxw = co.x + best * dir.x, pyw = co.y + best * dir.y;
+            int cx = (int)floorf(pxw * 8.0f), cy = (int)floorf(pyw * 8.0f);
+            int off = ((cx + cy) & 1) ? 3 : 0;
+            b0 = m.floor_rgb[off]; b1 = m.floor_rgb[off + 1]; b2 = m.floor_rgb[off + 2];
+        } else { b0 = m.geom_rgba[hit][0]; b1 = m.geom_rgba[hit][1]; b2 = m.geom_rgba[hit][2]; }
+        float shade = 0.4f + 0.6f * fmaxf(dot(nrm, L), 0.f);
+        c0 = b0 * shade; c1 = b1 * shade; c2 = b2 * shade;
+    }
+    rgb[3 * px] = to_u8(c0); rgb[3 * px + 1] = to_u8(c1); rgb[3 * px + 2] = to_u8(c2);
+}
+
+extern "C" int grip_render_camera_launch(const RenderGroup *group_dev, int env, const float *cam_dev, float fovy_deg, int w, int h, uint8_t *rgb_dev,
+                                         float *depth_dev, hipStream_t s) {
+    const int total = w * h;
+    hipLaunchKernelGGL(k_render_camera, dim3((total + 255) / 256), dim3(256), 0, s, group_dev, env, cam_dev, fovy_deg, w, h, rgb_dev, depth_dev);
+    return launch_status("grip_render_camera_launch");
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -1200,6 +1200,15 @@ extern "C" int grip_batch_observe(GripBatch *b, uint8_t *obs_dev, void *stream) 
     if (grip_render_launch((const RenderGroup *)b->d_rself, 1, nullptr, nullptr, b->n, b->nplanes, obs_dev, nullptr, nullptr, (hipStream_t)stream)) return -1;
     return 0;
 }
+extern "C" int grip_render_camera_launch(const RenderGroup *group_dev, int env, const float *cam_dev, float fovy_deg, int w, int h, uint8_t *rgb_dev,
+                                         float *depth_dev, hipStream_t s);
+extern "C" int grip_batch_render_camera(GripBatch *b, int env, const float *cam_pose_dev, float fovy_deg, int width, int height, uint8_t *rgb_dev,
+                                        float *depth_dev, void *stream) {
+    if (!b || env < 0 || env >= b->n || width <= 0 || height <= 0 || width > 4096 || height > 4096 || (!rgb_dev && !depth_dev) || !(fovy_deg > 0.f && fovy_deg < 180.f))
+        return fail("grip_batch_render_camera: bad argument");
+    HIPCHK(hipSetDevice(b->device));
+    return grip_render_camera_launch((const RenderGroup *)b->d_rself, env, cam_pose_dev, fovy_deg, width, height, rgb_dev, depth_dev, (hipStream_t)stream);
+}
 extern "C" int grip_batch_observe_list(GripBatch *b, const int32_t *list_dev, const int32_t *count_dev, int capacity, uint8_t *obs_dev,
                                        uint8_t *records_dev, const int64_t *record_row_dev, void *stream) {
     if (!b || !obs_dev || !list_dev || !count_dev || capacity <= 0 || (records_dev && !record_row_dev)) return fail("grip_batch_observe_list: bad argument");

@@ -104,7 +104,7 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_set_flags", "grip_batch_substep", "grip_batch_debug_forward", "grip_batch_target_pose",
            "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward", "grip_obs_preprocess",
            "grip_batch_set_state_storage", "grip_batchset_create", "grip_batchset_destroy", "grip_batchset_refresh", "grip_batchset_num_envs",
-           "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list", "grip_conv1_u8"]
+           "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list", "grip_conv1_u8", "grip_batch_render_camera"]
 
 
 def lib():
@@ -152,6 +152,7 @@ def lib():
     L.grip_batchset_observe.argtypes = [vp, vp, vp]
     L.grip_batchset_observe_list.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
     L.grip_conv1_u8.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int64), vp, vp, vp, vp, vp]
+    L.grip_batch_render_camera.argtypes = [vp, C.c_int, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp]
     L.grip_rollout_tick.argtypes = [vp, vp]
     L.grip_rollout_gae.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
     _lib = L
@@ -293,6 +294,25 @@ class Batch:
             obs = self.torch.empty((self.n, self.obs_channels, 64, 64), dtype=self.torch.uint8, device=self.device)
         _chk(lib().grip_batch_observe(self.ptr, C.c_void_p(obs.data_ptr()), self._stream()))
         return obs
+
+    def render_camera(self, env_index=0, cam_pos=None, cam_R=None, fovy=None, width=64, height=64, depth=False):
+        """RobotEnv.render's camera view (grip_batch_render_camera): uint8 [H, W, 3] RGB, or float32 [H, W] metres with depth=True.
+        cam_pos / cam_R (3 and 3 x 3, columns = camera axes in world coordinates, looking along -z) default to the gripper camera."""
+        t = self.torch
+        cam = None
+        if cam_pos is not None:
+            cam = t.tensor(list(np.asarray(cam_pos, np.float32).reshape(3)) + list(np.asarray(cam_R, np.float32).reshape(9)), dtype=t.float32, device=self.device)
+        out = t.empty((height, width) if depth else (height, width, 3), dtype=t.float32 if depth else t.uint8, device=self.device)
+        _chk(lib().grip_batch_render_camera(self.ptr, int(env_index), None if cam is None else C.c_void_p(cam.data_ptr()), float(fovy if fovy is not None else self.gripper_fovy),
+                                            int(width), int(height), None if depth else C.c_void_p(out.data_ptr()), C.c_void_p(out.data_ptr()) if depth else None, self._stream()))
+        return out
+
+    @property
+    def gripper_fovy(self):
+        from .model import blob
+        if not hasattr(self, "_fovy"):
+            self._fovy = float(blob.read_blob(self.model.path)["cam_fovy"][0])
+        return self._fovy
 
     # -- asynchronous stepping (grip_sim.h: grip_batch_advance) ------------------------------------
     def advance(self, slot_actions, slice_len, ready_list, ready_count, budget_us=0, lag=1):

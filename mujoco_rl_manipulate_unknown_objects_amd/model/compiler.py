@@ -299,12 +299,15 @@ def parse_mjcf(xml_path):
     wb = root.find("worldbody")
     for c in wb.findall("body"):
         walk(c, "world")
+    # the two static cameras of RobotEnv.render (robot xml :41-47): unnamed world bodies holding a `targetbodycom` camera on the object
+    static_cams = [dict(pos=_floats(c.attrib.get("pos", "0 0 0")), name=cam.attrib["name"], fovy=float(cam.attrib["fovy"]))
+                   for c in wb.findall("body") for cam in c.findall("camera") if cam.attrib.get("mode") == "targetbodycom"]
     floor = [dfl.get("geom", g) for g in wb.findall("geom")]
     lights = [l.attrib for l in wb.findall("light")]
     acts = [dfl.get("motor", a) for a in root.find("actuator").findall("motor")]
     znear = float(root.find("visual").find("map").attrib["znear"])
     return dict(opt=opt, bodies=bodies, floor=floor, acts=acts, meshes=meshes,
-                mats=mats, texs=texs, lights=lights, znear=znear,
+                mats=mats, texs=texs, lights=lights, znear=znear, static_cams=static_cams,
                 name=root.attrib.get("model", ""))
 
 
@@ -508,6 +511,9 @@ def compile_model(xml_path, mesh_dir, standin_acorn=False):
     cam = [c for c in B["ee"]["cameras"] if c["name"] == "gripper_camera"][0]
     mdl["cam_pos"] = _floats(cam["pos"]); mdl["cam_quat"] = euler_xyz_quat(_floats(cam["euler"]))
     mdl["cam_fovy"] = np.array([float(cam["fovy"])])
+    sc = {c["name"]: c for c in x["static_cams"]}                                 # camera ids 0 and 1 of RobotEnv.render (robot_env.py:302-340)
+    mdl["static_cam_pos"] = np.array([sc["workbench_camera"]["pos"], sc["upper_camera"]["pos"]])
+    mdl["static_cam_fovy"] = np.array([sc["workbench_camera"]["fovy"], sc["upper_camera"]["fovy"]])
     xpos, xmat, _, _ = body_jacobians(mdl, qpos0)
     cen = np.array([xpos[geom_body[g]] + xmat[geom_body[g]] @ geom_center[g] for g in range(1, NG)])
     lo = (cen - geom_rbound[1:, None]).min(0); hi = (cen + geom_rbound[1:, None]).max(0)

@@ -173,6 +173,42 @@ class ReplayBuffer:
                     rewards=self.rewards[t, e], dones=self.dones[t, e])
 
 
+class FlatReplayBuffer:
+    """Replay buffer for the time-sliced engine: transitions arrive in batches of varying size (the envs that finished a macro step this
+    tick), so storage is one flat ring of `buffer_size` rows and a batch is scattered behind a device-side write pointer -- no host
+    sync per tick. Same sample() contract as ReplayBuffer."""
+
+    def __init__(self, buffer_size, observation_space, action_space, device, **_):
+        self.cap, self.device = int(buffer_size), device
+        shp = tuple(observation_space["observation"].shape); A = int(np.prod(action_space.shape))
+        z = lambda *sh, dt=th.float32: th.zeros((self.cap + 1,) + sh, dtype=dt, device=device)      # row cap: dump row of masked scatters
+        self.obs, self.next_obs = z(*shp, dt=th.uint8), z(*shp, dt=th.uint8)
+        self.actions, self.rewards, self.dones = z(A), z(), z()
+        self.ptr = th.zeros(1, dtype=th.int64, device=device)           # rows written so far (monotonic)
+        self._host_size = 0
+
+    def add_rows(self, mask, obs, next_obs, action, reward, done):
+        """Append the rows where mask is set (all arguments have one row per ready-list slot)."""
+        m = mask.long()
+        pos = (self.ptr + th.cumsum(m, 0) - 1) % self.cap
+        pos = th.where(mask, pos, th.full_like(pos, self.cap))
+        self.obs.index_copy_(0, pos, obs); self.next_obs.index_copy_(0, pos, next_obs)
+        self.actions.index_copy_(0, pos, action); self.rewards.index_copy_(0, pos, reward); self.dones.index_copy_(0, pos, done)
+        self.ptr += m.sum()
+
+    def size(self):
+        return min(self._host_size, self.cap)
+
+    def sync_size(self):
+        self._host_size = int(self.ptr.item())
+        return self.size()
+
+    def sample(self, batch_size, generator=None):
+        hi = max(1, self.size())
+        i = th.randint(0, hi, (batch_size,), device=self.device, generator=generator)
+        return dict(obs={"observation": self.obs[i]}, next_obs={"observation": self.next_obs[i]}, actions=self.actions[i], rewards=self.rewards[i], dones=self.dones[i])
+
+
 class HerReplayBuffer(ReplayBuffer):
     """Hindsight relabelling with SB3's HerReplayBuffer arguments (train_agent.py:63-69): for n_sampled_goal out of
     n_sampled_goal + 1 sampled transitions the desired goal is replaced by a goal achieved later in the same episode
@@ -228,7 +264,12 @@ class HerReplayBuffer(ReplayBuffer):
 class SAC:
     def __init__(self, policy, env, learning_rate=3e-4, buffer_size=1_000_000, learning_starts=100, batch_size=256, tau=0.005, gamma=0.99,
                  train_freq=1, gradient_steps=1, replay_buffer_class=None, replay_buffer_kwargs=None, ent_coef="auto", target_entropy="auto",
-                 policy_kwargs=None, verbose=0, tensorboard_log=None, device=None, seed=None):
+                 policy_kwargs=None, verbose=0, tensorboard_log=None, device=None, seed=None, async_slice=0, async_capacity=None, async_budget_us=0):
+        """async_slice > 0: collect over the time-sliced engine (grip_batch_advance) instead of lock-step vector-env steps -- every tick
+        gives each env at most `async_slice` calls of physics.step(), the envs that finished are rendered, their transition (previous
+        observation and action of that env, reward, done, new observation) goes into a flat replay ring, the actor decides for them, and
+        `gradient_steps` updates follow every `train_freq` ticks. Off-policy replay absorbs the asynchrony natively: no lag correction."""
+        self.async_slice, self.async_capacity, self.async_budget_us = int(async_slice), async_capacity, int(async_budget_us)
         self.env = env
         self.n_envs = getattr(env, "num_envs", 1)
         self.device = th.device(device) if device is not None else getattr(env, "device", th.device("cuda" if th.cuda.is_available() else "cpu"))
@@ -252,8 +293,13 @@ class SAC:
         init = float(ent_coef.split("_")[1]) if self.auto_ent and "_" in ent_coef else 1.0
         self.log_ent_coef = th.log(th.ones(1, device=self.device) * (init if self.auto_ent else float(ent_coef))).requires_grad_(self.auto_ent)
         self.ent_opt = th.optim.Adam([self.log_ent_coef], lr=learning_rate) if self.auto_ent else None
-        rb = replay_buffer_class or ReplayBuffer
-        self.replay_buffer = rb(buffer_size, env.observation_space, env.action_space, self.device, n_envs=self.n_envs, **(replay_buffer_kwargs or {}))
+        if self.async_slice > 0:
+            if replay_buffer_class is not None and replay_buffer_class is not FlatReplayBuffer:
+                raise NotImplementedError("the time-sliced collector stores transitions in a FlatReplayBuffer (hindsight relabelling needs episode order: use lock-step collection)")
+            self.replay_buffer = FlatReplayBuffer(buffer_size, env.observation_space, env.action_space, self.device)
+        else:
+            rb = replay_buffer_class or ReplayBuffer
+            self.replay_buffer = rb(buffer_size, env.observation_space, env.action_space, self.device, n_envs=self.n_envs, **(replay_buffer_kwargs or {}))
         self.num_timesteps, self._n_updates = 0, 0
         self._last_obs = None
         self.logger = {}
@@ -326,6 +372,45 @@ class SAC:
         return self.logger
 
     # ------------------------------------------------------------------ SB3 surface
+    def _learn_async(self, total_timesteps, callback, log_interval):
+        """Collection over the time-sliced engine (see __init__). Per-env previous decision lives in HBM (obs 20 KB x N)."""
+        from .async_rollout import BatchEngineAdapter
+        eng = self.env if hasattr(self.env, "advance") else BatchEngineAdapter(self.env, self.async_budget_us)
+        N, A, dev = eng.num_envs, eng.action_dim, self.device
+        Ccap = min(int(self.async_capacity) if self.async_capacity else max(1, N // 4), N)
+        lst = th.full((Ccap,), -1, dtype=th.int32, device=dev); cnt = th.zeros(1, dtype=th.int32, device=dev)
+        slot_act = th.zeros(Ccap, A, device=dev); stage = th.zeros((Ccap,) + tuple(eng.obs_shape), dtype=th.uint8, device=dev)
+        prev_obs = th.zeros((N + 1,) + tuple(eng.obs_shape), dtype=th.uint8, device=dev); prev_act = th.zeros(N + 1, A, device=dev)
+        has_prev = th.zeros(N + 1, dtype=th.bool, device=dev); ar = th.arange(Ccap, device=dev)
+        eng.reset()
+        t0, tick, last_sync = time.time(), 0, 0
+        self._async_ticks = 0
+        while self.num_timesteps < total_timesteps:
+            out = eng.advance(slot_act, self.async_slice, lst, cnt)
+            eng.observe_list(lst, cnt, stage)
+            valid = (ar < cnt) & (lst >= 0)
+            env = th.where(valid, lst, th.full_like(lst, N)).long()                  # row N: dump
+            envc = env.clamp(max=N - 1)
+            self.replay_buffer.add_rows(valid & has_prev[env], prev_obs[env], stage, prev_act[env], out["reward"][envc].float(), out["done"][envc].float())
+            if self.num_timesteps < self.learning_starts:
+                a = th.rand(Ccap, A, device=dev) * 2 - 1                              # warm-up: uniform actions
+            else:
+                with th.no_grad():
+                    a, _ = self.policy.action_log_prob({"observation": stage})
+            prev_obs.index_copy_(0, env, stage); prev_act.index_copy_(0, env, a); has_prev.index_fill_(0, env, True); has_prev[N] = False
+            slot_act.copy_(self._scale(a))
+            tick += 1; self._async_ticks = tick
+            if tick % 8 == 0 or tick == 1:                                            # the only host sync: every 8 ticks
+                self.replay_buffer.sync_size()
+                self.num_timesteps = self.replay_buffer._host_size                   # transitions stored so far
+            if callback is not None and not callback.on_step():
+                break
+            if self.num_timesteps >= self.learning_starts and tick % self.train_freq == 0 and self.replay_buffer.size() >= self.batch_size:
+                self.train(self.gradient_steps)
+            if self.verbose and tick % (log_interval * 100) == 0:
+                print(f"[sac async] ticks {tick} timesteps {self.num_timesteps} fps {self.num_timesteps / max(1e-9, time.time() - t0):.0f} updates {self._n_updates}")
+        return self
+
     def learn(self, total_timesteps, callback=None, reset_num_timesteps=True, log_interval=4):
         if isinstance(callback, (list, tuple)):
             callback = CallbackList(list(callback))
@@ -333,6 +418,11 @@ class SAC:
             callback.init_callback(self); callback.on_training_start(locals(), globals())
         if reset_num_timesteps:
             self.num_timesteps = 0
+        if self.async_slice > 0:
+            self._learn_async(total_timesteps, callback, log_interval)
+            if callback is not None:
+                callback.on_training_end()
+            return self
         if self._last_obs is None:
             self._last_obs = self._obs_t(self.env.reset())
         t0, step = time.time(), 0

@@ -112,3 +112,62 @@ class DummyVecEnv:
     def close(self):
         for e in self.envs:
             e.close()
+
+
+class VecVideoRecorder:
+    """stable_baselines3.common.vec_env.VecVideoRecorder's call shape (train_agent.py:25-29): wraps a VecEnv, starts a recording when
+    `record_video_trigger(step)` fires and stops it `video_length` steps later. Frames come from the wrapped env's
+    `render(mode='rgb_array')` (robot_env.py:302-340); the clip is written as an animated GIF (`<name_prefix>-step-<a>-to-step-<b>.gif`:
+    PIL is what this image has, ffmpeg is not)."""
+
+    def __init__(self, venv, video_folder, record_video_trigger, video_length=200, name_prefix="rl-video"):
+        self.venv, self.video_folder, self.trigger, self.video_length, self.name_prefix = venv, video_folder, record_video_trigger, int(video_length), name_prefix
+        self.num_envs = venv.num_envs
+        self.observation_space, self.action_space = venv.observation_space, venv.action_space
+        os.makedirs(video_folder, exist_ok=True)
+        self.step_id, self.frames, self.start, self.recording, self.saved = 0, [], 0, False, []
+
+    def _env0(self):
+        e = self.venv
+        while hasattr(e, "venv"):
+            e = e.venv
+        return e.envs[0] if hasattr(e, "envs") else getattr(e, "env", e)
+
+    def _frame(self):
+        return np.asarray(self._env0().render(mode="rgb_array"))
+
+    def _maybe_start(self):
+        if not self.recording and self.trigger(self.step_id):
+            self.recording, self.frames, self.start = True, [self._frame()], self.step_id
+
+    def reset(self):
+        obs = self.venv.reset()
+        self._maybe_start()
+        return obs
+
+    def step(self, actions):
+        out = self.venv.step(actions)
+        self.step_id += 1
+        if self.recording:
+            self.frames.append(self._frame())
+            if len(self.frames) > self.video_length:
+                self.close_video_recorder()
+        else:
+            self._maybe_start()
+        return out
+
+    def close_video_recorder(self):
+        if self.recording and self.frames:
+            from PIL import Image
+            path = os.path.join(self.video_folder, f"{self.name_prefix}-step-{self.start}-to-step-{self.start + self.video_length}.gif")
+            imgs = [Image.fromarray(f) for f in self.frames]
+            imgs[0].save(path, format="GIF", append_images=imgs[1:], save_all=True, duration=100, loop=0)
+            self.saved.append(path)
+        self.recording, self.frames = False, []
+
+    def close(self):
+        self.close_video_recorder()
+        self.venv.close()
+
+    def __getattr__(self, name):
+        return getattr(self.venv, name)

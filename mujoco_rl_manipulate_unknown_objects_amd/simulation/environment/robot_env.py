@@ -39,7 +39,7 @@ class Status(Enum):
 
 
 class BatchedRobotEnv:
-    metadata = {'render.modes': ['rgb_array', 'depth_array']}
+    metadata = {'render.modes': ['human', 'rgb_array', 'depth_array']}
     Status = Status
 
     def __init__(self, config, n_envs=1, device_index=0, auto_reset=False):
@@ -114,13 +114,60 @@ class BatchedRobotEnv:
             r = r + 1 / np.exp(dist)
         return r
 
-    def render(self, mode='rgb_array', env_index=0):
-        """Gripper-camera image of one env (robot_env.py:302-340 renders three cameras at a zoomed size;
-        only the observation camera exists here: SURVEY.md §8(f) n4)."""
-        o = self.batch.observe(self.batch.torch.empty_like(self._obs))[env_index].cpu().numpy()
-        if mode == 'depth_array':
-            return o[3]
-        return o[:3].transpose(1, 2, 0)
+    # -- RobotEnv.render (robot_env.py:302-340): camera 0 workbench, 1 upper (both `targetbodycom` on the object), 2 gripper, 3 = all
+    def _camera_pose(self, camera_id, env_index):
+        """(optical centre, rotation, fovy) of a reference camera for one env; None pose = the model's gripper camera.
+        A `targetbodycom` camera keeps its body position, looks at the object's centre of mass (camera -z) and keeps world z up
+        (MuJoCo's camera tracking [3P-recall]: z = unit(cam - target), x = unit(z_world x z), y = z x x)."""
+        from ...model import blob
+        if not hasattr(self, "_mdl"):
+            b = self.batch.parts[0] if hasattr(self.batch, "parts") else self.batch
+            self._mdl = blob.read_blob(b.model.path)
+        if camera_id == 2:
+            return None, None, float(self._mdl["cam_fovy"][0])
+        q = self.batch.get_state()[0][env_index].astype(np.float64)
+        w, x, y, z = q[10:14] / np.linalg.norm(q[10:14])
+        Ro = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                       [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                       [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        target = q[7:10] + Ro @ self._mdl["body_ipos"][7]
+        pos = self._mdl["static_cam_pos"][camera_id]
+        zc = pos - target; zc /= np.linalg.norm(zc)
+        xc = np.cross([0.0, 0.0, 1.0], zc)
+        xc = np.array([1.0, 0.0, 0.0]) if np.linalg.norm(xc) < 1e-9 else xc / np.linalg.norm(xc)
+        yc = np.cross(zc, xc)
+        return pos, np.stack([xc, yc, zc], axis=1), float(self._mdl["static_cam_fovy"][camera_id])
+
+    def render_images(self, camera_id, w_zoom=1, h_zoom=1, env_index=0):
+        """RGBDSensor.render_images (sensor.py:56-77): (rgb uint8 [H, W, 3], depth through transform_depth [H, W])."""
+        from ..utils.utils import transform_depth
+        W, H = int(self.config.width_capture * w_zoom), int(self.config.height_capture * h_zoom)
+        pos, R, fovy = self._camera_pose(camera_id, env_index)
+        rgb = self.batch.render_camera(env_index, pos, R, fovy, W, H).cpu().numpy()
+        depth = self.batch.render_camera(env_index, pos, R, fovy, W, H, depth=True).cpu().numpy()
+        return rgb, transform_depth(depth)
+
+    def render(self, mode='human', env_index=0):
+        """robot_env.py:302-340: the configured camera (config.camera_id in 0..2) or cameras 0..camera_id-1 side by side, at the zoomed
+        size (64 * rendering_zoom_width x 64 * rendering_zoom_height); 'rgb_array' / 'depth_array' return the image, 'human' shows it
+        (cv2 window when OpenCV is installed; otherwise the frame is kept in `last_frame` for the caller to display or save)."""
+        kind = 'depth' if mode == 'depth_array' else 'rgb'
+        def view(cam):
+            rgb, depth = self.render_images(cam, self.config.rendering_zoom_width, self.config.rendering_zoom_height, env_index)
+            return depth if kind == 'depth' else rgb
+        cid = int(self.config.camera_id)
+        result = view(cid) if cid in (0, 1, 2) else np.hstack([view(c) for c in range(cid)])
+        if mode in ('rgb_array', 'depth_array'):
+            return result
+        if mode == 'human':
+            self.last_frame = result
+            try:
+                import cv2
+                cv2.imshow("Camera", cv2.cvtColor(result, cv2.COLOR_BGR2RGB)); cv2.waitKey(1)
+            except ImportError:
+                pass
+            return None
+        raise ValueError(f"unknown render mode {mode!r}")
 
     def seed(self, seed=None):
         self.np_random = np.random.default_rng(seed)

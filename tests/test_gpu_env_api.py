@@ -1,4 +1,6 @@
 """-m gpu: the Gym / SB3-shaped surfaces (RobotEnv, GpuVecEnv, PPO) on the real engine."""
+import os
+
 import numpy as np
 import pytest
 
@@ -28,7 +30,63 @@ def test_robot_env_surface(torch):
     assert isinstance(reward, float) and isinstance(done, bool) and info["status"] == Status.RUNNING and info["episode_step"] == 1
     r2 = env.compute_reward(obs["achieved_goal"], obs["desired_goal"], info)
     assert float(r2) == pytest.approx(reward, abs=1e-4)
-    assert env.render(mode="rgb_array").shape == (64, 64, 3)
+    assert env.render(mode="rgb_array").shape == (480, 1920, 3)    # robot_env.py:302-340: cameras 0..2 side by side at 64 * (10, 7.5)
+    env.close()
+
+
+def test_render_cameras_video_and_gif(torch, orc, tmp_path):
+    """n4: RobotEnv.render (robot_env.py:302-340) -- the three cameras at the zoomed size, rgb / depth / human modes; the gripper view
+    at zoom 1 is the observation's own RGB; the general-camera kernel agrees with the oracle's ray caster at another size; the video
+    recorder of train_agent.py:25-29 and the GIF / 3-D plot of eval_agent.py:11-25,72-76 write their files."""
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import RobotEnv, default_config
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3 import DummyVecEnv, VecVideoRecorder
+    from mujoco_rl_manipulate_unknown_objects_amd.visuals import make_gif, plot_3D
+    env = RobotEnv(default_config(sim_env="/xmls/sugar_cube_env.xml"))
+    obs = env.reset()
+    rng = np.random.default_rng(3)
+    for _ in range(3):
+        a = rng.uniform(-1, 1, 6).astype(np.float32); a[0] = abs(a[0])
+        obs, _, _, info = env.step(a)
+    allcams = env.render(mode="rgb_array")
+    assert allcams.shape == (480, 1920, 3) and allcams.dtype == np.uint8
+    for k in range(3):                                              # every panel shows a scene, not a constant image
+        assert allcams[:, 640 * k:640 * (k + 1)].reshape(-1, 3).std(0).max() > 5
+    d = env.render(mode="depth_array")
+    assert d.shape == (480, 1920) and np.isfinite(d).all() and 0 <= d.min() and d.max() <= 255
+    assert env.render(mode="human") is None and env.last_frame.shape == (480, 1920, 3)
+    # gripper camera, zoom 1: the same pixels as the observation (two kernels, one scene)
+    env.config.camera_id, env.config.rendering_zoom_width, env.config.rendering_zoom_height = 2, 1, 1
+    g = env.render(mode="rgb_array")
+    assert g.shape == (64, 64, 3)
+    o = obs["observation"][:3].transpose(1, 2, 0).astype(int)
+    assert (np.abs(g.astype(int) - o) <= 1).mean() > 0.99
+    # the general-camera kernel against the oracle's ray caster at 128 x 96
+    import ctypes as C
+    m = orc.Model("sugar_cube"); e = orc.EnvOracle(m); e.reset()
+    q = env.batch.get_state()[0][0]
+    e.d.qpos[:] = [float(x) for x in q]; orc.lib().orc_fwd_position(m.ptr, C.byref(e.e.d))
+    rgb_o = np.zeros((96, 128, 3), np.uint8); dep_o = np.zeros((96, 128), np.float32)
+    orc.lib().orc_render(m.ptr, C.byref(e.e.d), 128, 96, rgb_o.ctypes.data_as(C.POINTER(C.c_ubyte)), dep_o.ctypes.data_as(C.POINTER(C.c_float)))
+    rgb_g = env.batch.render_camera(0, width=128, height=96).cpu().numpy(); dep_g = env.batch.render_camera(0, width=128, height=96, depth=True).cpu().numpy()
+    assert (np.abs(rgb_g.astype(int) - rgb_o.astype(int)) <= 1).mean() > 0.98
+    near = dep_o < 5
+    assert (np.abs(dep_g - dep_o)[near] < 1e-3).mean() > 0.98
+    # upper camera looks straight down on the object: the object's colour is at the image centre
+    env.config.camera_id, env.config.rendering_zoom_width, env.config.rendering_zoom_height = 1, 2, 2
+    up = env.render(mode="rgb_array")
+    assert up.shape == (128, 128, 3)
+    # video recorder + GIF + 3-D plot
+    env.config.camera_id = 2
+    venv = VecVideoRecorder(DummyVecEnv([lambda: env]), video_folder=str(tmp_path / "videos"), record_video_trigger=lambda x: x % 4 == 0, video_length=3, name_prefix="probe")
+    venv.reset()
+    frames, gp, op = [], [], []
+    for _ in range(6):
+        ob, r, dn, infos = venv.step([rng.uniform(-1, 1, 6).astype(np.float32)])
+        frames.append(env.render(mode="rgb_array")); gp.append(infos[0]["gripper_position"]); op.append(infos[0]["object_position"])
+    venv.close_video_recorder()
+    assert len(venv.saved) >= 1 and all(os.path.getsize(p) > 500 for p in venv.saved)
+    gif = make_gif(frames, str(tmp_path / "gifs" / "traj.gif")); png = plot_3D(gp, op, str(tmp_path / "plot.png"))
+    assert os.path.getsize(gif) > 500 and os.path.getsize(png) > 2000
     env.close()
 
 
@@ -221,3 +279,27 @@ def test_integration_md_ctypes_stub_runs(torch):
     assert torch.equal(out["reward"], ns["reward"]) and torch.equal(out["done"], ns["done"]) and torch.equal(ref_obs, ns["obs"])
     ns["L"].grip_batch_destroy(ns["batch"]); ns["L"].grip_model_free(ns["model"])
     b.close()
+
+
+def test_sac_over_the_time_sliced_engine(torch):
+    """n1 on the asynchronous schedule (train_agent.py:82-92 is SAC): collection through grip_batch_advance, transitions of the envs
+    that finished a macro step go into the flat replay ring, updates run between ticks. The stored chains are consistent (a
+    transition's next observation is a real rendered frame that differs from its observation), losses are finite, parameters move."""
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import BatchedRobotEnv, default_config
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3 import SAC, GpuVecEnv
+    from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
+    env = GpuVecEnv(BatchedRobotEnv(default_config(sim_env="/xmls/sand_ball_env.xml", time_horizon=20), n_envs=256, auto_reset=True))
+    model = SAC("MultiInputPolicy", env, buffer_size=4096, learning_starts=600, batch_size=128, seed=0, async_slice=48, async_capacity=128, async_budget_us=0,
+                policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]))
+    before = [p.detach().clone() for p in model.policy.parameters()]
+    model.learn(total_timesteps=1500)
+    rb = model.replay_buffer
+    n = rb.sync_size()
+    assert n >= 1500 and model._n_updates > 0
+    assert np.isfinite(float(model.logger["critic_loss"])) and np.isfinite(float(model.logger["actor_loss"]))
+    assert any(not torch.equal(a, b) for a, b in zip(before, model.policy.parameters()))
+    o, no = rb.obs[:n], rb.next_obs[:n]
+    assert int((o != no).flatten(1).any(1).sum()) > 0.9 * n                # the env moved between the two frames
+    assert float(rb.dones[:n].mean()) > 0 and float(rb.rewards[:n].abs().max()) < 10
+    assert (rb.actions[:n].abs() <= 1).all()
+    env.close()

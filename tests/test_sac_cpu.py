@@ -88,3 +88,56 @@ def test_her_future_relabelling():
     pb = ReplayBuffer(200, env.observation_space, env.action_space, torch.device("cpu"), n_envs=4)
     pb.add(obs, obs, torch.zeros(4, 6), torch.ones(4), torch.zeros(4))
     assert pb.sample(8)["rewards"].shape == (8,)
+
+
+def test_flat_replay_ring_and_sac_over_a_scripted_time_sliced_engine():
+    """n1 on the time-sliced schedule: the flat ring scatters varying batches behind a device-side pointer and wraps; SAC.learn over a
+    scripted asynchronous engine (envs finish on their own clocks) stores, for every env, the chain obs_t -> next_obs == obs_{t+1}."""
+    import torch as th
+    from mujoco_rl_manipulate_unknown_objects_amd import spaces
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3 import SAC, FlatReplayBuffer
+    osp = spaces.Dict({"observation": spaces.Box(0, 255, shape=(5, 64, 64), dtype=np.uint8)}); asp = spaces.Box(-1., 1., shape=(6,), dtype=np.float32)
+    rb = FlatReplayBuffer(10, osp, asp, th.device("cpu"))
+    for k in range(4):
+        mask = th.tensor([True, False, True, True]); val = th.arange(4).float() + 10 * k
+        rb.add_rows(mask, th.zeros(4, 5, 64, 64, dtype=th.uint8), th.ones(4, 5, 64, 64, dtype=th.uint8), th.zeros(4, 6), val, th.zeros(4))
+    assert rb.sync_size() == 10 and int(rb.ptr) == 12
+    # rows 10, 11 wrapped onto slots 0, 1: rewards of batch 3 are 30 (row 9), 32 (row 10 -> slot 0), 33 (row 11 -> slot 1)
+    assert rb.rewards[:10].tolist() == [32.0, 33.0, 3.0, 10.0, 12.0, 13.0, 20.0, 22.0, 23.0, 30.0]
+
+    class Eng:                                             # env e finishes a macro step every (1 + e % 3) ticks; obs of env e at its k-th decision = 40 e + k
+        num_envs, action_dim, device, obs_shape = 6, 6, th.device("cpu"), (5, 64, 64)
+        observation_space, action_space = osp, asp
+
+        def __init__(self):
+            self.k = th.zeros(6, dtype=th.int64); self.clock = th.zeros(6, dtype=th.int64); self.waiting = th.ones(6, dtype=th.bool)
+            self.out = {"reward": th.zeros(6), "done": th.zeros(6, dtype=th.uint8), "n_substeps": th.zeros(6, dtype=th.int32)}
+            self.listed = th.zeros(0, dtype=th.int64)
+
+        def reset(self):
+            pass
+
+        def advance(self, slot_actions, slice_len, ready_list, ready_count, lag=1):
+            got = ready_list[:int(ready_count.item())]; got = got[got >= 0].long()
+            self.waiting[got] = False
+            self.clock[~self.waiting] += 1
+            fin = (~self.waiting) & (self.clock % (1 + th.arange(6) % 3) == 0)
+            self.k[fin] += 1; self.out["reward"][fin] = self.k[fin].float(); self.waiting |= fin
+            ids = self.waiting.nonzero().flatten()[:ready_list.numel()]
+            ready_list.fill_(-1); ready_list[:ids.numel()] = ids.int(); ready_count.fill_(ids.numel()); self.listed = ids
+            return self.out
+
+        def observe_list(self, ready_list, ready_count, obs_rows, records=None, record_row=None):
+            obs_rows.zero_()
+            for r, e in enumerate(self.listed.tolist()):
+                obs_rows[r].fill_(int(40 * e + self.k[e]))
+    eng = Eng()
+    s = SAC("MultiInputPolicy", eng, buffer_size=64, learning_starts=10_000, batch_size=8, device="cpu", seed=0, async_slice=4, async_capacity=6,
+            policy_kwargs=dict(share_features_extractor=True, net_arch=[256, 256]))
+    s.learn(40)
+    n = s.replay_buffer.sync_size()
+    assert n >= 40
+    o = s.replay_buffer.obs[:n, 0, 0, 0].long(); no = s.replay_buffer.next_obs[:n, 0, 0, 0].long(); r = s.replay_buffer.rewards[:n]
+    assert th.equal(no, o + 1)                              # next observation of a transition = that env's next decision point
+    assert th.equal(r.long(), no % 40)                      # and the reward is the one reported when the env was listed again
+    assert set((o // 40).tolist()) == set(range(6))         # every env contributes, on its own clock
