@@ -997,6 +997,10 @@ DEVI float impedance(const float *si, float pos, float margin) {
     if (x <= 0.f) return si[0];
     float mid = si[3], power = si[4], y;
     if (power <= 1.f + 1e-6f) y = x;
+    else if (power == 2.f) {            // the reference's solimp (robot xml :12: "0.9 0.95 0.001 0.5 2"): squares, not four pow() expansions
+        const float u = 1.f - x;        // (a model-uniform branch: the generic path below costs ~80 instructions per pow)
+        y = x <= mid ? x * x / mid : 1.f - u * u / (1.f - mid);
+    }
     else if (x <= mid) y = __powf(x, power) / __powf(mid, power - 1.f);
     else y = 1.f - __powf(1.f - x, power) / __powf(1.f - mid, power - 1.f);
     return si[0] + y * (si[1] - si[0]);
@@ -1072,18 +1076,33 @@ DEVI void make_constraints(const DevModel &m, const Kin &k, const float (&qpos)[
         laref = own ? -m.b_lim * (sgn * vj) - m.k_lim * imp * dist : 0.f;
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        c.aref[r] = 0.f; c.jar[r] = 0.f; c.jv[r] = 0.f;
+    for (int r = 0; r < 4; r++) { c.aref[r] = 0.f; c.jar[r] = 0.f; c.jv[r] = 0.f; }
+    if (!live) {
 #pragma unroll
-        for (int i = 0; i < 13; i++) c.J[r][i] = 0.f;
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int i = 0; i < 13; i++) c.J[r][i] = 0.f;
     }
     if (live) {
         V3 t1, t2; make_tangents(c.n, t1, t2);
-        // the only place where the rigid-group case analysis runs: afterwards every pass is 4 x 13 dot products
-        row_add(k, c.J[0], c.gB, c.p, c.n, 1.f, false); row_add(k, c.J[0], c.gA, c.p, c.n, -1.f, false);
-        row_add(k, c.J[1], c.gB, c.p, t1, 1.f, false);  row_add(k, c.J[1], c.gA, c.p, t1, -1.f, false);
-        row_add(k, c.J[2], c.gB, c.p, t2, 1.f, false);  row_add(k, c.J[2], c.gA, c.p, t2, -1.f, false);
-        row_add(k, c.J[3], c.gB, c.p, c.n, 1.f, true);  row_add(k, c.J[3], c.gA, c.p, c.n, -1.f, true);
+        // Rows of (body B) - (body A) without a case analysis per body: a dof contributes with the signed difference of "B hangs on
+        // it" and "A hangs on it" -- sG for the five ee dofs (any gripper group), sL / sR for the knuckle hinges, sO for the object's
+        // six -- so every entry is one product, and a pair inside the gripper (finger against finger) gets its exact zeros from sG = 0.
+        const float gB_grip = (c.gB == GRP_G || c.gB == GRP_L || c.gB == GRP_R) ? 1.f : 0.f, gA_grip = (c.gA == GRP_G || c.gA == GRP_L || c.gA == GRP_R) ? 1.f : 0.f;
+        const float sG = gB_grip - gA_grip, sL = (c.gB == GRP_L ? 1.f : 0.f) - (c.gA == GRP_L ? 1.f : 0.f), sR = (c.gB == GRP_R ? 1.f : 0.f) - (c.gA == GRP_R ? 1.f : 0.f),
+                    sO = (c.gB == GRP_O ? 1.f : 0.f) - (c.gA == GRP_O ? 1.f : 0.f);
+        const V3 rE = c.p - k.pe, rL = c.p - k.pk[0], rR = c.p - k.pk[1], rO = c.p - k.po;
+        auto linear_row = [&](float (&j)[13], V3 e) {
+            const V3 cg = cross(rE, e), al = multv(k.Ro, cross(rO, e));
+            j[0] = sG * e.x; j[1] = sG * e.y; j[2] = sG * e.z; j[3] = sG * cg.x; j[4] = sG * dot(k.a4, cg);
+            j[5] = sL * dot(k.ak[0], cross(rL, e)); j[6] = sR * dot(k.ak[1], cross(rR, e));
+            j[7] = sO * e.x; j[8] = sO * e.y; j[9] = sO * e.z; j[10] = sO * al.x; j[11] = sO * al.y; j[12] = sO * al.z;
+        };
+        linear_row(c.J[0], c.n); linear_row(c.J[1], t1); linear_row(c.J[2], t2);
+        {   const V3 al = multv(k.Ro, c.n);               // torsion: relative angular velocity about the normal
+            float (&j)[13] = c.J[3];
+            j[0] = j[1] = j[2] = 0.f; j[3] = sG * c.n.x; j[4] = sG * dot(k.a4, c.n); j[5] = sL * dot(k.ak[0], c.n); j[6] = sR * dot(k.ak[1], c.n);
+            j[7] = j[8] = j[9] = 0.f; j[10] = sO * al.x; j[11] = sO * al.y; j[12] = sO * al.z; }
         float imp = impedance(m.solimp, c.dist, m.margin);
         float R0 = fmaxf(1e-15f, (1.f - imp) * c.tran / imp);
         c.D0 = 1.0f / R0;
