@@ -720,20 +720,34 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const GroupArgs *_
 // the idle envs, whose workgroups retire at once.
 #define CP_THREADS 1024
 // id_offset: added to the env ids written to `list` (0 for a single batch, the group's first global env id in a set)
+// inclusive prefix sum of one int per thread over the 1024-thread block: wave-level shuffles, then the 16 wave totals through LDS
+// (two barriers per scan instead of the twenty of a Hillis-Steele sweep through LDS: the compaction runs between every two slices)
+DEVI int block_scan_incl(int v, int *wsum, int &total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int x = __shfl_up(v, d); if (lane >= d) v += x; }
+    __syncthreads();                                    // wsum may still be read by the previous scan
+    if (lane == 63) wsum[w] = v;
+    __syncthreads();
+    int before = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < CP_THREADS / 64; i++) { int x = wsum[i]; before += i < w ? x : 0; tot += x; }
+    total = tot;
+    return v + before;
+}
+
 DEVI void compact_body(const MacroCtx &mc, int n, int capacity, int *list, int *count, int *order, int id_offset) {
     // the rotation advances with a device-side tick counter, so that a captured (hipGraph) tick keeps rotating
     const int rot = (int)(((long long)mc.tick[0] * capacity) % n);
-    __shared__ int sa[CP_THREADS];
+    __shared__ int wsum[CP_THREADS / 64];
     __shared__ int cls_total[CP_CLASSES];
     const int t = threadIdx.x, chunk = (n + CP_THREADS - 1) / CP_THREADS;
     // pass 1: slots for the waiting envs, in rotated order
     int c = 0;
     const int tick = mc.tick[0];
     for (int i = 0; i < chunk; i++) { int v = t * chunk + i; if (v < n) { int e = v + rot; if (e >= n) e -= n; c += (mc.astate[e] != 0 && mc.slot[e] < 0); } }
-    sa[t] = c; __syncthreads();
-    for (int d = 1; d < CP_THREADS; d <<= 1) { int x = t >= d ? sa[t - d] : 0; __syncthreads(); sa[t] += x; __syncthreads(); }
-    int base = sa[t] - c, total = sa[CP_THREADS - 1];
-    __syncthreads();
+    int total;
+    int base = block_scan_incl(c, wsum, total) - c;
     for (int i = 0; i < chunk; i++) {
         int v = t * chunk + i;
         if (v < n) {
@@ -751,12 +765,11 @@ DEVI void compact_body(const MacroCtx &mc, int n, int capacity, int *list, int *
     for (int k = 0; k < CP_CLASSES; k++) mine[k] = 0;
     for (int i = 0; i < chunk; i++) { int e = t * chunk + i; if (e < n) mine[cls_of(e)]++; }
     for (int k = 0; k < CP_CLASSES; k++) {
-        sa[t] = mine[k]; __syncthreads();
-        for (int d = 1; d < CP_THREADS; d <<= 1) { int x = t >= d ? sa[t - d] : 0; __syncthreads(); sa[t] += x; __syncthreads(); }
-        before[k] = sa[t] - mine[k];
-        if (t == CP_THREADS - 1) cls_total[k] = sa[t];
-        __syncthreads();
+        int tot;
+        before[k] = block_scan_incl(mine[k], wsum, tot) - mine[k];
+        if (t == 0) cls_total[k] = tot;
     }
+    __syncthreads();
     int start = 0;
     for (int k = 0; k < CP_CLASSES; k++) { before[k] += start; start += cls_total[k]; }
     for (int i = 0; i < chunk; i++) { int e = t * chunk + i; if (e < n) order[before[cls_of(e)]++] = e; }

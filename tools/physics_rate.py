@@ -29,4 +29,5 @@ for _ in range(T): tick()
 torch.cuda.synchronize(); dt = time.time() - t0; c1, s1 = int(total.item()), int(subs.item())
 kms, kn = b.kernel_time(True)
 print(json.dumps({"lib": var, "object": obj, "slice": S, "budget_us": bud, "env_steps_per_s": (c1 - c0) / dt, "substeps_per_s": (s1 - s0) / dt,
-                  "substeps_per_env_step": (s1 - s0) / max(1, c1 - c0), "ms_per_tick": dt / T * 1e3, "slice_kernel_ms": kms, "fault_max": int(b.out["fault"].max())}))
+                  "substeps_per_env_step": (s1 - s0) / max(1, c1 - c0), "ms_per_tick": dt / T * 1e3, "slice_kernel_ms": kms, "fault_max": int(b.out["fault"].max()),
+                  "all_ticks": pre + T, "all_substeps_of_finished_macro_steps": s1, "all_env_steps": c1}))
