@@ -19,7 +19,8 @@ and the update trains on the log-probabilities of those actions, so the arithmet
 does not drift as the policy learns. `--actions policy` samples from the (randomly initialised, learning) policy instead.
 Before the W warm-up steps an UNTIMED pre-roll of `--preroll` rollout-only steps takes the envs from the common reset state to
 desynchronised, mixed episode phases (fresh episodes are free motion: 160 physics.step() calls per macro step; the stationary mix
-of pushing / grasping / failing episodes needs ~290), so that the value does not depend on K and W.
+of pushing / grasping / failing episodes ~235 under uniform actions; all envs start in step, and the synchrony of their episodes takes
+a few episode lengths to decay: 800 steps), so that the value does not depend on K and W (20 / 5 and 200 / 20 agree within 2 %).
 
 Default schedule: asynchronous time slices (grip_batch_advance; sb3/async_rollout.py) -- every env runs on its own clock, finished
 envs are re-decided every tick, and a step is counted when `--envs` transitions have completed, whichever envs they came from. Only
@@ -105,7 +106,7 @@ def main():
     ap.add_argument("--fixed-slice", action="store_true", help="keep --slice / --budget-us for the whole run (default: they follow the measured length of the macro steps)")
     ap.add_argument("--actions", choices=["rng", "policy"], default=None, help="default: rng with the time-sliced schedule, policy with --lockstep. ""rng: synthetic U(-1,1) action stream keyed by (seed, rank, env, t) (SURVEY.md 8d); "
                                                                                  "policy: samples of the learning policy")
-    ap.add_argument("--preroll", type=int, default=300, help="untimed rollout-only steps before the warm-up: desynchronised, mixed episode phases")
+    ap.add_argument("--preroll", type=int, default=800, help="untimed rollout-only steps before the warm-up: desynchronised, mixed episode phases")
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
     if a.capacity <= 0:
@@ -327,10 +328,14 @@ def main():
                                             f"{pm['hbm_bytes_per_launch_raw']:.0f} B")
                     # the bound that really binds this kernel: VALU issue. lane-operations per physics.step() of one env from the PMC
                     # pass (SQ_INSTS_VALU x 64 lanes / env-substeps of the launch) x the LIVE physics.step() rate of this run
-                    lane_ops = pm["valu_lane_ops_per_env_substep"] * (total_sub / dt) / world
+                    # the bound that really binds this kernel: VALU issue. Lane-operations of one launch from the PMC pass (SQ_INSTS_VALU x 64
+                    # lanes, same command and configuration) / the LIVE launch duration of this run -- formed like the HBM figure above
+                    lane_ops = pm["SQ_INSTS_VALU"] * 64.0 / (k_ms * 1e-3) if k_ms > 0 else 0.0
                     rf["valu"] = {"achieved": lane_ops, "peak": VALU_PEAK_LANE_OPS, "unit": "fp32 lane-ops/s", "frac": lane_ops / VALU_PEAK_LANE_OPS,
-                                  "lane_ops_per_env_substep": pm["valu_lane_ops_per_env_substep"], "valu_active_frac": pm["active_inst_valu_frac"],
-                                  "wait_frac": pm["wait_any_frac"], "source": "profiles/r02_pmc_summary.json (SQ_INSTS_VALU, SQ_WAVE_CYCLES) x live physics.step() rate"}
+                                  "lane_ops_per_launch": pm["SQ_INSTS_VALU"] * 64.0, "lane_ops_per_env_substep": pm["valu_lane_ops_per_env_substep"],
+                                  "valu_active_frac": pm["active_inst_valu_frac"], "wait_frac": pm["wait_any_frac"],
+                                  "source": "profiles/r02_pmc_summary.json (SQ_INSTS_VALU per launch of the same command) / live launch duration; one wave per SIMD "
+                                            "issues a VALU instruction in 4 cycles at best, i.e. 50 % of this peak"}
             except Exception:
                 pass
         if not a.no_cpu_baseline and world == 1:
