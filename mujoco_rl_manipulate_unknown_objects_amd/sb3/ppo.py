@@ -204,8 +204,9 @@ class PPO:
         off = 0
         for p in params:
             k = p.numel()
-            view = self._flat_grad[off:off + k].view(p.shape)
-            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+            # same strides as the parameter (conv weights are channels_last on the GPU: the fused optimiser wants grad and param alike)
+            view = th.as_strided(self._flat_grad, p.size(), p.stride(), storage_offset=off)
+            if p.grad is None or p.grad.data_ptr() != view.data_ptr() or p.grad.stride() != view.stride():
                 p.grad = view
             off += k
 

@@ -29,3 +29,21 @@ def test_two_ranks_over_rccl_stay_bit_identical():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["replicas_identical"] is True
     assert d["env_steps_counted"] == 2 * 512 * 4 and d["short_rollouts"] == 0
+
+
+def test_two_ranks_rehearsed_on_one_gpu_with_gloo():
+    """The same N > 1 code path on the one-GPU box: `bench.py --gpus 2` without a launcher (it spawns its ranks), both ranks on device 0,
+    gloo instead of RCCL (GRIP_BENCH_REHEARSAL=1: never a headline number). Exercises the self-launch, the flat gradient bucket as
+    .grad storage under the captured update graphs (channels_last parameters included), the learn-loop agreement and the replica check."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GRIP_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--envs", "1024", "--rollout", "2",
+                        "--minibatch", "1024", "--preroll", "8", "--no-cpu-baseline", "--object", "sand_ball"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["replicas_identical"] is True and d["env_steps_counted"] == 2 * 1024 * 6 and d["short_rollouts"] == 0
