@@ -116,6 +116,9 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise GripError(f"{LIB_PATH} is not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
                         "There is no CPU fallback for the product path.")
+    # PyTorch-ROCm first: it carries its own HIP runtime, and the library must bind to THAT copy (loaded second, libgrip_sim.so would pull
+    # /opt/rocm's libamdhip64 in as a second runtime that sees no device once torch has initialised the first)
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.grip_last_error.restype = C.c_char_p
