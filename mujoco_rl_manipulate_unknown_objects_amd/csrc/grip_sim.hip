@@ -285,7 +285,11 @@ struct StatePtrs { float *qpos, *qvel, *ctrl, *warm; int *episode_step, *status,
 // heavy: hull-hull contacts the env had at its last physics.step() -- the cost class k_compact sorts the work order by;
 // gen: number of the compaction that gave the slot (tick[0] counts compactions): a slot-holder starts `lag` launches later.
 struct MacroCtx { int *ints; float *flts; int *astate; int *slot; int *heavy; int *tick; int *gen; unsigned long long *t0; float *memo; };
-#define MC_MEMO_WORDS 13       // per lane: has, 3 vertex-pair ids, 3 query directions (the narrow phase's portal memory)
+// per lane: word 0 = has | has_sep << 1 | (h1 + 1) << 2 | (h2 + 1) << 14 (portal flag, separating-direction flag, the two support-vertex
+// hints), 3 vertex-pair ids, 3 query directions (the portal memory), the separating direction: EVERYTHING collide() remembers between
+// calls, so that a resumed macro step takes the same branches -- per-lane or cooperative support evaluation included -- as the
+// uninterrupted one and time-sliced results equal lock-step results bit for bit in contact too (tests/test_gpu_contact.py)
+#define MC_MEMO_WORDS 16
 enum { MC_PHASE = 0, MC_CNT, MC_NSUB, MC_GRASPED, MC_FLAGS, MC_FAULT, MC_NINT };
 enum { MC_TARGET = 0, MC_INITQ = 5, MC_OPENCLOSE = 10, MC_TQ = 11, MC_INITOBJ = 12, MC_NFLT = 15 };
 
@@ -493,7 +497,9 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
     // the time slices end (lock-step keeps it in registers for the whole macro step)
     if (sliced && valid && !first) {
         const float *mm = mc.memo + ((size_t)cx.sub * N + e);
-        sep.has = __float_as_int(mm[0]);
+        const int w0 = __float_as_int(mm[0]);
+        sep.has = w0 & 1; sep.h1 = ((w0 >> 2) & 0xfff) - 1; sep.h2 = ((w0 >> 14) & 0xfff) - 1;
+        if (w0 & 2) sep.sep = v3(mm[(size_t)13 * 16 * N], mm[(size_t)14 * 16 * N], mm[(size_t)15 * 16 * N]);
         if (sep.has) {                                      // only lanes whose pair was in contact carry more than the flag
 #pragma unroll
             for (int k = 0; k < 3; k++) {
@@ -659,7 +665,9 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
 #ifndef GRIP_COLD_PORTAL
     if (sliced && valid && phase != PH_DONE) {              // every lane parks its pair's portal memory (the flag; the portal if there is one)
         float *mm = mc.memo + ((size_t)cx.sub * N + e);
-        mm[0] = __int_as_float(sep.has);
+        const bool has_sep = dot(sep.sep, sep.sep) > 0.5f;
+        mm[0] = __int_as_float((sep.has & 1) | (has_sep ? 2 : 0) | (((sep.h1 + 1) & 0xfff) << 2) | (((sep.h2 + 1) & 0xfff) << 14));
+        if (has_sep) { mm[(size_t)13 * 16 * N] = sep.sep.x; mm[(size_t)14 * 16 * N] = sep.sep.y; mm[(size_t)15 * 16 * N] = sep.sep.z; }
         if (sep.has) {
 #pragma unroll
             for (int k = 0; k < 3; k++) {
