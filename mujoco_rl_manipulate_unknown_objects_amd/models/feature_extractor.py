@@ -12,8 +12,34 @@ from torch import nn
 from ..sb3.torch_layers import BaseFeaturesExtractor
 
 
+class _Conv1U8(th.autograd.Function):
+    """First layer of the extractor for TRAINING on raw uint8 CUDA observations: forward = grip_conv1_u8 (normalisation, Conv2d(4, 32, 8, 4),
+    bias and ReLU as one f32-MFMA launch, the kernel the rollouts use: 48 us per 4096 samples against 64 + 256 + 30 us for the uint8 ->
+    float pass, the tensor library's implicit GEMM and the ReLU); backward = ReLU mask, then the library's weight-gradient kernel on the
+    float image, which is recomputed from the bytes (64 us) instead of being kept from the forward (268 MB per 4096-sample minibatch).
+    The input needs no gradient. Same arithmetic as the reference path up to summation order (tests/test_gpu_env_api.py)."""
+
+    @staticmethod
+    def forward(ctx, obs, weight, bias):
+        from ..engine import conv1_u8
+        out, other = conv1_u8(obs, weight, bias)
+        ctx.save_for_backward(obs, weight, out)
+        ctx.mark_non_differentiable(other)
+        return out, other
+
+    @staticmethod
+    def backward(ctx, gout, _gother):
+        from ..engine import obs_preprocess
+        obs, weight, out = ctx.saved_tensors
+        g = th.ops.aten.threshold_backward(gout.contiguous(memory_format=th.channels_last), out, 0.0)      # ReLU
+        x, _ = obs_preprocess(obs)
+        _, gw, gb = th.ops.aten.convolution_backward(g, x, weight, [weight.shape[0]], [4, 4], [0, 0], [1, 1], False, [0, 0], 1, [False, True, True])
+        return None, gw, gb
+
+
 class AugmentedNatureCNN(BaseFeaturesExtractor):
     accepts_raw_uint8 = True        # forward() normalises raw uint8 CUDA observations itself (one fused kernel)
+    fused_first_layer_training = True   # the update's first layer through grip_conv1_u8 too (_Conv1U8); False: the tensor library's convolution
 
     def __init__(self, observation_space, features_dim: int = 514):
         super().__init__(observation_space, features_dim)
@@ -36,6 +62,13 @@ class AugmentedNatureCNN(BaseFeaturesExtractor):
             # rollouts (no autograd): normalisation, first convolution, bias and ReLU in one f32-MFMA launch (csrc/grip_policy.hip)
             from ..engine import conv1_u8
             x, other = conv1_u8(obs.contiguous(), c0.weight, c0.bias)
+            for layer in list(self.cnn)[2:]:
+                x = layer(x)
+            return th.cat((self.linear(x), other.to(x.dtype)), dim=1)
+        if (self.fused_first_layer_training and obs.dtype == th.uint8 and obs.is_cuda and th.is_grad_enabled() and num_direct_features == 2
+                and tuple(obs.shape[1:]) == (5, 64, 64) and tuple(c0.weight.shape) == (32, 4, 8, 8) and c0.stride == (4, 4) and c0.padding == (0, 0)
+                and c0.weight.dtype == th.float32 and not th.is_autocast_enabled()):
+            x, other = _Conv1U8.apply(obs.contiguous(), c0.weight, c0.bias)
             for layer in list(self.cnn)[2:]:
                 x = layer(x)
             return th.cat((self.linear(x), other.to(x.dtype)), dim=1)
