@@ -179,3 +179,26 @@ def test_intrinsic_reward_restatements_agree(orc):
         assert abs(orc.intrinsic_reward(a, b, full) - ref) < 1e-5 * max(1.0, abs(ref))
         assert abs(IntrinsicReward(config=Cfg())(a, b, np.zeros(3), np.zeros(3), np.array([1, 0]), True, np.zeros(2), 0) - ref) < 1e-5 * max(1.0, abs(ref))
         assert orc.intrinsic_reward(a, a, full) == 0.0
+
+
+def test_coulomb_threshold_of_the_elliptic_friction_cone(orc):
+    """First-principles check of the contact model: the sugar cube (1 kg, friction 1 against the floor: robot xml :54,98) resting on the floor
+    is pushed horizontally through its base line (a force at the centre of mass plus the torque that cancels its tipping moment). Below the
+    Coulomb limit mu m g = 9.81 N it sticks -- the soft constraints allow a creep of well under a millimetre per second -- and above it it
+    slides: 0.4 s after the push starts the velocity is at least (F - mu m g) t / m."""
+    m = orc.Model("sugar_cube")
+    s = orc.Sim(m)
+    s.qpos[0] = -2.0                                     # gripper out of the way
+    s.d.xfrc[1][2] = 0.438 * G
+    s.fwd_position(); s.step(1500)                       # settle
+    assert s.d.ncon >= 3 and np.abs(s.qvel[7:]).max() < 1e-9
+    zc = float(np.array(s.d.xipos[7])[2])
+    for F, slides in ((2.0, False), (6.0, False), (9.0, False), (9.5, False), (10.3, True), (12.0, True)):
+        t = orc.Sim(m)
+        t.qpos[:] = np.array(s.qpos); t.qacc_warmstart[:] = np.array(s.qacc_warmstart); t.d.xfrc[1][2] = 0.438 * G
+        t.d.xfrc[7][0] = F; t.d.xfrc[7][4] = -F * zc
+        t.fwd_position(); t.step(200)
+        if slides:
+            assert t.qvel[7] >= (F - 1.0 * 1.0 * G) * 0.4 - 1e-3, (F, t.qvel[7])
+        else:
+            assert abs(t.qvel[7]) < 1e-3 and abs(t.qpos[7] - s.qpos[7]) < 2e-4, (F, t.qvel[7], t.qpos[7] - s.qpos[7])
