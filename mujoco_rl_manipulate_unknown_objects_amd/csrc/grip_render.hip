@@ -54,6 +54,43 @@ __device__ static void compute_frames(const DevModel &m, const float *qpos, int 
 }
 
 
+// The same frames, one per thread: role 0..5 = geom frame role (base, left knuckle, left finger, right knuckle, right finger, object),
+// role 6 = the gripper camera. Every thread walks only its own chain ee -> base -> knuckle -> finger with the expressions of
+// compute_frames (bit-identical frames), so the observation kernel's prologue holds two matrices per thread instead of the whole tree
+// (compute_frames needs 98 VGPRs and, called from k_observe, halved that kernel's occupancy).
+__device__ __forceinline__ void frame_role(const DevModel &m, const float *qpos, int n, int e, int half, int role, Frames &f) {
+    auto Q = [&](int i) { return ld_word(qpos, (size_t)i * n + e, half); };
+    V3 P; M3 R;
+    if (role == 5) {
+        const float q0 = Q(10), q1 = Q(11), q2 = Q(12), q3 = Q(13);
+        const float qn = rsqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+        P = v3(Q(7), Q(8), Q(9)); R = quat_mat(q0 * qn, q1 * qn, q2 * qn, q3 * qn);
+    } else {
+        const V3 pe = v3(m.ee_pos0[0] + Q(0), m.ee_pos0[1] + Q(1), m.ee_pos0[2] + Q(2));
+        const float q3 = Q(3), q4 = Q(4);
+        const float sr = sinf(q3), cr = cosf(q3), sy = sinf(q4), cy = cosf(q4);
+        M3 Re;
+        Re.m[0] = cy; Re.m[1] = -sy; Re.m[2] = 0.f; Re.m[3] = cr * sy; Re.m[4] = cr * cy; Re.m[5] = -sr; Re.m[6] = sr * sy; Re.m[7] = sr * cy; Re.m[8] = cr;
+        if (role == 6) { P = pe + mulv(Re, ldv(m.cam_pos)); R = mulm(Re, ldm(m.cam_R)); }
+        else {
+            P = pe + mulv(Re, ldv(m.base_pos)); R = mulm(Re, ldm(m.base_R));
+            if (role >= 1) {
+                const int s = role >= 3 ? 1 : 0;
+                const V3 pk = P + mulv(R, ldv(m.kn_pos[s])); const M3 Rk0 = mulm(R, ldm(m.kn_R[s]));
+                const float qk = Q(5 + s);
+                const float sq = sinf(qk), cq = cosf(qk);
+                M3 Ry; Ry.m[0] = cq; Ry.m[1] = 0; Ry.m[2] = sq; Ry.m[3] = 0; Ry.m[4] = 1; Ry.m[5] = 0; Ry.m[6] = -sq; Ry.m[7] = 0; Ry.m[8] = cq;
+                P = pk; R = mulm(Rk0, Ry);
+                if (role == 2 || role == 4) { const V3 pf = P + mulv(R, ldv(m.fin_pos[s])); const M3 Rf = mulm(R, ldm(m.fin_R[s])); P = pf; R = Rf; }
+            }
+        }
+    }
+    float *op = role == 6 ? f.cam_o : f.p[role], *oR = role == 6 ? f.cam_R : f.R[role];
+    op[0] = P.x; op[1] = P.y; op[2] = P.z;
+#pragma unroll
+    for (int i = 0; i < 9; i++) oR[i] = R.m[i];
+}
+
 __device__ static uint8_t to_u8(float v) { v *= 255.f; v = fminf(fmaxf(v, 0.f), 255.f); return (uint8_t)v; }
 
 // Per env, every hull plane n.x <= d (body frame) is first rewritten for rays leaving the camera origin in CAMERA
@@ -73,30 +110,37 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
     __shared__ Frames fr;
     __shared__ float gsph[GN_GEOM][4];          // bounding sphere centre in camera coordinates, radius^2
     extern __shared__ float4 spl[];             // camera-space plane table of this env (sized by the launcher: planes x 16 B)
-    __shared__ int gadr[GN_GEOM], gnum[GN_GEOM];
+    __shared__ int gadr[GN_GEOM], gnum[GN_GEOM], gnf[GN_GEOM];   // table start, planes, planes facing the camera (listed first)
+    __shared__ int wcnt[RTHREADS / 64];
     __shared__ float red[RTHREADS];
     __shared__ int redi[RTHREADS];
     const int tid = threadIdx.x;
-    if (tid == 0) {
-        compute_frames(m, qpos, n, e, cfg.state_half, fr);
+    if (tid < 7) frame_role(m, qpos, n, e, cfg.state_half, tid, fr);
+    __syncthreads();
+    if (tid >= 1 && tid < GN_GEOM) {                                    // thread g: hull g's bounding sphere in camera coordinates
+        const int g = tid;
         V3 co = ldv(fr.cam_o); M3 Rc = ldm(fr.cam_R);
-        int adr = 0;
-        for (int g = 1; g < GN_GEOM; g++) {
-            V3 p = ldv(fr.p[g - 1]); M3 R = ldm(fr.R[g - 1]);
-            V3 c = multv(Rc, p + mulv(R, ldv(m.geom_center[g])) - co);
-            float r = m.geom_rbound[g];
-            gsph[g][0] = c.x; gsph[g][1] = c.y; gsph[g][2] = c.z; gsph[g][3] = r * r;
-            bool vis = c.z - r < 0.f;                                   // some of the sphere is in front of the camera
-            gadr[g] = adr; gnum[g] = vis ? m.hull_pnum[g - 1] : 0;
-            if (vis) adr += NBOX + m.hull_pnum[g - 1];
-        }
+        V3 p = ldv(fr.p[g - 1]); M3 R = ldm(fr.R[g - 1]);
+        V3 c = multv(Rc, p + mulv(R, ldv(m.geom_center[g])) - co);
+        float r = m.geom_rbound[g];
+        gsph[g][0] = c.x; gsph[g][1] = c.y; gsph[g][2] = c.z; gsph[g][3] = r * r;
+        gnum[g] = c.z - r < 0.f ? m.hull_pnum[g - 1] : 0;               // some of the sphere is in front of the camera
     }
     __syncthreads();
+    if (tid == 0) {
+        int adr = 0;
+        for (int g = 1; g < GN_GEOM; g++) { gadr[g] = adr; if (gnum[g]) adr += NBOX + gnum[g]; }
+    }
+    __syncthreads();
+    {
     const V3 co = ldv(fr.cam_o); const M3 Rc = ldm(fr.cam_R);
     // plane n.x <= d of a hull (body frame), rewritten for rays from the camera origin in camera coordinates dc = (x, y, -1):
     // t (A.dc) <= B with A = (Rg^T Rc)^T n, B = d - n.(Rg^T (co - pg)); one float4 per plane of the visible hulls in LDS.
     // Each hull's table starts with the six planes of its vertices' bounding box (same form): a ray that misses the box misses
-    // the hull, and a wave whose 256 rays all miss it skips the hull's whole plane list.
+    // the hull, and a wave whose 256 rays all miss it skips the hull's whole plane list. The hull's own planes follow in two runs:
+    // those the camera is outside of (B < 0: the only ones a ray can enter through), in their model order, then the others (they can
+    // only end a ray's stay inside) -- a stable partition by ballot prefix sums, so the entering face of a ray does not depend on timing.
+    const int wv = tid >> 6, ln = tid & 63;
     for (int g = 1; g < GN_GEOM; g++) {
         const int np = gnum[g];
         if (np == 0) continue;
@@ -104,22 +148,43 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
         M3 Mx = mulm(M3{{R.m[0], R.m[3], R.m[6], R.m[1], R.m[4], R.m[7], R.m[2], R.m[5], R.m[8]}}, Rc);      // Rg^T Rc
         V3 ol = multv(R, co - p);
         const float *pl = m.hull_planes + 4 * m.hull_padr[g - 1];
-        for (int i = tid; i < np + NBOX; i += RTHREADS) {
-            V3 nn; float d;
-            if (i < NBOX) {
-                const int ax = i >> 1; const bool hi = i & 1;
-                nn = v3(ax == 0 ? 1.f : 0.f, ax == 1 ? 1.f : 0.f, ax == 2 ? 1.f : 0.f);
-                if (!hi) nn = -nn;
-                d = (hi ? m.hull_aabb[g - 1][3 + ax] : -m.hull_aabb[g - 1][ax]) + 1e-6f;
-            } else {
-                const int j = i - NBOX;
-                nn = v3(pl[4 * j], pl[4 * j + 1], pl[4 * j + 2]); d = pl[4 * j + 3];
-            }
+        float4 *tab = spl + gadr[g];
+        if (tid < NBOX) {
+            const int ax = tid >> 1; const bool hi = tid & 1;
+            V3 nn = v3(ax == 0 ? 1.f : 0.f, ax == 1 ? 1.f : 0.f, ax == 2 ? 1.f : 0.f);
+            if (!hi) nn = -nn;
+            const float d = (hi ? m.hull_aabb[g - 1][3 + ax] : -m.hull_aabb[g - 1][ax]) + 1e-6f;
             V3 A = multv(Mx, nn);
-            spl[gadr[g] + i] = make_float4(A.x, A.y, A.z, d - dot(nn, ol));
+            tab[tid] = make_float4(A.x, A.y, A.z, d - dot(nn, ol));
         }
+        int nfront = 0;
+        for (int j0 = 0; j0 < np; j0 += RTHREADS) {
+            const int j = j0 + tid;
+            float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < np) {
+                V3 nn = v3(pl[4 * j], pl[4 * j + 1], pl[4 * j + 2]);
+                V3 A = multv(Mx, nn);
+                P = make_float4(A.x, A.y, A.z, pl[4 * j + 3] - dot(nn, ol));
+            }
+            const bool front = j < np && P.w < 0.f;
+            const unsigned long long bal = __ballot(front);
+            if (ln == 0) wcnt[wv] = __popcll(bal);
+            __syncthreads();
+            int before = 0, tot = 0;
+#pragma unroll
+            for (int k = 0; k < RTHREADS / 64; k++) { const int c = wcnt[k]; before += k < wv ? c : 0; tot += c; }
+            const int fpos = nfront + before + __popcll(bal & ((1ull << ln) - 1ull));       // camera-facing planes before this one
+            if (j < np) tab[NBOX + (front ? fpos : np - 1 - (j - fpos))] = P;
+            nfront += tot;
+            __syncthreads();
+        }
+        if (tid == 0) gnf[g] = nfront;
+    }
     }
     __syncthreads();
+    // the camera frame is read again where it is needed (ray set-up, shading) rather than held in 12 registers across the plane loops
+    const Frames *frl = &fr;
+    asm volatile("" : "+v"(frl));
     const int nch = cfg.full_observation ? 5 : 4;
     uint8_t *o = obs + (size_t)blockIdx.x * nch * RPIX;
     uint8_t *o2 = obs2 ? obs2 + (size_t)(row2[0] + blockIdx.x) * nch * RPIX : nullptr;
@@ -138,9 +203,9 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
 #pragma unroll
     for (int q = 0; q < TPX; q++) {
         float x = xs[q % TW], y = ys[q / TW];
-        float dz = Rc.m[6] * x + Rc.m[7] * y - Rc.m[8];
+        float dz = frl->cam_R[6] * x + frl->cam_R[7] * y - frl->cam_R[8];
         best[q] = m.zfar; hitent[q] = -1;
-        if (dz < 0.f) { float t = -co.z / dz; if (t > m.znear && t < best[q]) { best[q] = t; hitent[q] = 0; } }
+        if (dz < 0.f) { float t = -frl->cam_o[2] / dz; if (t > m.znear && t < best[q]) { best[q] = t; hitent[q] = 0; } }
     }
     for (int g = 1; g < GN_GEOM; g++) {
         const int np = gnum[g];
@@ -179,19 +244,22 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
             for (int q = 0; q < TPX; q++) if (bin[q] > bout[q] || bout[q] < 0.f || bin[q] > best[q]) mask &= ~(1u << q);
         }
         if (mask == 0u) continue;
+        // Cyrus-Beck without a division per plane. Every ray starts at the camera, so a plane's B is one number for all rays: through a
+        // plane with B < 0 (camera outside) a ray enters at t = B / den (den = A.dc < 0) or, when den >= 0, never reaches the hull at all;
+        // a plane with B >= 0 bounds the stay from above (t den <= B). First run: the latest entry max B_i / den_i as an arg-max over
+        // fractions compared by cross-multiplication (both denominators negative), one division at its end; second run: the entry
+        // point must satisfy every other plane, t_in den_i <= B_i -- two FMAs and a max per plane and ray.
         const float4 *sp = spl + gadr[g] + NBOX;
-        float tin[TPX], tout[TPX]; int ent[TPX];
+        const int nf = gnf[g];
+        float bn[TPX], bd[TPX], dmax[TPX]; int ent[TPX];
 #pragma unroll
-        for (int q = 0; q < TPX; q++) { tin[q] = -3.0e38f; tout[q] = 3.0e38f; ent[q] = -1; }
-        // Cyrus-Beck: u = B / |A.dc| by v_rcp_f32 (1 ulp). Entering planes (A.dc < 0) raise t_in = -u, the others lower
-        // t_out = u; a parallel plane with the origin outside gives u = -inf and so t_in > t_out: a miss, as it must be.
-        for (int pi = 0; pi < np; pi++) {
-            // every 16 planes: rays that are already clipped away (t_in > t_out) stay missed; when that holds for every ray of the
-            // wave the rest of the list is skipped (tiles next to a hull's silhouette pass its box but miss the hull)
+        for (int q = 0; q < TPX; q++) { bn[q] = 0.f; bd[q] = -1.f; dmax[q] = -3.0e38f; ent[q] = -1; }
+        for (int pi = 0; pi < nf; pi++) {
+            // every 16 planes: a wave none of whose rays can still reach the hull leaves the list (tiles next to a silhouette pass the box)
             if ((pi & 15) == 0 && pi > 0) {
                 bool alive = false;
 #pragma unroll
-                for (int q = 0; q < TPX; q++) alive |= ((mask >> q) & 1u) && !(tin[q] > tout[q]);
+                for (int q = 0; q < TPX; q++) alive |= ((mask >> q) & 1u) && dmax[q] < 0.f;
                 if (!__any(alive)) break;
             }
             const float4 P = sp[pi];
@@ -200,21 +268,52 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
             for (int a = 0; a < TW; a++) cxa[a] = fmaf(P.x, xs[a], -P.z);
 #pragma unroll
             for (int q = 0; q < TPX; q++) {
-                float den = fmaf(P.y, ys[q / TW], cxa[q % TW]);
-                float u = P.w * rcp(fabsf(den));
-                bool in = den < 0.f, up = in && -u > tin[q];
-                tin[q] = up ? -u : tin[q]; ent[q] = up ? pi : ent[q];
-                tout[q] = (!in && u < tout[q]) ? u : tout[q];
+                const float den = fmaf(P.y, ys[q / TW], cxa[q % TW]);
+                const bool up = P.w * bd[q] > bn[q] * den;              // B_i / den_i > B_b / den_b, both denominators negative
+                bn[q] = up ? P.w : bn[q]; bd[q] = up ? den : bd[q]; ent[q] = up ? pi : ent[q];
+                dmax[q] = fmaxf(dmax[q], den);
+            }
+        }
+        float tin[TPX];
+        bool any_left = false;
+#pragma unroll
+        for (int q = 0; q < TPX; q++) {
+            tin[q] = bn[q] * rcp(bd[q]);
+            const bool ok = ((mask >> q) & 1u) && dmax[q] < 0.f && ent[q] >= 0 && tin[q] > 0.f && tin[q] > m.znear && tin[q] < best[q];
+            if (!ok) mask &= ~(1u << q);
+            any_left |= ok;
+        }
+        if (!__any(any_left)) continue;
+        float viol[TPX];
+#pragma unroll
+        for (int q = 0; q < TPX; q++) viol[q] = ((mask >> q) & 1u) ? -3.0e38f : 3.0e38f;
+        for (int pi = nf; pi < np; pi++) {
+            if (((pi - nf) & 15) == 0 && pi > nf) {
+                bool alive = false;
+#pragma unroll
+                for (int q = 0; q < TPX; q++) alive |= !(viol[q] > 0.f);
+                if (!__any(alive)) break;
+            }
+            const float4 P = sp[pi];
+            float cxa[TW];
+#pragma unroll
+            for (int a = 0; a < TW; a++) cxa[a] = fmaf(P.x, xs[a], -P.z);
+#pragma unroll
+            for (int q = 0; q < TPX; q++) {
+                const float den = fmaf(P.y, ys[q / TW], cxa[q % TW]);
+                viol[q] = fmaxf(viol[q], fmaf(tin[q], den, -P.w));
             }
         }
 #pragma unroll
         for (int q = 0; q < TPX; q++) {
-            bool ok = ((mask >> q) & 1u) && !(tin[q] > tout[q]) && ent[q] >= 0 && tin[q] > 0.f && tin[q] > m.znear && tin[q] < best[q];
+            const bool ok = !(viol[q] > 0.f);
             best[q] = ok ? tin[q] : best[q]; hitent[q] = ok ? ((g << 16) | ent[q]) : hitent[q];
         }
     }
     // shading (flat Lambert, headlight-free: the scene's first directional light) and the RGB bytes
     const V3 L = normalized(v3(-m.light_dir[0][0], -m.light_dir[0][1], -m.light_dir[0][2]));
+    asm volatile("" : "+v"(frl));
+    const V3 co = ldv(frl->cam_o); const M3 Rc = ldm(frl->cam_R);
     float lmin = 3.0e38f;
 #pragma unroll
     for (int q = 0; q < TPX; q++) {
@@ -235,8 +334,8 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
                 b0 = m.floor_rgb[off]; b1 = m.floor_rgb[off + 1]; b2 = m.floor_rgb[off + 2];
             } else {
                 b0 = m.geom_rgba[hit][0]; b1 = m.geom_rgba[hit][1]; b2 = m.geom_rgba[hit][2];
-                const float *pl = m.hull_planes + 4 * (m.hull_padr[hit - 1] + (hitent[q] & 0xffff));
-                nrm = mulv(ldm(fr.R[hit - 1]), v3(pl[0], pl[1], pl[2]));
+                const float4 P = spl[gadr[hit] + NBOX + (hitent[q] & 0xffff)];        // the entering plane's normal in camera coordinates
+                nrm = mulv(Rc, v3(P.x, P.y, P.z));
             }
             float shade = 0.4f + 0.6f * fmaxf(dot(nrm, L), 0.f);
             c0 = b0 * shade; c1 = b1 * shade; c2 = b2 * shade;
