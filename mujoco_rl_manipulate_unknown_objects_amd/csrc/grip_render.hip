@@ -99,6 +99,9 @@ __device__ static uint8_t to_u8(float v) { v *= 255.f; v = fminf(fmaxf(v, 0.f), 
 // Hulls whose bounding sphere lies behind the camera plane are dropped for the whole env (the gripper base always is).
 // Every thread owns a TW x TW pixel tile (1024 threads per env) and keeps its rays' (t_in, t_out, entering plane) in registers, so that a plane is
 // read from LDS once per 16 rays and costs one FMA + rcp + a few selects per ray; depth never leaves registers.
+typedef float f2 __attribute__((ext_vector_type(2)));         // two rays of a tile row: v_pk_fma_f32 / v_pk_mul_f32 work on both at once
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 bc2(float x) { return (f2){x, x}; }
 #define TW 2                // tile width: every thread owns a TW x TW pixel tile
 #define TPX (TW * TW)
 #define NBOX 6              // bounding-box planes in front of every hull's plane list
@@ -110,7 +113,7 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
     __shared__ Frames fr;
     __shared__ float gsph[GN_GEOM][4];          // bounding sphere centre in camera coordinates, radius^2
     extern __shared__ float4 spl[];             // camera-space plane table of this env (sized by the launcher: planes x 16 B)
-    __shared__ int gadr[GN_GEOM], gnum[GN_GEOM], gnf[GN_GEOM];   // table start, planes, planes facing the camera (listed first)
+    __shared__ int gadr[GN_GEOM], gnum[GN_GEOM], gnf[GN_GEOM], gbf[GN_GEOM];   // table start, planes, planes / box planes facing the camera (listed first)
     __shared__ int wcnt[RTHREADS / 64];
     __shared__ float red[RTHREADS];
     __shared__ int redi[RTHREADS];
@@ -149,13 +152,21 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
         V3 ol = multv(R, co - p);
         const float *pl = m.hull_planes + 4 * m.hull_padr[g - 1];
         float4 *tab = spl + gadr[g];
-        if (tid < NBOX) {
-            const int ax = tid >> 1; const bool hi = tid & 1;
-            V3 nn = v3(ax == 0 ? 1.f : 0.f, ax == 1 ? 1.f : 0.f, ax == 2 ? 1.f : 0.f);
-            if (!hi) nn = -nn;
-            const float d = (hi ? m.hull_aabb[g - 1][3 + ax] : -m.hull_aabb[g - 1][ax]) + 1e-6f;
-            V3 A = multv(Mx, nn);
-            tab[tid] = make_float4(A.x, A.y, A.z, d - dot(nn, ol));
+        if (wv == 0) {                                                  // the box planes, partitioned the same way inside the first wave
+            float4 P = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tid < NBOX) {
+                const int ax = tid >> 1; const bool hi = tid & 1;
+                V3 nn = v3(ax == 0 ? 1.f : 0.f, ax == 1 ? 1.f : 0.f, ax == 2 ? 1.f : 0.f);
+                if (!hi) nn = -nn;
+                const float d = (hi ? m.hull_aabb[g - 1][3 + ax] : -m.hull_aabb[g - 1][ax]) + 1e-6f;
+                V3 A = multv(Mx, nn);
+                P = make_float4(A.x, A.y, A.z, d - dot(nn, ol));
+            }
+            const bool front = tid < NBOX && P.w < 0.f;
+            const unsigned long long bal = __ballot(front);
+            const int fpos = __popcll(bal & ((1ull << ln) - 1ull));
+            if (tid < NBOX) tab[front ? fpos : NBOX - 1 - (tid - fpos)] = P;
+            if (tid == 0) gbf[g] = __popcll(bal);
         }
         int nfront = 0;
         for (int j0 = 0; j0 < np; j0 += RTHREADS) {
@@ -199,6 +210,7 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
         xs[a] = (2.0f * (TW * tx + a + 0.5f) / RW - 1.0f) * tanh_;
         ys[a] = (1.0f - 2.0f * (TW * ty + a + 0.5f) / RH) * tanh_;
     }
+    const f2 xs2 = {xs[0], xs[1]};
     float best[TPX]; int hitent[TPX];                                   // hit geom << 16 | entering plane; -1 = sky
 #pragma unroll
     for (int q = 0; q < TPX; q++) {
@@ -222,92 +234,106 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
             mask |= pass ? (1u << q) : 0u;
         }
         if (mask == 0u) continue;
-        {   // bounding box first: six planes, no entering-plane bookkeeping
-            const float4 *sb = spl + gadr[g];
-            float bin[TPX], bout[TPX];
-#pragma unroll
-            for (int q = 0; q < TPX; q++) { bin[q] = -3.0e38f; bout[q] = 3.0e38f; }
-#pragma unroll
-            for (int pi = 0; pi < NBOX; pi++) {
-                const float4 P = sb[pi];
-#pragma unroll
-                for (int q = 0; q < TPX; q++) {
-                    float den = fmaf(P.y, ys[q / TW], fmaf(P.x, xs[q % TW], -P.z));
-                    float u = P.w * rcp(fabsf(den));
-                    bool in = den < 0.f;
-                    bin[q] = (in && -u > bin[q]) ? -u : bin[q];
-                    bout[q] = (!in && u < bout[q]) ? u : bout[q];
-                }
-            }
-            // ... and a box that starts behind what the ray has already hit (floor, nearer hull) cannot give a nearer hit
-#pragma unroll
-            for (int q = 0; q < TPX; q++) if (bin[q] > bout[q] || bout[q] < 0.f || bin[q] > best[q]) mask &= ~(1u << q);
-        }
-        if (mask == 0u) continue;
         // Cyrus-Beck without a division per plane. Every ray starts at the camera, so a plane's B is one number for all rays: through a
         // plane with B < 0 (camera outside) a ray enters at t = B / den (den = A.dc < 0) or, when den >= 0, never reaches the hull at all;
         // a plane with B >= 0 bounds the stay from above (t den <= B). First run: the latest entry max B_i / den_i as an arg-max over
         // fractions compared by cross-multiplication (both denominators negative), one division at its end; second run: the entry
-        // point must satisfy every other plane, t_in den_i <= B_i -- two FMAs and a max per plane and ray.
-        const float4 *sp = spl + gadr[g] + NBOX;
-        const int nf = gnf[g];
-        float bn[TPX], bd[TPX], dmax[TPX]; int ent[TPX];
+        // point must satisfy every other plane, B_i - t_in den_i >= 0. The rays of a tile row go through the packed fp32 pipe in pairs
+        // (index q = 2 * row + column); "every denominator negative" and "no plane violated" are kept as sign bits (AND / OR of the raw words).
+        const float4 *sb = spl + gadr[g];
+        f2 bn[TW], bd[TW]; int dneg[TPX];
 #pragma unroll
-        for (int q = 0; q < TPX; q++) { bn[q] = 0.f; bd[q] = -1.f; dmax[q] = -3.0e38f; ent[q] = -1; }
+        for (int r = 0; r < TW; r++) { bn[r] = bc2(0.f); bd[r] = bc2(-1.f); dneg[2 * r] = dneg[2 * r + 1] = -1; }
+        {   // bounding box first: six planes, no entering-plane bookkeeping
+            const int bf = gbf[g];
+            for (int pi = 0; pi < bf; pi++) {
+                const float4 P = sb[pi];
+                const f2 cxa = fma2(bc2(P.x), xs2, bc2(-P.z));
+#pragma unroll
+                for (int r = 0; r < TW; r++) {
+                    const f2 den = fma2(bc2(P.y), bc2(ys[r]), cxa);
+                    const f2 lhs = bc2(P.w) * bd[r], rhs = bn[r] * den;
+                    const bool u0 = lhs.x > rhs.x, u1 = lhs.y > rhs.y;
+                    bn[r].x = u0 ? P.w : bn[r].x; bd[r].x = u0 ? den.x : bd[r].x;
+                    bn[r].y = u1 ? P.w : bn[r].y; bd[r].y = u1 ? den.y : bd[r].y;
+                    dneg[2 * r] &= __float_as_int(den.x); dneg[2 * r + 1] &= __float_as_int(den.y);
+                }
+            }
+            f2 tb[TW]; int vio[TPX];
+#pragma unroll
+            for (int r = 0; r < TW; r++) { tb[r] = bn[r] * (f2){rcp(bd[r].x), rcp(bd[r].y)}; vio[2 * r] = vio[2 * r + 1] = 0; }
+            for (int pi = bf; pi < NBOX; pi++) {
+                const float4 P = sb[pi];
+                const f2 cxa = fma2(bc2(P.x), xs2, bc2(-P.z));
+#pragma unroll
+                for (int r = 0; r < TW; r++) {
+                    const f2 den = fma2(bc2(P.y), bc2(ys[r]), cxa);
+                    const f2 w = fma2(-tb[r], den, bc2(P.w));
+                    vio[2 * r] |= __float_as_int(w.x); vio[2 * r + 1] |= __float_as_int(w.y);
+                }
+            }
+            // ... and a box that starts behind what the ray has already hit (floor, nearer hull) cannot give a nearer hit
+#pragma unroll
+            for (int q = 0; q < TPX; q++) if (dneg[q] >= 0 || vio[q] < 0 || tb[q / TW][q % TW] > best[q]) mask &= ~(1u << q);
+        }
+        if (mask == 0u) continue;
+        const float4 *sp = sb + NBOX;
+        const int nf = gnf[g];
+        int ent[TPX];
+#pragma unroll
+        for (int r = 0; r < TW; r++) { bn[r] = bc2(0.f); bd[r] = bc2(-1.f); dneg[2 * r] = dneg[2 * r + 1] = -1; ent[2 * r] = ent[2 * r + 1] = -1; }
         for (int pi = 0; pi < nf; pi++) {
             // every 16 planes: a wave none of whose rays can still reach the hull leaves the list (tiles next to a silhouette pass the box)
             if ((pi & 15) == 0 && pi > 0) {
                 bool alive = false;
 #pragma unroll
-                for (int q = 0; q < TPX; q++) alive |= ((mask >> q) & 1u) && dmax[q] < 0.f;
+                for (int q = 0; q < TPX; q++) alive |= ((mask >> q) & 1u) && dneg[q] < 0;
                 if (!__any(alive)) break;
             }
             const float4 P = sp[pi];
-            float cxa[TW];
+            const f2 cxa = fma2(bc2(P.x), xs2, bc2(-P.z));
 #pragma unroll
-            for (int a = 0; a < TW; a++) cxa[a] = fmaf(P.x, xs[a], -P.z);
-#pragma unroll
-            for (int q = 0; q < TPX; q++) {
-                const float den = fmaf(P.y, ys[q / TW], cxa[q % TW]);
-                const bool up = P.w * bd[q] > bn[q] * den;              // B_i / den_i > B_b / den_b, both denominators negative
-                bn[q] = up ? P.w : bn[q]; bd[q] = up ? den : bd[q]; ent[q] = up ? pi : ent[q];
-                dmax[q] = fmaxf(dmax[q], den);
+            for (int r = 0; r < TW; r++) {
+                const f2 den = fma2(bc2(P.y), bc2(ys[r]), cxa);
+                const f2 lhs = bc2(P.w) * bd[r], rhs = bn[r] * den;     // B_i / den_i > B_b / den_b, both denominators negative
+                const bool u0 = lhs.x > rhs.x, u1 = lhs.y > rhs.y;
+                bn[r].x = u0 ? P.w : bn[r].x; bd[r].x = u0 ? den.x : bd[r].x; ent[2 * r] = u0 ? pi : ent[2 * r];
+                bn[r].y = u1 ? P.w : bn[r].y; bd[r].y = u1 ? den.y : bd[r].y; ent[2 * r + 1] = u1 ? pi : ent[2 * r + 1];
+                dneg[2 * r] &= __float_as_int(den.x); dneg[2 * r + 1] &= __float_as_int(den.y);
             }
         }
-        float tin[TPX];
+        f2 tin[TW]; int vio[TPX];
         bool any_left = false;
 #pragma unroll
+        for (int r = 0; r < TW; r++) tin[r] = bn[r] * (f2){rcp(bd[r].x), rcp(bd[r].y)};
+#pragma unroll
         for (int q = 0; q < TPX; q++) {
-            tin[q] = bn[q] * rcp(bd[q]);
-            const bool ok = ((mask >> q) & 1u) && dmax[q] < 0.f && ent[q] >= 0 && tin[q] > 0.f && tin[q] > m.znear && tin[q] < best[q];
-            if (!ok) mask &= ~(1u << q);
+            const float t = tin[q / TW][q % TW];
+            const bool ok = ((mask >> q) & 1u) && dneg[q] < 0 && ent[q] >= 0 && t > 0.f && t > m.znear && t < best[q];
+            vio[q] = ok ? 0 : (int)0x80000000;
             any_left |= ok;
         }
         if (!__any(any_left)) continue;
-        float viol[TPX];
-#pragma unroll
-        for (int q = 0; q < TPX; q++) viol[q] = ((mask >> q) & 1u) ? -3.0e38f : 3.0e38f;
         for (int pi = nf; pi < np; pi++) {
             if (((pi - nf) & 15) == 0 && pi > nf) {
                 bool alive = false;
 #pragma unroll
-                for (int q = 0; q < TPX; q++) alive |= !(viol[q] > 0.f);
+                for (int q = 0; q < TPX; q++) alive |= vio[q] >= 0;
                 if (!__any(alive)) break;
             }
             const float4 P = sp[pi];
-            float cxa[TW];
+            const f2 cxa = fma2(bc2(P.x), xs2, bc2(-P.z));
 #pragma unroll
-            for (int a = 0; a < TW; a++) cxa[a] = fmaf(P.x, xs[a], -P.z);
-#pragma unroll
-            for (int q = 0; q < TPX; q++) {
-                const float den = fmaf(P.y, ys[q / TW], cxa[q % TW]);
-                viol[q] = fmaxf(viol[q], fmaf(tin[q], den, -P.w));
+            for (int r = 0; r < TW; r++) {
+                const f2 den = fma2(bc2(P.y), bc2(ys[r]), cxa);
+                const f2 w = fma2(-tin[r], den, bc2(P.w));              // B_i - t_in den_i: negative = the entry point lies outside plane i
+                vio[2 * r] |= __float_as_int(w.x); vio[2 * r + 1] |= __float_as_int(w.y);
             }
         }
 #pragma unroll
         for (int q = 0; q < TPX; q++) {
-            const bool ok = !(viol[q] > 0.f);
-            best[q] = ok ? tin[q] : best[q]; hitent[q] = ok ? ((g << 16) | ent[q]) : hitent[q];
+            const bool ok = vio[q] >= 0;
+            best[q] = ok ? tin[q / TW][q % TW] : best[q]; hitent[q] = ok ? ((g << 16) | ent[q]) : hitent[q];
         }
     }
     // shading (flat Lambert, headlight-free: the scene's first directional light) and the RGB bytes
