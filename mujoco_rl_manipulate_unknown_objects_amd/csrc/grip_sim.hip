@@ -727,6 +727,7 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const GroupArgs *_
 // one or two, more -- so that the 4 envs of a wave and the 16 of a workgroup cost about the same per physics.step(), then
 // the idle envs, whose workgroups retire at once.
 #define CP_THREADS 1024
+#define CP_FAST_CHUNK 16    // batches up to 16384 envs sort their work order by the ballot / single-scan path
 // id_offset: added to the env ids written to `list` (0 for a single batch, the group's first global env id in a set)
 // inclusive prefix sum of one int per thread over the 1024-thread block: wave-level shuffles, then the 16 wave totals through LDS
 // (two barriers per scan instead of the twenty of a Hillis-Steele sweep through LDS: the compaction runs between every two slices)
@@ -767,20 +768,54 @@ DEVI void compact_body(const MacroCtx &mc, int n, int capacity, int *list, int *
     for (int p = cnt + t; p < capacity; p += CP_THREADS) list[p] = -1;
     if (t == 0) *count = cnt;
     __syncthreads();
-    // pass 2: counting sort of the envs by class (0..2 = running by cost, 3 = idle), stable within a class
+    // pass 2: counting sort of the envs by class (0..14 = running by cost, 15 = idle), stable within a class
     auto cls_of = [&](int e) { bool run = mc.astate[e] == 0 || mc.slot[e] >= 0; return !run ? CP_CLASSES - 1 : min(max(mc.heavy[e], 0), CP_CLASSES - 2); };
-    int mine[CP_CLASSES], before[CP_CLASSES];
-    for (int k = 0; k < CP_CLASSES; k++) mine[k] = 0;
-    for (int i = 0; i < chunk; i++) { int e = t * chunk + i; if (e < n) mine[cls_of(e)]++; }
-    for (int k = 0; k < CP_CLASSES; k++) {
+    if (chunk <= CP_FAST_CHUNK) {
+        // env e = i * 1024 + t: per chunk row i and wave w the class counts come from 16 ballots; one block scan over the table
+        // [class][row][wave] gives every (class, row, wave) cell its first position, a lane's rank inside its cell is a popcount.
+        // Same order[] as the general path below (class-major, env-ascending), four barriers instead of thirty-four.
+        __shared__ int hist[CP_CLASSES * CP_FAST_CHUNK * (CP_THREADS / 64)];
+        const int lane = t & 63, w = t >> 6;
+        for (int i = 0; i < chunk; i++) {
+            const int e = i * CP_THREADS + t;
+            const int k = e < n ? cls_of(e) : -1;
+            for (int kk = 0; kk < CP_CLASSES; kk++) {
+                const unsigned long long mk = __ballot(k == kk);
+                if (lane == kk) hist[(kk * chunk + i) * (CP_THREADS / 64) + w] = __popcll(mk);
+            }
+        }
+        __syncthreads();
+        const int cells = CP_CLASSES * chunk * (CP_THREADS / 64), per = (cells + CP_THREADS - 1) / CP_THREADS;
+        int sum = 0;
+        for (int j = 0; j < per; j++) { const int c2 = t * per + j; if (c2 < cells) sum += hist[c2]; }
         int tot;
-        before[k] = block_scan_incl(mine[k], wsum, tot) - mine[k];
-        if (t == 0) cls_total[k] = tot;
+        int run = block_scan_incl(sum, wsum, tot) - sum;
+        for (int j = 0; j < per; j++) { const int c2 = t * per + j; if (c2 < cells) { const int v = hist[c2]; hist[c2] = run; run += v; } }
+        __syncthreads();
+        for (int i = 0; i < chunk; i++) {
+            const int e = i * CP_THREADS + t;
+            const int k = e < n ? cls_of(e) : -1;
+            int rank = 0;
+            for (int kk = 0; kk < CP_CLASSES; kk++) {
+                const unsigned long long mk = __ballot(k == kk);
+                if (k == kk) rank = __popcll(mk & ((1ull << lane) - 1ull));
+            }
+            if (k >= 0) order[hist[(k * chunk + i) * (CP_THREADS / 64) + w] + rank] = e;
+        }
+    } else {
+        int mine[CP_CLASSES], before[CP_CLASSES];
+        for (int k = 0; k < CP_CLASSES; k++) mine[k] = 0;
+        for (int i = 0; i < chunk; i++) { int e = t * chunk + i; if (e < n) mine[cls_of(e)]++; }
+        for (int k = 0; k < CP_CLASSES; k++) {
+            int tot;
+            before[k] = block_scan_incl(mine[k], wsum, tot) - mine[k];
+            if (t == 0) cls_total[k] = tot;
+        }
+        __syncthreads();
+        int start = 0;
+        for (int k = 0; k < CP_CLASSES; k++) { before[k] += start; start += cls_total[k]; }
+        for (int i = 0; i < chunk; i++) { int e = t * chunk + i; if (e < n) order[before[cls_of(e)]++] = e; }
     }
-    __syncthreads();
-    int start = 0;
-    for (int k = 0; k < CP_CLASSES; k++) { before[k] += start; start += cls_total[k]; }
-    for (int i = 0; i < chunk; i++) { int e = t * chunk + i; if (e < n) order[before[cls_of(e)]++] = e; }
     if (t == 0) { mc.tick[0] = mc.tick[0] + 1; mc.t0[0] = 0ULL; }     // every thread read the old tick before the first barrier
 }
 // one block per group: segment g of the list gets the group's waiting envs (global ids), -1 beyond its count (counts[g]);
