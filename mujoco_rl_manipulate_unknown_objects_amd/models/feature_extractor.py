@@ -54,6 +54,34 @@ class AugmentedNatureCNN(BaseFeaturesExtractor):
             n_flatten = self.cnn(th.zeros(1, n_input_channels, shape[1], shape[2])).shape[1]
         self.linear = nn.Sequential(nn.Linear(n_flatten, features_dim - 2), nn.ReLU())
 
+    # ---- rollout-side features for ActorCriticPolicy's merged-heads forward (no autograd): the fused first layer, the library's
+    # convolutions, and the linear layer applied to the NHWC tensor as it lies in memory (its weight's columns re-ordered once per
+    # refresh) instead of to the NCHW copy nn.Flatten makes of a channels_last tensor.
+    _wl_nhwc = None
+
+    @th.no_grad()
+    def refresh_rollout_cache(self):
+        lw = self.linear[0].weight
+        c3 = self.cnn[4].out_channels
+        hw = int(round((lw.shape[1] // c3) ** 0.5))
+        if self._wl_nhwc is None or self._wl_nhwc.device != lw.device:
+            self._wl_nhwc = th.empty_like(lw)
+        self._wl_nhwc.copy_(lw.view(lw.shape[0], c3, hw, hw).permute(0, 2, 3, 1).reshape(lw.shape[0], -1))
+
+    def rollout_features(self, observations):
+        """[B, features_dim] for raw uint8 CUDA observations of the default layout, None otherwise (the caller then uses forward())."""
+        obs = observations["observation"]
+        c0 = self.cnn[0]
+        if not (self._wl_nhwc is not None and obs.dtype == th.uint8 and obs.is_cuda and not th.is_grad_enabled() and tuple(obs.shape[1:]) == (5, 64, 64)
+                and tuple(c0.weight.shape) == (32, 4, 8, 8) and c0.stride == (4, 4) and c0.padding == (0, 0) and c0.weight.dtype == th.float32
+                and not th.is_autocast_enabled()):
+            return None
+        from ..engine import conv1_u8
+        x, other = conv1_u8(obs.contiguous(), c0.weight, c0.bias)
+        x = th.relu_(self.cnn[2](x)); x = th.relu_(self.cnn[4](x))
+        xf = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)          # a view: the tensor is channels_last
+        return th.cat((th.relu_(th.addmm(self.linear[0].bias, xf, self._wl_nhwc.t())), other), dim=1)
+
     def forward(self, observations, num_direct_features: int = 2) -> th.Tensor:
         obs = observations["observation"]
         c0 = self.cnn[0]

@@ -90,8 +90,65 @@ class ActorCriticPolicy(nn.Module):
 
     def forward_parts(self, obs):
         """(mean, log_std, values): the Gaussian head left un-sampled, for callers that sample and score in a fused kernel."""
+        if self._rollout_cache is not None and not th.is_grad_enabled():
+            return self._forward_parts_merged(obs)
         lp, lv = self._latents(obs)
         return self.action_net(lp).float(), self.log_std.float(), self.value_net(lv).float().squeeze(-1)
+
+    # ---- rollout-side forward with merged heads (no autograd): the policy and value MLPs have the same shape, so their first layers
+    # are one GEMM on the shared features, the deeper ones block-diagonal, the action and value heads one [A + 1]-row GEMM; the
+    # extractor hands over its features without the NCHW copy nn.Flatten makes of a channels_last tensor. Half the launches of the
+    # module-by-module forward (232 -> 192 us per 1024 rows on MI355X, tools/policy_fwd_bench.py), the same sums up to fp32 rounding.
+    # The merged weights live at fixed addresses (a captured rollout tick keeps reading them): refresh_rollout_cache() after
+    # every change of the parameters -- PPO calls it at the start of each collect_rollouts().
+    _rollout_cache = None
+
+    def enable_rollout_cache(self):
+        """Switch forward_parts() under no_grad to the merged-heads path when the architecture allows it; returns whether it did."""
+        pl = [m for m in self.policy_net if isinstance(m, nn.Linear)]; vl = [m for m in self.value_net_mlp if isinstance(m, nn.Linear)]
+        ok = (self.vf_features_extractor is None and len(pl) == len(vl) >= 1 and all(a.weight.shape == b.weight.shape for a, b in zip(pl, vl))
+              and all(isinstance(m, (nn.Linear, nn.Tanh)) for m in list(self.policy_net) + list(self.value_net_mlp))
+              and hasattr(self.features_extractor, "rollout_features") and self.action_net.weight.is_cuda)
+        if not ok:
+            return False
+        dev, A = self.action_net.weight.device, self.action_dim
+        c = {"W": [], "b": [], "pl": pl, "vl": vl}
+        for i, (a, b) in enumerate(zip(pl, vl)):
+            o, k = a.weight.shape
+            c["W"].append(th.zeros(2 * o, k if i == 0 else 2 * k, device=dev)); c["b"].append(th.zeros(2 * o, device=dev))
+        hd = pl[-1].weight.shape[0]
+        c["Wh"] = th.zeros(A + 1, 2 * hd, device=dev); c["bh"] = th.zeros(A + 1, device=dev)
+        self._rollout_cache = c
+        self.refresh_rollout_cache()
+        return True
+
+    @th.no_grad()
+    def refresh_rollout_cache(self):
+        c = self._rollout_cache
+        if c is None:
+            return
+        for i, (a, b) in enumerate(zip(c["pl"], c["vl"])):
+            o, k = a.weight.shape
+            if i == 0:
+                c["W"][i][:o].copy_(a.weight); c["W"][i][o:].copy_(b.weight)
+            else:
+                c["W"][i][:o, :k].copy_(a.weight); c["W"][i][o:, k:].copy_(b.weight)
+            c["b"][i][:o].copy_(a.bias); c["b"][i][o:].copy_(b.bias)
+        A, hd = self.action_dim, c["pl"][-1].weight.shape[0]
+        c["Wh"][:A, :hd].copy_(self.action_net.weight); c["Wh"][A, hd:].copy_(self.value_net.weight[0])
+        c["bh"][:A].copy_(self.action_net.bias); c["bh"][A:].copy_(self.value_net.bias)
+        self.features_extractor.refresh_rollout_cache()
+
+    def _forward_parts_merged(self, obs):
+        c = self._rollout_cache
+        h = self.features_extractor.rollout_features(self._prep(obs))
+        if h is None:                                               # not the observation layout the extractor's fast path handles
+            lp, lv = self._latents(obs)
+            return self.action_net(lp).float(), self.log_std.float(), self.value_net(lv).float().squeeze(-1)
+        for W, b in zip(c["W"], c["b"]):
+            h = th.tanh_(th.addmm(b, h, W.t()))
+        o = th.addmm(c["bh"], h, c["Wh"].t())
+        return o[:, :self.action_dim], self.log_std.float(), o[:, self.action_dim]
 
     def evaluate_actions(self, obs, actions):
         lp, lv = self._latents(obs)

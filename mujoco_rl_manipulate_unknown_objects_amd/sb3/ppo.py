@@ -132,6 +132,8 @@ class PPO:
             self._async = AsyncRollout(eng, policy_fn, policy_parts_fn=parts, target=n_steps * self.n_envs, capacity=min(cap, self.n_envs), slice_len=async_slice,
                                        gamma=gamma, gae_lambda=gae_lambda, action_low=env.action_space.low, action_high=env.action_space.high)
             self.rollout_buffer = None
+            if self.device.type == "cuda" and hasattr(self.policy_rollout, "enable_rollout_cache"):
+                self.policy_rollout.enable_rollout_cache()       # merged policy / value heads for the no-grad rollout forward
             if async_auto_slice:
                 self._async.set_slice_ladder()
         self.num_timesteps = 0
@@ -158,6 +160,8 @@ class PPO:
                 # rollout weights of this rollout are in place; in stream order this also means the update before the last
                 # one is done, i.e. the record window this rollout is about to overwrite is free
                 th.cuda.current_stream(self.device).wait_event(self._ev_copy)
+            if getattr(self.policy_rollout, "_rollout_cache", None) is not None:
+                self.policy_rollout.refresh_rollout_cache()          # merged-head weights of the rollout forward follow the update
             state = {"n": 0, "ok": True}
 
             def on_poll(done_n):

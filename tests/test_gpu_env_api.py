@@ -336,3 +336,49 @@ def test_fused_first_layer_gradients_match_the_library_path(torch):
         feats[fused] = net({"observation": obs}).detach()
         assert feats[fused].requires_grad is False
     assert (feats[True] - feats[False]).abs().max() < 2e-5 * (1 + feats[False].abs().max())
+
+
+def test_merged_heads_rollout_forward_matches_the_module_forward(torch):
+    """ActorCriticPolicy.forward_parts with the rollout cache (policy | value MLPs as merged GEMMs, NHWC flatten as a view) against the
+    module-by-module forward on the same weights: fp32 both ways, sums re-associated -- 2e-5 on means and values of order 0.1..1. The
+    cache follows the parameters only through refresh_rollout_cache(): checked by changing them."""
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3.policies import ActorCriticPolicy
+    from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.controller.sensor import RGBDSensor
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.controller.actuator import Actuator
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import default_config
+    cfg = default_config()
+    torch.manual_seed(3)
+    pol = ActorCriticPolicy(RGBDSensor(config=cfg).setup_observation_space(), Actuator(config=cfg).setup_action_space(),
+                            features_extractor_class=AugmentedNatureCNN, net_arch=[256, 256]).cuda().to(memory_format=torch.channels_last)
+    with torch.no_grad():                                   # biases and the action head away from their zero / 0.01 initialisation
+        for p in pol.parameters():
+            if p.ndim == 1:
+                p.add_(0.1 * torch.randn_like(p))
+        pol.action_net.weight.mul_(30.0)
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    for n in (1, 130, 1024):
+        obs = {"observation": torch.randint(0, 256, (n, 5, 64, 64), dtype=torch.uint8, device="cuda", generator=g)}
+        with torch.no_grad():
+            ref = pol.forward_parts(obs)
+        assert pol._rollout_cache is None and pol.enable_rollout_cache()
+        with torch.no_grad():
+            got = pol.forward_parts(obs)
+        assert got[0].shape == ref[0].shape == (n, 6) and got[2].shape == ref[2].shape == (n,)
+        assert (got[0] - ref[0]).abs().max() < 2e-5 and (got[2] - ref[2]).abs().max() < 2e-5 and torch.equal(got[1], ref[1])
+        assert ref[0].abs().max() > 0.05 and ref[2].abs().max() > 0.05
+        # with autograd on the module path runs (the update never sees the cache)
+        assert pol.forward_parts(obs)[0].requires_grad
+        pol._rollout_cache = None
+    pol.enable_rollout_cache()
+    with torch.no_grad():
+        before = pol.forward_parts(obs)[0].clone()
+        pol.action_net.bias.add_(1.0)
+        stale = pol.forward_parts(obs)[0].clone()
+        pol.refresh_rollout_cache()
+        fresh = pol.forward_parts(obs)[0]
+    assert (stale - before).abs().max() < 1e-6 and (fresh - before - 1.0).abs().max() < 1e-5
+    # value-only extractor or unequal MLP shapes: no merged path
+    pol2 = ActorCriticPolicy(RGBDSensor(config=cfg).setup_observation_space(), Actuator(config=cfg).setup_action_space(),
+                             features_extractor_class=AugmentedNatureCNN, net_arch=dict(pi=[64], vf=[64, 64])).cuda()
+    assert not pol2.enable_rollout_cache() and pol2._rollout_cache is None

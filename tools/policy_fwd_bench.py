@@ -56,3 +56,34 @@ pol2 = ActorCriticPolicy(RGBDSensor(config=cfg).setup_observation_space(), Actua
 timeit("forward_parts, cudnn.benchmark=True", lambda: pol2.forward_parts({"observation": obs}))
 with torch.autocast("cuda", dtype=torch.bfloat16):
     timeit("forward_parts bf16 autocast", lambda: pol2.forward_parts({"observation": obs}))
+
+# merged heads: pi | vf first layers as one GEMM, second layers block-diagonal, both heads one GEMM; the flatten as a view of the NHWC tensor
+torch.backends.cudnn.benchmark = False
+pn, vn = pol.policy_net, pol.value_net_mlp
+with torch.no_grad():
+    W1 = torch.cat((pn[0].weight, vn[0].weight), 0).contiguous(); b1 = torch.cat((pn[0].bias, vn[0].bias))
+    W2 = torch.block_diag(pn[2].weight, vn[2].weight).contiguous(); b2 = torch.cat((pn[2].bias, vn[2].bias))
+    W3 = torch.zeros(7, 512, device="cuda"); W3[:6, :256] = pol.action_net.weight; W3[6, 256:] = pol.value_net.weight[0]
+    b3 = torch.cat((pol.action_net.bias, pol.value_net.bias))
+    lw = fe.linear[0].weight                                     # [512, 64*4*4] in (c, h, w) order
+    Wl = lw.view(512, 64, 4, 4).permute(0, 2, 3, 1).reshape(512, 1024).contiguous(); bl = fe.linear[0].bias
+def merged():
+    x, other = conv1_u8(obs, c0.weight, c0.bias)
+    x = torch.relu_(fe.cnn[2](x)); x = torch.relu_(fe.cnn[4](x))
+    xf = x.permute(0, 2, 3, 1).reshape(x.shape[0], 1024)
+    f = torch.cat((torch.relu_(torch.addmm(bl, xf, Wl.t())), other), 1)
+    h = torch.tanh_(torch.addmm(b1, f, W1.t()))
+    h = torch.tanh_(torch.addmm(b2, h, W2.t()))
+    o = torch.addmm(b3, h, W3.t())
+    return o[:, :6], pol.log_std, o[:, 6]
+out = timeit("merged heads + NHWC flatten view", merged)
+print("max |d mean|", (out[0] - ref[0]).abs().max().item(), "max |d value|", (out[2] - ref[2]).abs().max().item())
+def tail_only():
+    f = torch.cat((torch.relu_(torch.addmm(bl, XF, Wl.t())), OTHER), 1)
+    h = torch.tanh_(torch.addmm(b1, f, W1.t()))
+    h = torch.tanh_(torch.addmm(b2, h, W2.t()))
+    return torch.addmm(b3, h, W3.t())
+XF = torch.randn(B, 1024, device="cuda"); OTHER = torch.rand(B, 2, device="cuda")
+timeit("  dense tail alone (merged)", tail_only)
+X1 = torch.randn(B, 32, 15, 15, device="cuda").contiguous(memory_format=torch.channels_last)
+timeit("  conv2 + relu + conv3 + relu alone", lambda: torch.relu_(fe.cnn[4](torch.relu_(fe.cnn[2](X1)))))
