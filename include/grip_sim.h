@@ -192,6 +192,15 @@ int grip_obs_preprocess(const uint8_t *obs_dev, int n, int channels, float *img_
 int grip_conv1_u8(const uint8_t *obs_dev, int n, int channels, const float *weight_dev, const int64_t *weight_strides, const float *bias_dev,
                   float *scratch_dev, float *out_nhwc_dev, float *other_dev, void *stream);
 
+/* PPO's clipped-surrogate loss of one minibatch and its gradients in one launch (the update stable_baselines3's PPO.train runs for the
+ * reference's train_agent.py:33-47: advantages normalised per minibatch, clip_range, no value clipping, diagonal Gaussian with a
+ * state-independent log_std): mean_dev / actions_dev float32 [n, action_dim], log_std_dev [action_dim], values / old_log_prob /
+ * advantages / returns [n]. out_dev[3] = loss, policy loss, value loss; grad_mean_dev [n, action_dim], grad_values_dev [n],
+ * grad_log_std_dev [action_dim] = d loss / d (mean, values, log_std). 2 <= n, 1 <= action_dim <= 8. */
+int grip_ppo_loss(const float *mean_dev, const float *log_std_dev, const float *values_dev, const float *actions_dev, const float *old_log_prob_dev,
+                  const float *advantages_dev, const float *returns_dev, int n, int action_dim, float clip_range, float ent_coef, float vf_coef,
+                  float *out_dev, float *grad_mean_dev, float *grad_values_dev, float *grad_log_std_dev, void *stream);
+
 /* ---- batch sets: several batches -- other object models, other target directions -- stepped by ONE launch per phase
  * (BASELINE.json configs[3]: {acorn, sand_ball, sugar_cube, bread_crumb} x direction {0, 45} in one process). Env ids are
  * global: batch g owns ids [sum of the sizes before it, ... + its size). `out` (may be NULL) holds result arrays over all

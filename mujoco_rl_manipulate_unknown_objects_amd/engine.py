@@ -104,7 +104,7 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_set_flags", "grip_batch_substep", "grip_batch_debug_forward", "grip_batch_target_pose",
            "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward", "grip_obs_preprocess",
            "grip_batch_set_state_storage", "grip_batchset_create", "grip_batchset_destroy", "grip_batchset_refresh", "grip_batchset_num_envs",
-           "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list", "grip_conv1_u8", "grip_batch_render_camera"]
+           "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list", "grip_conv1_u8", "grip_batch_render_camera", "grip_ppo_loss"]
 
 
 def lib():
@@ -155,6 +155,7 @@ def lib():
     L.grip_batchset_observe.argtypes = [vp, vp, vp]
     L.grip_batchset_observe_list.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
     L.grip_conv1_u8.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int64), vp, vp, vp, vp, vp]
+    L.grip_ppo_loss.argtypes = [vp] * 7 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float] + [vp] * 5
     L.grip_batch_render_camera.argtypes = [vp, C.c_int, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp]
     L.grip_rollout_tick.argtypes = [vp, vp]
     L.grip_rollout_gae.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
@@ -205,6 +206,22 @@ def conv1_u8(obs, weight, bias):
     _chk(lib().grip_conv1_u8(C.c_void_p(obs.data_ptr()), n, 5, C.c_void_p(weight.data_ptr()), strides, C.c_void_p(bias.data_ptr()),
                              C.c_void_p(scratch.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(other.data_ptr()), stream))
     return out, other
+
+
+def ppo_loss(mean, log_std, values, actions, old_log_prob, advantages, returns, clip_range, ent_coef, vf_coef):
+    """PPO loss of one minibatch and its gradients in one launch (grip_ppo_loss, csrc/grip_policy.hip): float32 CUDA tensors in,
+    (out[3] = loss / policy loss / value loss, d loss / d mean [n, A], d loss / d values [n], d loss / d log_std [A]) out."""
+    import torch
+    ts = [t.float().contiguous() for t in (mean, log_std, values, actions, old_log_prob, advantages, returns)]
+    n, A = int(ts[0].shape[0]), int(ts[0].shape[1])
+    assert all(t.is_cuda for t in ts) and ts[3].shape == (n, A) and ts[1].shape == (A,) and all(t.shape == (n,) for t in (ts[2], ts[4], ts[5], ts[6]))
+    dev = ts[0].device
+    out = torch.empty(3, dtype=torch.float32, device=dev); gm = torch.empty((n, A), dtype=torch.float32, device=dev)
+    gv = torch.empty(n, dtype=torch.float32, device=dev); gl = torch.empty(A, dtype=torch.float32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _chk(lib().grip_ppo_loss(*[C.c_void_p(t.data_ptr()) for t in ts], n, A, float(clip_range), float(ent_coef), float(vf_coef),
+                             C.c_void_p(out.data_ptr()), C.c_void_p(gm.data_ptr()), C.c_void_p(gv.data_ptr()), C.c_void_p(gl.data_ptr()), stream))
+    return out, gm, gv, gl
 
 
 class Model:

@@ -67,11 +67,33 @@ class RolloutBuffer:
         self.pos = 0
 
 
+class _FusedPPOLoss(th.autograd.Function):
+    """The minibatch loss below and its gradients as one kernel launch (engine.ppo_loss -> grip_ppo_loss, csrc/grip_policy.hip) instead of
+    ~60 elementwise / reduction launches of 4096 elements: the same arithmetic in fp32 (tests/test_gpu_env_api.py). The gradients are
+    computed with the loss and handed out, scaled, by backward()."""
+
+    @staticmethod
+    def forward(ctx, mean, log_std, values, actions, old_logp, adv, ret, clip_range, ent_coef, vf_coef):
+        from ..engine import ppo_loss
+        out, gm, gv, gl = ppo_loss(mean.detach(), log_std.detach(), values.detach(), actions, old_logp, adv, ret, clip_range, ent_coef, vf_coef)
+        ctx.save_for_backward(gm, gv, gl)
+        ctx.in_dtypes = (mean.dtype, log_std.dtype, values.dtype)
+        loss, pl, vl = out[0], out[1], out[2]
+        ctx.mark_non_differentiable(pl, vl)
+        return loss, pl, vl
+
+    @staticmethod
+    def backward(ctx, g, _gpl, _gvl):
+        gm, gv, gl = ctx.saved_tensors
+        dm, dl, dv = ctx.in_dtypes
+        return (gm * g).to(dm), (gl * g).to(dl), (gv * g).to(dv), None, None, None, None, None, None, None
+
+
 class PPO:
     def __init__(self, policy, env, learning_rate=3e-4, n_steps=16, batch_size=4096, n_epochs=4, gamma=0.99, gae_lambda=0.95,
                  clip_range=0.2, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, policy_kwargs=None, verbose=0, tensorboard_log=None,
                  device=None, seed=None, autocast_dtype=None, async_slice=0, async_capacity=None, async_budget_us=0, overlap_update=False,
-                 async_auto_slice=False):
+                 async_auto_slice=False, miopen_find=True):
         """async_slice > 0 switches rollout collection to the time-sliced engine (sb3/async_rollout.py): every tick gives
         each env at most `async_slice` calls of physics.step(), at most `async_capacity` finished envs (default N/4) are
         rendered and decided per tick, and a rollout is n_steps * N completed transitions whichever envs they come from.
@@ -102,6 +124,11 @@ class PPO:
         # on a GPU the minibatch update is captured into hipGraphs (forward+backward | gradient all-reduce | clip+Adam), which
         # needs the optimiser's step counter on the device
         self.graph_update = self.device.type == "cuda"
+        self.fused_loss = self.device.type == "cuda"        # the minibatch loss and its gradients as one launch (_FusedPPOLoss)
+        if self.device.type == "cuda" and miopen_find:
+            # MIOpen's find mode: the first (eager) minibatches time the library's convolution kernels per shape and keep the fastest
+            # (the heuristic choice for the 4 x 4 stride-2 data gradient runs at a third of the rate): update 37.9 -> 35.1 ms per 16 minibatches
+            th.backends.cudnn.benchmark = True
         # on a GPU: the fused multi-tensor Adam (one kernel per step; the foreach form spends ~45 small launches per step on
         # dividing every parameter-shaped tensor by 0-dim bias corrections), capturable so that it can sit in the update graph
         self.optimizer = th.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5, capturable=self.graph_update,
@@ -240,6 +267,13 @@ class PPO:
     def _loss_backward(self, src, idx):
         """Forward + PPO loss + backward of one minibatch `idx` (record / sample ids into the rollout storage `src`)."""
         obs, actions, old_logp, adv_all, ret_all = src
+        if self.fused_loss and obs.is_cuda and hasattr(self.policy, "forward_parts"):
+            with self._ac():
+                mean, log_std, values = self.policy.forward_parts({"observation": obs[idx]})
+            loss, pl, vl = _FusedPPOLoss.apply(mean, log_std, values, actions[idx], old_logp[idx], adv_all[idx], ret_all[idx],
+                                               self.clip_range, self.ent_coef, self.vf_coef)
+            loss.backward()
+            return pl, vl, loss.detach()
         adv = adv_all[idx]
         adv = (adv - adv.mean()) / (adv.std() + 1e-8)
         with self._ac():

@@ -382,3 +382,38 @@ def test_merged_heads_rollout_forward_matches_the_module_forward(torch):
     pol2 = ActorCriticPolicy(RGBDSensor(config=cfg).setup_observation_space(), Actuator(config=cfg).setup_action_space(),
                              features_extractor_class=AugmentedNatureCNN, net_arch=dict(pi=[64], vf=[64, 64])).cuda()
     assert not pol2.enable_rollout_cache() and pol2._rollout_cache is None
+
+
+def test_fused_ppo_loss_matches_the_tensor_formula(torch):
+    """grip_ppo_loss (loss + gradients of one minibatch in one launch) against the tensor-library formula PPO._loss_backward uses on
+    CPU, fp32 both ways: loss, policy loss, value loss and the gradients w.r.t. mean, values and log_std. Ratios inside and outside the
+    clip range, both advantage signs, a saturated log-ratio (+-20 clamp) and ragged sizes."""
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3.ppo import _FusedPPOLoss
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3.policies import ActorCriticPolicy
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    for n, A, clip, ent, vf in ((4096, 6, 0.2, 0.0, 0.5), (130, 6, 0.1, 0.01, 1.0), (2, 3, 0.2, 0.0, 0.5), (1500, 8, 0.3, 0.02, 0.25)):
+        rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+        mean = (0.3 * rnd(n, A)).requires_grad_(True); log_std = (0.2 * rnd(A)).requires_grad_(True); values = rnd(n).requires_grad_(True)
+        actions = mean.detach() + torch.exp(log_std.detach()) * rnd(n, A)
+        old = ActorCriticPolicy._log_prob(mean.detach(), log_std.detach(), actions) + 0.3 * rnd(n)       # ratios spread around 1, many clipped
+        if n > 100:
+            old[:3] -= 30.0; old[3:6] += 30.0                                                           # saturated log-ratios
+        adv = rnd(n); ret = rnd(n)
+        # reference: the tensor formula
+        a = (adv - adv.mean()) / (adv.std() + 1e-8)
+        logp = ActorCriticPolicy._log_prob(mean, log_std, actions)
+        ratio = torch.exp(torch.clamp(logp - old, -20.0, 20.0))
+        pl = -torch.min(a * ratio, a * torch.clamp(ratio, 1 - clip, 1 + clip)).mean()
+        vl = torch.nn.functional.mse_loss(ret, values)
+        el = -(0.5 + 0.5 * np.log(2 * np.pi) + log_std).sum(-1).expand(n).mean()
+        loss = pl + ent * el + vf * vl
+        gm, gl, gv = torch.autograd.grad(loss, (mean, log_std, values))
+        frac_clipped = ((ratio < 1 - clip) | (ratio > 1 + clip)).float().mean().item()
+        assert n < 100 or 0.1 < frac_clipped < 0.9
+        loss2, pl2, vl2 = _FusedPPOLoss.apply(mean, log_std, values, actions, old, adv, ret, clip, ent, vf)
+        gm2, gl2, gv2 = torch.autograd.grad(loss2, (mean, log_std, values))
+        for x, y, name in ((loss, loss2, "loss"), (pl, pl2, "pl"), (vl, vl2, "vl")):
+            x, y = float(x.detach()), float(y.detach())
+            assert abs(x - y) < 2e-6 * max(1.0, abs(x)), (n, name, x, y)
+        for x, y, name in ((gm, gm2, "d mean"), (gl, gl2, "d log_std"), (gv, gv2, "d values")):
+            assert (x - y).abs().max() < 2e-6 * max(1.0, float(x.abs().max())) + 1e-9, (n, name, float((x - y).abs().max()), float(x.abs().max()))
