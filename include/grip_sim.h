@@ -192,6 +192,17 @@ int grip_obs_preprocess(const uint8_t *obs_dev, int n, int channels, float *img_
 int grip_conv1_u8(const uint8_t *obs_dev, int n, int channels, const float *weight_dev, const int64_t *weight_strides, const float *bias_dev,
                   float *scratch_dev, float *out_nhwc_dev, float *other_dev, void *stream);
 
+/* Rollout-side second and third layers of AugmentedNatureCNN (models/feature_extractor.py:17-21) in one launch on the matrix cores
+ * (v_mfma_f32_16x16x4_f32: fp32 products and sums): y1_nhwc_dev float32 [n, 15, 15, 32] (grip_conv1_u8's output) ->
+ * out_nhwc_dev float32 [n, 4, 4, 64] = relu(conv2d(relu(conv2d(y1, w2, b2, stride 2)), w3, b3, stride 1)), i.e. a channels-last
+ * [n, 64, 4, 4] tensor. The weights are passed as the GEMMs' B matrices, which grip_conv23_prep writes from w2 float32 [64, 32, 4, 4]
+ * and w3 float32 [64, 64, 3, 3] (element strides w*_strides[4], any layout) into b2_mat_dev (512 x 64 floats) and b3_mat_dev
+ * (576 x 64 floats): call it again whenever the weights change. Inference only. */
+int grip_conv23_prep(const float *w2_dev, const int64_t *w2_strides, const float *w3_dev, const int64_t *w3_strides, float *b2_mat_dev, float *b3_mat_dev,
+                     void *stream);
+int grip_conv23(const float *y1_nhwc_dev, int n, const float *b2_mat_dev, const float *bias2_dev, const float *b3_mat_dev, const float *bias3_dev,
+                float *out_nhwc_dev, void *stream);
+
 /* PPO's clipped-surrogate loss of one minibatch and its gradients in one launch (the update stable_baselines3's PPO.train runs for the
  * reference's train_agent.py:33-47: advantages normalised per minibatch, clip_range, no value clipping, diagonal Gaussian with a
  * state-independent log_std): mean_dev / actions_dev float32 [n, action_dim], log_std_dev [action_dim], values / old_log_prob /

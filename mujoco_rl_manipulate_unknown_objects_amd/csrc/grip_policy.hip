@@ -213,3 +213,191 @@ extern "C" int grip_ppo_loss(const float *mean_dev, const float *log_std_dev, co
     if (e != hipSuccess) { char buf[160]; snprintf(buf, sizeof buf, "grip_ppo_loss: %s", hipGetErrorString(e)); return grip_fail(buf); }
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Rollout-side second and third layers of AugmentedNatureCNN (models/feature_extractor.py:17-21) in one launch:
+//   y2 = relu(conv2d(y1, w2, b2, stride 2)),  y1 [n, 15, 15, 32] NHWC (what k_conv1_u8 writes), w2 [64, 32, 4, 4]  -> [n, 6, 6, 64]
+//   y3 = relu(conv2d(y2, w3, b3, stride 1)),                                               w3 [64, 64, 3, 3]  -> [n, 4, 4, 64] NHWC
+// as two implicit GEMMs on v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulation), y2 never leaving LDS. As tensor-library calls
+// the pair is two implicit-GEMM launches plus bias and ReLU passes, 97 us per 1024 images; this kernel: one workgroup (4 waves) per
+// C2_G = 4 images -- GEMM 1: M = 144 (image, oy, ox) rows = 9 tiles of 16, N = 64, K = 4 x 4 x 32 = 512; GEMM 2: M = 64 = 4 tiles (one per image), N = 64,
+// K = 3 x 3 x 64 = 576. Wave w owns output channels 16 w .. 16 w + 15 and every M tile (9, then 4 independent accumulators: the 40-cycle
+// dependent latency of the instruction never shows). A comes from LDS: a lane's row (l & 15) fixes a pixel base, its k (l >> 4) a channel
+// offset; pixel strides of 34 / 68 floats spread the 64 lanes of a read over all banks. B comes straight from global memory (the weights
+// as B[k][n], k = (ky, kx, ci), 275 KB for both layers: L2-resident, rewritten by grip_conv23_prep whenever the weights change), one
+// dword per lane and k-step, fetched one (ky, kx) block = 8 or 16 k-steps ahead of its use.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define C2_G 4
+#define C2_PS1 34                       // floats per y1 pixel in LDS (32 channels + 2: row stride 2 pixels = 68 floats = 4 banks)
+#define C2_PS2 68                       // floats per y2 pixel in LDS (64 channels + 4)
+#define C2_LDS_FLOATS (C2_G * 225 * C2_PS1)         // y1 of the group; y2 (C2_G * 36 * C2_PS2 floats) reuses the space once GEMM 1 is done
+
+// B2[k][n] = w2[n][ci][ky][kx], k = (ky * 4 + kx) * 32 + ci;  B3[k][n] = w3[n][ci][ky][kx], k = (ky * 3 + kx) * 64 + ci  (element strides given)
+__global__ void __launch_bounds__(256) k_conv23_prep(const float *__restrict__ w2, long long s2o, long long s2c, long long s2y, long long s2x,
+                                                     const float *__restrict__ w3, long long s3o, long long s3c, long long s3y, long long s3x,
+                                                     float *__restrict__ B2, float *__restrict__ B3) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 512 * 64) {
+        const int n = i & 63, k = i >> 6, ci = k & 31, kx = (k >> 5) & 3, ky = k >> 7;
+        B2[i] = w2[n * s2o + ci * s2c + ky * s2y + kx * s2x];
+    }
+    if (i < 576 * 64) {
+        const int n = i & 63, k = i >> 6, ci = k & 63, kk = k >> 6, kx = kk % 3, ky = kk / 3;
+        B3[i] = w3[n * s3o + ci * s3c + ky * s3y + kx * s3x];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_conv23(const float *__restrict__ y1, int n_img, const float *__restrict__ B2, const float *__restrict__ bias2,
+                                                const float *__restrict__ B3, const float *__restrict__ bias3, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float c2_lds[];
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r16 = l & 15, kq = l >> 4;
+    const int img0 = blockIdx.x * C2_G, nimg = min(C2_G, n_img - img0);
+    // y1 of the group -> LDS (missing images of the last group as zeros); eight 16-byte loads in flight per thread, then their stores
+    for (int b0 = 0; b0 < C2_G * 1800; b0 += 256 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = b0 + u * 256 + tid, g = i / 1800, q = i - g * 1800;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < C2_G * 1800 && g < nimg) v[u] = *reinterpret_cast<const float4 *>(y1 + ((size_t)(img0 + g) * 225) * 32 + (size_t)q * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = b0 + u * 256 + tid, g = i / 1800, q = i - g * 1800, px = q >> 3, c4 = (q & 7) * 4;
+            if (i < C2_G * 1800) {
+                float2 *d = reinterpret_cast<float2 *>(c2_lds + (g * 225 + px) * C2_PS1 + c4);
+                d[0] = make_float2(v[u].x, v[u].y); d[1] = make_float2(v[u].z, v[u].w);
+            }
+        }
+    }
+    __syncthreads();
+    const int ncol = 16 * w + r16;
+    // ---- GEMM 1
+    f32x4 acc[9];
+    int abase[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        const int m = t * 16 + r16, g = m / 36, p = m - g * 36, oy = p / 6, ox = p - oy * 6;
+        abase[t] = (g * 225 + 2 * oy * 15 + 2 * ox) * C2_PS1 + kq;
+        acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    {
+        const float *Bp = B2 + (size_t)kq * 64 + ncol;              // k = 4 j + kq -> Bp[j * 256]
+        float bcur[8], bnext[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) bcur[i] = Bp[i * 256];
+        float acur[9];
+#pragma unroll
+        for (int t = 0; t < 9; t++) acur[t] = c2_lds[abase[t]];
+        for (int c = 0; c < 16; c++) {                               // (ky, kx) blocks of 8 k-steps (32 channels)
+            const int cn = min(c + 1, 15);
+#pragma unroll
+            for (int i = 0; i < 8; i++) bnext[i] = Bp[(cn * 8 + i) * 256];
+            const int off = ((c >> 2) * 15 + (c & 3)) * C2_PS1;
+            const int offn = ((cn >> 2) * 15 + (cn & 3)) * C2_PS1;
+            // A of k-step i + 1 is read while the nine MFMAs of k-step i issue (9 x 32 cycles cover the LDS latency)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                float an[9];
+#pragma unroll
+                for (int t = 0; t < 9; t++) an[t] = c2_lds[abase[t] + (i < 7 ? off + 4 * (i + 1) : offn)];
+                __builtin_amdgcn_sched_barrier(0);                   // keep the reads above the MFMAs (the scheduler sinks them to their uses)
+#pragma unroll
+                for (int t = 0; t < 9; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[t], bcur[i], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 9; t++) acur[t] = an[t];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) bcur[i] = bnext[i];
+        }
+    }
+    __syncthreads();                                                 // every wave is done reading y1
+    {   // y2 = relu(acc + bias) into LDS: lane holds rows 4 kq + r of tile t, column ncol
+        const float bn = bias2[ncol];
+#pragma unroll
+        for (int t = 0; t < 9; t++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = t * 16 + 4 * kq + r;                    // = g * 36 + position
+                c2_lds[m * C2_PS2 + ncol] = fmaxf(acc[t][r] + bn, 0.f);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- GEMM 2: tile g = image g, row r16 = (oy, ox) of the 4 x 4 output
+    f32x4 acc3[C2_G];
+    int a3[C2_G];
+#pragma unroll
+    for (int g = 0; g < C2_G; g++) {
+        a3[g] = (g * 36 + (r16 >> 2) * 6 + (r16 & 3)) * C2_PS2 + kq;
+        acc3[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    {
+        const float *Bp = B3 + (size_t)kq * 64 + ncol;
+        float bcur[16], bnext[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) bcur[i] = Bp[i * 256];
+        float acur[C2_G];
+#pragma unroll
+        for (int g = 0; g < C2_G; g++) acur[g] = c2_lds[a3[g]];
+        for (int c = 0; c < 9; c++) {                                // (ky, kx) blocks of 16 k-steps (64 channels)
+            const int cn = min(c + 1, 8);
+#pragma unroll
+            for (int i = 0; i < 16; i++) bnext[i] = Bp[(cn * 16 + i) * 256];
+            const int off = ((c / 3) * 6 + (c % 3)) * C2_PS2;
+            const int offn = ((cn / 3) * 6 + (cn % 3)) * C2_PS2;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                float an[C2_G];
+#pragma unroll
+                for (int g = 0; g < C2_G; g++) an[g] = c2_lds[a3[g] + (i < 15 ? off + 4 * (i + 1) : offn)];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < C2_G; g++) acc3[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[g], bcur[i], acc3[g], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < C2_G; g++) acur[g] = an[g];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) bcur[i] = bnext[i];
+        }
+    }
+    {
+        const float bn = bias3[ncol];
+#pragma unroll
+        for (int g = 0; g < C2_G; g++) {
+            if (g < nimg) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) out[((size_t)(img0 + g) * 16 + 4 * kq + r) * 64 + ncol] = fmaxf(acc3[g][r] + bn, 0.f);
+            }
+        }
+    }
+}
+
+extern "C" int grip_conv23_prep(const float *w2_dev, const int64_t *w2_strides, const float *w3_dev, const int64_t *w3_strides, float *b2_mat_dev, float *b3_mat_dev,
+                                void *stream) {
+    if (!w2_dev || !w2_strides || !w3_dev || !w3_strides || !b2_mat_dev || !b3_mat_dev) return grip_fail("grip_conv23_prep: need both weight tensors, their strides and the two outputs");
+    hipLaunchKernelGGL(k_conv23_prep, dim3(576 * 64 / 256), dim3(256), 0, (hipStream_t)stream, w2_dev, (long long)w2_strides[0], (long long)w2_strides[1],
+                       (long long)w2_strides[2], (long long)w2_strides[3], w3_dev, (long long)w3_strides[0], (long long)w3_strides[1], (long long)w3_strides[2],
+                       (long long)w3_strides[3], b2_mat_dev, b3_mat_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { char buf[160]; snprintf(buf, sizeof buf, "grip_conv23_prep: %s", hipGetErrorString(e)); return grip_fail(buf); }
+    return 0;
+}
+
+extern "C" int grip_conv23(const float *y1_nhwc_dev, int n, const float *b2_mat_dev, const float *bias2_dev, const float *b3_mat_dev, const float *bias3_dev,
+                           float *out_nhwc_dev, void *stream) {
+    if (!y1_nhwc_dev || !b2_mat_dev || !bias2_dev || !b3_mat_dev || !bias3_dev || !out_nhwc_dev || n <= 0)
+        return grip_fail("grip_conv23: need y1 [n, 15, 15, 32], the two weight matrices of grip_conv23_prep, both biases and the output [n, 4, 4, 64]");
+    static bool attr_set = false;
+    const size_t lds = (size_t)C2_LDS_FLOATS * sizeof(float);
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)k_conv23, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return grip_fail("grip_conv23: cannot reserve LDS");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_conv23, dim3((n + C2_G - 1) / C2_G), dim3(256), lds, (hipStream_t)stream, y1_nhwc_dev, n, b2_mat_dev, bias2_dev, b3_mat_dev, bias3_dev, out_nhwc_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { char buf[160]; snprintf(buf, sizeof buf, "grip_conv23: %s", hipGetErrorString(e)); return grip_fail(buf); }
+    return 0;
+}

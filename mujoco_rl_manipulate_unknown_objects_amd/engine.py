@@ -104,7 +104,7 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_set_flags", "grip_batch_substep", "grip_batch_debug_forward", "grip_batch_target_pose",
            "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward", "grip_obs_preprocess",
            "grip_batch_set_state_storage", "grip_batchset_create", "grip_batchset_destroy", "grip_batchset_refresh", "grip_batchset_num_envs",
-           "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list", "grip_conv1_u8", "grip_batch_render_camera", "grip_ppo_loss"]
+           "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list", "grip_conv1_u8", "grip_batch_render_camera", "grip_ppo_loss", "grip_conv23_prep", "grip_conv23"]
 
 
 def lib():
@@ -155,6 +155,8 @@ def lib():
     L.grip_batchset_observe.argtypes = [vp, vp, vp]
     L.grip_batchset_observe_list.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
     L.grip_conv1_u8.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int64), vp, vp, vp, vp, vp]
+    L.grip_conv23_prep.argtypes = [vp, C.POINTER(C.c_int64), vp, C.POINTER(C.c_int64), vp, vp, vp]
+    L.grip_conv23.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.grip_ppo_loss.argtypes = [vp] * 7 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float] + [vp] * 5
     L.grip_batch_render_camera.argtypes = [vp, C.c_int, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp]
     L.grip_rollout_tick.argtypes = [vp, vp]
@@ -206,6 +208,33 @@ def conv1_u8(obs, weight, bias):
     _chk(lib().grip_conv1_u8(C.c_void_p(obs.data_ptr()), n, 5, C.c_void_p(weight.data_ptr()), strides, C.c_void_p(bias.data_ptr()),
                              C.c_void_p(scratch.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(other.data_ptr()), stream))
     return out, other
+
+
+def conv23_prep(w2, w3, b2_mat=None, b3_mat=None):
+    """The weights of AugmentedNatureCNN's second and third convolutions as the B matrices grip_conv23 reads (float32 [512, 64] and
+    [576, 64]); pass the previous pair to rewrite it in place (fixed addresses for a captured rollout tick)."""
+    import torch
+    assert w2.is_cuda and w2.dtype == torch.float32 and tuple(w2.shape) == (64, 32, 4, 4) and w3.dtype == torch.float32 and tuple(w3.shape) == (64, 64, 3, 3)
+    if b2_mat is None:
+        b2_mat = torch.empty((512, 64), dtype=torch.float32, device=w2.device); b3_mat = torch.empty((576, 64), dtype=torch.float32, device=w2.device)
+    s2 = (C.c_int64 * 4)(*w2.stride()); s3 = (C.c_int64 * 4)(*w3.stride())
+    stream = C.c_void_p(torch.cuda.current_stream(w2.device).cuda_stream)
+    _chk(lib().grip_conv23_prep(C.c_void_p(w2.data_ptr()), s2, C.c_void_p(w3.data_ptr()), s3, C.c_void_p(b2_mat.data_ptr()), C.c_void_p(b3_mat.data_ptr()), stream))
+    return b2_mat, b3_mat
+
+
+def conv23(y1, b2_mat, bias2, b3_mat, bias3):
+    """relu(conv3(relu(conv2(y1)))) of AugmentedNatureCNN for rollouts in one launch (grip_conv23, csrc/grip_policy.hip): y1 = conv1_u8's
+    channels-last float32 [n, 32, 15, 15] -> channels-last float32 [n, 64, 4, 4]. No autograd."""
+    import torch
+    n = int(y1.shape[0])
+    assert y1.is_cuda and y1.dtype == torch.float32 and tuple(y1.shape[1:]) == (32, 15, 15) and y1.is_contiguous(memory_format=torch.channels_last)
+    assert tuple(b2_mat.shape) == (512, 64) and tuple(b3_mat.shape) == (576, 64) and bias2.is_contiguous() and bias3.is_contiguous()
+    out = torch.empty((n, 64, 4, 4), dtype=torch.float32, device=y1.device, memory_format=torch.channels_last)
+    stream = C.c_void_p(torch.cuda.current_stream(y1.device).cuda_stream)
+    _chk(lib().grip_conv23(C.c_void_p(y1.data_ptr()), n, C.c_void_p(b2_mat.data_ptr()), C.c_void_p(bias2.data_ptr()), C.c_void_p(b3_mat.data_ptr()),
+                           C.c_void_p(bias3.data_ptr()), C.c_void_p(out.data_ptr()), stream))
+    return out
 
 
 def ppo_loss(mean, log_std, values, actions, old_log_prob, advantages, returns, clip_range, ent_coef, vf_coef):

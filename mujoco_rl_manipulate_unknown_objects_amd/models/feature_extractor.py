@@ -58,6 +58,8 @@ class AugmentedNatureCNN(BaseFeaturesExtractor):
     # convolutions, and the linear layer applied to the NHWC tensor as it lies in memory (its weight's columns re-ordered once per
     # refresh) instead of to the NCHW copy nn.Flatten makes of a channels_last tensor.
     _wl_nhwc = None
+    _b23 = None             # second / third convolution's weights as grip_conv23's GEMM operands (fixed addresses)
+    _b23_store = None
 
     @th.no_grad()
     def refresh_rollout_cache(self):
@@ -67,6 +69,13 @@ class AugmentedNatureCNN(BaseFeaturesExtractor):
         if self._wl_nhwc is None or self._wl_nhwc.device != lw.device:
             self._wl_nhwc = th.empty_like(lw)
         self._wl_nhwc.copy_(lw.view(lw.shape[0], c3, hw, hw).permute(0, 2, 3, 1).reshape(lw.shape[0], -1))
+        c2, c3m = self.cnn[2], self.cnn[4]
+        self._b23 = None
+        if (lw.is_cuda and tuple(c2.weight.shape) == (64, 32, 4, 4) and c2.stride == (2, 2) and c2.padding == (0, 0) and tuple(c3m.weight.shape) == (64, 64, 3, 3)
+                and c3m.stride == (1, 1) and c3m.padding == (0, 0) and c2.weight.dtype == th.float32):
+            from ..engine import conv23_prep
+            self._b23_store = conv23_prep(c2.weight, c3m.weight, *(self._b23_store or (None, None)))
+            self._b23 = self._b23_store
 
     def rollout_features(self, observations):
         """[B, features_dim] for raw uint8 CUDA observations of the default layout, None otherwise (the caller then uses forward())."""
@@ -78,7 +87,11 @@ class AugmentedNatureCNN(BaseFeaturesExtractor):
             return None
         from ..engine import conv1_u8
         x, other = conv1_u8(obs.contiguous(), c0.weight, c0.bias)
-        x = th.relu_(self.cnn[2](x)); x = th.relu_(self.cnn[4](x))
+        if self._b23 is not None:                                   # both remaining convolutions + ReLUs as one f32-MFMA launch
+            from ..engine import conv23
+            x = conv23(x, self._b23[0], self.cnn[2].bias, self._b23[1], self.cnn[4].bias)
+        else:
+            x = th.relu_(self.cnn[2](x)); x = th.relu_(self.cnn[4](x))
         xf = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)          # a view: the tensor is channels_last
         return th.cat((th.relu_(th.addmm(self.linear[0].bias, xf, self._wl_nhwc.t())), other), dim=1)
 

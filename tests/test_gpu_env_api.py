@@ -417,3 +417,35 @@ def test_fused_ppo_loss_matches_the_tensor_formula(torch):
             assert abs(x - y) < 2e-6 * max(1.0, abs(x)), (n, name, x, y)
         for x, y, name in ((gm, gm2, "d mean"), (gl, gl2, "d log_std"), (gv, gv2, "d values")):
             assert (x - y).abs().max() < 2e-6 * max(1.0, float(x.abs().max())) + 1e-9, (n, name, float((x - y).abs().max()), float(x.abs().max()))
+
+
+def test_fused_second_and_third_convolution_match_the_tensor_library(torch):
+    """grip_conv23 (conv2 + ReLU + conv3 + ReLU of AugmentedNatureCNN on f32 MFMA, y2 kept in LDS) against torch.nn.functional on the same
+    weights: contiguous and channels-last weight layouts, batch sizes that are not multiples of the 4 images a workgroup takes, and an
+    exact-integer case that pins the operand / accumulator lane maps. fp32 both ways: 2e-5 relative to the activations' scale."""
+    import torch.nn.functional as F
+    from mujoco_rl_manipulate_unknown_objects_amd.engine import conv23, conv23_prep
+    g = torch.Generator(device="cuda"); g.manual_seed(2)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    for n in (1, 3, 4, 130, 1024):
+        y1 = torch.relu(rnd(n, 32, 15, 15)).contiguous(memory_format=torch.channels_last)
+        w2 = rnd(64, 32, 4, 4) / 22.0; b2 = 0.1 * rnd(64); w3 = rnd(64, 64, 3, 3) / 24.0; b3 = 0.1 * rnd(64)
+        ref = F.relu(F.conv2d(F.relu(F.conv2d(y1, w2, b2, stride=2)), w3, b3))
+        for cl in (False, True):
+            w2x = w2.contiguous(memory_format=torch.channels_last) if cl else w2
+            w3x = w3.contiguous(memory_format=torch.channels_last) if cl else w3
+            mats = conv23_prep(w2x, w3x)
+            out = conv23(y1, mats[0], b2, mats[1], b3)
+            assert out.shape == (n, 64, 4, 4) and out.is_contiguous(memory_format=torch.channels_last)
+            assert (out - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max())), (n, cl, float((out - ref).abs().max()), float(ref.abs().max()))
+        assert float(ref.abs().max()) > 0.5 and float((ref > 0).float().mean()) > 0.2
+    # exact integers: small integer activations and one-hot-ish integer weights, every product and sum exact in fp32
+    y1 = torch.randint(0, 4, (6, 32, 15, 15), device="cuda", generator=g).float().contiguous(memory_format=torch.channels_last)
+    w2 = torch.randint(-1, 2, (64, 32, 4, 4), device="cuda", generator=g).float(); w3 = torch.randint(-1, 2, (64, 64, 3, 3), device="cuda", generator=g).float()
+    b2 = torch.randint(-3, 4, (64,), device="cuda", generator=g).float(); b3 = torch.randint(-3, 4, (64,), device="cuda", generator=g).float()
+    ref = F.relu(F.conv2d(F.relu(F.conv2d(y1, w2, b2, stride=2)), w3, b3))
+    mats = conv23_prep(w2, w3)
+    assert torch.equal(conv23(y1, mats[0], b2, mats[1], b3), ref)
+    # rewriting the operand matrices in place keeps their addresses
+    p0 = mats[0].data_ptr(); mats2 = conv23_prep(w2 * 2, w3, *mats)
+    assert mats2[0].data_ptr() == p0 and torch.equal(conv23(y1, mats2[0], b2, mats2[1], b3), F.relu(F.conv2d(F.relu(F.conv2d(y1, 2 * w2, b2, stride=2)), w3, b3)))

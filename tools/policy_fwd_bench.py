@@ -87,3 +87,10 @@ XF = torch.randn(B, 1024, device="cuda"); OTHER = torch.rand(B, 2, device="cuda"
 timeit("  dense tail alone (merged)", tail_only)
 X1 = torch.randn(B, 32, 15, 15, device="cuda").contiguous(memory_format=torch.channels_last)
 timeit("  conv2 + relu + conv3 + relu alone", lambda: torch.relu_(fe.cnn[4](torch.relu_(fe.cnn[2](X1)))))
+
+# the shipped rollout path: merged heads + conv2 / conv3 as one f32-MFMA launch (ActorCriticPolicy.enable_rollout_cache)
+pol.enable_rollout_cache()
+out = timeit("forward_parts with the rollout cache", lambda: pol.forward_parts({"observation": obs}))
+print("max |d mean|", (out[0] - ref[0]).abs().max().item(), "max |d value|", (out[2] - ref[2]).abs().max().item())
+from mujoco_rl_manipulate_unknown_objects_amd.engine import conv23
+timeit("  conv23 alone", lambda: conv23(X1, fe._b23[0], fe.cnn[2].bias, fe._b23[1], fe.cnn[4].bias))
