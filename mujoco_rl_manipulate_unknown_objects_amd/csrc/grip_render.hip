@@ -112,6 +112,7 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
                                              int n, int e, uint8_t *obs, uint8_t *obs2, const long long *row2) {
     __shared__ Frames fr;
     __shared__ float gsph[GN_GEOM][4];          // bounding sphere centre in camera coordinates, radius^2
+    __shared__ float gmx[GN_GEOM][12];          // plane transform of a hull: Rg^T Rc (row-major), Rg^T (co - pg)
     extern __shared__ float4 spl[];             // camera-space plane table of this env (sized by the launcher: planes x 16 B)
     __shared__ int gadr[GN_GEOM], gnum[GN_GEOM], gnf[GN_GEOM], gbf[GN_GEOM];   // table start, planes, planes / box planes facing the camera (listed first)
     __shared__ int wcnt[RTHREADS / 64];
@@ -128,6 +129,14 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
         float r = m.geom_rbound[g];
         gsph[g][0] = c.x; gsph[g][1] = c.y; gsph[g][2] = c.z; gsph[g][3] = r * r;
         gnum[g] = c.z - r < 0.f ? m.hull_pnum[g - 1] : 0;               // some of the sphere is in front of the camera
+        // the hull's plane transform, once per env: Mx = Rg^T Rc and ol = Rg^T (co - pg); the table build reads them from LDS, which keeps it
+        // inside the kernel's 64 VGPRs (held in registers by every thread they were the build's 18 spilled registers: 150 MB of scratch
+        // traffic per launch)
+        M3 Mx = mulm(M3{{R.m[0], R.m[3], R.m[6], R.m[1], R.m[4], R.m[7], R.m[2], R.m[5], R.m[8]}}, Rc);
+        V3 ol = multv(R, co - p);
+#pragma unroll
+        for (int i = 0; i < 9; i++) gmx[g][i] = Mx.m[i];
+        gmx[g][9] = ol.x; gmx[g][10] = ol.y; gmx[g][11] = ol.z;
     }
     __syncthreads();
     if (tid == 0) {
@@ -136,7 +145,6 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
     }
     __syncthreads();
     {
-    const V3 co = ldv(fr.cam_o); const M3 Rc = ldm(fr.cam_R);
     // plane n.x <= d of a hull (body frame), rewritten for rays from the camera origin in camera coordinates dc = (x, y, -1):
     // t (A.dc) <= B with A = (Rg^T Rc)^T n, B = d - n.(Rg^T (co - pg)); one float4 per plane of the visible hulls in LDS.
     // Each hull's table starts with the six planes of its vertices' bounding box (same form): a ray that misses the box misses
@@ -147,9 +155,7 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
     for (int g = 1; g < GN_GEOM; g++) {
         const int np = gnum[g];
         if (np == 0) continue;
-        V3 p = ldv(fr.p[g - 1]); M3 R = ldm(fr.R[g - 1]);
-        M3 Mx = mulm(M3{{R.m[0], R.m[3], R.m[6], R.m[1], R.m[4], R.m[7], R.m[2], R.m[5], R.m[8]}}, Rc);      // Rg^T Rc
-        V3 ol = multv(R, co - p);
+        const M3 Mx = ldm(gmx[g]); const V3 ol = v3(gmx[g][9], gmx[g][10], gmx[g][11]);
         const float *pl = m.hull_planes + 4 * m.hull_padr[g - 1];
         float4 *tab = spl + gadr[g];
         if (wv == 0) {                                                  // the box planes, partitioned the same way inside the first wave
