@@ -347,9 +347,9 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
     asm volatile("" : "+v"(frl));
     const V3 co = ldv(frl->cam_o); const M3 Rc = ldm(frl->cam_R);
     float lmin = 3.0e38f;
+    unsigned cb[3][TPX];
 #pragma unroll
     for (int q = 0; q < TPX; q++) {
-        const int i = TW * ty + q / TW, j = TW * tx + q % TW, px = i * RW + j;
         const float x = xs[q % TW], y = ys[q / TW];
         const V3 dir = mulv(Rc, v3(x, y, -1.f));
         const int hit = hitent[q] < 0 ? -1 : (hitent[q] >> 16);
@@ -372,10 +372,21 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
             float shade = 0.4f + 0.6f * fmaxf(dot(nrm, L), 0.f);
             c0 = b0 * shade; c1 = b1 * shade; c2 = b2 * shade;
         }
-        o[px] = to_u8(c0); o[RPIX + px] = to_u8(c1); o[2 * RPIX + px] = to_u8(c2);
-        if (o2) { o2[px] = to_u8(c0); o2[RPIX + px] = to_u8(c1); o2[2 * RPIX + px] = to_u8(c2); o2[(nch - 1) * RPIX + px] = 0; }
+        cb[0][q] = to_u8(c0); cb[1][q] = to_u8(c1); cb[2][q] = to_u8(c2);
         lmin = fminf(lmin, best[q]);
-        o[(nch - 1) * RPIX + px] = 0;
+    }
+    // the two pixels of a tile row leave as one 16-bit store per channel (the tile's column is even: 2-byte aligned)
+    auto put2 = [&](int ch, int r, unsigned lo, unsigned hi) {
+        const int px = (TW * ty + r) * RW + TW * tx;
+        const uint16_t v = (uint16_t)(lo | (hi << 8));
+        *reinterpret_cast<uint16_t *>(o + ch * RPIX + px) = v;
+        if (o2) *reinterpret_cast<uint16_t *>(o2 + ch * RPIX + px) = v;
+    };
+#pragma unroll
+    for (int r = 0; r < TW; r++) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) put2(ch, r, cb[ch][2 * r], cb[ch][2 * r + 1]);
+        put2(nch - 1, r, 0u, 0u);
     }
     // transform_depth (utils.py:11-19): depth -= min; depth /= 2 * mean(depth[depth <= 1]); 255 * clip(depth, 0, 1)
     red[tid] = lmin; __syncthreads();
@@ -388,14 +399,15 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
     for (int s = RTHREADS / 2; s > 0; s >>= 1) { if (tid < s) { red[tid] += red[tid + s]; redi[tid] += redi[tid + s]; } __syncthreads(); }
     float scale = 2.0f * (red[0] / (float)redi[0]);
     if (cfg.full_observation) {
+        unsigned db[TPX];
 #pragma unroll
         for (int q = 0; q < TPX; q++) {
-            const int px = (TW * ty + q / TW) * RW + TW * tx + q % TW;
             float v = (best[q] - dmin) / scale; v = fminf(fmaxf(v, 0.f), 1.f);
             float p = 255.0f * v;
-            o[3 * RPIX + px] = (p != p) ? (uint8_t)0 : (uint8_t)p;
-            if (o2) o2[3 * RPIX + px] = (p != p) ? (uint8_t)0 : (uint8_t)p;
+            db[q] = (p != p) ? 0u : (unsigned)(uint8_t)p;
         }
+#pragma unroll
+        for (int r = 0; r < TW; r++) put2(3, r, db[2 * r], db[2 * r + 1]);
     }
     __syncthreads();
     if (tid == 0) {
