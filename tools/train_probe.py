@@ -1,5 +1,5 @@
 """Sanity probe: PPO over the time-sliced engine for a minute; prints episode return / length and losses per rollout.
-    python tools/train_probe.py <object|mixed> <seconds> [overlap] [--seed S] [--dtype f32|bf16] [--steps N]
+    python tools/train_probe.py <object|mixed> <seconds> [overlap] [--seed S] [--dtype f32|bf16] [--steps N] [no-find] [no-fused-loss]
 --steps N: stop after N env transitions instead of after <seconds> (learning curves of variants compared at equal samples)."""
 import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import BatchedRobotEnv, MixedBatchedRobotEnv, default_config
@@ -18,8 +18,10 @@ if obj == "mixed":          # four objects x two directions, 512 envs each, one 
 else:
     cfg = default_config(sim_env=f"/xmls/{obj}_env.xml", time_horizon=50)
     env = GpuVecEnv(BatchedRobotEnv(cfg, n_envs=4096, device_index=0, auto_reset=True))
-model = PPO("MultiInputPolicy", env, n_steps=8, batch_size=4096, n_epochs=2, seed=seed, autocast_dtype=torch.bfloat16 if dtype == "bf16" else None, async_slice=96, async_capacity=1024, async_budget_us=2000, ent_coef=0.0, overlap_update=overlap,
+model = PPO("MultiInputPolicy", env, n_steps=8, batch_size=4096, n_epochs=2, seed=seed, autocast_dtype=torch.bfloat16 if dtype == "bf16" else None, async_slice=96, async_capacity=1024, async_budget_us=2000, ent_coef=0.0, overlap_update=overlap, miopen_find="no-find" not in sys.argv[3:],
             policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]))
+if "no-fused-loss" in sys.argv[3:]:
+    model.fused_loss = False
 ar = model._async
 t0 = time.time(); it = 0; last = (0.0, 0.0, 0.0)
 while (model.num_timesteps < max_steps) if max_steps else (time.time() - t0 < secs):
@@ -33,4 +35,4 @@ while (model.num_timesteps < max_steps) if max_steps else (time.time() - t0 < se
               f"ep_len {(l - last[2]) / dc:6.1f} loss {float(st['loss']):9.4f} value_loss {float(st['value_loss']):9.4f}", flush=True)
         last = (c, r, l)
 model.finish_updates()
-print("fps", model.num_timesteps / (time.time() - t0), "overlap_update", overlap, "seed", seed, "policy dtype", dtype)
+print("fps", model.num_timesteps / (time.time() - t0), "overlap_update", overlap, "seed", seed, "policy dtype", dtype, "options", [x for x in sys.argv[3:] if x.startswith("no-")])
