@@ -282,9 +282,11 @@ def main():
 
     if rank == 0:
         value = total_env_steps / dt            # transitions that completed and were trained on, all ranks / max-over-ranks time
-        # async: one launch = one time slice = state + suspended macro-step context in and out (21 words each way) per env, plus the
-        # narrow phase's portal memory: a flag per lane each way, and 12 more words each way for the ~0.5 pairs in contact per env
-        macro_bytes = (MACRO_BYTES_PER_ENV if ar is None else (47 + 40 + 2 * 21) * 4 + 8 + 2 * 16 * 4 + 2 * 12 * 4 // 2) * a.envs
+        # async: one launch = one time slice = state + suspended macro-step context in and out (21 words each way) per env, plus what the
+        # narrow phase remembers per pair lane across slices (csrc/grip_sim.hip, MC_MEMO_WORDS): the flag / support-hint word and the
+        # separating direction (1 + 3 words) for each of the 16 lanes each way, and the portal (12 more words each way) for the ~0.5
+        # pairs in contact per env
+        macro_bytes = (MACRO_BYTES_PER_ENV if ar is None else (47 + 40 + 2 * 21) * 4 + 8 + 2 * 16 * 4 * 4 + 2 * 12 * 4 // 2) * a.envs
         if a.state_dtype == "f16":      # 34 of the 47 words read and 27 of the 40 written (qpos, qvel, ctrl) are 2 bytes
             macro_bytes -= (34 + 27) * 2 * a.envs
         sched = ("lock-step vector env" if ar is None else
