@@ -280,7 +280,9 @@ static constexpr int LDS_MAX_BYTES = 160 * 1024;
 struct StatePtrs { float *qpos, *qvel, *ctrl, *warm; int *episode_step, *status, *gripper_open, *pad_grasp, *pad_pher; int n; int half; };
 
 // A macro step suspended between two time slices (grip_batch_advance): everything k_macro_step keeps in registers across
-// its physics.step() loop, SoA [field][N]. astate: 0 = macro step in flight, 1 = finished, waiting for an action;
+// its physics.step() loop, one record per env (MCI / MCF below: 32 + 64 bytes, so a scattered env of the cost-sorted work order
+// touches whole sectors of its own instead of one 4-byte word in each of 21 sectors). astate, slot, heavy, gen stay [N] arrays: k_compact
+// scans them over all envs. astate: 0 = macro step in flight, 1 = finished, waiting for an action;
 // slot: row of the compact action / observation arrays this waiting env was given by the last k_compact (-1 = none yet);
 // heavy: hull-hull contacts the env had at its last physics.step() -- the cost class k_compact sorts the work order by;
 // gen: number of the compaction that gave the slot (tick[0] counts compactions): a slot-holder starts `lag` launches later.
@@ -290,8 +292,16 @@ struct MacroCtx { int *ints; float *flts; int *astate; int *slot; int *heavy; in
 // calls, so that a resumed macro step takes the same branches -- per-lane or cooperative support evaluation included -- as the
 // uninterrupted one and time-sliced results equal lock-step results bit for bit in contact too (tests/test_gpu_contact.py)
 #define MC_MEMO_WORDS 16
+// memory layout of the pair memory: [env][block of 4 words][lane][4]: block 0 = {word 0, separating direction} of the 16 lanes (256
+// contiguous bytes per env, one 16-byte access per lane), blocks 1..3 = the portal (vertex-pair ids, query directions) of the lanes in contact
+#define MEMO4(mc, e, blk, sub) (reinterpret_cast<float4 *>((mc).memo) + (((size_t)(e) * 4 + (blk)) * 16 + (sub)))
+#define MC_NINT_PAD 8
+#define MC_NFLT_PAD 16
+#define MCI(mc, f, e) (mc).ints[(size_t)(e) * MC_NINT_PAD + (f)]
+#define MCF(mc, f, e) (mc).flts[(size_t)(e) * MC_NFLT_PAD + (f)]
 enum { MC_PHASE = 0, MC_CNT, MC_NSUB, MC_GRASPED, MC_FLAGS, MC_FAULT, MC_NINT };
 enum { MC_TARGET = 0, MC_INITQ = 5, MC_OPENCLOSE = 10, MC_TQ = 11, MC_INITOBJ = 12, MC_NFLT = 15 };
+static_assert(MC_NINT <= MC_NINT_PAD && MC_NFLT <= MC_NFLT_PAD, "suspended-context record too small");
 
 DEVI void ld_state(const StatePtrs &p, int e, LaneState &s) {
 #pragma unroll
@@ -476,14 +486,14 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
             int sl = mc.slot[e];
             if (sl >= 0 && mc.gen[e] <= mc.tick[0] - lag) arow = (size_t)sl; else phase = PH_DONE;
         } else {                                        // in flight: resume
-            phase = mc.ints[(size_t)MC_PHASE * N + e]; cnt = mc.ints[(size_t)MC_CNT * N + e]; nsub = mc.ints[(size_t)MC_NSUB * N + e];
-            grasped = mc.ints[(size_t)MC_GRASPED * N + e]; fault = mc.ints[(size_t)MC_FAULT * N + e];
-            int fl = mc.ints[(size_t)MC_FLAGS * N + e];
+            phase = MCI(mc, MC_PHASE, e); cnt = MCI(mc, MC_CNT, e); nsub = MCI(mc, MC_NSUB, e);
+            grasped = MCI(mc, MC_GRASPED, e); fault = MCI(mc, MC_FAULT, e);
+            int fl = MCI(mc, MC_FLAGS, e);
             reached_target = fl & 1; reached_initial = fl & 2; first = false;
 #pragma unroll
-            for (int i = 0; i < 5; i++) { target[i] = mc.flts[(size_t)(MC_TARGET + i) * N + e]; init_q[i] = mc.flts[(size_t)(MC_INITQ + i) * N + e]; }
-            open_close = mc.flts[(size_t)MC_OPENCLOSE * N + e]; tq = mc.flts[(size_t)MC_TQ * N + e];
-            init_obj = v3(mc.flts[(size_t)MC_INITOBJ * N + e], mc.flts[(size_t)(MC_INITOBJ + 1) * N + e], mc.flts[(size_t)(MC_INITOBJ + 2) * N + e]);
+            for (int i = 0; i < 5; i++) { target[i] = MCF(mc, MC_TARGET + i, e); init_q[i] = MCF(mc, MC_INITQ + i, e); }
+            open_close = MCF(mc, MC_OPENCLOSE, e); tq = MCF(mc, MC_TQ, e);
+            init_obj = v3(MCF(mc, MC_INITOBJ, e), MCF(mc, MC_INITOBJ + 1, e), MCF(mc, MC_INITOBJ + 2, e));
         }
     }
     if (first && phase != PH_DONE) {
@@ -496,16 +506,14 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
     // the portal memory lives as long as the macro step: a resumed env gets it back, so that the result does not depend on where
     // the time slices end (lock-step keeps it in registers for the whole macro step)
     if (sliced && valid && !first) {
-        const float *mm = mc.memo + ((size_t)cx.sub * N + e);
-        const int w0 = __float_as_int(mm[0]);
+        const float4 m0 = *MEMO4(mc, e, 0, cx.sub);
+        const int w0 = __float_as_int(m0.x);
         sep.has = w0 & 1; sep.h1 = ((w0 >> 2) & 0xfff) - 1; sep.h2 = ((w0 >> 14) & 0xfff) - 1;
-        if (w0 & 2) sep.sep = v3(mm[(size_t)13 * 16 * N], mm[(size_t)14 * 16 * N], mm[(size_t)15 * 16 * N]);
-        if (sep.has) {                                      // only lanes whose pair was in contact carry more than the flag
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                sep.pi[k] = __float_as_int(mm[(size_t)(1 + k) * 16 * N]);
-                sep.pd[k] = v3(mm[(size_t)(4 + 3 * k) * 16 * N], mm[(size_t)(5 + 3 * k) * 16 * N], mm[(size_t)(6 + 3 * k) * 16 * N]);
-            }
+        if (w0 & 2) sep.sep = v3(m0.y, m0.z, m0.w);
+        if (sep.has) {                                      // only lanes whose pair was in contact carry more than the first block
+            const float4 m1 = *MEMO4(mc, e, 1, cx.sub), m2 = *MEMO4(mc, e, 2, cx.sub), m3 = *MEMO4(mc, e, 3, cx.sub);
+            sep.pi[0] = __float_as_int(m1.x); sep.pi[1] = __float_as_int(m1.y); sep.pi[2] = __float_as_int(m1.z);
+            sep.pd[0] = v3(m1.w, m2.x, m2.y); sep.pd[1] = v3(m2.z, m2.w, m3.x); sep.pd[2] = v3(m3.y, m3.z, m3.w);
         }
     }
 #endif
@@ -664,16 +672,13 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
     }
 #ifndef GRIP_COLD_PORTAL
     if (sliced && valid && phase != PH_DONE) {              // every lane parks its pair's portal memory (the flag; the portal if there is one)
-        float *mm = mc.memo + ((size_t)cx.sub * N + e);
         const bool has_sep = dot(sep.sep, sep.sep) > 0.5f;
-        mm[0] = __int_as_float((sep.has & 1) | (has_sep ? 2 : 0) | (((sep.h1 + 1) & 0xfff) << 2) | (((sep.h2 + 1) & 0xfff) << 14));
-        if (has_sep) { mm[(size_t)13 * 16 * N] = sep.sep.x; mm[(size_t)14 * 16 * N] = sep.sep.y; mm[(size_t)15 * 16 * N] = sep.sep.z; }
+        const int w0 = (sep.has & 1) | (has_sep ? 2 : 0) | (((sep.h1 + 1) & 0xfff) << 2) | (((sep.h2 + 1) & 0xfff) << 14);
+        *MEMO4(mc, e, 0, cx.sub) = make_float4(__int_as_float(w0), sep.sep.x, sep.sep.y, sep.sep.z);     // the direction is read back only under its flag
         if (sep.has) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                mm[(size_t)(1 + k) * 16 * N] = __int_as_float(sep.pi[k]);
-                mm[(size_t)(4 + 3 * k) * 16 * N] = sep.pd[k].x; mm[(size_t)(5 + 3 * k) * 16 * N] = sep.pd[k].y; mm[(size_t)(6 + 3 * k) * 16 * N] = sep.pd[k].z;
-            }
+            *MEMO4(mc, e, 1, cx.sub) = make_float4(__int_as_float(sep.pi[0]), __int_as_float(sep.pi[1]), __int_as_float(sep.pi[2]), sep.pd[0].x);
+            *MEMO4(mc, e, 2, cx.sub) = make_float4(sep.pd[0].y, sep.pd[0].z, sep.pd[1].x, sep.pd[1].y);
+            *MEMO4(mc, e, 3, cx.sub) = make_float4(sep.pd[1].z, sep.pd[2].x, sep.pd[2].y, sep.pd[2].z);
         }
     }
 #endif
@@ -681,13 +686,13 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
         st_state(st, e, s);
         st.status[e] = status; st.gripper_open[e] = gripper_open;
         mc.astate[e] = 0;
-        mc.ints[(size_t)MC_PHASE * N + e] = phase; mc.ints[(size_t)MC_CNT * N + e] = cnt; mc.ints[(size_t)MC_NSUB * N + e] = nsub;
-        mc.ints[(size_t)MC_GRASPED * N + e] = grasped; mc.ints[(size_t)MC_FAULT * N + e] = fault;
-        mc.ints[(size_t)MC_FLAGS * N + e] = (reached_target ? 1 : 0) | (reached_initial ? 2 : 0);
+        MCI(mc, MC_PHASE, e) = phase; MCI(mc, MC_CNT, e) = cnt; MCI(mc, MC_NSUB, e) = nsub;
+        MCI(mc, MC_GRASPED, e) = grasped; MCI(mc, MC_FAULT, e) = fault;
+        MCI(mc, MC_FLAGS, e) = (reached_target ? 1 : 0) | (reached_initial ? 2 : 0);
 #pragma unroll
-        for (int i = 0; i < 5; i++) { mc.flts[(size_t)(MC_TARGET + i) * N + e] = target[i]; mc.flts[(size_t)(MC_INITQ + i) * N + e] = init_q[i]; }
-        mc.flts[(size_t)MC_OPENCLOSE * N + e] = open_close; mc.flts[(size_t)MC_TQ * N + e] = tq;
-        mc.flts[(size_t)MC_INITOBJ * N + e] = init_obj.x; mc.flts[(size_t)(MC_INITOBJ + 1) * N + e] = init_obj.y; mc.flts[(size_t)(MC_INITOBJ + 2) * N + e] = init_obj.z;
+        for (int i = 0; i < 5; i++) { MCF(mc, MC_TARGET + i, e) = target[i]; MCF(mc, MC_INITQ + i, e) = init_q[i]; }
+        MCF(mc, MC_OPENCLOSE, e) = open_close; MCF(mc, MC_TQ, e) = tq;
+        MCF(mc, MC_INITOBJ, e) = init_obj.x; MCF(mc, MC_INITOBJ + 1, e) = init_obj.y; MCF(mc, MC_INITOBJ + 2, e) = init_obj.z;
     }
 }
 
@@ -1009,7 +1014,7 @@ static int batch_build(GripBatch *b, const GripModel *m) {
     HIPCHK(hipMalloc(&b->episode_step, N * sizeof(int))); HIPCHK(hipMalloc(&b->status, N * sizeof(int)));
     HIPCHK(hipMalloc(&b->gripper_open, N * sizeof(int))); HIPCHK(hipMalloc(&b->pad_grasp, N * sizeof(int)));
     HIPCHK(hipMalloc(&b->pad_pher, N * sizeof(int))); HIPCHK(hipMalloc(&b->reset_info, 4 * sizeof(float)));
-    HIPCHK(hipMalloc(&b->mc_ints, MC_NINT * N * sizeof(int))); HIPCHK(hipMalloc(&b->mc_flts, MC_NFLT * N * sizeof(float)));
+    HIPCHK(hipMalloc(&b->mc_ints, (size_t)MC_NINT_PAD * N * sizeof(int))); HIPCHK(hipMalloc(&b->mc_flts, (size_t)MC_NFLT_PAD * N * sizeof(float)));
     HIPCHK(hipMalloc(&b->mc_astate, N * sizeof(int))); HIPCHK(hipMalloc(&b->mc_slot, N * sizeof(int))); HIPCHK(hipMalloc(&b->mc_order, N * sizeof(int)));
     HIPCHK(hipMalloc(&b->mc_heavy, N * sizeof(int))); HIPCHK(hipMemset(b->mc_heavy, 0, N * sizeof(int)));
     HIPCHK(hipMalloc(&b->mc_tick, sizeof(int))); HIPCHK(hipMemset(b->mc_tick, 0, sizeof(int)));
