@@ -23,9 +23,23 @@
 #include "grip_device.h"
 
 #define KL 16                           // lanes per environment
-#define EPW (WAVE / KL)                 // environments per wave
-#define WG_THREADS 256
-#define EPB (WG_THREADS / KL)           // environments per workgroup
+// Environments a wave works on. 4: every 16-lane row of the wave is an env, 1024 waves for 4096 envs = ONE per SIMD. 2: only the
+// lower two rows are envs (the upper 32 lanes idle, a wave instruction costs the same for 32 or 64 lanes), 2048 waves = TWO per SIMD:
+// a gfx950 SIMD issues a lone wave's VALU stream at one instruction per 4 cycles but two waves' streams at one per 2 cycles each
+// way, and each wave covers the other's LDS / s_waitcnt stalls. Needs the kernel inside 256 registers.
+#ifndef GRIP_EPW
+#define GRIP_EPW 4
+#endif
+#define EPW GRIP_EPW                    // environments per wave
+#define EPB 16                          // environments per workgroup
+#define WG_THREADS (EPB / EPW * WAVE)
+#define WG_WAVES_PER_SIMD (WG_THREADS / 256)
+// slot of the calling lane's environment within its workgroup; `active`: the lane belongs to an env row of its wave
+DEVI int wg_env_slot(bool &active) {
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    active = lane < EPW * KL;
+    return w * EPW + ((lane & (EPW * KL - 1)) / KL);
+}
 
 // per-env LDS region (floats)
 #define EF_FRAMES 0                     // 6 geom frames x 12 (pos3, R9)
@@ -172,7 +186,7 @@ DEVI Ctx stage_tables(const DevModel &m, float *lds) {
     c.T.nbr = reinterpret_cast<const unsigned short *>(dst + m.hull_off_nbr);
     c.T.lut = reinterpret_cast<const unsigned short *>(dst + m.hull_off_lut);
     c.T.gt = gt;
-    c.envl = lds + LDS_ENV_BASE(m.hull_words) + (threadIdx.x / KL) * ENV_FLOATS;
+    bool act_; c.envl = lds + LDS_ENV_BASE(m.hull_words) + wg_env_slot(act_) * ENV_FLOATS;
     return c;
 }
 

@@ -424,12 +424,12 @@ extern __shared__ float lds_dyn[];
 #define STAMPS_INIT
 #endif
 
-__global__ void __launch_bounds__(WG_THREADS, 1) k_reset(const DevModel m, DevConfig cfg, StatePtrs st, const uint8_t *mask, StepOutDev out, float *reset_info, MacroCtx mc) {
+__global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_reset(const DevModel m, DevConfig cfg, StatePtrs st, const uint8_t *mask, StepOutDev out, float *reset_info, MacroCtx mc) {
     const Ctx cx = stage_tables(m, lds_dyn);
     STAMPS_DECL
-    int e = blockIdx.x * EPB + threadIdx.x / KL;
-    bool valid = e < st.n;
-    if (!valid) e = st.n - 1;
+    bool act_; int e = blockIdx.x * EPB + wg_env_slot(act_);
+    bool valid = act_ && e < st.n;
+    if (e >= st.n) e = st.n - 1;          // (idle rows of a 2-env wave mirror the env of the row 32 lanes below: same reads, no writes)
     bool doit = valid && (mask == nullptr || mask[e] != 0);
     LaneState s; reset_lane(m, s);
     Kin k; Contact con; int ncon = 0, fault = 0;
@@ -463,9 +463,9 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
                           const float *reset_info, float xfrc_z, const MacroCtx &mc, int slice, const int *order, long long budget_ticks, int lag, int block) {
     const Ctx cx = stage_tables(m, lds_dyn);
     STAMPS_DECL
-    int e = block * EPB + threadIdx.x / KL;
-    const bool valid = e < st.n;
-    if (!valid) e = st.n - 1;
+    bool act_; int e = block * EPB + wg_env_slot(act_);
+    const bool valid = act_ && e < st.n;
+    if (e >= st.n) e = st.n - 1;          // (idle rows of a 2-env wave mirror the env of the row 32 lanes below: same reads, no writes)
     if (order) e = order[e];
     const bool writer = valid && cx.sub == 0;
     const bool sliced = slice > 0;
@@ -714,7 +714,7 @@ DEVI int group_of_block(const GroupArgs *__restrict__ groups, int ngroups, int b
 
 // out1 (use_out1 != 0): result arrays given with the call (grip_batch_step / _advance of a single batch) instead of the ones
 // bound to the set. slice <= 0: actions float32 [total envs, adim] (lock-step); slice > 0: [ngroups * seg_rows, adim].
-__global__ void __launch_bounds__(WG_THREADS, 1) k_macro_step(const GroupArgs *__restrict__ groups, int ngroups, StepOutDev out1, int use_out1, const float *actions,
+__global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_macro_step(const GroupArgs *__restrict__ groups, int ngroups, StepOutDev out1, int use_out1, const float *actions,
                                                               int seg_rows, int slice, long long budget_ticks, int lag) {
     const int g = group_of_block(groups, ngroups, (int)blockIdx.x);
     const GroupArgs &ga = groups[g];
@@ -832,12 +832,12 @@ __global__ void __launch_bounds__(CP_THREADS) k_compact(const GroupArgs *__restr
 }
 
 // k calls of physics.step() with the stored ctrl (test hook / micro-benchmark)
-__global__ void __launch_bounds__(WG_THREADS, 1) k_substep(const DevModel m, StatePtrs st, int nsteps, float xfrc_z, int *fault_out) {
+__global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_substep(const DevModel m, StatePtrs st, int nsteps, float xfrc_z, int *fault_out) {
     const Ctx cx = stage_tables(m, lds_dyn);
     STAMPS_DECL
-    int e = blockIdx.x * EPB + threadIdx.x / KL;
-    const bool valid = e < st.n;
-    if (!valid) e = st.n - 1;
+    bool act_; int e = blockIdx.x * EPB + wg_env_slot(act_);
+    const bool valid = act_ && e < st.n;
+    if (e >= st.n) e = st.n - 1;          // (idle rows of a 2-env wave mirror the env of the row 32 lanes below: same reads, no writes)
     LaneState s; ld_state(st, e, s);
     Kin k; Contact con; int ncon = 0, fault = 0;
     PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1; PAIRMEMO_EXTRA_INIT(sep)
@@ -851,13 +851,13 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_substep(const DevModel m, Sta
 #endif
 }
 
-__global__ void __launch_bounds__(WG_THREADS, 1) k_debug_forward(const DevModel m, StatePtrs st, float xfrc_z, int getenv_dbgH, int *ncon_out, float *con_out, float *xpos_out,
+__global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_debug_forward(const DevModel m, StatePtrs st, float xfrc_z, int getenv_dbgH, int *ncon_out, float *con_out, float *xpos_out,
                                                                  float *qacc_out, float *qs_out, float *M_out, float *bias_out) {
     const Ctx cx = stage_tables(m, lds_dyn);
     STAMPS_DECL
-    int e = blockIdx.x * EPB + threadIdx.x / KL;
-    const bool valid = e < st.n;
-    if (!valid) e = st.n - 1;
+    bool act_; int e = blockIdx.x * EPB + wg_env_slot(act_);
+    const bool valid = act_ && e < st.n;
+    if (e >= st.n) e = st.n - 1;          // (idle rows of a 2-env wave mirror the env of the row 32 lanes below: same reads, no writes)
     LaneState s; ld_state(st, e, s);
     Kin k; Contact con; int ncon = 0, fault = 0, iters = 0;
     PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1; PAIRMEMO_EXTRA_INIT(sep)
@@ -886,11 +886,11 @@ __global__ void __launch_bounds__(WG_THREADS, 1) k_debug_forward(const DevModel 
     if (!getenv_dbgH) for (int i = 0; i < 169; i++) M_out[(size_t)e * 169 + i] = cx.envl[EF_M + i];
 }
 
-__global__ void __launch_bounds__(WG_THREADS, 1) k_target_pose(const DevModel m, DevConfig cfg, StatePtrs st, const float *actions, float *target_out) {
+__global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_target_pose(const DevModel m, DevConfig cfg, StatePtrs st, const float *actions, float *target_out) {
     const Ctx cx = stage_tables(m, lds_dyn);
-    int e = blockIdx.x * EPB + threadIdx.x / KL;
-    const bool valid = e < st.n;
-    if (!valid) e = st.n - 1;
+    bool act_; int e = blockIdx.x * EPB + wg_env_slot(act_);
+    const bool valid = act_ && e < st.n;
+    if (e >= st.n) e = st.n - 1;          // (idle rows of a 2-env wave mirror the env of the row 32 lanes below: same reads, no writes)
     LaneState s; ld_state(st, e, s);
     Kin k; kinematics(m, s.qpos, k, cx, false);
     const int adim = cfg.include_roll ? 6 : 5;
@@ -1407,9 +1407,9 @@ extern "C" int grip_debug_counters(unsigned long long *out8) {   // 16 collide()
 #endif
 
 // ---- self-test hook of the lane-distributed Cholesky (tests only): x = A^-1 b for n SPD 13x13 systems
-__global__ void __launch_bounds__(WG_THREADS, 1) k_test_chol(const float *A, const float *b, float *x, int n) {
-    int e = blockIdx.x * EPB + threadIdx.x / KL, sub = threadIdx.x & (KL - 1);
-    bool valid = e < n; if (!valid) e = n - 1;
+__global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_test_chol(const float *A, const float *b, float *x, int n) {
+    bool act_; int e = blockIdx.x * EPB + wg_env_slot(act_), sub = threadIdx.x & (KL - 1);
+    bool valid = act_ && e < n; if (e >= n) e = n - 1;
     float row[13];
     for (int j = 0; j < 13; j++) row[j] = sub < 13 ? A[(size_t)e * 169 + min(sub, 12) * 13 + j] : 0.f;
     if (sub >= 13) row[12] = 1.f;

@@ -113,6 +113,9 @@ def lib():
         return _lib
     if os.environ.get("GRIP_COLD_PORTAL") == "1" and LIB_PATH == os.path.join(CSRC, "libgrip_sim.so"):
         LIB_PATH = COLD_LIB_PATH
+    variant = os.environ.get("GRIP_LIB_VARIANT")           # development only: an experimental build made by tools/build_variant.py
+    if variant and LIB_PATH == os.path.join(CSRC, "libgrip_sim.so"):
+        LIB_PATH = os.path.join(CSRC, f"libgrip_sim_{variant}.so")
     if not os.path.exists(LIB_PATH):
         raise GripError(f"{LIB_PATH} is not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
                         "There is no CPU fallback for the product path.")

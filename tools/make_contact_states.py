@@ -86,7 +86,7 @@ def well_conditioned(m, cfg, st, act, o_ref, rng, trials=3, amp=5e-7, vamp=3e-5)
     physics.step() decides the integer outputs. Such rows cannot tell a wrong implementation from a rounding difference. Keep a row
     only if the oracle's own outputs survive that noise: orc_set_step_noise2(amp, vamp) perturbs qpos by amp * (1 + |x|) * U(-1, 1) and
     qvel by vamp * (1 + |v|) * U(-1, 1) after every physics.step(). The amplitudes are the measured one-step errors of the fp32 kernel
-    started from the oracle's own states along contact trajectories (tools/contact_diag2.py on MI355X: qpos median 3e-8 / p99 4e-7,
+    started from the oracle's own states along contact trajectories (measured on MI355X, tests/test_gpu_contact.py::test_one_step_parity_along_contact_trajectories: qpos median 3e-8 / p99 4e-7,
     qvel median 1e-6 / p99 2e-4 -- the velocity error is the Newton solve stopping at the fp32 noise floor of its gradient). Three
     seeds; integer outputs identical, reward within 2e-3, gripper and object within 2e-4 m of the noise-free run."""
     del rng
