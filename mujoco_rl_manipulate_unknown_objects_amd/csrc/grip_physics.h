@@ -47,14 +47,33 @@ DEVI int wg_env_slot(bool &active) {
 #define ST_STRIDE 11                    // pos3, n3, dist, meta, fs, ft, tran
 #define EF_M (EF_STAGE + G_MAXC * ST_STRIDE)   // 13 x 13 mass matrix, row-major
 #define EF_U ((EF_M + 169 + 3) & ~3)     // per-contact Hessian vectors (16-byte aligned): G_MAXC x 6 slots x U_STRIDE (13 entries + weight)
-#define U_STRIDE 16                    // 13 entries + weight, padded to 64 B so a slot is four ds_read_b128
-#define ENV_FLOATS (EF_U + G_MAXC * 6 * U_STRIDE)
+#define U_STRIDE 16                    // a slot is four ds_read_b128: [ g0 .. g6 | w ][ o0 .. o5 | 0 | w ] -- the seven gripper columns, the six object
+                                       // columns, the slot's weight at the end of both halves (a dof lane reads only its block's half when no
+                                       // contact couples gripper and object, i.e. when H is block diagonal)
+#define UPOS(j) ((j) + ((j) >= 7 ? 1 : 0))   // position of dof column j in a slot
+// The env's STATE lives here too, not in registers: every value below is the same in the env's 16 lanes, so one copy in LDS replaces 16 x
+// ~150 registers that were live across collide() and the solver (the kernel had 467 of them and ran one wave per SIMD). Each phase loads what
+// it needs with 16-byte broadcast reads and lane 0 stores what it changes.
+#define ES_QPOS (EF_U + G_MAXC * 6 * U_STRIDE)  // qpos[14]            (16 slots)
+#define ES_QVEL (ES_QPOS + 16)          // qvel[13]            (16)
+#define ES_CTRL (ES_QVEL + 16)          // ctrl[7]             (8)
+#define ES_WARM (ES_CTRL + 8)           // qacc_warmstart[13]  (16)
+#define ES_QFS (ES_WARM + 16)           // qfrc_smooth[13] of this step (16), dense block -> integrator
+#define ES_QS (ES_QFS + 16)             // qacc_smooth[13] of this step (16), dense block -> solver
+#define ES_MAC (ES_QS + 16)             // macro step: target[5], init_q[5], open_close, tq, init_obj[3] (16; same order as the suspended record MCF)
+#define ENV_FLOATS (ES_MAC + 16)
+// what the constraint rows need of the kinematics (pe, a4, pk[2], ak[2], po, Ro: 30 floats): kinematics() -> make_constraints(). It sits in the
+// last two Hessian-vector slots of the LAST contact, which nobody writes before hessian_vectors() of the following solve.
+#define ES_KIN (EF_U + (G_MAXC - 1) * 6 * U_STRIDE + 4 * U_STRIDE)
+// the integrator's exchange vector (qfrc_smooth + J^T f, one component per dof lane): the staging area is free once the solve is over
+#define ES_ACC EF_STAGE
 // The Newton step's linear system, gathered so that EVERY lane holds all of it: row r of H at EF_H + 16 r (13 entries), the negative
 // gradient at EF_HG. It reuses the geom frames and the staging area (226 floats, dead between collide() and the next kinematics()) and
 // overwrites EF_FORCE / EF_P, which the next pricing rewrites before anybody reads them.
 #define EF_H EF_FRAMES
 #define EF_HG (EF_FRAMES + 208)
 static_assert(EF_HG + 13 <= EF_M, "the gathered Hessian must fit the frames + staging area");
+static_assert(ES_QPOS % 4 == 0 && ENV_FLOATS % 4 == 0 && ES_KIN % 4 == 0, "state vectors are read with 16-byte loads");
 // per-workgroup geom table (floats per geom): centre3, rbound, fs, ft, invweight, group, hull_vadr
 #define GT_STRIDE 10
 #define GT_FLOATS (GN_GEOM * GT_STRIDE)
@@ -88,6 +107,12 @@ DEVI unsigned long long stamp_now() { __builtin_amdgcn_sched_barrier(0); unsigne
 // 6 hill-climb hops (all lanes), 7 support_vertex calls (all lanes)
 __device__ unsigned long long g_dbg_cnt[16];   // 8..11: wave-level (first wave of a workgroup): cycles / trips with per-lane supports, cycles / trips of pure cooperative refinement; 12: cycles of collide() outside the loop
 #define DBG_COUNT(i, n) do { if (blockIdx.x == 0) atomicAdd(&g_dbg_cnt[i], (unsigned long long)(n)); } while (0)      // first workgroup only: thousands of lanes on 16 counters would distort the timings
+// per env and physics.step() (lane 0 of every env, all workgroups): 0..7 Newton iterations 0..6, 7+; 8..15 contacts 0, 1-2, 3-4, 5-6, 7-8, 9-10, 11-12, 13-14;
+// 16 steps, 17 constrained, 18 gripper block constrained (13 x 13 solve), 19 any hull-hull contact, 20 active joint limit, 21 line-search evaluations,
+// 24..31 wave trips by the number of Newton iterations the wave ran (max over its envs) 0..6, 7+
+__device__ unsigned long long g_dbg_hist[96];   // 64..71 gradient decade at the chosen start; 72 warm start taken; 73 solves; 74..76 hull contacts by cone zone (top, middle, bottom) at the start; 77..79 at the end; 80 hull contacts whose zone changed; 81..83 / 84..86 / 87 the same for floor contacts   // 32 + 8 k + b: after Newton iteration k + 1 (k = 0..3) the scaled gradient was in decade b (< 1e-7, 1e-7.., ..., >= 1e-1)
+#define DBG_HIST(i, n) atomicAdd(&g_dbg_hist[i], (unsigned long long)(n))
+#define HAVE_DBG_HIST 1
 #elif defined(GRIP_MARKS)      // listing build only (hipcc -S -DGRIP_MARKS): phase boundaries as comments in the ISA, to count instructions per phase
 #define DBG_COUNT(i, n) do { } while (0)
 struct Stamps { int dummy; };
@@ -145,7 +170,6 @@ struct Kin {
 // tables staged in LDS, shared by the workgroup
 struct Tables {
     const float *v;                 // hull vertices [nvert][4]
-    const unsigned short *nadr;     // CSR over all hull vertices
     const unsigned short *nbr;      // neighbour ids, local to the hull
     const unsigned short *lut;      // [6][LUT_CELLS] start vertices
     const float *gt;                // geom table [GN_GEOM][GT_STRIDE]
@@ -158,6 +182,27 @@ struct Ctx {
 };
 
 constexpr DEVI int pidx(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+// N floats of a 16-byte aligned LDS vector (padded to a multiple of 4) into registers: ceil(N / 4) ds_read_b128, all lanes of an env read
+// the same address (broadcast)
+template <int N> DEVI void lds_ld(const float *p, float (&v)[N]) {
+    const float4 *p4 = reinterpret_cast<const float4 *>(p);
+#pragma unroll
+    for (int i = 0; i < (N + 3) / 4; i++) {
+        const float4 t = p4[i];
+        v[4 * i] = t.x;
+        if (4 * i + 1 < N) v[4 * i + 1] = t.y;
+        if (4 * i + 2 < N) v[4 * i + 2] = t.z;
+        if (4 * i + 3 < N) v[4 * i + 3] = t.w;
+    }
+}
+// ... and back (the caller masks to one lane); the padding words are written too
+template <int N> DEVI void lds_st(float *p, const float (&v)[N]) {
+    float4 *p4 = reinterpret_cast<float4 *>(p);
+#pragma unroll
+    for (int i = 0; i < (N + 3) / 4; i++)
+        p4[i] = make_float4(v[4 * i], 4 * i + 1 < N ? v[4 * i + 1] : 0.f, 4 * i + 2 < N ? v[4 * i + 2] : 0.f, 4 * i + 3 < N ? v[4 * i + 3] : 0.f);
+}
 
 // workgroup prologue: hulls + geom table into LDS; returns the context of the calling lane
 DEVI Ctx stage_tables(const DevModel &m, float *lds) {
@@ -182,7 +227,6 @@ DEVI Ctx stage_tables(const DevModel &m, float *lds) {
     Ctx c;
     c.lane = threadIdx.x & (WAVE - 1); c.sub = threadIdx.x & (KL - 1);
     c.T.v = reinterpret_cast<const float *>(dst);
-    c.T.nadr = reinterpret_cast<const unsigned short *>(dst + m.hull_off_nadr);
     c.T.nbr = reinterpret_cast<const unsigned short *>(dst + m.hull_off_nbr);
     c.T.lut = reinterpret_cast<const unsigned short *>(dst + m.hull_off_lut);
     c.T.gt = gt;
@@ -192,16 +236,30 @@ DEVI Ctx stage_tables(const DevModel &m, float *lds) {
 
 // ---------------------------------------------------------------- kinematics (redundant in the 16 lanes)
 DEVI void store_frame(float *envl, int g, V3 p, const M3 &R) {
-    float *f = envl + EF_FRAMES + (g - 1) * 12;
-    f[0] = p.x; f[1] = p.y; f[2] = p.z;
-#pragma unroll
-    for (int i = 0; i < 9; i++) f[3 + i] = R.m[i];
+    float4 *f = reinterpret_cast<float4 *>(envl + EF_FRAMES + (g - 1) * 12);
+    f[0] = make_float4(p.x, p.y, p.z, R.m[0]); f[1] = make_float4(R.m[1], R.m[2], R.m[3], R.m[4]); f[2] = make_float4(R.m[5], R.m[6], R.m[7], R.m[8]);
 }
 DEVI void load_frame(const float *envl, int g, V3 &p, M3 &R) {
-    const float *f = envl + EF_FRAMES + (g - 1) * 12;
-    p = v3(f[0], f[1], f[2]);
-#pragma unroll
-    for (int i = 0; i < 9; i++) R.m[i] = f[3 + i];
+    const float4 *f = reinterpret_cast<const float4 *>(envl + EF_FRAMES + (g - 1) * 12);
+    const float4 a = f[0], b = f[1], c = f[2];
+    p = v3(a.x, a.y, a.z);
+    R.m[0] = a.w; R.m[1] = b.x; R.m[2] = b.y; R.m[3] = b.z; R.m[4] = b.w; R.m[5] = c.x; R.m[6] = c.y; R.m[7] = c.z; R.m[8] = c.w;
+}
+
+// what make_constraints() needs of the kinematics, parked in LDS across collide() (ES_KIN)
+struct KinC { V3 pe, a4, pk[2], ak[2], po; M3 Ro; };
+DEVI void kinc_store(float *envl, const V3 &pe, const V3 &a4, const V3 (&pk)[2], const V3 (&ak)[2], const V3 &po, const M3 &Ro) {
+    float4 *f = reinterpret_cast<float4 *>(envl + ES_KIN);
+    f[0] = make_float4(pe.x, pe.y, pe.z, a4.x); f[1] = make_float4(a4.y, a4.z, pk[0].x, pk[0].y); f[2] = make_float4(pk[0].z, pk[1].x, pk[1].y, pk[1].z);
+    f[3] = make_float4(ak[0].x, ak[0].y, ak[0].z, ak[1].x); f[4] = make_float4(ak[1].y, ak[1].z, po.x, po.y);
+    f[5] = make_float4(po.z, Ro.m[0], Ro.m[1], Ro.m[2]); f[6] = make_float4(Ro.m[3], Ro.m[4], Ro.m[5], Ro.m[6]); f[7] = make_float4(Ro.m[7], Ro.m[8], 0.f, 0.f);
+}
+DEVI void kinc_load(const float *envl, KinC &k) {
+    const float4 *f = reinterpret_cast<const float4 *>(envl + ES_KIN);
+    const float4 a = f[0], b = f[1], c = f[2], d = f[3], e = f[4], g = f[5], h = f[6], i = f[7];
+    k.pe = v3(a.x, a.y, a.z); k.a4 = v3(a.w, b.x, b.y); k.pk[0] = v3(b.z, b.w, c.x); k.pk[1] = v3(c.y, c.z, c.w);
+    k.ak[0] = v3(d.x, d.y, d.z); k.ak[1] = v3(d.w, e.x, e.y); k.po = v3(e.z, e.w, g.x);
+    k.Ro.m[0] = g.y; k.Ro.m[1] = g.z; k.Ro.m[2] = g.w; k.Ro.m[3] = h.x; k.Ro.m[4] = h.y; k.Ro.m[5] = h.z; k.Ro.m[6] = h.w; k.Ro.m[7] = i.x; k.Ro.m[8] = i.y;
 }
 
 DEVI void kinematics(const DevModel &m, float (&qpos)[14], Kin &k, const Ctx &cx, bool store) {
@@ -242,6 +300,12 @@ DEVI void kinematics(const DevModel &m, float (&qpos)[14], Kin &k, const Ctx &cx
     rot_sym(k.Re, m.grp_inertia[0], k.Ic[0]);
     k.c[3] = k.po + mulv(k.Ro, ldv(m.grp_com[3]));
     rot_sym(k.Ro, m.grp_inertia[3], k.Ic[3]);
+    if (wr) {
+        kinc_store(cx.envl, k.pe, k.a4, k.pk, k.ak, k.po, k.Ro);
+        // the normalised quaternion is the state's (mj_kinematics normalises qpos in place)
+        float4 *q4 = reinterpret_cast<float4 *>(cx.envl + ES_QPOS);
+        q4[2] = make_float4(qpos[8], qpos[9], qpos[10], qpos[11]); q4[3] = make_float4(qpos[12], qpos[13], 0.f, 0.f);
+    }
 }
 
 // ---------------------------------------------------------------- mass matrix: gripper 7x7 (Mg) and object 6x6 (Mo), packed lower
@@ -532,17 +596,30 @@ DEVI void gathered_solve(const Ctx &cx, const float (&row)[13], float gi, float 
     for (int i = 0; i < N; i++) p[LO + i] = x[i];
 }
 
-// this lane's row of the env's mass matrix (zero in lanes 13..15)
-DEVI void load_mrow(const Ctx &cx, float (&mrow)[13]) {
-    const float *M = cx.envl + EF_M + min(cx.sub, 12) * 13;
+// The same for a block-diagonal H: every lane factorises only ITS block -- gripper 7 x 7 in lanes 0..6, object 6 x 6 (padded with an
+// identity row) in the others -- 28 packed entries instead of 91, a fifth of the multiply-adds; both blocks at once, in different lanes.
+// Lane i < 13 publishes the seven entries of its row and its gradient component as two 16-byte stores, reads its block back (14 16-byte
+// loads) and returns the block's part of the Newton direction in x (x[6] = 0 in the object block).
+DEVI void gathered_solve_block(const Ctx &cx, const float (&row)[7], float gi, float (&x)[7]) {
+    float4 *H4 = reinterpret_cast<float4 *>(cx.envl + EF_H);
+    if (cx.sub < 13) { H4[2 * cx.sub] = make_float4(row[0], row[1], row[2], row[3]); H4[2 * cx.sub + 1] = make_float4(row[4], row[5], row[6], -gi); }
+    wave_sync();
+    const bool grip = cx.sub < 7;
+    const int base = grip ? 0 : 7;
+    float A[28];
 #pragma unroll
-    for (int j = 0; j < 13; j++) mrow[j] = cx.sub < 13 ? M[j] : 0.f;
-}
-DEVI float row_dot(const float (&row)[13], const float (&v)[13]) {
-    float s = 0.f;
+    for (int i = 0; i < 7; i++) {
+        const int r = (i < 6 || grip) ? base + i : base;            // row 13 does not exist: the object block's seventh row is the identity
+        const float4 a = H4[2 * r], b = H4[2 * r + 1];
+        const float e[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+        const bool pad = i == 6 && !grip;
 #pragma unroll
-    for (int j = 0; j < 13; j++) s = fmaf(row[j], v[j], s);
-    return s;
+        for (int j = 0; j <= i; j++) A[pidx(i, j)] = pad ? (j == 6 ? 1.f : 0.f) : e[j];
+        x[i] = pad ? 0.f : b.w;
+    }
+    wave_sync();                                        // the area is rewritten by the next pricing: reads first (one wave, in order)
+    chol_packed<7>(A);
+    chol_solve_packed<7>(A, x);
 }
 
 // ---------------------------------------------------------------- collision
@@ -732,10 +809,11 @@ struct PairMemo { V3 sep; int h1, h2; int has; int pi[3]; V3 pd[3]; };      // +
 struct PairMemo { V3 sep; int h1, h2; };
 #endif
 
+// (its constraint Jacobian rows -- normal, tangent 1, tangent 2, torsion -- are built once per step by make_constraints() and live in the
+// contact's LDS slots, EF_U + 6 U_STRIDE c: 52 registers per lane less across the solver)
 struct Contact {
     V3 p, n; float dist; int g1, g2, gA, gB; float fs, ft, tran, D0;
-    float aref[4], jar[4], jv[4];
-    float J[4][13];             // the contact's constraint Jacobian rows (normal, tangent 1, tangent 2, torsion), built once per step
+    float jar[4], jv[4];
 };
 
 // Narrow phase of one state, one item per lane and round. Items 0..5: floor vs hull geom item + 1 (support along -z,
@@ -1059,45 +1137,69 @@ DEVI float cone_quad(const Cone &c, const float (&jv)[4]) {
     return q + c.ka * da * da - c.kb * db * db;
 }
 
-// relative motion rows of this lane's contact for group twists t: (n.v, t1.v, t2.v, n.w)
-template <bool OBJ>
-DEVI void contact_rows(const Kin &k, const Twist &t, const Contact &c, V3 t1, V3 t2, float (&r)[4]) {
-    V3 dv, dw;
-    if (OBJ) { dv = t.vO + cross(t.wO, c.p - k.po); dw = t.wO; }
-    else {
-        V3 vA, wA, vB, wB;
-        group_motion(k, t, c.gA, c.p, vA, wA); group_motion(k, t, c.gB, c.p, vB, wB);
-        dv = vB - vA; dw = wB - wA;
-    }
-    r[0] = dot(c.n, dv); r[1] = dot(t1, dv); r[2] = dot(t2, dv); r[3] = dot(c.n, dw);
+// What the solver needs of this lane besides its contact: the joint limit it owns (lanes 0..6), the residuals jar = J x - aref of the two
+// candidate starts (x = qacc_smooth, x = qacc_warmstart), its components of both and (M (warm - qacc_smooth))_i.
+struct LaneCon { float lsgn, lD, laref; float jar_s[4], jar_w[4]; float Md_w, qsi, warmi; bool grip, constrained, coupled; };
+
+// this lane's row of the env's mass matrix (zero in lanes 13..15)
+DEVI void load_mrow(const Ctx &cx, float (&mrow)[13]) {
+    const float *M = cx.envl + EF_M + min(cx.sub, 12) * 13;
+#pragma unroll
+    for (int j = 0; j < 13; j++) mrow[j] = cx.sub < 13 ? M[j] : 0.f;
+}
+DEVI float row_dot(const float (&row)[13], const float (&v)[13]) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 13; j++) s = fmaf(row[j], v[j], s);
+    return s;
 }
 
-// reference accelerations and regularisation (mj_makeConstraint / mj_makeImpedance): limits redundantly, this lane's contact
-DEVI void make_constraints(const DevModel &m, const Kin &k, const float (&qpos)[14], const float (&qvel)[13],
-                           int sub, float &lsgn, float &lD, float &laref, Contact &c, bool live) {
-    // joint limit of dof `sub` (lanes 0..6; mj_instantiateLimit + mj_makeImpedance): only the owning lane needs it
+// Reference accelerations and regularisation (mj_makeConstraint / mj_makeImpedance) and the solver's starting data. The joint limit of dof
+// `sub` belongs to lane `sub`, contact c to lane c. A contact's four Jacobian rows are formed one at a time -- 13 registers, not 52 -- and go
+// straight to its LDS slots (rows 0..3 of EF_U + 6 U_STRIDE c, where pricing, Hessian assembly and J p read them); on the way each row yields
+// its velocity (-> aref) and its two start residuals. State comes from the env's LDS vectors, the kinematics from ES_KIN.
+DEVI void make_constraints(const DevModel &m, const Ctx &cx, Contact &c, int ncon, LaneCon &lc) {
+    float *S = cx.envl;
+    const int sub = cx.sub;
+    const bool live = sub < ncon;
     {   const int j = min(sub, 6);
-        float qj = 0.f, vj = 0.f, r0 = 0.f, r1 = 0.f, iw = 0.f;
+        const float qj = S[ES_QPOS + j], vj = S[ES_QVEL + j];
+        float r0 = 0.f, r1 = 0.f, iw = 0.f;
 #pragma unroll
-        for (int q = 0; q < 7; q++) { bool h = j == q; qj = h ? qpos[q] : qj; vj = h ? qvel[q] : vj; r0 = h ? m.range[q][0] : r0; r1 = h ? m.range[q][1] : r1; iw = h ? m.dof_invweight0[q] : iw; }
+        for (int q = 0; q < 7; q++) { bool h = j == q; r0 = h ? m.range[q][0] : r0; r1 = h ? m.range[q][1] : r1; iw = h ? m.dof_invweight0[q] : iw; }
         float lo = qj - r0, hi = r1 - qj;
         float sgn = 0.f, dist = 0.f;
         if (lo < 0.f) { sgn = 1.f; dist = lo; } else if (hi < 0.f) { sgn = -1.f; dist = hi; }
         float imp = impedance(m.lim_solimp, dist, 0.f);
         float R = fmaxf(1e-15f, (1.f - imp) * iw / imp);
         const bool own = sub < 7;
-        lsgn = own ? sgn : 0.f; lD = own ? 1.0f / R : 0.f;
-        laref = own ? -m.b_lim * (sgn * vj) - m.k_lim * imp * dist : 0.f;
+        lc.lsgn = own ? sgn : 0.f; lc.lD = own ? 1.0f / R : 0.f;
+        lc.laref = own ? -m.b_lim * (sgn * vj) - m.k_lim * imp * dist : 0.f;
     }
+    const bool anylim = group_bits(__ballot(lc.lsgn != 0.f), cx.lane) != 0u;
+    lc.constrained = ncon > 0 || anylim;
+    // when no constraint touches the gripper (no joint limit, only floor-object contacts) its block of the problem is
+    // unconstrained and decoupled: start it at qacc_smooth, which is then already optimal for those 7 dofs
+    lc.grip = anylim || group_bits(__ballot(live && !(c.g1 == 0 && c.g2 == 6)), cx.lane) != 0u;
+    // a gripper part against the object: the only contacts that couple the gripper's 7 x 7 block of the Hessian to the object's 6 x 6 block
+    lc.coupled = group_bits(__ballot(live && c.g1 != 0 && (c.g1 == 6 || c.g2 == 6)), cx.lane) != 0u;
 #pragma unroll
-    for (int r = 0; r < 4; r++) { c.aref[r] = 0.f; c.jar[r] = 0.f; c.jv[r] = 0.f; }
-    if (!live) {
+    for (int r = 0; r < 4; r++) { lc.jar_s[r] = 0.f; lc.jar_w[r] = 0.f; c.jar[r] = 0.f; c.jv[r] = 0.f; }
+    lc.qsi = sub < 13 ? S[ES_QS + min(sub, 12)] : 0.f;
+    lc.warmi = sub >= 13 ? 0.f : (sub < 7 && !lc.grip) ? lc.qsi : S[ES_WARM + min(sub, 12)];
+    lc.Md_w = 0.f;
+    if (!__any(lc.constrained)) return;                      // nobody in the wave solves: the rest is not needed
+    float qs[13], dw[13];
+    lds_ld<13>(S + ES_QS, qs);
+    {   float warm[13]; lds_ld<13>(S + ES_WARM, warm);
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-#pragma unroll
-            for (int i = 0; i < 13; i++) c.J[r][i] = 0.f;
+        for (int i = 0; i < 13; i++) dw[i] = ((i < 7 && !lc.grip) ? qs[i] : warm[i]) - qs[i];
+        float mrow[13]; load_mrow(cx, mrow);
+        lc.Md_w = row_dot(mrow, dw);
     }
     if (live) {
+        float qvel[13]; lds_ld<13>(S + ES_QVEL, qvel);
+        KinC k; kinc_load(S, k);
         V3 t1, t2; make_tangents(c.n, t1, t2);
         // Rows of (body B) - (body A) without a case analysis per body: a dof contributes with the signed difference of "B hangs on
         // it" and "A hangs on it" -- sG for the five ee dofs (any gripper group), sL / sR for the knuckle hinges, sO for the object's
@@ -1106,30 +1208,37 @@ DEVI void make_constraints(const DevModel &m, const Kin &k, const float (&qpos)[
         const float sG = gB_grip - gA_grip, sL = (c.gB == GRP_L ? 1.f : 0.f) - (c.gA == GRP_L ? 1.f : 0.f), sR = (c.gB == GRP_R ? 1.f : 0.f) - (c.gA == GRP_R ? 1.f : 0.f),
                     sO = (c.gB == GRP_O ? 1.f : 0.f) - (c.gA == GRP_O ? 1.f : 0.f);
         const V3 rE = c.p - k.pe, rL = c.p - k.pk[0], rR = c.p - k.pk[1], rO = c.p - k.po;
+        const float imp = impedance(m.solimp, c.dist, m.margin);
+        const float R0 = fmaxf(1e-15f, (1.f - imp) * c.tran / imp);
+        c.D0 = 1.0f / R0;
+        float4 *U = reinterpret_cast<float4 *>(S + EF_U + sub * 6 * U_STRIDE);
+        // velocity of the row -> aref, residuals of the two starts, and the row itself into its LDS slot (weight word zero until hessian_vectors)
+        auto finish_row = [&](int r, const float (&j)[13], float kterm) {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < 13; i++) v = fmaf(j[i], qvel[i], v);
+            const float aref = -m.b_con * v - kterm;
+            float vs = -aref, vw = 0.f;
+#pragma unroll
+            for (int i = 0; i < 13; i++) { vs = fmaf(j[i], qs[i], vs); vw = fmaf(j[i], dw[i], vw); }
+            lc.jar_s[r] = vs; lc.jar_w[r] = vs + vw;
+            U[4 * r] = make_float4(j[0], j[1], j[2], j[3]); U[4 * r + 1] = make_float4(j[4], j[5], j[6], 0.f);
+            U[4 * r + 2] = make_float4(j[7], j[8], j[9], j[10]); U[4 * r + 3] = make_float4(j[11], j[12], 0.f, 0.f);
+        };
         auto linear_row = [&](float (&j)[13], V3 e) {
             const V3 cg = cross(rE, e), al = multv(k.Ro, cross(rO, e));
             j[0] = sG * e.x; j[1] = sG * e.y; j[2] = sG * e.z; j[3] = sG * cg.x; j[4] = sG * dot(k.a4, cg);
             j[5] = sL * dot(k.ak[0], cross(rL, e)); j[6] = sR * dot(k.ak[1], cross(rR, e));
             j[7] = sO * e.x; j[8] = sO * e.y; j[9] = sO * e.z; j[10] = sO * al.x; j[11] = sO * al.y; j[12] = sO * al.z;
         };
-        linear_row(c.J[0], c.n); linear_row(c.J[1], t1); linear_row(c.J[2], t2);
+        {   float j[13]; linear_row(j, c.n); finish_row(0, j, m.k_con * imp * (c.dist - m.margin)); }
+        {   float j[13]; linear_row(j, t1); finish_row(1, j, 0.f); }
+        {   float j[13]; linear_row(j, t2); finish_row(2, j, 0.f); }
         {   const V3 al = multv(k.Ro, c.n);               // torsion: relative angular velocity about the normal
-            float (&j)[13] = c.J[3];
+            float j[13];
             j[0] = j[1] = j[2] = 0.f; j[3] = sG * c.n.x; j[4] = sG * dot(k.a4, c.n); j[5] = sL * dot(k.ak[0], c.n); j[6] = sR * dot(k.ak[1], c.n);
-            j[7] = j[8] = j[9] = 0.f; j[10] = sO * al.x; j[11] = sO * al.y; j[12] = sO * al.z; }
-        float imp = impedance(m.solimp, c.dist, m.margin);
-        float R0 = fmaxf(1e-15f, (1.f - imp) * c.tran / imp);
-        c.D0 = 1.0f / R0;
-        float vel[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            float v = 0.f;
-#pragma unroll
-            for (int i = 0; i < 13; i++) v = fmaf(c.J[r][i], qvel[i], v);
-            vel[r] = v;
-        }
-        c.aref[0] = -m.b_con * vel[0] - m.k_con * imp * (c.dist - m.margin);
-        c.aref[1] = -m.b_con * vel[1]; c.aref[2] = -m.b_con * vel[2]; c.aref[3] = -m.b_con * vel[3];
+            j[7] = j[8] = j[9] = 0.f; j[10] = sO * al.x; j[11] = sO * al.y; j[12] = sO * al.z;
+            finish_row(3, j, 0.f); }
     }
 }
 
@@ -1157,7 +1266,7 @@ DEVI float price_constraints(const DevModel &m, const Ctx &cx, float lsgn, float
     cost += lact ? 0.5f * lD * ljar * ljar : 0.f;
     hdiag = lact ? lD : 0.f;
     wave_sync();
-    const int isub = min(cx.sub, 12);
+    const int isub = UPOS(min(cx.sub, 12));
     for (int k = 0; k < ncon; k++) {
         const float4 f = *reinterpret_cast<const float4 *>(cx.envl + EF_FORCE + 4 * k);
         const float *u = cx.envl + EF_U + k * 6 * U_STRIDE + isub;
@@ -1168,52 +1277,60 @@ DEVI float price_constraints(const DevModel &m, const Ctx &cx, float lsgn, float
 }
 
 // The contact's six weighted Hessian vectors  J^T s'' J = sum_r w_r J_r J_r^T + ka ua ua^T - kb ub ub^T  go to the env's
-// LDS slots (rows J_r themselves are already there: written once per step by publish_rows), from where every lane
-// assembles its own row of H (assemble_rows).
-DEVI void hessian_vectors(const Ctx &cx, const Contact &c, bool live, const Cone &cn) {
+// LDS slots (rows J_r themselves are already there: written once per step by make_constraints), from where every lane
+// assembles its own row of H (assemble_rows). The rows are re-read from the lane's own slots, four columns at a time.
+DEVI void hessian_vectors(const Ctx &cx, bool live, const Cone &cn) {
     if (!live) return;
-    float *U = cx.envl + EF_U + cx.sub * 6 * U_STRIDE;
+    float *Uf = cx.envl + EF_U + cx.sub * 6 * U_STRIDE;
+    float4 *U = reinterpret_cast<float4 *>(Uf);
 #pragma unroll
-    for (int r = 0; r < 4; r++) U[r * U_STRIDE + 13] = cn.w[r];
+    for (int r = 0; r < 4; r++) { Uf[r * U_STRIDE + 7] = cn.w[r]; Uf[r * U_STRIDE + 15] = cn.w[r]; }
 #pragma unroll
-    for (int i = 0; i < 13; i++) {
-        U[4 * U_STRIDE + i] = cn.a[0] * c.J[0][i] + cn.a[1] * c.J[1][i] + cn.a[2] * c.J[2][i] + cn.a[3] * c.J[3][i];
-        U[5 * U_STRIDE + i] = cn.b[1] * c.J[1][i] + cn.b[2] * c.J[2][i] + cn.b[3] * c.J[3][i];
+    for (int q = 0; q < 4; q++) {
+        const float4 j0 = U[q], j1 = U[4 + q], j2 = U[8 + q], j3 = U[12 + q];
+        float4 ua, ub;
+        ua.x = cn.a[0] * j0.x + cn.a[1] * j1.x + cn.a[2] * j2.x + cn.a[3] * j3.x; ub.x = cn.b[1] * j1.x + cn.b[2] * j2.x + cn.b[3] * j3.x;
+        ua.y = cn.a[0] * j0.y + cn.a[1] * j1.y + cn.a[2] * j2.y + cn.a[3] * j3.y; ub.y = cn.b[1] * j1.y + cn.b[2] * j2.y + cn.b[3] * j3.y;
+        if (q != 3) {
+            ua.z = cn.a[0] * j0.z + cn.a[1] * j1.z + cn.a[2] * j2.z + cn.a[3] * j3.z; ub.z = cn.b[1] * j1.z + cn.b[2] * j2.z + cn.b[3] * j3.z;
+        } else { ua.z = 0.f; ub.z = 0.f; }                                                 // the object half's unused seventh column
+        if (q == 0 || q == 2) {
+            ua.w = cn.a[0] * j0.w + cn.a[1] * j1.w + cn.a[2] * j2.w + cn.a[3] * j3.w; ub.w = cn.b[1] * j1.w + cn.b[2] * j2.w + cn.b[3] * j3.w;
+        } else { ua.w = cn.ka; ub.w = -cn.kb; }                                            // the slot's weight closes both halves
+        U[16 + q] = ua; U[20 + q] = ub;
     }
-    U[4 * U_STRIDE + 13] = cn.ka; U[5 * U_STRIDE + 13] = -cn.kb;
 }
-DEVI void publish_rows(const Ctx &cx, const Contact &c, bool live) {
+// jv = J p for this lane's contact: rows from its LDS slots, the search direction from EF_P in the slots' column layout (zeros at the
+// weight / padding positions, so the products there vanish)
+DEVI void contact_jp(const Ctx &cx, bool live, float (&jv)[4]) {
     if (!live) return;
-    float *U = cx.envl + EF_U + cx.sub * 6 * U_STRIDE;
+    const float4 *U = reinterpret_cast<const float4 *>(cx.envl + EF_U + cx.sub * 6 * U_STRIDE);
+    const float4 *P = reinterpret_cast<const float4 *>(cx.envl + EF_P);
+    const float4 p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3];
 #pragma unroll
-    for (int r = 0; r < 4; r++)
-#pragma unroll
-        for (int i = 0; i < 13; i++) U[r * U_STRIDE + i] = c.J[r][i];
+    for (int r = 0; r < 4; r++) {
+        const float4 a = U[4 * r], b = U[4 * r + 1], c4 = U[4 * r + 2], d = U[4 * r + 3];
+        float v = 0.f;
+        v = fmaf(a.x, p0.x, v); v = fmaf(a.y, p0.y, v); v = fmaf(a.z, p0.z, v); v = fmaf(a.w, p0.w, v);
+        v = fmaf(b.x, p1.x, v); v = fmaf(b.y, p1.y, v); v = fmaf(b.z, p1.z, v);
+        v = fmaf(c4.x, p2.x, v); v = fmaf(c4.y, p2.y, v); v = fmaf(c4.z, p2.z, v); v = fmaf(c4.w, p2.w, v);
+        v = fmaf(d.x, p3.x, v); v = fmaf(d.y, p3.y, v);
+        jv[r] = v;
+    }
 }
 
-// row `sub` of  H = M + sum over the env's contact slots of  w u u^T  (+ this lane's joint-limit term on the diagonal)
-// full = false: only columns 7..12 (the object block) are needed -- chol_rows_obj reads nothing else
-DEVI void assemble_rows(const Ctx &cx, int ncon, const float (&mrow)[13], float hdiag, float (&row)[13], bool full) {
-#pragma unroll
-    for (int j = 0; j < 13; j++) row[j] = mrow[j];
-    const int isub = min(cx.sub, 12);
+// row `sub` of  H = M + sum over the env's contact slots of  w u u^T  (+ this lane's joint-limit term on the diagonal), all 13 columns:
+// needed only when a gripper part touches the object (lc.coupled)
+DEVI void assemble_rows(const Ctx &cx, int ncon, float hdiag, float (&row)[13]) {
+    load_mrow(cx, row);
+    const int isub = UPOS(min(cx.sub, 12));
     const float *U = cx.envl + EF_U;
-    if (!full) {
-#pragma unroll 4
-        for (int s = 0; s < 6 * ncon; s++) {
-            const float4 *u4 = reinterpret_cast<const float4 *>(U + s * U_STRIDE);
-            float4 b = u4[1], c4 = u4[2], d = u4[3];
-            float wi = d.y * U[s * U_STRIDE + isub];
-            row[7] = fmaf(wi, b.w, row[7]); row[8] = fmaf(wi, c4.x, row[8]); row[9] = fmaf(wi, c4.y, row[9]);
-            row[10] = fmaf(wi, c4.z, row[10]); row[11] = fmaf(wi, c4.w, row[11]); row[12] = fmaf(wi, d.x, row[12]);
-        }
-    } else
 #pragma unroll 4
     for (int s = 0; s < 6 * ncon; s++) {
         const float4 *u4 = reinterpret_cast<const float4 *>(U + s * U_STRIDE);
         float4 a = u4[0], b = u4[1], c4 = u4[2], d = u4[3];
-        float u[13] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c4.x, c4.y, c4.z, c4.w, d.x};
-        float wi = d.y * U[s * U_STRIDE + isub];    // zero weights (inactive cone zones) simply add nothing
+        float u[13] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, c4.x, c4.y, c4.z, c4.w, d.x, d.y};
+        float wi = b.w * U[s * U_STRIDE + isub];    // zero weights (inactive cone zones) simply add nothing
 #pragma unroll
         for (int j = 0; j < 13; j++) row[j] = fmaf(wi, u[j], row[j]);
     }
@@ -1223,6 +1340,27 @@ DEVI void assemble_rows(const Ctx &cx, int ncon, const float (&mrow)[13], float 
 #pragma unroll
         for (int j = 0; j < 13; j++) row[j] = 0.f;
     }
+}
+// The same row when H is block diagonal (no gripper-object contact: 93 % of the wave trips of the bench workload): the seven entries of
+// the lane's own block -- gripper dofs 0..6 for lanes 0..6, object dofs 7..12 (+ a zero) for the others -- from the matching half of
+// every slot: two 16-byte reads and seven multiply-adds per slot instead of four and thirteen. A slot of the other block has an exact
+// zero in this lane's column, so it adds nothing, as in the full row.
+DEVI void assemble_rows_block(const Ctx &cx, int ncon, const float (&mrow7)[7], float hdiag, float (&row)[7]) {
+#pragma unroll
+    for (int j = 0; j < 7; j++) row[j] = mrow7[j];
+    const int isub = UPOS(min(cx.sub, 12)), half = cx.sub < 7 ? 0 : 2;
+    const float *U = cx.envl + EF_U;
+#pragma unroll 4
+    for (int s = 0; s < 6 * ncon; s++) {
+        const float4 *u4 = reinterpret_cast<const float4 *>(U + s * U_STRIDE) + half;
+        const float4 a = u4[0], b = u4[1];
+        const float wi = b.w * U[s * U_STRIDE + isub];
+        row[0] = fmaf(wi, a.x, row[0]); row[1] = fmaf(wi, a.y, row[1]); row[2] = fmaf(wi, a.z, row[2]); row[3] = fmaf(wi, a.w, row[3]);
+        row[4] = fmaf(wi, b.x, row[4]); row[5] = fmaf(wi, b.y, row[5]); row[6] = fmaf(wi, b.z, row[6]);
+    }
+    const int own = cx.sub < 7 ? cx.sub : cx.sub - 7;
+#pragma unroll
+    for (int j = 0; j < 7; j++) row[j] += own == j ? hdiag : 0.f;
 }
 
 // phi'(alpha), phi''(alpha) of the total cost along the search direction: this lane's contact and limit, then all-reduce
@@ -1267,7 +1405,7 @@ DEVI void price_two_starts(const DevModel &m, const Ctx &cx, float lsgn, float l
     {   float lj = lsgn * xw - laref; bool la = lsgn != 0.f && lj < 0.f;
         jt_w = la ? -lD * lj * lsgn : 0.f; lc_w += la ? 0.5f * lD * lj * lj : 0.f; hd_w = la ? lD : 0.f; }
     wave_sync();
-    const int isub = min(cx.sub, 12);
+    const int isub = UPOS(min(cx.sub, 12));
     for (int k = 0; k < ncon; k++) {
         const float4 f = *reinterpret_cast<const float4 *>(cx.envl + EF_FORCE + 4 * k);
         const float4 g = *reinterpret_cast<const float4 *>(cx.envl + EF_FORCE2 + 4 * k);
@@ -1293,34 +1431,25 @@ DEVI void cone_sel(Cone &d, bool take, const Cone &s) {
 // registers, the exact line search all-reduces two scalars per evaluation (its first evaluation, at alpha = 0, reuses the cone the
 // pricing just evaluated), then the new point is priced: one pricing per iteration, none repeated. All control flow depends only on
 // all-reduced values, so the 16 lanes of an env always agree.
-DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, float laref,
-                       const float (&qs)[13], float qsi, const float (&warm)[13], Contact &c, bool live, int ncon,
-                       float (&qacc)[13], float (&jtf)[13], int &fault, int &iters, Stamps &st, bool objonly, float *dbgH = nullptr) {
+DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Contact &c, bool live, int ncon,
+                       float &xi_out, float &jtfi_out, int &fault, int &iters, Stamps &st, float *dbgH = nullptr) {
+    const float lsgn = lc.lsgn, lD = lc.lD, laref = lc.laref, qsi = lc.qsi, warmi = lc.warmi, Md_w = lc.Md_w;
     const float scale = 1.0f / (m.meaninertia * 13.f);
     const float tol = fmaxf(m.tolerance, NEWTON_TOL);       // fp32 noise floor of the scaled gradient is ~1e-6
-    float mrow[13]; load_mrow(cx, mrow);
-    const float warmi = pick13(warm, cx.sub);
-    // the two candidate starts: jar = J x - aref and M (x - a_s) for x = qacc_smooth and x = qacc_warmstart
-    float jar_s[4] = {0.f, 0.f, 0.f, 0.f}, jar_w[4] = {0.f, 0.f, 0.f, 0.f}, Md_w;
-    {   float dw[13];
+    // this lane's row of the (always block-diagonal) mass matrix, the seven entries of its own block
+    float mrow[7];
+    {   const float *M = cx.envl + EF_M + min(cx.sub, 12) * 13 + (cx.sub < 7 ? 0 : 7);
 #pragma unroll
-        for (int i = 0; i < 13; i++) dw[i] = warm[i] - qs[i];
-        Md_w = row_dot(mrow, dw);
-        if (live) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float vs = -c.aref[r], vw = 0.f;
-#pragma unroll
-                for (int i = 0; i < 13; i++) { vs = fmaf(c.J[r][i], qs[i], vs); vw = fmaf(c.J[r][i], dw[i], vw); }
-                jar_s[r] = vs; jar_w[r] = vs + vw;
-            }
-        }
+        for (int j = 0; j < 7; j++) mrow[j] = (cx.sub < 13 && (j < 6 || cx.sub < 7)) ? M[min(j, cx.sub < 7 ? 6 : 5)] : 0.f;
     }
     STAMP(st, 14);
-    // ---- both starts priced at once
-    float xi, Mdi, jtfi, hdiag, cost; Cone cn; bool gconv;
+    // ---- both starts priced at once (their residuals jar = J x - aref and M (x - a_s) come from make_constraints)
+    float xi, Mdi, jtfi, hdiag; Cone cn; bool gconv;
+#ifdef HAVE_DBG_HIST
+    bool take_w_dbg = false; float g2w_dbg = 0.f, g2s_dbg = 0.f;
+#endif
     {   Cone cn_w; float lc_s, lc_w, jt_s, jt_w, hd_s, hd_w;
-        price_two_starts(m, cx, lsgn, lD, laref, qsi, warmi, ncon, c, live, jar_s, jar_w, cn, cn_w, lc_s, lc_w, jt_s, jt_w, hd_s, hd_w);
+        price_two_starts(m, cx, lsgn, lD, laref, qsi, warmi, ncon, c, live, lc.jar_s, lc.jar_w, cn, cn_w, lc_s, lc_w, jt_s, jt_w, hd_s, hd_w);
         const float cost_s = sum16(lc_s);                                   // M (x - a_s) = 0 at x = a_s
         const float cost_w = sum16(0.5f * Md_w * (warmi - qsi) + lc_w);
         // converged when the scaled gradient is below the model's tolerance -- or below what fp32 can resolve: g = M(x - a_s) - J^T f
@@ -1331,52 +1460,85 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
         const bool conv_s = scale * sqrtf(g2s) < tol || g2s < NEWTON_GRAD_NOISE * NEWTON_GRAD_NOISE * t2s;
         const bool conv_w = scale * sqrtf(g2w) < tol || g2w < NEWTON_GRAD_NOISE * NEWTON_GRAD_NOISE * t2w;
         const bool take_w = !conv_s && cost_w < cost_s;                     // qacc_smooth already optimal: keep it (constraints inactive)
+#ifdef HAVE_DBG_HIST
+        take_w_dbg = take_w; g2w_dbg = g2w; g2s_dbg = g2s;
+#endif
         xi = take_w ? warmi : qsi; Mdi = take_w ? Md_w : 0.f; jtfi = take_w ? jt_w : jt_s; hdiag = take_w ? hd_w : hd_s;
-        cost = take_w ? cost_w : cost_s; gconv = take_w ? conv_w : conv_s;
+        gconv = take_w ? conv_w : conv_s;
         cone_sel(cn, take_w, cn_w);
 #pragma unroll
-        for (int r = 0; r < 4; r++) c.jar[r] = take_w ? jar_w[r] : jar_s[r];
+        for (int r = 0; r < 4; r++) c.jar[r] = take_w ? lc.jar_w[r] : lc.jar_s[r];
     }
     STAMP(st, 6);
     bool done = gconv;
     iters = 0;
+#ifdef HAVE_DBG_HIST
+    auto zone_of = [&](const float (&jar)[4]) {
+        const float mu = c.fs * rsqrtf(m.impratio);
+        const float N = mu * jar[0], T = sqrtf(c.fs * jar[1] * c.fs * jar[1] + c.fs * jar[2] * c.fs * jar[2] + c.ft * jar[3] * c.ft * jar[3]);
+        return (N >= mu * T || (T <= 0.f && N >= 0.f)) ? 0 : (mu * N + T <= 0.f || (T <= 0.f && N < 0.f)) ? 2 : 1;
+    };
+    const int zone0 = zone_of(c.jar);
+    if (cx.sub == 0) { const float sg = scale * sqrtf(take_w_dbg ? g2w_dbg : g2s_dbg); int b = 0; for (float t = 1e-7f; b < 7 && sg >= t; t *= 10.f) b++; DBG_HIST(64 + b, 1); DBG_HIST(72, take_w_dbg ? 1 : 0); DBG_HIST(73, 1); }
+    if (live) DBG_HIST((c.g1 != 0 ? 74 : 81) + zone0, 1);
+#endif
     while (__any(!done)) {
         if (!done) {
             // ---- one Newton iteration from the priced point (xi, Mdi, jtfi, cn, hdiag, cost)
             const float gi = Mdi - jtfi;                                    // gradient component of this lane
             STAMP(st, 15);
-            hessian_vectors(cx, c, live, cn);
+            hessian_vectors(cx, live, cn);
             wave_sync();                                    // the contact lanes' Hessian vectors are in LDS
-            float row[13];
             STAMP(st, 16);
-            // no limit and only floor-object contacts in every env of the wave that is still iterating: H is block
-            // diagonal and the gripper block's gradient is exactly zero, so only the object's 6 x 6 block is needed
-            const bool full = __any(!objonly);
-            assemble_rows(cx, ncon, mrow, hdiag, row, full);
-            STAMP(st, 8);
-            if (dbgH && iters == 0 && cx.sub < 13) {
+            // H couples the gripper's and the object's dofs only through a gripper-object contact: unless an env of the wave that is still
+            // iterating has one, every lane assembles and factorises its own diagonal block only
+            const bool full = __any(lc.coupled);
+            float x[7];                                     // the Newton direction's components in this lane's block
+            if (full) {
+                float row[13];
+                assemble_rows(cx, ncon, hdiag, row);
+                STAMP(st, 8);
+                if (dbgH && iters == 0 && cx.sub < 13) {
 #pragma unroll
-                for (int j = 0; j < 13; j++) dbgH[cx.sub * 13 + j] = row[j];
-            }
-            float p[13];
-            if (full) gathered_solve<0>(cx, row, gi, p); else gathered_solve<7>(cx, row, gi, p);
-            STAMP(st, 9);
-            const float pi = cx.sub < 13 ? pick13(p, cx.sub) : 0.f;
-            STAMP(st, 7);
-            float Mpi = row_dot(mrow, p);
-            float g0 = sum16(Mpi * (xi - qsi)), g1 = sum16(Mpi * pi);
-            if (live) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float v = 0.f;
-#pragma unroll
-                    for (int i = 0; i < 13; i++) v = fmaf(c.J[r][i], p[i], v);
-                    c.jv[r] = v;
+                    for (int j = 0; j < 13; j++) dbgH[cx.sub * 13 + j] = row[j];
                 }
+                float p[13];
+                gathered_solve<0>(cx, row, gi, p);
+#pragma unroll
+                for (int j = 0; j < 7; j++) x[j] = cx.sub < 7 ? p[j] : (j < 6 ? p[7 + j] : 0.f);
+            } else {
+                float row[7];
+                assemble_rows_block(cx, ncon, mrow, hdiag, row);
+                STAMP(st, 8);
+                if (dbgH && iters == 0 && cx.sub < 13) {
+#pragma unroll
+                    for (int j = 0; j < 13; j++) {
+                        const int k = j - (cx.sub < 7 ? 0 : 7);
+                        float v = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 7; q++) v = k == q ? row[q] : v;
+                        dbgH[cx.sub * 13 + j] = (k >= 0 && k < (cx.sub < 7 ? 7 : 6)) ? v : 0.f;
+                    }
+                }
+                gathered_solve_block(cx, row, gi, x);
             }
+            STAMP(st, 9);
+            // the direction goes to EF_P in the slots' column layout ([g0..g6, 0 | o0..o5, 0, 0]): the first lane of each block writes its half
+            if (cx.sub == 0 || cx.sub == 7) {
+                float4 *P = reinterpret_cast<float4 *>(cx.envl + EF_P) + (cx.sub == 0 ? 0 : 2);
+                P[0] = make_float4(x[0], x[1], x[2], x[3]); P[1] = make_float4(x[4], x[5], cx.sub == 0 ? x[6] : 0.f, 0.f);
+            }
+            wave_sync();
+            const float pi = cx.sub < 13 ? cx.envl[EF_P + UPOS(min(cx.sub, 12))] : 0.f;
+            STAMP(st, 7);
+            float Mpi = 0.f;
+#pragma unroll
+            for (int j = 0; j < 7; j++) Mpi = fmaf(mrow[j], x[j], Mpi);
+            float g0 = sum16(Mpi * (xi - qsi)), g1 = sum16(Mpi * pi);
+            contact_jp(cx, live, c.jv);
             STAMP(st, 17);
             // exact line search: safeguarded 1-D Newton on phi'(alpha); one evaluation site
-            float lo = 0.f, hi = -1.f, alpha = 0.f, gtol = 0.f;
+            float lo = 0.f, hi = -1.f, alpha = 0.f, gtol = 0.f, dp0 = 0.f;
             bool lsdone = false, descent = true;
             {   // alpha = 0: the cone of the current point is the one the pricing evaluated (cn)
                 float dp = 0.f, hp = 0.f;
@@ -1389,6 +1551,7 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
                     bool act = lsgn != 0.f && xx < 0.f;
                     dp += act ? lD * xx * jv : 0.f; hp += act ? lD * jv * jv : 0.f; }
                 dp = sum16(dp) + g0; hp = sum16(hp) + g1;
+                dp0 = dp;
                 if (dp >= 0.f) { descent = false; lsdone = true; }
                 gtol = LS_GTOL * fabsf(dp) + 1e-30f;
                 if (!lsdone) alpha = -dp * rcp(fmaxf(hp, 1e-30f));
@@ -1419,114 +1582,142 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, float lsgn, float lD, f
                 iters++;
                 // ---- price the new point; stop on the gradient, on a stalled cost, or at the iteration limit
                 STAMP(st, 4);
-                float lc = price_constraints(m, cx, lsgn, lD, laref, xi, ncon, c, live, cn, jtfi, hdiag);
-                const float newcost = sum16(0.5f * Mdi * (xi - qsi) + lc);
+                price_constraints(m, cx, lsgn, lD, laref, xi, ncon, c, live, cn, jtfi, hdiag);
                 const float gn = Mdi - jtfi;
                 const float g2 = sum16(gn * gn), t2 = sum16(Mdi * Mdi + jtfi * jtfi);
                 bool stop = scale * sqrtf(g2) < tol || g2 < NEWTON_GRAD_NOISE * NEWTON_GRAD_NOISE * t2;
-                if (scale * (cost - newcost) < tol) stop = true;
-                cost = newcost;
+                // mj_solNewton also stops when the step improved the cost by less than the tolerance. The difference of the two costs is
+                // fp32 rounding noise here (costs of 1e2-1e3 against a threshold of ~1e-5: an ill-conditioned solve stopped or went on by the
+                // last bit of a sum, with accelerations several m/s^2 apart). The exact line search gives the improvement without a
+                // cancellation: phi' rises monotonically from phi'(0) = dp0 < 0 to 0 at alpha, so the decrease -int phi' is alpha |dp0| / 2
+                // for a quadratic and within a factor of two of that across cone-zone kinks.
+                if (scale * (-0.5f * alpha * dp0) < tol) stop = true;
+#ifdef HAVE_DBG_HIST
+                if (cx.sub == 0 && iters <= 4) { const float sg = scale * sqrtf(g2); int b = 0; for (float t = 1e-7f; b < 7 && sg >= t; t *= 10.f) b++; DBG_HIST(32 + 8 * (iters - 1) + b, 1); }
+#endif
                 if (!stop && iters >= NEWTON_MAXIT) { stop = true; fault |= 4; }
                 done = stop;
                 STAMP(st, 6);
             }
         }
     }
-    // the optimum and its constraint force as full vectors (Euler step and warm start want them in every lane)
+#ifdef HAVE_DBG_HIST
+    if (live) { const int z1 = zone_of(c.jar); DBG_HIST((c.g1 != 0 ? 77 : 84) + z1, 1); if (z1 != zone0) DBG_HIST(c.g1 != 0 ? 80 : 87, 1); }
+#endif
+    // the optimum and its constraint force stay distributed: lane i holds component i (the integrator exchanges them through LDS)
     STAMP(st, 18);
-    gather13(xi, qacc); gather13(jtfi, jtf);
+    xi_out = xi; jtfi_out = jtfi;
     STAMP(st, 19);
 }
 
 // ---------------------------------------------------------------- one physics.step()
-struct LaneState { float qpos[14], qvel[13], ctrl[7], warm[13]; };
+// The env's state (qpos, qvel, ctrl, qacc_warmstart) lives in its LDS region; a step is
+//   kinematics()  ->  [forward_dense()]  ->  collide()  ->  forward_acc()  ->  integrate()
+// kinematics + collide are mj_step1's share (the state of "now": contacts as check_grasp sees them), the rest mj_step2's. The dense block
+// (mass matrix, bias, qacc_smooth) does not depend on the contacts and runs BEFORE collide(), straight from the kinematics in registers, so
+// that nothing of it is live across the narrow phase.
 
-// position stage (mj_step1's share): kinematics + collision of the current state; lane c then owns contact c.
-DEVI void forward_pos(const DevModel &m, const Ctx &cx, LaneState &s, Kin &k, Contact &con, int &ncon, int &fault, Stamps &st, PairMemo &sep) {
-    kinematics(m, s.qpos, k, cx, true);
+// position stage: kinematics from the LDS state. Returns qpos (the caller's control hooks want the first seven) and the full kinematics.
+DEVI void forward_kin(const DevModel &m, const Ctx &cx, float (&qpos)[14], Kin &k) {
+    lds_ld<14>(cx.envl + ES_QPOS, qpos);
+    kinematics(m, qpos, k, cx, true);
     wave_sync();
-    STAMP(st, 0);
-    ncon = collide(m, cx, con, fault, sep, st);
-    STAMP(st, 1);
 }
 
-// dynamics stage (mj_step2's share up to qacc) on top of forward_pos
-DEVI void forward_acc(const DevModel &m, const Ctx &cx, LaneState &s, float xfrc_z, const Kin &k, Contact &con, int ncon, int &fault,
-                      float (&qfrc_smooth)[13], float (&qacc)[13], float (&jtf)[13], int &iters,
-                      float *dbg_qs, float *dbg_bias, Stamps &st, float *dbgH = nullptr) {
-    float Mg[28], Mo[21];
-    {   mass_matrix(m, k, Mg, Mo);
-        if (cx.sub == 0) {                  // one lane publishes the env's mass matrix, every lane then owns a row of it
-            float *M = cx.envl + EF_M;
+// mass matrix -> EF_M, qfrc_smooth -> ES_QFS, qacc_smooth -> ES_QS (all redundantly in the 16 lanes, lane 0 stores)
+DEVI void forward_dense(const DevModel &m, const Ctx &cx, const Kin &k, const float (&ctrl)[8], float xfrc_z, float *dbg_bias, Stamps &st) {
+    float *S = cx.envl;
+    // bias forces first, the mass matrix after them: the two together would be live next to the whole kinematics
+    float qfs[13];
+    {   float qvel[13]; lds_ld<13>(S + ES_QVEL, qvel);
+        float bias[13];
+        bias_forces(m, k, qvel, bias);
+        if (dbg_bias) {
 #pragma unroll
-            for (int i = 0; i < 13; i++)
-#pragma unroll
-                for (int j = 0; j < 13; j++) M[i * 13 + j] = (i < 7 && j < 7) ? Mg[pidx(i, j)] : (i >= 7 && j >= 7) ? Mo[pidx(i - 7, j - 7)] : 0.f;
+            for (int i = 0; i < 13; i++) dbg_bias[i] = bias[i];
         }
-    }
-    wave_sync();
-    float bias[13];
-    bias_forces(m, k, s.qvel, bias);
-    if (dbg_bias) {
 #pragma unroll
-        for (int i = 0; i < 13; i++) dbg_bias[i] = bias[i];
+        for (int i = 0; i < 13; i++) qfs[i] = -m.damping[i] * qvel[i] - bias[i];
     }
 #pragma unroll
-    for (int i = 0; i < 13; i++) qfrc_smooth[i] = -m.damping[i] * s.qvel[i] - bias[i];
-#pragma unroll
-    for (int u = 0; u < 7; u++) qfrc_smooth[u] += m.gear[u] * fminf(fmaxf(s.ctrl[u], m.ctrlrange[u][0]), m.ctrlrange[u][1]);
+    for (int u = 0; u < 7; u++) qfs[u] += m.gear[u] * fminf(fmaxf(ctrl[u], m.ctrlrange[u][0]), m.ctrlrange[u][1]);
     // xfrc_applied on body ee (force along z at its COM = frame origin): only the z slide sees it
-    qfrc_smooth[2] += xfrc_z;
+    qfs[2] += xfrc_z;
+#pragma unroll
+    for (int i = 0; i < 13; i++) opaque(qfs[i]);         // (keeps the scheduler from pulling the mass matrix up into the bias block)
+    float Mg[28], Mo[21];
+    mass_matrix(m, k, Mg, Mo);
+    if (cx.sub == 0) {                  // one lane publishes the env's mass matrix, every lane then owns a row of it (the off-diagonal
+        float *M = S + EF_M;            // blocks are zero for good: env_lds_init)
+#pragma unroll
+        for (int i = 0; i < 7; i++)
+#pragma unroll
+            for (int j = 0; j < 7; j++) M[i * 13 + j] = Mg[pidx(i, j)];
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j < 6; j++) M[(7 + i) * 13 + 7 + j] = Mo[pidx(i, j)];
+    }
     // qacc_smooth = M^-1 qfrc_smooth: block-diagonal (gripper 7x7, object 6x6), cheap enough to do redundantly in registers
-    float qs[13], qsi;
+    float qs[13];
 #pragma unroll
-    for (int i = 0; i < 13; i++) qs[i] = qfrc_smooth[i];
+    for (int i = 0; i < 13; i++) qs[i] = qfs[i];
     block_solve(Mg, Mo, qs);
-    qsi = pick13(qs, cx.sub);
-    if (dbg_qs) {
-#pragma unroll
-        for (int i = 0; i < 13; i++) dbg_qs[i] = qs[i];
-    }
+    if (cx.sub == 0) { lds_st<13>(S + ES_QFS, qfs); lds_st<13>(S + ES_QS, qs); }
+    wave_sync();
     STAMP(st, 2);
-    float lsgn, lD, laref;
-    const bool live = cx.sub < ncon;
-    make_constraints(m, k, s.qpos, s.qvel, cx.sub, lsgn, lD, laref, con, live);
-    publish_rows(cx, con, live);
+}
+// once per kernel: the parts of the env's LDS region that no step rewrites (the mass matrix' off-diagonal blocks)
+DEVI void env_lds_init(const Ctx &cx) {
+    float *M = cx.envl + EF_M;
+    for (int i = cx.sub; i < 169; i += KL) M[i] = 0.f;
+    wave_sync();
+}
+
+// dynamics stage up to qacc: constraints + Newton solve. Lane i < 13 returns component i of qacc and of the constraint force J^T f.
+DEVI void forward_acc(const DevModel &m, const Ctx &cx, Contact &con, int ncon, int &fault, float &qacci, float &jtfi, int &iters, Stamps &st, float *dbgH = nullptr) {
+    LaneCon lc;
+    make_constraints(m, cx, con, ncon, lc);
+    wave_sync();
     STAMP(st, 3);
-    // lane j < 7 owns joint limit j
-    const bool anylim = group_bits(__ballot(lsgn != 0.f), cx.lane) != 0u;
-    iters = 0;
-    const bool constrained = ncon > 0 || anylim;
-    // when no constraint touches the gripper (no joint limit, only floor-object contacts) its block of the problem is
-    // unconstrained and decoupled: start it at qacc_smooth, which is then already optimal for those 7 dofs
-    const bool grip = anylim || group_bits(__ballot(live && !(con.g1 == 0 && con.g2 == 6)), cx.lane) != 0u;
-    float warm[13];
-#pragma unroll
-    for (int i = 0; i < 13; i++) { qacc[i] = qs[i]; jtf[i] = 0.f; warm[i] = (i < 7 && !grip) ? qs[i] : s.warm[i]; }
-    if (__any(constrained)) {
-        if (constrained) solve_newton(m, cx, lsgn, lD, laref, qs, qsi, warm, con, live, ncon, qacc, jtf, fault, iters, st, !grip, dbgH);
+    qacci = lc.qsi; jtfi = 0.f; iters = 0;
+    if (__any(lc.constrained)) {
+        if (lc.constrained) solve_newton(m, cx, lc, con, cx.sub < ncon, ncon, qacci, jtfi, fault, iters, st, dbgH);
     }
+#ifdef HAVE_DBG_HIST
+    if (cx.sub == 0) {
+        DBG_HIST(min(iters, 7), 1); DBG_HIST(8 + min((ncon + 1) / 2, 7), 1); DBG_HIST(16, 1); DBG_HIST(17, lc.constrained ? 1 : 0); DBG_HIST(18, lc.grip ? 1 : 0);
+    }
+    {   const bool hull = group_bits(__ballot(cx.sub < ncon && con.g1 != 0), cx.lane) != 0u, lim = group_bits(__ballot(lc.lsgn != 0.f), cx.lane) != 0u;
+        if (cx.sub == 0) { DBG_HIST(19, hull ? 1 : 0); DBG_HIST(20, lim ? 1 : 0); }
+        const bool coupled = group_bits(__ballot(cx.sub < ncon && con.g1 != 0 && (con.g1 == 6 || con.g2 == 6)), cx.lane) != 0u;     // a gripper part against the object
+        if (cx.sub == 0) DBG_HIST(22, coupled ? 1 : 0);
+        if (cx.lane == 0) { DBG_HIST(23, 1); }
+        if (__any(coupled) && cx.lane == 0) DBG_HIST(88, 1);
+        int mx = iters;
+        for (int o = 16; o < 64; o <<= 1) mx = max(mx, __shfl_xor(mx, o));
+        if (cx.lane == 0) DBG_HIST(24 + min(mx, 7), 1);
+    }
+#endif
     STAMP(st, 4);
 }
 
-// dynamics + integration of one physics.step(); forward_pos must have run on the current state
-DEVI void physics_advance(const DevModel &m, const Ctx &cx, LaneState &s, float xfrc_z, const Kin &k, Contact &con, int ncon, int &fault, Stamps &st,
-                          int *newton_iters = nullptr) {
-    float qfs[13], qacc[13], jtf[13]; int iters;
-    forward_acc(m, cx, s, xfrc_z, k, con, ncon, fault, qfs, qacc, jtf, iters, nullptr, nullptr, st);
-    if (newton_iters) *newton_iters = iters;
+// semi-implicit Euler with implicit joint damping: (M + h D) a' = qfrc_smooth + J^T f   (mj_Euler). The object block has
+// no damping, so a' = qacc there. The dof lanes hand their components over through LDS (new warm start = qacc, and qfrc_smooth + J^T f),
+// every lane integrates the whole state redundantly, lane 0 stores it. qnew: the gripper's new joint positions (control hooks).
+DEVI void integrate(const DevModel &m, const Ctx &cx, float qacci, float jtfi, int &fault, float (&qnew)[7], Stamps &st) {
+    float *S = cx.envl;
     const float h = m.timestep;
-    // semi-implicit Euler with implicit joint damping: (M + h D) a' = qfrc_smooth + J^T f   (mj_Euler). The object block has
-    // no damping, so a' = qacc there; the distributed solve covers all 13 dofs at once.
-    float acc[13];
+    if (cx.sub < 13) { S[ES_WARM + cx.sub] = qacci; S[ES_ACC + cx.sub] = S[ES_QFS + cx.sub] + jtfi; }
+    wave_sync();
+    float acc[13], qacc[13];
+    lds_ld<13>(S + ES_ACC, acc); lds_ld<13>(S + ES_WARM, qacc);
     {   float Ag[28];
-        const float *M = cx.envl + EF_M;
+        const float *M = S + EF_M;
 #pragma unroll
         for (int i = 0; i < 7; i++)
 #pragma unroll
             for (int j = 0; j <= i; j++) Ag[pidx(i, j)] = M[i * 13 + j] + (i == j ? h * m.damping[i] : 0.f);
-#pragma unroll
-        for (int i = 0; i < 13; i++) acc[i] = qfs[i] + jtf[i];
         const bool obj_damped = (m.damping[7] != 0.f) | (m.damping[8] != 0.f) | (m.damping[9] != 0.f) | (m.damping[10] != 0.f) |
                                 (m.damping[11] != 0.f) | (m.damping[12] != 0.f);
         if (obj_damped) {                                   // not the case for a <freejoint/> (no defaults apply), kept for generality
@@ -1547,31 +1738,56 @@ DEVI void physics_advance(const DevModel &m, const Ctx &cx, LaneState &s, float 
             for (int i = 7; i < 13; i++) acc[i] = qacc[i];
         }
     }
+    float qvel[13], qpos[14];
+    lds_ld<13>(S + ES_QVEL, qvel); lds_ld<14>(S + ES_QPOS, qpos);
 #pragma unroll
-    for (int i = 0; i < 13; i++) s.warm[i] = qacc[i];
+    for (int i = 0; i < 13; i++) qvel[i] = fmaf(h, acc[i], qvel[i]);
 #pragma unroll
-    for (int i = 0; i < 13; i++) s.qvel[i] = fmaf(h, acc[i], s.qvel[i]);
-#pragma unroll
-    for (int i = 0; i < 10; i++) s.qpos[i] = fmaf(h, s.qvel[i], s.qpos[i]);
-    V3 w = v3(s.qvel[10], s.qvel[11], s.qvel[12]);
+    for (int i = 0; i < 10; i++) qpos[i] = fmaf(h, qvel[i], qpos[i]);
+    V3 w = v3(qvel[10], qvel[11], qvel[12]);
     float ang = norm(w) * h;
     if (ang > 0.f) {
         V3 ax = normalized(w);
         float sh, ch; sincos_joint(0.5f * ang, sh, ch);
         float bw = ch, bx = ax.x * sh, by = ax.y * sh, bz = ax.z * sh;
-        float aw = s.qpos[10], axx = s.qpos[11], ay = s.qpos[12], az = s.qpos[13];
+        float aw = qpos[10], axx = qpos[11], ay = qpos[12], az = qpos[13];
         float rw = aw * bw - axx * bx - ay * by - az * bz;
         float rx = aw * bx + axx * bw + ay * bz - az * by;
         float ry = aw * by - axx * bz + ay * bw + az * bx;
         float rz = aw * bz + axx * by - ay * bx + az * bw;
         float inv = rsqrtf(rw * rw + rx * rx + ry * ry + rz * rz);
-        s.qpos[10] = rw * inv; s.qpos[11] = rx * inv; s.qpos[12] = ry * inv; s.qpos[13] = rz * inv;
+        qpos[10] = rw * inv; qpos[11] = rx * inv; qpos[12] = ry * inv; qpos[13] = rz * inv;
     }
     bool bad = false;
 #pragma unroll
-    for (int i = 0; i < 14; i++) bad |= !(fabsf(s.qpos[i]) < 1e6f);
+    for (int i = 0; i < 14; i++) bad |= !(fabsf(qpos[i]) < 1e6f);
 #pragma unroll
-    for (int i = 0; i < 13; i++) bad |= !(fabsf(s.qvel[i]) < 1e6f);
+    for (int i = 0; i < 13; i++) bad |= !(fabsf(qvel[i]) < 1e6f);
     if (bad) fault |= 1;
+    if (cx.sub == 0) { lds_st<14>(S + ES_QPOS, qpos); lds_st<13>(S + ES_QVEL, qvel); }
+#pragma unroll
+    for (int i = 0; i < 7; i++) qnew[i] = qpos[i];
+    wave_sync();
     STAMP(st, 5);
+}
+
+// dynamics + integration of one physics.step(); kinematics, forward_dense and collide must have run on the current state
+DEVI void physics_advance(const DevModel &m, const Ctx &cx, Contact &con, int ncon, int &fault, Stamps &st, float (&qnew)[7], int *newton_iters = nullptr) {
+    float qacci, jtfi; int iters;
+    forward_acc(m, cx, con, ncon, fault, qacci, jtfi, iters, st);
+    if (newton_iters) *newton_iters = iters;
+    integrate(m, cx, qacci, jtfi, fault, qnew, st);
+}
+
+// one whole physics.step() on the LDS state with the stored controls (k_substep, k_reset's position stage uses the first half)
+DEVI void physics_step(const DevModel &m, const Ctx &cx, float xfrc_z, Contact &con, int &ncon, int &fault, PairMemo &memo, Stamps &st) {
+    float qpos[14]; Kin k;
+    forward_kin(m, cx, qpos, k);
+    STAMP(st, 0);
+    float ctrl[8]; lds_ld<8>(cx.envl + ES_CTRL, ctrl);
+    forward_dense(m, cx, k, ctrl, xfrc_z, nullptr, st);
+    ncon = collide(m, cx, con, fault, memo, st);
+    STAMP(st, 1);
+    float qn[7];
+    physics_advance(m, cx, con, ncon, fault, st, qn);
 }

@@ -231,7 +231,7 @@ extern "C" int grip_model_load(const char *blob_path, GripModel **out) {
             const unsigned packed = (unsigned)nadr[i] | ((unsigned)deg << 16);
             memcpy(&vf[4*i+3], &packed, 4);
         }
-        m.hull_off_nadr = (int)hb.size(); pack16(hb, nadr);
+        m.hull_off_nadr = 0;                             // (the CSR offsets travel in the vertex records: the table itself is not staged)
         m.hull_off_nbr = (int)hb.size(); pack16(hb, nbr);
         m.hull_off_lut = (int)hb.size(); pack16(hb, lut);
         m.hull_words = (int)hb.size();
@@ -303,33 +303,33 @@ enum { MC_PHASE = 0, MC_CNT, MC_NSUB, MC_GRASPED, MC_FLAGS, MC_FAULT, MC_NINT };
 enum { MC_TARGET = 0, MC_INITQ = 5, MC_OPENCLOSE = 10, MC_TQ = 11, MC_INITOBJ = 12, MC_NFLT = 15 };
 static_assert(MC_NINT <= MC_NINT_PAD && MC_NFLT <= MC_NFLT_PAD, "suspended-context record too small");
 
-DEVI void ld_state(const StatePtrs &p, int e, LaneState &s) {
-#pragma unroll
-    for (int i = 0; i < 14; i++) s.qpos[i] = ld_word(p.qpos, (size_t)i * p.n + e, p.half);
-#pragma unroll
-    for (int i = 0; i < 13; i++) s.qvel[i] = ld_word(p.qvel, (size_t)i * p.n + e, p.half);
-#pragma unroll
-    for (int i = 0; i < 7; i++) s.ctrl[i] = ld_word(p.ctrl, (size_t)i * p.n + e, p.half);
-#pragma unroll
-    for (int i = 0; i < 13; i++) s.warm[i] = p.warm[(size_t)i * p.n + e];
+// global state arrays <-> the env's LDS state vectors: lane j moves component j (one load / store instruction per array)
+DEVI void ld_state(const StatePtrs &p, int e, const Ctx &cx) {
+    float *S = cx.envl; const int j = cx.sub;
+    if (j < 14) S[ES_QPOS + j] = ld_word(p.qpos, (size_t)j * p.n + e, p.half);
+    if (j < 13) S[ES_QVEL + j] = ld_word(p.qvel, (size_t)j * p.n + e, p.half);
+    if (j < 7) S[ES_CTRL + j] = ld_word(p.ctrl, (size_t)j * p.n + e, p.half);
+    if (j < 13) S[ES_WARM + j] = p.warm[(size_t)j * p.n + e];
+    wave_sync();
 }
-DEVI void st_state(const StatePtrs &p, int e, const LaneState &s) {
-#pragma unroll
-    for (int i = 0; i < 14; i++) st_word(p.qpos, (size_t)i * p.n + e, s.qpos[i], p.half);
-#pragma unroll
-    for (int i = 0; i < 13; i++) st_word(p.qvel, (size_t)i * p.n + e, s.qvel[i], p.half);
-#pragma unroll
-    for (int i = 0; i < 7; i++) st_word(p.ctrl, (size_t)i * p.n + e, s.ctrl[i], p.half);
-#pragma unroll
-    for (int i = 0; i < 13; i++) p.warm[(size_t)i * p.n + e] = s.warm[i];
+// `doit`: this lane's env is stored (all 16 lanes of an env agree)
+DEVI void st_state(const StatePtrs &p, int e, const Ctx &cx, bool doit) {
+    wave_sync();
+    const float *S = cx.envl; const int j = cx.sub;
+    if (doit) {
+        if (j < 14) st_word(p.qpos, (size_t)j * p.n + e, S[ES_QPOS + j], p.half);
+        if (j < 13) st_word(p.qvel, (size_t)j * p.n + e, S[ES_QVEL + j], p.half);
+        if (j < 7) st_word(p.ctrl, (size_t)j * p.n + e, S[ES_CTRL + j], p.half);
+        if (j < 13) p.warm[(size_t)j * p.n + e] = S[ES_WARM + j];
+    }
 }
-DEVI void reset_lane(const DevModel &m, LaneState &s) {
+// the reset state into the env's LDS vectors (lane 0 of the env)
+DEVI void reset_state(const DevModel &m, const Ctx &cx) {
+    float *S = cx.envl;
+    float q[14], z13[13] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, z7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 14; i++) s.qpos[i] = m.qpos0[i];
-#pragma unroll
-    for (int i = 0; i < 13; i++) { s.qvel[i] = 0.f; s.warm[i] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < 7; i++) s.ctrl[i] = 0.f;
+    for (int i = 0; i < 14; i++) q[i] = m.qpos0[i];
+    lds_st<14>(S + ES_QPOS, q); lds_st<13>(S + ES_QVEL, z13); lds_st<7>(S + ES_CTRL, z7); lds_st<13>(S + ES_WARM, z13);
 }
 
 // utils.py:30-31
@@ -431,14 +431,18 @@ __global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_reset(const D
     bool valid = act_ && e < st.n;
     if (e >= st.n) e = st.n - 1;          // (idle rows of a 2-env wave mirror the env of the row 32 lanes below: same reads, no writes)
     bool doit = valid && (mask == nullptr || mask[e] != 0);
-    LaneState s; reset_lane(m, s);
+    env_lds_init(cx);
+    if (cx.sub == 0) reset_state(m, cx);
+    wave_sync();
     Kin k; Contact con; int ncon = 0, fault = 0;
     PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1; PAIRMEMO_EXTRA_INIT(sep)
-    forward_pos(m, cx, s, k, con, ncon, fault, stm, sep);
+    float q0[14];
+    forward_kin(m, cx, q0, k);
+    ncon = collide(m, cx, con, fault, sep, stm);
     int grasp = check_grasp(cx, con, ncon), pher = pheromone_level(k.pe, cfg);
     if (blockIdx.x == 0 && threadIdx.x == 0 && reset_info) { reset_info[0] = (float)grasp; reset_info[1] = (float)pher; reset_info[2] = k.po.x; reset_info[3] = k.po.y; }
+    st_state(st, e, cx, doit);
     if (!doit || cx.sub != 0) return;
-    st_state(st, e, s);
     st.episode_step[e] = 0; st.status[e] = 0; st.gripper_open[e] = 1;
     st.pad_grasp[e] = grasp; st.pad_pher[e] = pher;
     mc.astate[e] = 1; mc.slot[e] = -1;                      // any macro step in flight is dropped
@@ -469,15 +473,13 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
     if (order) e = order[e];
     const bool writer = valid && cx.sub == 0;
     const bool sliced = slice > 0;
-    const int N = st.n;
-    LaneState s; ld_state(st, e, s);
+    float *S = cx.envl;
+    env_lds_init(cx);
+    ld_state(st, e, cx);
     int episode_step = st.episode_step[e], status = st.status[e], gripper_open = st.gripper_open[e];
     const int adim = cfg.include_roll ? 6 : 5;
-    float act[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    Kin k; Contact con; int ncon = 0, fault = 0;
-    float target[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, init_q[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, open_close = 0.f, delta_pre = 0.f, tq = 0.f;
-    V3 init_obj = v3(0, 0, 0);
+    Contact con; int ncon = 0, fault = 0;
     int phase = valid ? PH_MOVE : PH_DONE, cnt = 0, nsub = 0, grasped = 0;
     bool reached_target = false, reached_initial = false, first = true;
     size_t arow = (size_t)e;
@@ -490,16 +492,10 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
             grasped = MCI(mc, MC_GRASPED, e); fault = MCI(mc, MC_FAULT, e);
             int fl = MCI(mc, MC_FLAGS, e);
             reached_target = fl & 1; reached_initial = fl & 2; first = false;
-#pragma unroll
-            for (int i = 0; i < 5; i++) { target[i] = MCF(mc, MC_TARGET + i, e); init_q[i] = MCF(mc, MC_INITQ + i, e); }
-            open_close = MCF(mc, MC_OPENCLOSE, e); tq = MCF(mc, MC_TQ, e);
-            init_obj = v3(MCF(mc, MC_INITOBJ, e), MCF(mc, MC_INITOBJ + 1, e), MCF(mc, MC_INITOBJ + 2, e));
+            if (cx.sub < MC_NFLT) S[ES_MAC + cx.sub] = MCF(mc, cx.sub, e);         // targets etc.: the record has the layout of ES_MAC
         }
     }
-    if (first && phase != PH_DONE) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) act[i] = i < adim ? actions[arow * adim + i] : 0.f;
-    }
+    wave_sync();
     int budget = sliced ? slice : 0x7fffffff, last_iters = 0, sum_iters = 0, nsub_slice = 0;
     PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1; PAIRMEMO_EXTRA_INIT(sep)   // collide()'s per-lane memory of its pair's separating direction
 #ifndef GRIP_COLD_PORTAL
@@ -539,23 +535,58 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
         stm.acc[13] += 1;
 #endif
         if (phase != PH_DONE && (budget > 0 || phase == PH_FINAL)) {
-            forward_pos(m, cx, s, k, con, ncon, fault, stm, sep);  // state of "now": contacts as check_grasp sees them
-            if (first) {
-                first = false;
-                init_obj = k.po;
+            float delta_pre = 0.f;
+            {   // ---- position stage of "now" + everything that needs the full kinematics in registers: the first step's target pose,
+                // the control hooks (they read qpos and the targets only), the dense dynamics block
+                float q[14]; Kin k;
+                forward_kin(m, cx, q, k);
+                STAMP(stm, 0);
+                if (first) {
+                    first = false;
+                    float act[6], target[5], open_close;
 #pragma unroll
-                for (int i = 0; i < 5; i++) init_q[i] = s.qpos[i];
-                target_pose(cfg, act, s.qpos, k, target, open_close);
+                    for (int i = 0; i < 6; i++) act[i] = i < adim ? actions[arow * adim + i] : 0.f;
+                    target_pose(cfg, act, q, k, target, open_close);
+                    if (cx.sub == 0) {                  // targets, the joint positions to return to, the object's start (ES_MAC)
+                        float4 *M4 = reinterpret_cast<float4 *>(S + ES_MAC);
+                        M4[0] = make_float4(target[0], target[1], target[2], target[3]); M4[1] = make_float4(target[4], q[0], q[1], q[2]);
+                        M4[2] = make_float4(q[3], q[4], open_close, 0.f); M4[3] = make_float4(k.po.x, k.po.y, k.po.z, 0.f);
+                    }
+                    wave_sync();
+                }
+                if (phase != PH_FINAL) {
+                    // ---- pre-step hooks
+                    float ctrl[8]; lds_ld<8>(S + ES_CTRL, ctrl);
+                    if (phase == PH_MOVE || phase == PH_RETURN) {
+                        // Actuator.scale_control (actuator.py:46-48): MinMaxScaler.transform, no clipping
+                        float tg[8]; lds_ld<8>(S + ES_MAC + (phase == PH_RETURN ? MC_INITQ : MC_TARGET) / 4 * 4, tg);
+                        const int o = phase == PH_RETURN ? MC_INITQ % 4 : 0;
+                        float st_ = 2.0f / (2.0f * cfg.max_translation), sr_ = 2.0f / (2.0f * cfg.max_rotation);
+#pragma unroll
+                        for (int i = 0; i < 3; i++) ctrl[i] = ((o ? tg[i + 1] : tg[i]) - q[i]) * st_;
+#pragma unroll
+                        for (int i = 3; i < 5; i++) ctrl[i] = ((o ? tg[i + 1] : tg[i]) - q[i]) * sr_;
+                        if (cx.sub == 0) lds_st<8>(S + ES_CTRL, ctrl);
+                    } else {
+                        const float tq = S[ES_MAC + MC_TQ];
+                        delta_pre = fmaxf(fabsf(tq - q[5]), fabsf(tq - q[6]));
+                    }
+                    forward_dense(m, cx, k, ctrl, xfrc_z, nullptr, stm);
+                }
             }
+            ncon = collide(m, cx, con, fault, sep, stm);       // contacts as check_grasp sees them
+            STAMP(stm, 1);
             if (phase == PH_FINAL) {
                 // ---- robot_env.py:170-241 on the final state
-                V3 fo = k.po, fe = k.pe;
+                KinC kc; kinc_load(S, kc);
+                V3 fo = kc.po, fe = kc.pe;
+                V3 init_obj = v3(S[ES_MAC + MC_INITOBJ], S[ES_MAC + MC_INITOBJ + 1], S[ES_MAC + MC_INITOBJ + 2]);
                 float dxy = sqrtf((fo.x - fe.x) * (fo.x - fe.x) + (fo.y - fe.y) * (fo.y - fe.y));
                 if (dxy > 1.f) status = 1;
                 float p1 = project_dir(fo.x, fo.y, cfg);
                 float dgx = p1 * cfg.dir_x, dgy = p1 * cfg.dir_y;
                 float line;
-                float reward = agent_reward(init_obj, fo, cfg, gripper_open, s.ctrl[5], s.ctrl[6], grasped, line);
+                float reward = agent_reward(init_obj, fo, cfg, gripper_open, S[ES_CTRL + 5], S[ES_CTRL + 6], grasped, line);
                 if (cfg.her_buffer) { float gx = dgx - fo.x, gy = dgy - fo.y; reward += 1.0f / expf(sqrtf(gx * gx + gy * gy)); }
                 // a diverged env (NaN / runaway state, fault bit 0) is what dm_control reports as PhysicsError: the episode ends as a
                 // failure with zero reward and finite outputs, and the state is reset even without auto_reset -- one bad env
@@ -586,77 +617,74 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
                 }
                 float agx = fo.x, agy = fo.y;
                 if (done && (cfg.auto_reset || diverged)) {
-                    reset_lane(m, s); episode_step = 0; status = 0; gripper_open = 1;
+                    if (cx.sub == 0) reset_state(m, cx);
+                    episode_step = 0; status = 0; gripper_open = 1;
                     pg = (int)reset_info[0]; ph = (int)reset_info[1]; agx = reset_info[2]; agy = reset_info[3]; dgx = cfg.dir_x; dgy = cfg.dir_y;
                 }
+                st_state(st, e, cx, valid);
                 if (writer) {
                     if (out.achieved_goal) { out.achieved_goal[2 * e] = agx; out.achieved_goal[2 * e + 1] = agy; }
                     if (out.desired_goal) { out.desired_goal[2 * e] = dgx; out.desired_goal[2 * e + 1] = dgy; }
                     st.pad_grasp[e] = pg; st.pad_pher[e] = ph;
-                    st_state(st, e, s);
                     st.episode_step[e] = episode_step; st.status[e] = status; st.gripper_open[e] = gripper_open;
                     if (mc.astate) { mc.astate[e] = 1; mc.slot[e] = -1; }
                 }
                 phase = PH_DONE;
             } else {
-                // ---- pre-step hooks
-                if (phase == PH_MOVE || phase == PH_RETURN) {
-                    // Actuator.scale_control (actuator.py:46-48): MinMaxScaler.transform, no clipping
-                    float st_ = 2.0f / (2.0f * cfg.max_translation), sr_ = 2.0f / (2.0f * cfg.max_rotation);
-#pragma unroll
-                    for (int i = 0; i < 3; i++) s.ctrl[i] = (target[i] - s.qpos[i]) * st_;
-#pragma unroll
-                    for (int i = 3; i < 5; i++) s.ctrl[i] = (target[i] - s.qpos[i]) * sr_;
-                } else {
-                    delta_pre = fmaxf(fabsf(tq - s.qpos[5]), fabsf(tq - s.qpos[6]));
-                    if (phase == PH_CLOSE) grasped = check_grasp(cx, con, ncon);       // robot_env.py:155, before the step
-                }
-                physics_advance(m, cx, s, xfrc_z, k, con, ncon, fault, stm, &last_iters);
+                if (phase == PH_CLOSE) grasped = check_grasp(cx, con, ncon);       // robot_env.py:155, before the step
+                float qn[7];
+                physics_advance(m, cx, con, ncon, fault, stm, qn, &last_iters);
                 nsub++; cnt++; budget--; sum_iters += last_iters; nsub_slice++;
 #ifdef GRIP_STAMPS
                 stm.acc[11] += 1;               // env-substeps of this lane (lane 0 of each wave is reported)
 #endif
                 if (budget_ticks > 0 && wall_clock64() - t_start > budget_ticks) budget = 0;     // the wave's share of the tick is spent
                 // ---- post-step transitions
-                bool to_gripper = false, to_final = false;
+                bool to_gripper = false, to_final = false, set56 = false;
+                float c56 = 0.f;                            // new value of ctrl[5] = ctrl[6] (knuckle motors) when a transition sets them
                 if (phase == PH_MOVE || phase == PH_RETURN) {
+                    float tg[8]; lds_ld<8>(S + ES_MAC + (phase == PH_RETURN ? MC_INITQ : MC_TARGET) / 4 * 4, tg);
+                    const int o = phase == PH_RETURN ? MC_INITQ % 4 : 0;
                     float dmax = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 5; i++) dmax = fmaxf(dmax, fabsf(s.qpos[i] - target[i]));
+                    for (int i = 0; i < 5; i++) dmax = fmaxf(dmax, fabsf(qn[i] - (o ? tg[i + 1] : tg[i])));
                     bool reached = dmax < cfg.pos_tolerance;            // post-step qpos (quirk Q4)
-                    if (reached) {
-#pragma unroll
-                        for (int i = 0; i < 5; i++) s.ctrl[i] = 0.f;
+                    if (reached && cx.sub == 0) {                       // ctrl[0..4] = 0
+                        *reinterpret_cast<float4 *>(S + ES_CTRL) = make_float4(0.f, 0.f, 0.f, 0.f); S[ES_CTRL + 4] = 0.f;
                     }
                     if (phase == PH_MOVE) {
                         if (reached) reached_target = true;
                         if (cnt == cfg.max_steps) {                     // step_limit == 0 (:112), also when reached on the last try (Q5)
-                            phase = PH_RETURN; cnt = 0;
-#pragma unroll
-                            for (int i = 0; i < 5; i++) target[i] = init_q[i];
+                            phase = PH_RETURN; cnt = 0;                 // (the RETURN loop steers towards init_q: MC_INITQ of ES_MAC)
                         } else if (reached) to_gripper = true;
                     } else {
                         if (reached) reached_initial = true;
                         if (reached || cnt == cfg.max_steps) { if (reached_target) to_gripper = true; else to_final = true; }
                     }
                 } else if (phase == PH_OPEN) {
-                    bool stop = delta_pre < cfg.grasp_tolerance || (s.qpos[5] > tq && s.qpos[6] > tq);
+                    const float tq = S[ES_MAC + MC_TQ];
+                    bool stop = delta_pre < cfg.grasp_tolerance || (qn[5] > tq && qn[6] > tq);
                     if (stop) gripper_open = 1;
-                    if (stop || cnt == cfg.max_steps) { s.ctrl[5] = 0.f; s.ctrl[6] = 0.f; to_final = true; }
+                    if (stop || cnt == cfg.max_steps) { c56 = 0.f; set56 = true; to_final = true; }
                 } else {   // PH_CLOSE
                     bool stop = delta_pre < cfg.grasp_tolerance || grasped == 3;
                     if (stop) gripper_open = 0;
-                    if (stop || cnt == cfg.max_steps) { s.ctrl[5] = 0.f; s.ctrl[6] = 0.f; to_final = true; }
+                    if (stop || cnt == cfg.max_steps) { c56 = 0.f; set56 = true; to_final = true; }
                 }
                 if (to_gripper) {
-                    if (open_close > 0.f && !gripper_open) { phase = PH_OPEN; cnt = 0; tq = 0.4f; s.ctrl[5] = 0.5f; s.ctrl[6] = 0.5f; }
-                    else if (open_close < 0.f && gripper_open) { phase = PH_CLOSE; cnt = 0; tq = -0.4f; s.ctrl[5] = -1.f; s.ctrl[6] = -1.f; }
+                    const float open_close = S[ES_MAC + MC_OPENCLOSE];
+                    float tq = 0.f; bool set_tq = false;
+                    if (open_close > 0.f && !gripper_open) { phase = PH_OPEN; cnt = 0; tq = 0.4f; set_tq = true; c56 = 0.5f; set56 = true; }
+                    else if (open_close < 0.f && gripper_open) { phase = PH_CLOSE; cnt = 0; tq = -0.4f; set_tq = true; c56 = -1.f; set56 = true; }
                     else to_final = true;
+                    if (set_tq && cx.sub == 0) S[ES_MAC + MC_TQ] = tq;
                 }
                 if (to_final) {
                     if (!reached_target && !reached_initial) status = 1;       // robot_env.py:130-132
                     phase = PH_FINAL;
                 }
+                if (set56 && cx.sub == 0) { S[ES_CTRL + 5] = c56; S[ES_CTRL + 6] = c56; }
+                wave_sync();
             }
         }
     }
@@ -682,17 +710,16 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
         }
     }
 #endif
-    if (sliced && writer && phase != PH_DONE) {             // out of budget mid-step: suspend
-        st_state(st, e, s);
-        st.status[e] = status; st.gripper_open[e] = gripper_open;
-        mc.astate[e] = 0;
-        MCI(mc, MC_PHASE, e) = phase; MCI(mc, MC_CNT, e) = cnt; MCI(mc, MC_NSUB, e) = nsub;
-        MCI(mc, MC_GRASPED, e) = grasped; MCI(mc, MC_FAULT, e) = fault;
-        MCI(mc, MC_FLAGS, e) = (reached_target ? 1 : 0) | (reached_initial ? 2 : 0);
-#pragma unroll
-        for (int i = 0; i < 5; i++) { MCF(mc, MC_TARGET + i, e) = target[i]; MCF(mc, MC_INITQ + i, e) = init_q[i]; }
-        MCF(mc, MC_OPENCLOSE, e) = open_close; MCF(mc, MC_TQ, e) = tq;
-        MCF(mc, MC_INITOBJ, e) = init_obj.x; MCF(mc, MC_INITOBJ + 1, e) = init_obj.y; MCF(mc, MC_INITOBJ + 2, e) = init_obj.z;
+    if (sliced && phase != PH_DONE) {                       // out of budget mid-step: suspend
+        st_state(st, e, cx, valid);
+        if (valid && cx.sub < MC_NFLT) MCF(mc, cx.sub, e) = S[ES_MAC + cx.sub];
+        if (writer) {
+            st.status[e] = status; st.gripper_open[e] = gripper_open;
+            mc.astate[e] = 0;
+            MCI(mc, MC_PHASE, e) = phase; MCI(mc, MC_CNT, e) = cnt; MCI(mc, MC_NSUB, e) = nsub;
+            MCI(mc, MC_GRASPED, e) = grasped; MCI(mc, MC_FAULT, e) = fault;
+            MCI(mc, MC_FLAGS, e) = (reached_target ? 1 : 0) | (reached_initial ? 2 : 0);
+        }
     }
 }
 
@@ -838,14 +865,13 @@ __global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_substep(const
     bool act_; int e = blockIdx.x * EPB + wg_env_slot(act_);
     const bool valid = act_ && e < st.n;
     if (e >= st.n) e = st.n - 1;          // (idle rows of a 2-env wave mirror the env of the row 32 lanes below: same reads, no writes)
-    LaneState s; ld_state(st, e, s);
-    Kin k; Contact con; int ncon = 0, fault = 0;
+    env_lds_init(cx);
+    ld_state(st, e, cx);
+    Contact con; int ncon = 0, fault = 0;
     PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1; PAIRMEMO_EXTRA_INIT(sep)
-    for (int i = 0; i < nsteps; i++) {
-        forward_pos(m, cx, s, k, con, ncon, fault, stm, sep);
-        physics_advance(m, cx, s, xfrc_z, k, con, ncon, fault, stm);
-    }
-    if (valid && cx.sub == 0) { st_state(st, e, s); if (fault_out) fault_out[e] = fault; }
+    for (int i = 0; i < nsteps; i++) physics_step(m, cx, xfrc_z, con, ncon, fault, sep, stm);
+    st_state(st, e, cx, valid);
+    if (valid && cx.sub == 0 && fault_out) fault_out[e] = fault;
 #ifdef GRIP_STAMPS
     if (blockIdx.x == 0 && threadIdx.x == 0) for (int i = 0; i < NSTAMP; i++) g_stamp_acc[i] = stm.acc[i];
 #endif
@@ -858,15 +884,22 @@ __global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_debug_forward
     bool act_; int e = blockIdx.x * EPB + wg_env_slot(act_);
     const bool valid = act_ && e < st.n;
     if (e >= st.n) e = st.n - 1;          // (idle rows of a 2-env wave mirror the env of the row 32 lanes below: same reads, no writes)
-    LaneState s; ld_state(st, e, s);
+    env_lds_init(cx);
+    ld_state(st, e, cx);
     Kin k; Contact con; int ncon = 0, fault = 0, iters = 0;
     PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1; PAIRMEMO_EXTRA_INIT(sep)
-    forward_pos(m, cx, s, k, con, ncon, fault, stm, sep);
+    float q0[14], bias[13], ctrl[8];
+    forward_kin(m, cx, q0, k);
+    lds_ld<8>(cx.envl + ES_CTRL, ctrl);
+    forward_dense(m, cx, k, ctrl, xfrc_z, bias, stm);
+    ncon = collide(m, cx, con, fault, sep, stm);
     float gpos[18];                             // geom frame origins, read now: the solver reuses the frames' LDS area (EF_H)
     for (int g = 1; g <= 6; g++) { V3 p; M3 R; load_frame(cx.envl, g, p, R); gpos[3 * (g - 1)] = p.x; gpos[3 * (g - 1) + 1] = p.y; gpos[3 * (g - 1) + 2] = p.z; }
+    float qs[13]; lds_ld<13>(cx.envl + ES_QS, qs);
     wave_sync();
-    float qfs[13], qacc[13], jtf[13], qs[13], bias[13];
-    forward_acc(m, cx, s, xfrc_z, k, con, ncon, fault, qfs, qacc, jtf, iters, qs, bias, stm, getenv_dbgH ? M_out + (size_t)e * 169 : nullptr);
+    float qacci, jtfi, qacc[13];
+    forward_acc(m, cx, con, ncon, fault, qacci, jtfi, iters, stm, getenv_dbgH ? M_out + (size_t)e * 169 : nullptr);
+    gather13(qacci, qacc);
     if (!valid) return;
     if (cx.sub < G_MAXC) {                      // lane c reports contact c
         float *o = con_out + ((size_t)e * G_MAXC + cx.sub) * 10;
@@ -891,12 +924,13 @@ __global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_target_pose(c
     bool act_; int e = blockIdx.x * EPB + wg_env_slot(act_);
     const bool valid = act_ && e < st.n;
     if (e >= st.n) e = st.n - 1;          // (idle rows of a 2-env wave mirror the env of the row 32 lanes below: same reads, no writes)
-    LaneState s; ld_state(st, e, s);
-    Kin k; kinematics(m, s.qpos, k, cx, false);
+    ld_state(st, e, cx);
+    float q[14]; lds_ld<14>(cx.envl + ES_QPOS, q);
+    Kin k; kinematics(m, q, k, cx, false);
     const int adim = cfg.include_roll ? 6 : 5;
     float act[6], target[5], oc;
     for (int i = 0; i < 6; i++) act[i] = i < adim ? actions[(size_t)e * adim + i] : 0.f;
-    target_pose(cfg, act, s.qpos, k, target, oc);
+    target_pose(cfg, act, q, k, target, oc);
     if (valid && cx.sub == 0) for (int i = 0; i < 5; i++) target_out[(size_t)e * 5 + i] = target[i];
 }
 
@@ -1397,6 +1431,11 @@ extern "C" int grip_debug_stamps(unsigned long long *out8) {   // NSTAMP entries
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_stamp_acc), sizeof(unsigned long long) * NSTAMP) != hipSuccess) return -1;
     unsigned long long zero[NSTAMP] = {0};
     return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_acc), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+extern "C" int grip_debug_hist(unsigned long long *out64) {   // per-step histograms of the diagnostic build (grip_physics.h: g_dbg_hist), reset on read
+    static const unsigned long long zero[96] = {0};
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_dbg_hist), sizeof(unsigned long long) * 96) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_hist), zero, sizeof zero) == hipSuccess ? 0 : -1;
 }
 extern "C" int grip_debug_counters(unsigned long long *out8) {   // 16 collide() event counters (grip_physics.h), reset on read
     if (hipDeviceSynchronize() != hipSuccess) return -1;

@@ -1,0 +1,111 @@
+"""A/B check of two builds of the library on the contact fixture's states: one physics.step() (grip_batch_substep) and the forward
+dynamics hook (grip_batch_debug_forward) from every (qpos, qvel, ctrl, warm) row, per object.
+    python tools/ab_step.py dump <variant|-> <out.npz>      (one process per library: a process binds one build)
+    python tools/ab_step.py cmp a.npz b.npz"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def dump(var, out):
+    import torch
+    from mujoco_rl_manipulate_unknown_objects_amd import engine
+    if var != "-":
+        engine.LIB_PATH = os.path.join(engine.CSRC, f"libgrip_sim_{var}.so")
+    z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "contact_states.npz"))
+    res = {}
+    for obj in engine.OBJECTS:
+        q, v, c, w = (z[f"{obj}/{k}"] for k in ("qpos", "qvel", "ctrl", "warm"))
+        b = engine.Batch(obj, len(q)); b.set_state(q, v, c, w)
+        dbg = b.debug_forward()
+        for k, a in dbg.items():
+            res[f"{obj}/dbg_{k}"] = np.asarray(a)
+        for steps in (1, 5):
+            b.set_state(q, v, c, w); b.substep(steps); torch.cuda.synchronize()
+            gq, gv, gc, gw = b.get_state()
+            res[f"{obj}/q{steps}"] = gq; res[f"{obj}/v{steps}"] = gv; res[f"{obj}/w{steps}"] = gw
+        b.close()
+    np.savez(out, **res)
+
+
+def cmp(a, b):
+    A, B = np.load(a), np.load(b)
+    for k in A.files:
+        x, y = A[k].astype(np.float64), B[k].astype(np.float64)
+        d = np.abs(x - y)
+        rows = d.reshape(len(d), -1).max(1) if d.ndim > 1 else d
+        print(f"{k:28s} max {d.max():.3e}  rows>1e-4: {(rows > 1e-4).sum():4d}/{len(rows)}  worst row {int(rows.argmax())}")
+
+
+if __name__ == "__main__" and sys.argv[1] in ("dump", "cmp"):
+    if sys.argv[1] == "dump":
+        dump(sys.argv[2], sys.argv[3])
+    else:
+        cmp(sys.argv[2], sys.argv[3])
+
+
+def traj_dump(var, out, obj="acorn"):
+    """states along the oracle's contact trajectories (the one-step parity test's input); writes inputs, next states and debug hooks"""
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+    from mujoco_rl_manipulate_unknown_objects_amd import engine
+    if var != "-":
+        engine.LIB_PATH = os.path.join(engine.CSRC, f"libgrip_sim_{var}.so")
+    from oracle import orc
+    import test_gpu_contact as T
+    z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "contact_states.npz"))
+    m = orc.Model(obj); cat = z[f"{obj}/category"]
+    pick = []
+    for c, k in (("push_reward", 3), ("close_code3_break", 3), ("close_code1", 1), ("close_code2", 1), ("hull_contact_move", 2), ("pad_grasp_nonzero", 2)):
+        pick += list(np.where(cat == c)[0][:k])
+    pre, post = [], []
+    for i in pick:
+        a, b_, _, _ = T.oracle_trajectory(orc, m, z, obj, i); pre += a; post += b_
+    f32 = lambda k: np.array([s[k] for s in pre], np.float32)
+    b = engine.Batch(obj, len(pre)); b.set_state(f32(0), f32(1), f32(2), f32(3))
+    dbg = b.debug_forward(); b.substep(1); torch.cuda.synchronize()
+    gq, gv, gc, gw = b.get_state(); b.close()
+    res = {"q1": gq, "v1": gv, "w1": gw, "oq": np.array([s[0] for s in post]), "ov": np.array([s[1] for s in post]), "pq": f32(0), "pv": f32(1), "pc": f32(2), "pw": f32(3)}
+    for k, a in dbg.items():
+        res[f"dbg_{k}"] = np.asarray(a)
+    np.savez(out, **res)
+
+
+def traj_report(a, b):
+    A, B = np.load(a), np.load(b)
+    for name, Z in (("A", A), ("B", B)):
+        ev = np.abs(Z["v1"] - Z["ov"]).max(1)
+        print(name, "vs oracle: qvel err median %.2e p99 %.2e max %.2e; rows > 1e-3: %d" % (np.median(ev), np.quantile(ev, .99), ev.max(), (ev > 1e-3).sum()))
+    d = np.abs(A["v1"].astype(np.float64) - B["v1"]).max(1)
+    bad = np.argsort(-d)[:12]
+    print("A vs B qvel: max %.3e, rows > 1e-4: %d of %d" % (d.max(), (d > 1e-4).sum(), len(d)))
+    for r in bad:
+        print("row", r, "dv %.2e" % d[r], "ncon", int(A["dbg_ncon"][r]), int(B["dbg_ncon"][r]), "iters", A["dbg_con"][r, 0, 9], B["dbg_con"][r, 0, 9],
+              "pairs", [(int(B["dbg_con"][r, c, 7]), int(B["dbg_con"][r, c, 8])) for c in range(int(B["dbg_ncon"][r]))],
+              "q5,q6 %.3f %.3f" % (B["pq"][r, 5], B["pq"][r, 6]), "dqacc %.2e" % np.abs(A["dbg_qacc"][r] - B["dbg_qacc"][r]).max(),
+              "dw1 %.2e" % np.abs(A["w1"][r] - B["w1"][r]).max())
+
+
+if __name__ == "__main__" and sys.argv[1] in ("traj", "trajcmp"):
+    if sys.argv[1] == "traj":
+        traj_dump(sys.argv[2], sys.argv[3], *(sys.argv[4:5]))
+    else:
+        traj_report(sys.argv[2], sys.argv[3])
+
+
+def row_probe(var, src, row, out):
+    """one state of a traj dump replicated 32 times: does the result depend on the wave-mates? (plus the first Hessian with GRIP_DEBUG_H=1)"""
+    import torch
+    from mujoco_rl_manipulate_unknown_objects_amd import engine
+    if var != "-":
+        engine.LIB_PATH = os.path.join(engine.CSRC, f"libgrip_sim_{var}.so")
+    Z = np.load(src); r = int(row)
+    rep = lambda a: np.repeat(a[r:r + 1], 32, 0)
+    b = engine.Batch("acorn", 32); b.set_state(rep(Z["pq"]), rep(Z["pv"]), rep(Z["pc"]), rep(Z["pw"]))
+    dbg = b.debug_forward(); b.close()
+    print(var, "iters", dbg["con"][:, 0, 9], "qacc[0]", dbg["qacc"][0], "same in all 32:", bool((dbg["qacc"] == dbg["qacc"][0]).all()))
+    np.savez(out, **{k: np.asarray(v) for k, v in dbg.items()})
+
+
+if __name__ == "__main__" and sys.argv[1] == "row":
+    row_probe(*sys.argv[2:6])

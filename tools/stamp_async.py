@@ -4,7 +4,7 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
 from mujoco_rl_manipulate_unknown_objects_amd import engine
-engine.LIB_PATH = os.path.join(engine.CSRC, "libgrip_sim_stamps.so")
+engine.LIB_PATH = os.path.join(engine.CSRC, f"libgrip_sim_{os.environ.get('GRIP_STAMPS_LIB', 'stamps')}.so")
 obj = sys.argv[1] if len(sys.argv) > 1 else "acorn"
 n, cap = 4096, 1024
 b = engine.Batch(obj, n, auto_reset=1)
@@ -16,18 +16,39 @@ def ticks(k):
         b.advance(torch.randn(cap, 6, device="cuda", generator=g).clamp(-1, 1), 96, lst, cnt, 2000)
 warm = int(sys.argv[2]) if len(sys.argv) > 2 else 150        # 150 ticks: fresh episodes (free motion); ~3000: envs at mixed episode phases
 ticks(warm); engine.lib().grip_debug_stamps(out)
+engine.lib().grip_debug_hist((C.c_ulonglong * 96)())
 ticks(100); engine.lib().grip_debug_stamps(out)
-names = ["kinematics", "collide", "mass+bias+qs", "make_constraints", "solve: other (bookkeeping)", "integrate", "solve: constraint pass", "solve: tri-solves+gather", "solve: assemble rows", "solve: cholesky", "solve: line search"]
-names2 = {14: "solve: prologue (mrow, jar of both starts)", 15: "solve: stage logic after pricing", 16: "solve: hessian_vectors + sync",
-          17: "solve: p readback, M p, J p, g0/g1", 18: "solve: loop exit", 19: "solve: final gathers"}
-tot = sum(out[:11]) + sum(out[14:20])
-names3 = {20: "collide: prologue (frames, sphere tests, portal rebuild)", 21: "collide: votes + cooperative support", 22: "collide: per-lane support of geom 2",
-          23: "collide: per-lane support of geom 1", 24: "collide: floor branch (neighbours inside the margin)", 25: "collide: portal phase logic", 26: "collide: loop exit"}
-for i, nm in names3.items():
-    print(f"   {nm:58s} {100 * out[i] / tot:5.1f} %   (inside `collide`, whose own slot then holds only compaction + contact load)")
-for nm, v in zip(names, out):
-    print(f"{nm:34s} {100 * v / tot:5.1f} %")
-for i, nm in names2.items():
-    print(f"{nm:44s} {100 * out[i] / tot:5.1f} %")
+hist = (C.c_ulonglong * 96)()
+engine.lib().grip_debug_hist(hist)
+names = {0: "kinematics", 1: "collide: compaction + contact load", 2: "dense (bias, mass matrix, qacc_smooth)", 3: "make_constraints (+ rows, start residuals)",
+         4: "solve: other (bookkeeping)", 5: "integrate", 6: "solve: constraint pass", 7: "solve: tri-solves+gather", 8: "solve: assemble rows", 9: "solve: cholesky",
+         10: "solve: line search", 14: "solve: prologue (mrow)", 15: "solve: stage logic after pricing", 16: "solve: hessian_vectors + sync",
+         17: "solve: p readback, M p, J p, g0/g1", 18: "solve: loop exit (waiting for the wave-mates' iterations)", 19: "solve: hand-over",
+         20: "collide: prologue (frames, sphere tests, portal rebuild)", 21: "collide: votes + cooperative support", 22: "collide: per-lane support of geom 2",
+         23: "collide: per-lane support of geom 1", 24: "collide: floor branch (neighbours inside the margin)", 25: "collide: portal phase logic", 26: "collide: loop exit"}
+tot = sum(out[i] for i in names)
+grp = {"collide": [1, 20, 21, 22, 23, 24, 25, 26], "dense": [0, 2, 3, 5], "solver": [4, 6, 7, 8, 9, 10, 14, 15, 16, 17, 18, 19]}
+for g_, ids in grp.items():
+    print(f"== {g_}: {100 * sum(out[i] for i in ids) / tot:5.1f} %")
+    for i in ids:
+        print(f"   {names[i]:62s} {100 * out[i] / tot:5.1f} %")
 print("wave-cycles per lane-0 env-substep:", tot / max(1, out[11]))
 print("mean envs at work per wave loop trip: %.2f of 4;  wave-cycles per loop trip: %.0f" % (out[12] / max(1, out[13]), tot / max(1, out[13])))
+steps = max(1, hist[16])
+print("per env and physics.step(): Newton iterations 0..6, 7+ :", " ".join(f"{100 * hist[i] / steps:.1f}%" for i in range(8)),
+      "| mean %.2f" % (sum(i * hist[i] for i in range(8)) / steps))
+print("per wave trip: iterations the wave ran (max over its envs) 0..6, 7+ :", " ".join(f"{100 * hist[24 + i] / max(1, sum(hist[24:32])):.1f}%" for i in range(8)),
+      "| mean %.2f" % (sum(i * hist[24 + i] for i in range(8)) / max(1, sum(hist[24:32]))))
+print("contacts 0, 1-2, 3-4, ... 13-14 :", " ".join(f"{100 * hist[8 + i] / steps:.1f}%" for i in range(8)))
+print("constrained %.1f%%, gripper block in the solve %.1f%%, any hull contact %.1f%%, active joint limit %.1f%%" %
+      tuple(100 * hist[i] / steps for i in (17, 18, 19, 20)))
+for k in range(4):
+    t = max(1, sum(hist[32 + 8 * k: 40 + 8 * k]))
+    print(f"scaled gradient after Newton iteration {k + 1} (<1e-7, decades ..., >=1e-1):", " ".join(f"{100 * hist[32 + 8 * k + b] / t:.1f}%" for b in range(8)), f"({t} solves)")
+ns = max(1, hist[73])
+print("scaled gradient at the chosen start:", " ".join(f"{100 * hist[64 + b] / ns:.1f}%" for b in range(8)), f"; warm start taken {100 * hist[72] / ns:.1f}%")
+for nm, o in (("hull", 74), ("floor", 81)):
+    a = max(1, sum(hist[o:o + 3]))
+    print(f"{nm} contacts per solve {a / ns:.2f}: zone at start (top, middle, bottom)", " ".join(f"{100 * hist[o + z] / a:.1f}%" for z in range(3)),
+          "| at the end", " ".join(f"{100 * hist[o + 3 + z] / a:.1f}%" for z in range(3)), f"| zone changed {100 * hist[o + 6] / a:.1f}%")
+print(f"env-steps with a gripper-object contact (H couples the two blocks): {100 * hist[22] / steps:.1f}%; wave trips with at least one such env: {100 * hist[88] / max(1, hist[23]):.1f}%")
