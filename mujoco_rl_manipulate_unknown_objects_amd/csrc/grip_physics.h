@@ -28,7 +28,7 @@
 // a gfx950 SIMD issues a lone wave's VALU stream at one instruction per 4 cycles but two waves' streams at one per 2 cycles each
 // way, and each wave covers the other's LDS / s_waitcnt stalls. Needs the kernel inside 256 registers.
 #ifndef GRIP_EPW
-#define GRIP_EPW 4
+#define GRIP_EPW 2
 #endif
 #define EPW GRIP_EPW                    // environments per wave
 #define EPB 16                          // environments per workgroup
@@ -836,6 +836,19 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
         const int item = m.coop_items[cx.sub][round];
         const bool has = item >= 0;
         const bool plane = item < 6;
+        if (round > 0) {
+            // The later rounds hold what did not fit the 16 lanes: the floor test of the gripper base, which is out of reach of the floor
+            // nearly always. One bounding-sphere height per lane decides whether anybody in the wave needs the round at all (its
+            // prologue -- frames, table reads, portal set-up -- is ~370 instructions for all lanes).
+            bool need = has && !plane;
+            if (has && plane) {
+                const float *tq = T.gt + (item + 1) * GT_STRIDE;
+                V3 pq; M3 Rq; load_frame(cx.envl, item + 1, pq, Rq);
+                const float cz = pq.z + (Rq.m[6] * tq[0] + Rq.m[7] * tq[1] + Rq.m[8] * tq[2]);
+                need = cz <= tq[3] + m.margin;
+            }
+            if (!__any(need)) continue;
+        }
         const int g1 = plane ? 0 : m.pairs[max(item - 6, 0)][0], g2 = !has ? 1 : plane ? item + 1 : m.pairs[max(item - 6, 0)][1];
         const float *t1 = T.gt + g1 * GT_STRIDE, *t2 = T.gt + g2 * GT_STRIDE;
         V3 p1 = v3(0, 0, 0), p2; M3 R1, R2;
@@ -1444,7 +1457,7 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
     }
     STAMP(st, 14);
     // ---- both starts priced at once (their residuals jar = J x - aref and M (x - a_s) come from make_constraints)
-    float xi, Mdi, jtfi, hdiag; Cone cn; bool gconv;
+    float xi, Mdi, jtfi, hdiag, cost; Cone cn; bool gconv;
 #ifdef HAVE_DBG_HIST
     bool take_w_dbg = false; float g2w_dbg = 0.f, g2s_dbg = 0.f;
 #endif
@@ -1464,7 +1477,7 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
         take_w_dbg = take_w; g2w_dbg = g2w; g2s_dbg = g2s;
 #endif
         xi = take_w ? warmi : qsi; Mdi = take_w ? Md_w : 0.f; jtfi = take_w ? jt_w : jt_s; hdiag = take_w ? hd_w : hd_s;
-        gconv = take_w ? conv_w : conv_s;
+        cost = take_w ? cost_w : cost_s; gconv = take_w ? conv_w : conv_s;
         cone_sel(cn, take_w, cn_w);
 #pragma unroll
         for (int r = 0; r < 4; r++) c.jar[r] = take_w ? lc.jar_w[r] : lc.jar_s[r];
@@ -1582,7 +1595,7 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
                 iters++;
                 // ---- price the new point; stop on the gradient, on a stalled cost, or at the iteration limit
                 STAMP(st, 4);
-                price_constraints(m, cx, lsgn, lD, laref, xi, ncon, c, live, cn, jtfi, hdiag);
+                const float lcst = price_constraints(m, cx, lsgn, lD, laref, xi, ncon, c, live, cn, jtfi, hdiag);
                 const float gn = Mdi - jtfi;
                 const float g2 = sum16(gn * gn), t2 = sum16(Mdi * Mdi + jtfi * jtfi);
                 bool stop = scale * sqrtf(g2) < tol || g2 < NEWTON_GRAD_NOISE * NEWTON_GRAD_NOISE * t2;
@@ -1592,6 +1605,11 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
                 // cancellation: phi' rises monotonically from phi'(0) = dp0 < 0 to 0 at alpha, so the decrease -int phi' is alpha |dp0| / 2
                 // for a quadratic and within a factor of two of that across cone-zone kinks.
                 if (scale * (-0.5f * alpha * dp0) < tol) stop = true;
+                // ... and a solve that is still going after four iterations is allowed to stop on the measured difference too: what it gains
+                // per iteration is then at the rounding level of the cost anyway (rare: ~0.3 % of the solves get this far)
+                {   const float newcost = sum16(0.5f * Mdi * (xi - qsi) + lcst);
+                    if (iters >= 4 && scale * (cost - newcost) < tol) stop = true;
+                    cost = newcost; }
 #ifdef HAVE_DBG_HIST
                 if (cx.sub == 0 && iters <= 4) { const float sg = scale * sqrtf(g2); int b = 0; for (float t = 1e-7f; b < 7 && sg >= t; t *= 10.f) b++; DBG_HIST(32 + 8 * (iters - 1) + b, 1); }
 #endif

@@ -696,7 +696,18 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
         // last solve plus 1.5 per hull-hull contact (MPR refinement); k_compact sorts the work order by it
         int hv = __popc(group_bits(__ballot(cx.sub < ncon && con.g1 != 0), cx.lane));
         // (twice the mean Newton iteration count of this slice: single steps alternate between 1 and 2 iterations)
-        if (writer && nsub_slice > 0) mc.heavy[e] = min(CP_CLASSES - 2, (2 * sum_iters + nsub_slice / 2) / nsub_slice + 3 * min(hv, 3));
+#ifndef HEAVY_KEY
+#define HEAVY_KEY 0
+#endif
+        if (writer && nsub_slice > 0) {
+            int key;
+            if (HEAVY_KEY == 0) key = (2 * sum_iters + nsub_slice / 2) / nsub_slice + 3 * min(hv, 3);
+            else if (HEAVY_KEY == 1) key = (4 * sum_iters + nsub_slice / 2) / nsub_slice;                       // Newton iterations only, finer
+            else if (HEAVY_KEY == 2) key = (4 * sum_iters + nsub_slice / 2) / nsub_slice + (hv > 1 ? 4 : 0);
+            else if (HEAVY_KEY == 3) key = 2 * min(last_iters, 5) + ((2 * sum_iters + nsub_slice / 2) / nsub_slice > 4 ? 1 : 0);   // the last step's count first
+            else key = (3 * sum_iters + nsub_slice / 2) / nsub_slice + min(last_iters, 3);
+            mc.heavy[e] = min(CP_CLASSES - 2, key);
+        }
     }
 #ifndef GRIP_COLD_PORTAL
     if (sliced && valid && phase != PH_DONE) {              // every lane parks its pair's portal memory (the flag; the portal if there is one)

@@ -1,5 +1,5 @@
 """Physics-only rate of the time-sliced engine at mixed episode phases: the working metric of kernel optimisation.
-    python tools/physics_rate.py [variant-name|-] [object] [slice] [budget_us]
+    python tools/physics_rate.py [variant-name|-] [object] [slice] [budget_us] [pre-roll ticks] [list capacity]
 4096 envs, actions U(-1,1) (torch generator, fixed seed), `pre` ticks of pre-roll, then 400 timed ticks; no render, no policy.
 Prints env-steps/s, physics.step() calls/s and the mean slice-kernel time; `variant-name` picks csrc/libgrip_sim_<name>.so."""
 import sys, os, time, json; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,7 @@ obj = sys.argv[2] if len(sys.argv) > 2 else "acorn"
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 144
 bud = int(sys.argv[4]) if len(sys.argv) > 4 else 3000
 pre = int(sys.argv[5]) if len(sys.argv) > 5 else 1500
-n, cap = 4096, 1024
+n, cap = 4096, int(sys.argv[6]) if len(sys.argv) > 6 else 1024
 b = engine.Batch(obj, n, auto_reset=1)
 lst = torch.full((cap,), -1, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
 g = torch.Generator(device="cuda"); g.manual_seed(0)
@@ -29,5 +29,5 @@ for _ in range(T): tick()
 torch.cuda.synchronize(); dt = time.time() - t0; c1, s1 = int(total.item()), int(subs.item())
 kms, kn = b.kernel_time(True)
 print(json.dumps({"lib": var, "object": obj, "slice": S, "budget_us": bud, "env_steps_per_s": (c1 - c0) / dt, "substeps_per_s": (s1 - s0) / dt,
-                  "substeps_per_env_step": (s1 - s0) / max(1, c1 - c0), "ms_per_tick": dt / T * 1e3, "slice_kernel_ms": kms, "fault_max": int(b.out["fault"].max()),
+                  "substeps_per_env_step": (s1 - s0) / max(1, c1 - c0), "capacity": cap, "ready_per_tick": (c1 - c0) / T, "ms_per_tick": dt / T * 1e3, "slice_kernel_ms": kms, "fault_max": int(b.out["fault"].max()),
                   "all_ticks": pre + T, "all_substeps_of_finished_macro_steps": s1, "all_env_steps": c1}))
