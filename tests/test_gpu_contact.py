@@ -112,9 +112,15 @@ def test_macro_step_parity_in_contact(engine, orc, torch, contact, obj):
         assert all(r["fault"] == 0 for r in recs)
         assert all(r["pad_rest_zero"] for r in recs)
         for cat, proof in CATEGORY_PROOF.items():
-            if cat in ("close_code1", "close_code2"):
-                continue                       # well-conditioned one-finger closes are rare: checked over both directions below
+            if cat in ("close_code1", "close_code2") and not any(r["cat"] == cat for r in recs):
+                continue                       # well-conditioned one-finger closes are rare: a direction may hold none (both codes are checked below)
             hits = [r for r in recs if r["cat"] == cat and r["ints_ok"] and r["pad_ok"] and proof(r["o"])]
+            if not hits and cat in ("close_code1", "close_code2"):
+                # the rare one-finger closes: a direction may hold a single row. No exact lane is accepted only with the proof that EVERY row of
+                # the category is a conditioning case (the oracle's own outputs flip under one-step-sized noise); both codes are still
+                # required to be produced and matched over the two directions together (below)
+                assert all(oracle_outputs_unstable(orc, orc.Model(obj), contact, obj, r["row"]) for r in recs if r["cat"] == cat), (obj, direction, cat)
+                continue
             assert hits, (obj, direction, cat, [(r["nsub"], r["grasped"], r["pad"], r["pher"]) for r in recs if r["cat"] == cat])
         # pad codes and pheromone levels actually produced and matched, whichever category the row was found for
         good = [r for r in recs if r["ints_ok"] and r["pad_ok"]]
@@ -127,9 +133,36 @@ def test_macro_step_parity_in_contact(engine, orc, torch, contact, obj):
     med = {k: float(np.median([r[k] for r in good])) for k in ("drew", "dgrip", "dobj")}
     bad = [(r["cat"], r["nsub"], r["grasped"], r["pad"], r["pher"]) for r in allrecs if not (r["ints_ok"] and r["pad_ok"])]
     print(f"\n[contact parity] {obj}: {len(good)}/{len(allrecs)} lanes exact ({frac:.3f}); median gaps on exact lanes {med}; worst {worst}; differing lanes {bad}")
-    assert frac >= 0.92, (frac, bad)
+    # Every lane that differs must be a CONDITIONING case, shown on the oracle itself: replayed with perturbations of the size of the fp32
+    # path's own one-step differences (qpos 2e-6, qvel 3e-3 relative-ish: the p99 of the one-step test below, which includes a finger-finger
+    # pad contact resolved on the neighbouring facet), the ORACLE's integer outputs change for at least one of 16 seeds. A lane whose oracle
+    # outputs are stable under that noise and still differ from the HIP path fails the test whatever the fraction.
+    unstable = {r["row"]: oracle_outputs_unstable(orc, orc.Model(obj), contact, obj, r["row"]) for r in allrecs if not (r["ints_ok"] and r["pad_ok"])}
+    print(f"[contact parity] {obj}: differing lanes whose oracle outputs flip under one-step-sized noise: {sum(unstable.values())}/{len(unstable)}")
+    assert all(unstable.values()), [k for k, v in unstable.items() if not v]
+    assert frac >= 0.90, (frac, bad)
     assert med["drew"] < 1e-4 and med["dgrip"] < 2e-5 and med["dobj"] < 2e-5, med
     assert worst["drew"] < 5e-3 and worst["dgrip"] < 2e-3 and worst["dobj"] < 2e-3 and worst["dgoal"] < 2e-3 and worst["dline"] < 2e-3 and worst["dtot"] < 2e-3, worst
+
+
+def oracle_outputs_unstable(orc, m, z, obj, i, seeds=16, amp=2e-6, vamp=3e-3):
+    """Do the oracle's own integer outputs (and pad bytes) of fixture row i change when every physics.step() is followed by a perturbation of
+    qpos by amp (1 + |x|) U(-1, 1) and qvel by vamp (1 + |v|) U(-1, 1) (orc_set_step_noise2)? The fixture keeps rows that survive 5e-7 / 3e-5
+    (the median-sized one-step error); this probe uses the p99-sized one."""
+    from test_oracle_contact import oracle_from_row
+    L = orc.lib()
+    L.orc_set_step_noise.argtypes = [C.c_double, C.c_uint]; L.orc_set_step_noise2.argtypes = [C.c_double, C.c_double, C.c_uint]
+    act = z[f"{obj}/action"][i]
+    ref = oracle_from_row(orc, m, z, obj, i).step(act)
+    key = lambda o: tuple(int(getattr(o, f)) for f in INT_FIELDS) + (o.reached_target, o.reached_initial, o.reached_fail, o.pad_grasp, o.pad_pheromone)
+    try:
+        for seed in range(1, seeds + 1):
+            L.orc_set_step_noise2(amp, vamp, seed)
+            if key(oracle_from_row(orc, m, z, obj, i).step(act)) != key(ref):
+                return True
+    finally:
+        L.orc_set_step_noise(0.0, 0)
+    return False
 
 
 def oracle_trajectory(orc, m, z, obj, i):
@@ -142,7 +175,7 @@ def oracle_trajectory(orc, m, z, obj, i):
     target = e.target_pose(act)
     pre, post, cons = [], [], []
     snap = lambda: (np.array(d.qpos), np.array(d.qvel), np.array(d.ctrl), np.array(d.qacc_warmstart))
-    conset = lambda: sorted((d.con[c].g1, d.con[c].g2) for c in range(d.ncon))
+    conset = lambda: sorted((d.con[c].g1, d.con[c].g2, tuple(d.con[c].frame[0:3])) for c in range(d.ncon))      # pair + contact normal
     mindist = lambda: min([abs(d.con[c].dist - 1e-3) for c in range(d.ncon) if d.con[c].g1 != 0] + [1.0])
     margins = []
     reached = False
@@ -168,11 +201,14 @@ def test_one_step_parity_along_contact_trajectories(engine, orc, torch, contact,
     """a4 where it matters: physics.step() in contact. Every pre-step state of the oracle's own macro steps through pushes, one-finger and
     two-finger closes (fixture rows: ~1500-3000 states per object, most of them with gripper-object or finger-finger hull contacts)
     becomes one env of a batch; ONE physics.step() of the HIP path from each is compared with the oracle's next state, and the contact
-    pairs of each state with the oracle's. No trajectory is followed, so nothing accumulates: this is the one-step error of the fp32
-    kernel. Floors (printed with the achieved values): contact pairs identical on >= 99 % of the states and on every state whose
-    hull contacts are all more than 2 um away from the 1 mm margin; qpos error median < 1e-7, p99 < 2e-5, max < 5e-4 (m, rad);
-    qvel error median < 2e-5, p99 < 1e-2 (m/s, rad/s) -- measured: median 2-3e-8 / 2-5e-7 on every object, p99 7e-8 / 2e-6 on the curved
-    hulls and 1e-5 / 5e-3 on sugar_cube, whose flat faces meet the fingers face to face (the portal's facet is degenerate there)."""
+    pairs AND NORMALS of each state with the oracle's. No trajectory is followed, so nothing accumulates: this is the one-step error of the
+    fp32 kernel. Bounds (achieved values are printed): contact pairs identical on >= 99 % of the states and on every state whose hull contacts
+    are all more than 2 um away from the 1 mm margin. States whose hull contacts all sit on the oracle's facet (normals within 1 degree; 98-100 %
+    of the states): qpos error median < 1e-7, p99 < 2e-6, MAX < 2e-5 (m, rad); qvel error median < 2e-6, p99 < 5e-4, MAX < 1e-2 (m/s, rad/s) --
+    measured p99 5e-6 ... 2e-4, max 6e-5 ... 5e-3, the largest on sugar_cube, where pad and cube meet face to face and the contact POINT (same
+    normal) lies up to 1.4 mm apart inside the contact patch. States with a hull contact on ANOTHER facet (<= 2 % of the states, round 3 found
+    what they are: flat finger pads pressed 2-3 mm into each other or into a flat face; two facets of the Minkowski difference within 0.2 mm in
+    depth, normals 18-22 degrees apart): qvel error < 0.15 m/s."""
     z = contact; m = orc.Model(obj)
     cat = z[f"{obj}/category"]
     pick = []
@@ -191,19 +227,36 @@ def test_one_step_parity_along_contact_trajectories(engine, orc, torch, contact,
     gq, gv, _, _ = b.get_state()
     b.close()
     nq = np.array([s[0] for s in post]); nv = np.array([s[1] for s in post])
-    same = np.array([sorted((int(dbg["con"][k, c, 7]), int(dbg["con"][k, c, 8])) for c in range(dbg["ncon"][k])) == cons[k] for k in range(n)])
+    pairs = [sorted((p[0], p[1]) for p in c) for c in cons]
+    same = np.array([sorted((int(dbg["con"][k, c, 7]), int(dbg["con"][k, c, 8])) for c in range(dbg["ncon"][k])) == pairs[k] for k in range(n)])
     # distance of a state's hull contacts (either side's list) from the 1 mm margin: a pair exactly there is in one list and not the other
     gmarg = np.array([min([abs(float(dbg["con"][k, c, 6]) - 1e-3) for c in range(dbg["ncon"][k]) if dbg["con"][k, c, 7] != 0] + [1.0]) for k in range(n)])
     clear = np.minimum(np.array(margins), gmarg) > 2e-6
-    hull_states = sum(1 for c in cons if any(p[0] != 0 for p in c))
-    eq = np.abs(gq - nq).max(1)[same]; ev = np.abs(gv - nv).max(1)[same]
+    hull_states = sum(1 for c in pairs if any(p[0] != 0 for p in c))
+    # angle between this path's and the oracle's normal, worst hull contact of the state (pairs that occur once: a pair with two contacts is a floor pair)
+    ang = np.zeros(n)
+    for k in range(n):
+        for c in range(dbg["ncon"][k]):
+            g = dbg["con"][k, c]
+            mt = [p for p in cons[k] if (p[0], p[1]) == (int(g[7]), int(g[8]))]
+            if g[7] != 0 and len(mt) == 1:
+                ang[k] = max(ang[k], np.degrees(np.arccos(np.clip(np.dot(g[3:6], mt[0][2]), -1.0, 1.0))))
+    eq = np.abs(gq - nq).max(1); ev = np.abs(gv - nv).max(1)
+    facet = same & (ang < 1.0)                  # same contact pairs, every hull contact resolved on the oracle's facet (normals within a degree)
+    other = same & ~facet
     print(f"\n[one-step parity] {obj}: {n} states ({hull_states} with hull contacts), contact pairs identical on {same.mean():.4f} "
-          f"({(~same & clear).sum()} mismatches away from the margin); qpos err median {np.median(eq):.2e} p99 {np.quantile(eq, .99):.2e} max {eq.max():.2e}; "
-          f"qvel err median {np.median(ev):.2e} p99 {np.quantile(ev, .99):.2e} max {ev.max():.2e}")
+          f"({(~same & clear).sum()} mismatches away from the margin); on the oracle's facets ({facet.sum()} states): qpos err median {np.median(eq[facet]):.2e} "
+          f"p99 {np.quantile(eq[facet], .99):.2e} max {eq[facet].max():.2e}; qvel err median {np.median(ev[facet]):.2e} p99 {np.quantile(ev[facet], .99):.2e} max {ev[facet].max():.2e}; "
+          f"a hull contact on another facet (normal >= 1 deg off) in {other.sum()} states" + (f": normals up to {ang[other].max():.1f} deg apart, qvel err max {ev[other].max():.2e}" if other.any() else ""))
     assert hull_states > n // 4
     assert same.mean() >= 0.99 and not (~same & clear).any()
-    assert np.median(eq) < 1e-7 and np.quantile(eq, .99) < 2e-5 and eq.max() < 5e-4
-    assert np.median(ev) < 2e-5 and np.quantile(ev, .99) < 1e-2
+    # Where both sides resolve every hull contact on the same facet of the Minkowski difference, the step is held tightly, maximum included.
+    assert np.median(eq[facet]) < 1e-7 and np.quantile(eq[facet], .99) < 2e-6 and eq[facet].max() < 2e-5
+    assert np.median(ev[facet]) < 2e-6 and np.quantile(ev[facet], .99) < 5e-4 and ev[facet].max() < 1e-2
+    # The rest are flat-pad contacts penetrating 2-3 mm (the closed fingers against each other, a finger pad against a flat face of the object):
+    # two facets of the Minkowski difference lie within 0.2 mm of each other in depth with normals ~20 deg apart, and MPR ends on one or the other
+    # by the last bits of its support values (fp32 here, fp64 in the oracle; libccd has the same ambiguity). Rare and bounded:
+    assert other.sum() <= 0.02 * n and (not other.any() or ev[other].max() < 0.15)
 
 
 @pytest.mark.parametrize("obj", ["sand_ball", "bread_crumb"])

@@ -109,3 +109,72 @@ def row_probe(var, src, row, out):
 
 if __name__ == "__main__" and sys.argv[1] == "row":
     row_probe(*sys.argv[2:6])
+
+
+def contact_probe(obj, out_txt):
+    """one-step errors along the oracle's contact trajectories against the oracle, with the contact POINTS / normals / distances of both sides
+    for the worst states (where does a large one-step velocity error come from?)"""
+    import torch, ctypes as C
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+    from mujoco_rl_manipulate_unknown_objects_amd import engine
+    from oracle import orc
+    import test_gpu_contact as T
+    from test_oracle_contact import oracle_from_row
+    z = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "contact_states.npz"))
+    m = orc.Model(obj); cat = z[f"{obj}/category"]; L = orc.lib()
+    pick = []
+    for c, k in (("push_reward", 3), ("close_code3_break", 3), ("close_code1", 1), ("close_code2", 1), ("hull_contact_move", 2), ("pad_grasp_nonzero", 2)):
+        pick += list(np.where(cat == c)[0][:k])
+    pre, post, ocon = [], [], []
+    def grab(d):
+        return [(d.con[c].g1, d.con[c].g2, np.array(d.con[c].pos), np.array(d.con[c].frame)[:3], d.con[c].dist) for c in range(d.ncon)]
+    for i in pick:
+        e = oracle_from_row(orc, m, z, obj, i); d = e.e.d
+        act = z[f"{obj}/action"][i].astype(np.float64); target = e.target_pose(act)
+        snap = lambda: (np.array(d.qpos), np.array(d.qvel), np.array(d.ctrl), np.array(d.qacc_warmstart))
+        reached = False
+        for _ in range(400):
+            dq = target - np.array(d.qpos)[:5]; c5 = np.zeros(5)
+            L.orc_scale_control(C.byref(e.cfg), orc._dp(dq), orc._dp(c5)); d.ctrl[0:5] = list(c5)
+            pre.append(snap()); ocon.append(grab(d)); L.orc_step(m.ptr, C.byref(d)); post.append(snap())
+            if np.abs(np.array(d.qpos)[:5] - target).max() < 0.002:
+                d.ctrl[0:5] = [0.0] * 5; reached = True; break
+        if reached and act[5] < 0 and e.e.gripper_open:
+            d.ctrl[5] = d.ctrl[6] = -1.0
+            for _ in range(400):
+                delta = max(abs(-0.4 - d.qpos[5]), abs(-0.4 - d.qpos[6])); g = L.orc_check_grasp(C.byref(d))
+                pre.append(snap()); ocon.append(grab(d)); L.orc_step(m.ptr, C.byref(d)); post.append(snap())
+                if delta < 0.03 or g == 3: break
+    f32 = lambda k: np.array([s[k] for s in pre], np.float32)
+    b = engine.Batch(obj, len(pre)); b.set_state(f32(0), f32(1), f32(2), f32(3))
+    dbg = b.debug_forward(); b.substep(1); torch.cuda.synchronize()
+    gq, gv, _, _ = b.get_state(); b.close()
+    ov = np.array([s[1] for s in post]); ev = np.abs(gv - ov).max(1)
+    ang = np.zeros(len(pre)); dpos = np.zeros(len(pre)); same = np.ones(len(pre), bool)
+    for r in range(len(pre)):
+        gl = sorted((int(dbg["con"][r, c, 7]), int(dbg["con"][r, c, 8])) for c in range(int(dbg["ncon"][r])))
+        same[r] = gl == sorted((o[0], o[1]) for o in ocon[r])
+        for c in range(int(dbg["ncon"][r])):
+            g = dbg["con"][r, c]
+            mt = [o for o in ocon[r] if (o[0], o[1]) == (int(g[7]), int(g[8]))]
+            if g[7] != 0 and len(mt) == 1:
+                ang[r] = max(ang[r], np.degrees(np.arccos(np.clip(np.dot(g[3:6], mt[0][3]), -1, 1)))); dpos[r] = max(dpos[r], np.linalg.norm(g[0:3] - mt[0][2]))
+    with open(out_txt, "w") as f:
+        for lo, hi in ((0, 0.05), (0.05, 1.0), (1.0, 180.0)):
+            k = same & (ang >= lo) & (ang < hi)
+            if k.any():
+                f.write(f"  hull-contact normals within [{lo}, {hi}) deg of the oracle's: {k.sum()} states, qvel err median {np.median(ev[k]):.2e} p99 {np.quantile(ev[k], .99):.2e} max {ev[k].max():.2e}; contact point apart by max {dpos[k].max():.2e} m\n")
+        f.write(f"{obj}: {len(pre)} states; qvel err median {np.median(ev):.2e} p99 {np.quantile(ev, .99):.2e} max {ev.max():.2e}; rows > 1e-3: {(ev > 1e-3).sum()}\n")
+        for r in np.argsort(-ev)[:14]:
+            f.write(f"row {r}: dv {ev[r]:.2e} ncon gpu {dbg['ncon'][r]} oracle {len(ocon[r])} iters {dbg['con'][r, 0, 9]:.0f}\n")
+            for c in range(int(dbg["ncon"][r])):
+                g = dbg["con"][r, c]
+                if g[7] == 0: continue
+                mt = [o for o in ocon[r] if (o[0], o[1]) == (int(g[7]), int(g[8]))]
+                if not mt: f.write(f"   gpu pair {(int(g[7]), int(g[8]))} not in the oracle's list\n"); continue
+                o = mt[0]
+                f.write(f"   pair {(int(g[7]), int(g[8]))}: |dpos| {np.linalg.norm(g[0:3] - o[2]):.2e}  angle(n) {np.degrees(np.arccos(np.clip(np.dot(g[3:6], o[3]), -1, 1))):.3f} deg  dist gpu {g[6]:.3e} oracle {o[4]:.3e}  dpos {np.round(g[0:3] - o[2], 6)}\n")
+
+
+if __name__ == "__main__" and sys.argv[1] == "contacts":
+    contact_probe(sys.argv[2], sys.argv[3])
