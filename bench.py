@@ -279,16 +279,24 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         replicas_identical = bool(torch.equal(lo, hi))
     k_ms, k_n = batch.kernel_time(reset=True)
+    ar_ms, ar_n = (model.allreduce_ms() if (world > 1 and hasattr(model, "allreduce_ms")) else (None, 0))
 
     if rank == 0:
         value = total_env_steps / dt            # transitions that completed and were trained on, all ranks / max-over-ranks time
-        # async: one launch = one time slice = state + suspended macro-step context in and out (21 words each way) per env, plus what the
-        # narrow phase remembers per pair lane across slices (csrc/grip_sim.hip, MC_MEMO_WORDS): the flag / support-hint word and the
-        # separating direction (1 + 3 words) for each of the 16 lanes each way, and the portal (12 more words each way) for the ~0.5
-        # pairs in contact per env
-        macro_bytes = (MACRO_BYTES_PER_ENV if ar is None else (47 + 40 + 2 * 21) * 4 + 8 + 2 * 16 * 4 * 4 + 2 * 12 * 4 // 2) * a.envs
-        if a.state_dtype == "f16":      # 34 of the 47 words read and 27 of the 40 written (qpos, qvel, ctrl) are 2 bytes
-            macro_bytes -= (34 + 27) * 2 * a.envs
+        # ALGORITHMIC bytes of one launch, as SURVEY.md 8(d) defines them -- state only: qpos 14 + qvel 13 + ctrl 7 + warm start 13 words in,
+        # qpos 14 + qvel 13 + warm start 13 words out per env (348 B f32; qpos / qvel / ctrl are 2-byte words with --state-dtype f16), plus, for
+        # the envs whose macro step ends in this launch, the action read (24 B) and the outputs written (reward 4, done 1, goals 16, info 64).
+        # What the kernel's OWN bookkeeping moves is listed separately as overhead_bytes_per_launch and is not part of `achieved`: the
+        # suspended macro-step context of the time-sliced schedule (32 + 64-byte record each way) and what the narrow phase remembers per
+        # pair lane across slices (16 lanes x 16 B each way, + the 48-byte portal each way for the ~0.5 pairs in contact per env).
+        state_bytes = (47 + 40) * 4 - ((34 + 27) * 2 if a.state_dtype == "f16" else 0)
+        if ar is None:
+            fin_per_launch = float(a.envs); overhead_bytes = 0
+        else:
+            n_ticks = max(1, ar.total_ticks - ticks0)
+            fin_per_launch = total_env_steps / max(world, 1) / n_ticks
+            overhead_bytes = (2 * (32 + 64) + 2 * 16 * 16 + 2 * 48 // 2) * a.envs
+        macro_bytes = state_bytes * a.envs + int(fin_per_launch * (24 + 85))
         sched = ("lock-step vector env" if ar is None else
                  f"asynchronous time slices (<= {ar.S} physics steps and <= {ar.eng.budget_us} us per wavefront and tick"
                  + (f" at the end of the run: slice / budget follow the measured macro-step length, {ar.ladder}" if ar.ladder else "")
@@ -307,17 +315,23 @@ def main():
                                    f"PPO update every {a.rollout} steps ({a.epochs} epochs, minibatch {a.minibatch})",
                        "envs_per_gpu": a.envs, "parallelism": f"dp{world}", "ppo_in_timed_region": not a.no_ppo, "schedule": sched,
                        "step": f"{a.envs} completed env transitions per GPU"},
-            "mj_substeps_per_s": total_sub / dt, "mean_substeps_per_env_step": total_sub / max(total_env_steps, 1.0),
-            "replicas_identical": replicas_identical, "env_steps_counted": total_env_steps, "env_steps_nominal": a.envs * world * a.steps, "short_rollouts": short_rollouts,
+            # the workload-independent companion of `value`: physics.step() calls per second (env-steps/s depends on how many calls the action
+            # source makes a macro step cost: ~232 for the synthetic U(-1,1) stream, ~312 for actions sampled from the learning policy)
+            "action_source": a.actions, "mj_substeps_per_s": total_sub / dt, "mean_substeps_per_env_step": total_sub / max(total_env_steps, 1.0),
+            "replicas_identical": replicas_identical,
+            # N > 1: device time of the one collective per optimiser step (the flat 4 MB fp32 gradient bucket over RCCL), rank 0's view
+            "allreduce_ms_per_optimizer_step": ar_ms, "allreduce_steps_timed": ar_n, "env_steps_counted": total_env_steps, "env_steps_nominal": a.envs * world * a.steps, "short_rollouts": short_rollouts,
             "roofline": {"bound": "hbm", "kernel": "k_macro_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms_avg": k_ms, "launches": k_n,
-                         "algorithmic_bytes_per_launch": macro_bytes,
-                         "note": "the macro-step kernel is VALU-issue-bound, not HBM-bound (DESIGN.md §4)"},
+                         "algorithmic_bytes_per_launch": macro_bytes, "overhead_bytes_per_launch": overhead_bytes,
+                         "bytes_definition": "SURVEY.md 8(d): physics state in + out (348 B f32 per env and launch) + action / outputs of the macro steps that end in the launch; "
+                                             "overhead = suspended macro-step context + narrow-phase pair memory of the time-sliced schedule (not counted in achieved)",
+                         "note": "the macro-step kernel is latency / VALU-issue-bound, not HBM-bound (DESIGN.md §4)"},
         }
         if ar is not None:
             out["ticks"] = ar.total_ticks - ticks0
             # HBM traffic and instruction counts cannot be read from inside the process: they come from the committed rocprofv3 --pmc
-            # passes of THIS command at THIS configuration (profiles/r02_pmc_summary.json: separate passes, gfx950 FETCH_SIZE
+            # passes of THIS command at THIS configuration (profiles/r03_pmc_summary.json: separate passes, gfx950 FETCH_SIZE
             # correction) and are attached only when the run is that configuration; otherwise traffic stays null.
             try:
                 pmj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
@@ -326,7 +340,7 @@ def main():
                 if same_cfg and not a.lockstep:
                     rf = out["roofline"]
                     rf["traffic"] = pm["hbm_bytes_per_launch_fetch_doubled"]
-                    rf["traffic_source"] = ("profiles/r02_pmc_summary.json, same command and configuration: (2 x FETCH_SIZE + WRITE_SIZE) per launch; raw "
+                    rf["traffic_source"] = ("profiles/r03_pmc_summary.json, same command and configuration: (2 x FETCH_SIZE + WRITE_SIZE) per launch; raw "
                                             f"{pm['hbm_bytes_per_launch_raw']:.0f} B")
                     # the bound that really binds this kernel: VALU issue. lane-operations per physics.step() of one env from the PMC
                     # pass (SQ_INSTS_VALU x 64 lanes / env-substeps of the launch) x the LIVE physics.step() rate of this run
@@ -334,10 +348,9 @@ def main():
                     # lanes, same command and configuration) / the LIVE launch duration of this run -- formed like the HBM figure above
                     lane_ops = pm["SQ_INSTS_VALU"] * 64.0 / (k_ms * 1e-3) if k_ms > 0 else 0.0
                     rf["valu"] = {"achieved": lane_ops, "peak": VALU_PEAK_LANE_OPS, "unit": "fp32 lane-ops/s", "frac": lane_ops / VALU_PEAK_LANE_OPS,
-                                  "lane_ops_per_launch": pm["SQ_INSTS_VALU"] * 64.0, "lane_ops_per_env_substep": pm["valu_lane_ops_per_env_substep"],
+                                  "lane_ops_per_launch": pm["SQ_INSTS_VALU"] * 64.0, "lane_ops_per_env_substep": pm.get("valu_lane_ops_per_env_substep"),
                                   "valu_active_frac": pm["active_inst_valu_frac"], "wait_frac": pm["wait_any_frac"],
-                                  "source": "profiles/r02_pmc_summary.json (SQ_INSTS_VALU per launch of the same command) / live launch duration; one wave per SIMD "
-                                            "issues a VALU instruction in 4 cycles at best, i.e. 50 % of this peak"}
+                                  "source": "profiles/r03_pmc_summary.json (SQ_INSTS_VALU per launch of the same command) / live launch duration"}
             except Exception:
                 pass
         if not a.no_cpu_baseline and world == 1:

@@ -13,6 +13,7 @@
 // (two ds_read_b32, 4-byte aligned because the stride is 4) and converts the four bytes of its k-half with
 // v_cvt_f32_ubyte; lanes 0-31 / 32-63 read consecutive 128-byte rows of B: conflict-free.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <cstdio>
 
@@ -390,11 +391,16 @@ extern "C" int grip_conv23(const float *y1_nhwc_dev, int n, const float *b2_mat_
                            float *out_nhwc_dev, void *stream) {
     if (!y1_nhwc_dev || !b2_mat_dev || !bias2_dev || !b3_mat_dev || !bias3_dev || !out_nhwc_dev || n <= 0)
         return grip_fail("grip_conv23: need y1 [n, 15, 15, 32], the two weight matrices of grip_conv23_prep, both biases and the output [n, 4, 4, 64]");
-    static bool attr_set = false;
     const size_t lds = (size_t)C2_LDS_FLOATS * sizeof(float);
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)k_conv23, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return grip_fail("grip_conv23: cannot reserve LDS");
-        attr_set = true;
+    {   // the dynamic-LDS opt-in is a per-DEVICE function attribute: remember it per device (a process may drive several GPUs, from several threads)
+        static std::atomic<unsigned long long> attr_set_mask{0ULL};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return grip_fail("grip_conv23: no current device");
+        const unsigned long long bit = 1ULL << (dev & 63);
+        if (!(attr_set_mask.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute((const void *)k_conv23, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return grip_fail("grip_conv23: cannot reserve LDS");
+            attr_set_mask.fetch_or(bit, std::memory_order_release);
+        }
     }
     hipLaunchKernelGGL(k_conv23, dim3((n + C2_G - 1) / C2_G), dim3(256), lds, (hipStream_t)stream, y1_nhwc_dev, n, b2_mat_dev, bias2_dev, b3_mat_dev, bias3_dev, out_nhwc_dev);
     hipError_t e = hipGetLastError();

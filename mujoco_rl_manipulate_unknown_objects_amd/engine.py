@@ -538,6 +538,19 @@ class MixedBatch:
             p.set_state_storage(dtype)
         _chk(lib().grip_batchset_refresh(self.ptr))
 
+    def part_of(self, env_index):
+        """(part, index inside it) of global env `env_index` (envs are sorted by group)."""
+        e = int(env_index)
+        if not 0 <= e < self.n:
+            raise GripError(f"env index {e} out of range [0, {self.n})")
+        g = max(i for i, o in enumerate(self.offsets[:-1]) if o <= e)
+        return self.parts[g], e - self.offsets[g]
+
+    def render_camera(self, env_index=0, *args, **kw):
+        """RobotEnv.render's camera view of one env of the set: forwarded to the env's own batch (Batch.render_camera)."""
+        part, local = self.part_of(env_index)
+        return part.render_camera(local, *args, **kw)
+
     def reset(self, mask=None):
         if mask is not None:
             mask = mask.to(device=self.device, dtype=self.torch.uint8).contiguous()

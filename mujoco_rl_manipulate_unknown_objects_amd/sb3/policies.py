@@ -138,9 +138,18 @@ class ActorCriticPolicy(nn.Module):
         c["Wh"][:A, :hd].copy_(self.action_net.weight); c["Wh"][A, hd:].copy_(self.value_net.weight[0])
         c["bh"][:A].copy_(self.action_net.bias); c["bh"][A:].copy_(self.value_net.bias)
         self.features_extractor.refresh_rollout_cache()
+        c["stamp"] = self._param_stamp()
+
+    def _param_stamp(self):
+        """changes whenever a parameter is written in place (optimizer step, load_state_dict, copy_) or replaced"""
+        return tuple((id(p), p._version) for p in self.parameters())
 
     def _forward_parts_merged(self, obs):
         c = self._rollout_cache
+        # stale copies are refreshed here too (train() followed by an evaluation, load_state_dict, a foreign optimizer step ...), except
+        # inside a stream capture, where PPO has refreshed them before capturing and the graph must keep reading the same addresses
+        if c.get("stamp") != self._param_stamp() and not (obs.is_cuda and th.cuda.is_current_stream_capturing()):
+            self.refresh_rollout_cache()
         h = self.features_extractor.rollout_features(self._prep(obs))
         if h is None:                                               # not the observation layout the extractor's fast path handles
             lp, lv = self._latents(obs)

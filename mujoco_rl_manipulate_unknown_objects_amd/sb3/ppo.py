@@ -125,10 +125,10 @@ class PPO:
         # needs the optimiser's step counter on the device
         self.graph_update = self.device.type == "cuda"
         self.fused_loss = self.device.type == "cuda"        # the minibatch loss and its gradients as one launch (_FusedPPOLoss)
-        if self.device.type == "cuda" and miopen_find:
-            # MIOpen's find mode: the first (eager) minibatches time the library's convolution kernels per shape and keep the fastest
-            # (the heuristic choice for the 4 x 4 stride-2 data gradient runs at a third of the rate): update 37.9 -> 35.1 ms per 16 minibatches
-            th.backends.cudnn.benchmark = True
+        # MIOpen's find mode: the first (eager) minibatches time the library's convolution kernels per shape and keep the fastest
+        # (the heuristic choice for the 4 x 4 stride-2 data gradient runs at a third of the rate): update 37.9 -> 35.1 ms per 16 minibatches.
+        # The process-global switch is on only around those minibatches and the capture (_find_mode), not for the life of the process.
+        self.miopen_find = bool(self.device.type == "cuda" and miopen_find)
         # on a GPU: the fused multi-tensor Adam (one kernel per step; the foreach form spends ~45 small launches per step on
         # dividing every parameter-shaped tensor by 0-dim bias corrections), capturable so that it can sit in the update graph
         self.optimizer = th.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5, capturable=self.graph_update,
@@ -247,6 +247,15 @@ class PPO:
         else:
             self.optimizer.zero_grad(set_to_none=False)
 
+    def allreduce_ms(self):
+        """mean device time of the gradient all-reduce over the last (up to 64) optimiser steps, and how many were timed; (None, 0) when none"""
+        ev = getattr(self, "_ar_events", None)
+        if not ev or ev["n"] == 0:
+            return None, 0
+        k = min(ev["n"], 64)
+        th.cuda.synchronize(self.device)
+        return sum(a.elapsed_time(b) for a, b in ev["ring"][:k]) / k, ev["n"]
+
     def _allreduce_grads(self):
         """Sum the ranks' minibatch gradients (about 4 MB of fp32: one collective per optimiser step, latency-bound on xGMI) and
         average. The clip + Adam step needs the reduced gradient and the next minibatch's forward needs the stepped parameters, so
@@ -261,7 +270,16 @@ class PPO:
             for p, g in zip(self.policy.parameters(), old):
                 if g is not None:
                     p.grad.copy_(g)
+        timed = self._flat_grad.is_cuda and not th.cuda.is_current_stream_capturing()
+        if timed:                                   # device time of the collective, read back in allreduce_ms() (no sync here)
+            ev = getattr(self, "_ar_events", None)
+            if ev is None:
+                ev = self._ar_events = {"ring": [(th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)) for _ in range(64)], "n": 0}
+            e0, e1 = ev["ring"][ev["n"] % 64]
+            e0.record()
         dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
+        if timed:
+            e1.record(); ev["n"] += 1
         self._flat_grad.mul_(1.0 / dist.get_world_size())
 
     def _loss_backward(self, src, idx):
@@ -294,6 +312,12 @@ class PPO:
 
     def _minibatch_update(self, src, idx):
         """One optimiser step. Eager on CPU; on a GPU two captured graphs with the (eager) gradient all-reduce between them."""
+        if self.graph_update and (self._upd is None or self._upd.get("fwd") is None) and self.miopen_find:
+            with th.backends.cudnn.flags(enabled=th.backends.cudnn.enabled, benchmark=True):     # find mode for the eager steps and the capture only
+                return self._minibatch_update_impl(src, idx)
+        return self._minibatch_update_impl(src, idx)
+
+    def _minibatch_update_impl(self, src, idx):
         if not self.graph_update:
             self._zero_grads()
             out = self._loss_backward(src, idx)
@@ -343,7 +367,7 @@ class PPO:
                 warnings.warn(f"hipGraph capture of the PPO update failed ({ex}); continuing eagerly")
                 th.cuda.synchronize(self.device)
                 self.graph_update = False; self._upd = None
-                return self._minibatch_update(src, idx)
+                return self._minibatch_update_impl(src, idx)
         u["fwd"].replay()
         if self.distributed:
             self._allreduce_grads()
@@ -413,16 +437,17 @@ class PPO:
             # every rank must leave this loop after the same iteration: train() holds one all-reduce per minibatch, and a rank that
             # went on alone would wait in it for ever. The time-sliced rollout counts polled completions, which overshoot the target
             # by a rank-dependent amount, and a callback may stop one rank only: agree on both flags (MAX) once per iteration.
-            stop = th.tensor([0.0 if ok else 1.0, 1.0 if self.num_timesteps >= total_timesteps else 0.0], device=self.device)
-            if self.distributed:
+            stop_now, last = (not ok), self.num_timesteps >= total_timesteps
+            if self.distributed:                            # (single process: plain Python flags, no device tensor and no host sync)
+                stop = th.tensor([1.0 if stop_now else 0.0, 1.0 if last else 0.0], device=self.device)
                 dist.all_reduce(stop, op=dist.ReduceOp.MAX)
-            stop_now, last = bool(stop[0] > 0), bool(stop[1] > 0)
+                stop_now, last = bool(stop[0] > 0), bool(stop[1] > 0)
             if stop_now:
                 break
             self.train()
             it += 1
-            if last:
-                self.num_timesteps = max(self.num_timesteps, total_timesteps)
+            if last:                                        # another rank reached the target: leave with it; num_timesteps keeps what THIS rank collected
+                break
             if self.verbose and it % log_interval == 0:
                 fps = self.num_timesteps / max(1e-9, time.time() - t0)
                 print(f"[ppo] iter {it} timesteps {self.num_timesteps} fps {fps:.0f} loss {float(self.logger.get('loss', 0)):.4f}")

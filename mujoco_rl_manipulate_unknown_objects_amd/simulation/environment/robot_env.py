@@ -120,9 +120,14 @@ class BatchedRobotEnv:
         A `targetbodycom` camera keeps its body position, looks at the object's centre of mass (camera -z) and keeps world z up
         (MuJoCo's camera tracking [3P-recall]: z = unit(cam - target), x = unit(z_world x z), y = z x x)."""
         from ...model import blob
-        if not hasattr(self, "_mdl"):
-            b = self.batch.parts[0] if hasattr(self.batch, "parts") else self.batch
-            self._mdl = blob.read_blob(b.model.path)
+        # the env's OWN model: a mixed batch holds one per (object, direction) group, with its own object inertial frame and static cameras
+        part = self.batch.part_of(env_index)[0] if hasattr(self.batch, "part_of") else self.batch
+        if not hasattr(self, "_mdls"):
+            self._mdls = {}
+        mdl = self._mdls.get(part.model.path)
+        if mdl is None:
+            mdl = self._mdls[part.model.path] = blob.read_blob(part.model.path)
+        self._mdl = mdl
         if camera_id == 2:
             return None, None, float(self._mdl["cam_fovy"][0])
         q = self.batch.get_state()[0][env_index].astype(np.float64)

@@ -341,7 +341,7 @@ def test_fused_first_layer_gradients_match_the_library_path(torch):
 def test_merged_heads_rollout_forward_matches_the_module_forward(torch):
     """ActorCriticPolicy.forward_parts with the rollout cache (policy | value MLPs as merged GEMMs, NHWC flatten as a view) against the
     module-by-module forward on the same weights: fp32 both ways, sums re-associated -- 2e-5 on means and values of order 0.1..1. The
-    cache follows the parameters only through refresh_rollout_cache(): checked by changing them."""
+    cache follows the parameters: through refresh_rollout_cache() and, outside a stream capture, by itself (version stamps) -- checked by changing them."""
     from mujoco_rl_manipulate_unknown_objects_amd.sb3.policies import ActorCriticPolicy
     from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
     from mujoco_rl_manipulate_unknown_objects_amd.simulation.controller.sensor import RGBDSensor
@@ -374,10 +374,13 @@ def test_merged_heads_rollout_forward_matches_the_module_forward(torch):
     with torch.no_grad():
         before = pol.forward_parts(obs)[0].clone()
         pol.action_net.bias.add_(1.0)
-        stale = pol.forward_parts(obs)[0].clone()
+        auto = pol.forward_parts(obs)[0].clone()            # an in-place parameter change is noticed (version stamps): no stale weights
         pol.refresh_rollout_cache()
         fresh = pol.forward_parts(obs)[0]
-    assert (stale - before).abs().max() < 1e-6 and (fresh - before - 1.0).abs().max() < 1e-5
+        sd = {k: v.clone() for k, v in pol.state_dict().items()}; sd["action_net.bias"] = sd["action_net.bias"] - 1.0
+        pol.load_state_dict(sd)
+        loaded = pol.forward_parts(obs)[0]
+    assert (auto - before - 1.0).abs().max() < 1e-5 and (fresh - before - 1.0).abs().max() < 1e-5 and (loaded - before).abs().max() < 1e-5
     # value-only extractor or unequal MLP shapes: no merged path
     pol2 = ActorCriticPolicy(RGBDSensor(config=cfg).setup_observation_space(), Actuator(config=cfg).setup_action_space(),
                              features_extractor_class=AugmentedNatureCNN, net_arch=dict(pi=[64], vf=[64, 64])).cuda()

@@ -271,3 +271,31 @@ def test_random_episodes_resemble_the_reference_training_logs(engine, torch):
     assert 0.5 * ref_ret.mean() < rt.mean() < 2.0 * ref_ret.mean(), (rt.mean(), ref_ret.mean())
     assert rt.min() >= 0.0 and rt.max() < 60.0                   # progress reward is never negative (reward.py:18-41)
     mb.close()
+
+
+def test_mixed_env_renders_every_group_with_its_own_model(torch):
+    """RobotEnv.render on a mixed batch (robot_env.py:302-340): the global env index is mapped to its (object, direction) group's batch and
+    the camera pose is built from THAT group's model (object inertial frame, static cameras). The gripper camera's view at zoom 1 equals the
+    env's own observation RGB; the tracking cameras look at the env's own object; an env of another object renders a different image."""
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import MixedBatchedRobotEnv, BatchedRobotEnv, default_config
+    cfg = default_config(camera_id=2, rendering_zoom_width=1, rendering_zoom_height=1)
+    env = MixedBatchedRobotEnv(cfg, envs_per_group=4)
+    obs = env.reset()["observation"].cpu().numpy()
+    frames = {}
+    for e in (0, 9, 17, 30):                                   # acorn dir 0, sand_ball dir 0 (group 2), sugar_cube dir 0, bread_crumb dir 45
+        img = env.render("rgb_array", env_index=e)
+        assert img.shape == (64, 64, 3) and img.dtype == np.uint8
+        same = (np.abs(img.astype(int) - obs[e, :3].transpose(1, 2, 0).astype(int)) <= 1).mean()
+        assert same > 0.99, (e, same)
+        frames[e] = img
+    env.config.camera_id = 0                                   # workbench camera: tracks the env's own object
+    wb = {e: env.render("rgb_array", env_index=e) for e in (0, 9, 17, 30)}
+    assert all(w.shape == (64, 64, 3) for w in wb.values())
+    assert any((wb[0] != wb[e]).any() for e in (9, 17, 30))    # different objects, different pictures
+    # against the single-object env of the same group: identical pixels
+    solo = BatchedRobotEnv(default_config(sim_env="/xmls/sugar_cube_env.xml", camera_id=0, rendering_zoom_width=1, rendering_zoom_height=1), n_envs=1)
+    solo.reset()
+    assert np.array_equal(solo.render("rgb_array", env_index=0), wb[17])
+    depth = env.render("depth_array", env_index=30)
+    assert depth.shape == (64, 64) and np.isfinite(depth.astype(np.float64)).all()
+    solo.close(); env.close()

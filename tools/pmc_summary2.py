@@ -28,6 +28,21 @@ def main(src, out_path, prev_path=None):
                      "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) "
                      "streaming reads and is uncalibrated for other widths -- these kernels read 4 B per lane, so both the raw and the doubled figure are given"],
            "kernels": k}
+    probe_csv, probe_json = os.path.join(src, "probe_SQ.csv"), os.path.join(src, "probe.json")
+    if os.path.exists(probe_csv) and os.path.exists(probe_json):          # tools/pmc_probe.sh: the physics-only probe of THIS kernel, measured, not carried over
+        c = {r["counter"]: (float(r["sum"]), int(r["dispatches"])) for r in csv.DictReader(open(probe_csv))}
+        pj = json.loads(open(probe_json).read().strip().splitlines()[-1])
+        subs = float(pj["all_substeps_of_finished_macro_steps"]); n = c["SQ_INSTS_VALU"][1]
+        k["k_macro_step"]["physics_only_probe"] = {
+            "command": "python3 tools/physics_rate.py - acorn 144 3000 1500 2048 under rocprofv3 --pmc (SQ pass; tools/pmc_probe.sh)", "launches": n, "env_substeps": subs,
+            "substeps_per_s_under_the_profiler": pj["substeps_per_s"],
+            "valu_wave_instructions_per_env_substep": c["SQ_INSTS_VALU"][0] / subs, "wave_cycles_per_env_substep": 4 * c["SQ_WAVE_CYCLES"][0] / subs,
+            "active_inst_valu_frac": c["SQ_ACTIVE_INST_VALU"][0] / c["SQ_WAVE_CYCLES"][0], "wait_any_frac": c["SQ_WAIT_ANY"][0] / c["SQ_WAVE_CYCLES"][0],
+            "salu_per_valu": c["SQ_INSTS_SALU"][0] / c["SQ_INSTS_VALU"][0], "lds_per_valu": c["SQ_INSTS_LDS"][0] / c["SQ_INSTS_VALU"][0]}
+        k["k_macro_step"]["valu_lane_ops_per_env_substep"] = 64.0 * c["SQ_INSTS_VALU"][0] / subs
+        out["notes"].append("k_macro_step.physics_only_probe: measured on this kernel (tools/pmc_probe.sh); env_substeps = physics.step() calls of the macro steps that finished "
+                            "during the run (all ticks, pre-roll included, as the counters are)")
+        prev_path = None
     if prev_path:
         prev = json.load(open(prev_path))["kernels"]["k_macro_step"]
         for key in ("physics_only_probe", "valu_lane_ops_per_env_substep"):
