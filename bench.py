@@ -50,6 +50,41 @@ MACRO_BYTES_PER_ENV = 47 * 4 + 24 + 40 * 4 + 4 + 1 + 16 + 64
 OBS_BYTES_PER_ENV = 5 * 64 * 64 + 14 * 4 + 8
 
 
+def cpu_policy_leg(threads, seconds=4.0):
+    """AugmentedNatureCNN + PPO heads on the host cores (torch CPU, fp32): forward samples/s (no grad) and forward + backward samples/s,
+    a bounded sample (about `seconds` each) at batch 512 -- the rate is flat in the batch size well below BASELINE.md's 4096."""
+    try:
+        from mujoco_rl_manipulate_unknown_objects_amd.sb3.policies import ActorCriticPolicy
+        from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
+        from mujoco_rl_manipulate_unknown_objects_amd.simulation.controller.sensor import RGBDSensor
+        from mujoco_rl_manipulate_unknown_objects_amd.simulation.controller.actuator import Actuator
+        from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import default_config
+        cfg = default_config()
+        prev = torch.get_num_threads(); torch.set_num_threads(max(1, int(threads)))
+        pol = ActorCriticPolicy(RGBDSensor(config=cfg).setup_observation_space(), Actuator(config=cfg).setup_action_space(),
+                                features_extractor_class=AugmentedNatureCNN, net_arch=[256, 256])
+        B = 512
+        obs = {"observation": torch.randint(0, 256, (B, 5, 64, 64), dtype=torch.uint8)}
+        act = torch.zeros(B, 6)
+        with torch.no_grad():
+            pol(obs)
+        t0 = time.time(); k = 0
+        with torch.no_grad():
+            while time.time() - t0 < seconds:
+                pol(obs); k += 1
+        fwd = B * k / (time.time() - t0)
+        t0 = time.time(); k2 = 0
+        while time.time() - t0 < seconds:
+            v, lp, ent = pol.evaluate_actions(obs, act)
+            (lp.mean() + v.mean()).backward(); pol.zero_grad(set_to_none=True); k2 += 1
+        fb = B * k2 / (time.time() - t0)
+        torch.set_num_threads(prev)
+        return {"fwd_samples_per_s": fwd, "fwd_bwd_samples_per_s": fb, "threads": int(threads), "batch": B, "dtype": "f32",
+                "sample": f"{k} forward and {k2} forward + backward passes of batch {B}"}
+    except Exception as ex:          # noqa: BLE001 -- a reported baseline, never a reason to fail the bench
+        return {"error": str(ex)}
+
+
 def cpu_baseline(obj, seconds_target=15.0):
     """The C oracle (oracle/, `port`: the reference's own dm_control + SB3 stack is not installable here) timed
     on this box's host cores over a bounded sample of the same workload (macro step + observation, no policy)."""
@@ -73,8 +108,16 @@ def cpu_baseline(obj, seconds_target=15.0):
         if o.done:
             e.reset()
     dt1 = time.time() - t1
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{n} envs x {steps} macro steps incl. observation render, no policy; {sub / dt:.0f} mj-substeps/s",
+    pol = cpu_policy_leg(threads)
+    sim_rate = n * steps / dt
+    return {"value": sim_rate, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            # BASELINE.md section 2, "CPU policy": the actor-critic over AugmentedNatureCNN on the same host cores, and what the SAME work as the
+            # GPU line (macro step + observation + one policy forward per step + 2 epochs of forward / backward per sample) then runs at
+            "policy": pol,
+            "with_policy": (None if not pol.get("fwd_samples_per_s") else
+                            {"value": 1.0 / (1.0 / sim_rate + 1.0 / pol["fwd_samples_per_s"] + 2.0 / pol["fwd_bwd_samples_per_s"]), "unit": "env-steps/s",
+                             "what": "serial sum on the same cores: simulation + observation, one policy forward, 2 epochs of forward + backward per env step"}),
+            "sample": f"{n} envs x {steps} macro steps incl. observation render (value: no policy; with_policy: + the policy legs); {sub / dt:.0f} mj-substeps/s",
             "single_env_single_thread": {"value": k1 / dt1, "unit": "env-steps/s", "sample": f"1 env x {k1} macro steps incl. observation render"},
             "note": "reference dm_control+SB3 stack cannot be installed here; its recorded whole-training rate is 3.95-12.97 env-steps/s (BASELINE.md)"}
 

@@ -209,6 +209,81 @@ class FlatReplayBuffer:
         return dict(obs={"observation": self.obs[i]}, next_obs={"observation": self.next_obs[i]}, actions=self.actions[i], rewards=self.rewards[i], dones=self.dones[i])
 
 
+class FlatHerReplayBuffer(FlatReplayBuffer):
+    """Hindsight relabelling ('future', n_sampled_goal: train_agent.py:63-69) for the time-sliced collector. Transitions of an env arrive in
+    episode order but at arbitrary ring positions, so a row cannot find its episode's later rows by address. Every running episode owns a
+    slot of a trajectory store -- the goal achieved after each of its steps, [slot, step, 2] -- and a row remembers (slot, step, generation
+    of the slot). An episode that ends publishes its length; its slot is recycled after `n_slots` newer episodes, which the generation tells
+    a sampled row (it is then no longer relabelled, like a row of an episode still open -- SB3's online sampling draws from complete
+    episodes). Everything is batched tensor work on the ready-list rows of a tick: no host sync, no per-episode loop.
+    The relabelled reward swaps the goal-dependent term e^-|dg - ag| (robot_env.py:268-271) exactly as HerReplayBuffer does."""
+
+    def __init__(self, buffer_size, observation_space, action_space, device, n_envs=1, n_sampled_goal=4, goal_selection_strategy="future",
+                 online_sampling=True, max_episode_length=400, n_slots=None, **_):
+        super().__init__(buffer_size, observation_space, action_space, device)
+        if str(goal_selection_strategy).lower().split(".")[-1] != "future":
+            raise NotImplementedError("only goal_selection_strategy='future' (the reference's choice) is built")
+        self.her_ratio = 1.0 - 1.0 / (n_sampled_goal + 1)
+        self.L = int(max_episode_length or 400)
+        self.n_envs = int(n_envs)
+        # enough slots that a row usually outlives its slot's recycling only when the ring has overwritten it anyway
+        self.n_slots = int(n_slots) if n_slots else max(2 * self.n_envs, min(4 * self.n_envs + self.cap // 16, 1 << 16))
+        z = lambda *sh, dt=th.float32: th.zeros((self.cap + 1,) + sh, dtype=dt, device=device)
+        self.achieved, self.desired, self.next_achieved, self.next_desired = z(2), z(2), z(2), z(2)
+        self.row_slot, self.row_step, self.row_gen = z(dt=th.int64), z(dt=th.int64), z(dt=th.int64)
+        self.traj_goal = th.zeros(self.n_slots + 1, self.L, 2, device=device)           # slot n_slots: dump
+        self.traj_len = th.zeros(self.n_slots + 1, dtype=th.int64, device=device)         # 0 = episode still open
+        self.slot_gen = th.zeros(self.n_slots + 1, dtype=th.int64, device=device)
+        self.cur_slot = th.arange(self.n_envs + 1, dtype=th.int64, device=device) % self.n_slots   # env n_envs: dump
+        self.cur_step = th.zeros(self.n_envs + 1, dtype=th.int64, device=device)
+        self.alloc = th.full((1,), self.n_envs % self.n_slots, dtype=th.int64, device=device)      # next slot to hand out
+
+    def add_rows(self, mask, obs, next_obs, action, reward, done, env=None, goals=None):
+        """env: env id of every ready-list row (n_envs for masked-out rows); goals = (achieved, desired, next_achieved, next_desired), [rows, 2] each."""
+        m = mask.long()
+        pos = (self.ptr + th.cumsum(m, 0) - 1) % self.cap
+        pos = th.where(mask, pos, th.full_like(pos, self.cap))
+        super().add_rows(mask, obs, next_obs, action, reward, done)
+        e = th.where(mask, env, th.full_like(env, self.n_envs))
+        ag, dg, nag, ndg = goals
+        self.achieved.index_copy_(0, pos, ag); self.desired.index_copy_(0, pos, dg); self.next_achieved.index_copy_(0, pos, nag); self.next_desired.index_copy_(0, pos, ndg)
+        slot, step = self.cur_slot[e], self.cur_step[e].clamp(max=self.L - 1)
+        slot = th.where(mask, slot, th.full_like(slot, self.n_slots))
+        self.row_slot.index_copy_(0, pos, slot); self.row_step.index_copy_(0, pos, step); self.row_gen.index_copy_(0, pos, self.slot_gen[slot])
+        self.traj_goal[slot, step] = nag                      # the goal achieved AFTER this step: what 'future' hands to earlier steps
+        fin = mask & (done > 0)
+        self.cur_step.index_copy_(0, e, th.where(fin, th.zeros_like(step), step + 1)); self.cur_step[self.n_envs] = 0
+        # finished episodes publish their length and their envs move on to fresh slots (recycled oldest first: generation + 1)
+        self.traj_len.index_copy_(0, th.where(fin, slot, th.full_like(slot, self.n_slots)), step + 1); self.traj_len[self.n_slots] = 0
+        f = fin.long()
+        new = (self.alloc + th.cumsum(f, 0) - 1) % self.n_slots
+        new = th.where(fin, new, th.full_like(new, self.n_slots))
+        self.slot_gen.index_add_(0, new, f); self.traj_len.index_fill_(0, new, 0); self.slot_gen[self.n_slots] = 0
+        self.cur_slot.index_copy_(0, th.where(fin, e, th.full_like(e, self.n_envs)), new); self.cur_slot[self.n_envs] = self.n_slots
+        self.alloc += f.sum()
+
+    @staticmethod
+    def her_term(desired, achieved):
+        return th.exp(-th.linalg.norm(desired - achieved, dim=-1))
+
+    def sample(self, batch_size, generator=None):
+        hi = max(1, self.size())
+        i = th.randint(0, hi, (batch_size,), device=self.device, generator=generator)
+        slot, step = self.row_slot[i], self.row_step[i]
+        L = self.traj_len[slot]
+        alive = (self.slot_gen[slot] == self.row_gen[i]) & (L > step)            # the row's episode is complete and its slot not yet recycled
+        relabel = (th.rand(batch_size, device=self.device, generator=generator) < self.her_ratio) & alive
+        span = (L - 1 - step).clamp(min=0)                                        # 'future': this step ... the episode's last
+        k = step + th.minimum((th.rand(batch_size, device=self.device, generator=generator) * (span + 1).float()).long(), span)
+        new_goal = self.traj_goal[slot, k.clamp(max=self.L - 1)]
+        old = self.her_term(self.next_desired[i], self.next_achieved[i]); new = self.her_term(new_goal, self.next_achieved[i])
+        rewards = th.where(relabel, self.rewards[i] - old + new, self.rewards[i])
+        desired = th.where(relabel[:, None], new_goal, self.desired[i])
+        return dict(obs={"observation": self.obs[i], "achieved_goal": self.achieved[i], "desired_goal": desired},
+                    next_obs={"observation": self.next_obs[i], "achieved_goal": self.next_achieved[i], "desired_goal": desired},
+                    actions=self.actions[i], rewards=rewards, dones=self.dones[i], relabelled=relabel)
+
+
 class HerReplayBuffer(ReplayBuffer):
     """Hindsight relabelling with SB3's HerReplayBuffer arguments (train_agent.py:63-69): for n_sampled_goal out of
     n_sampled_goal + 1 sampled transitions the desired goal is replaced by a goal achieved later in the same episode
@@ -294,9 +369,15 @@ class SAC:
         self.log_ent_coef = th.log(th.ones(1, device=self.device) * (init if self.auto_ent else float(ent_coef))).requires_grad_(self.auto_ent)
         self.ent_opt = th.optim.Adam([self.log_ent_coef], lr=learning_rate) if self.auto_ent else None
         if self.async_slice > 0:
-            if replay_buffer_class is not None and replay_buffer_class is not FlatReplayBuffer:
-                raise NotImplementedError("the time-sliced collector stores transitions in a FlatReplayBuffer (hindsight relabelling needs episode order: use lock-step collection)")
-            self.replay_buffer = FlatReplayBuffer(buffer_size, env.observation_space, env.action_space, self.device)
+            # the time-sliced collector scatters varying batches into a flat ring; hindsight relabelling (the reference's HerReplayBuffer call,
+            # train_agent.py:57-79) gets the ring with per-episode goal trajectories
+            if replay_buffer_class is None or replay_buffer_class is FlatReplayBuffer:
+                self.replay_buffer = FlatReplayBuffer(buffer_size, env.observation_space, env.action_space, self.device)
+            elif replay_buffer_class in (HerReplayBuffer, FlatHerReplayBuffer):
+                self.replay_buffer = FlatHerReplayBuffer(buffer_size, env.observation_space, env.action_space, self.device, n_envs=self.n_envs,
+                                                         **(replay_buffer_kwargs or {}))
+            else:
+                raise NotImplementedError("the time-sliced collector stores transitions in a FlatReplayBuffer or, for hindsight relabelling, a FlatHerReplayBuffer")
         else:
             rb = replay_buffer_class or ReplayBuffer
             self.replay_buffer = rb(buffer_size, env.observation_space, env.action_space, self.device, n_envs=self.n_envs, **(replay_buffer_kwargs or {}))
@@ -382,16 +463,42 @@ class SAC:
         slot_act = th.zeros(Ccap, A, device=dev); stage = th.zeros((Ccap,) + tuple(eng.obs_shape), dtype=th.uint8, device=dev)
         prev_obs = th.zeros((N + 1,) + tuple(eng.obs_shape), dtype=th.uint8, device=dev); prev_act = th.zeros(N + 1, A, device=dev)
         has_prev = th.zeros(N + 1, dtype=th.bool, device=dev); ar = th.arange(Ccap, device=dev)
+        her = isinstance(self.replay_buffer, FlatHerReplayBuffer)
+        if her:                                             # goals of every env's previous decision point, and the target directions
+            prev_ag = th.zeros(N + 1, 2, device=dev); prev_dg = th.zeros(N + 1, 2, device=dev)
+            benv = getattr(self.env, "env", self.env)
+            tdir = th.as_tensor(np.asarray(getattr(eng, "target_direction", getattr(benv, "target_direction", (1.0, 0.0))), dtype=np.float32), device=dev)
+            tdir = tdir.expand(N, 2) if tdir.ndim == 1 else tdir
         eng.reset()
         t0, tick, last_sync = time.time(), 0, 0
         self._async_ticks = 0
+        # episode statistics on the device (read by probes / callbacks without a per-tick sync): running return and length per env, totals of finished episodes
+        ep_ret = th.zeros(N + 1, device=dev); ep_len = th.zeros(N + 1, device=dev)
+        self.ep_stats = {"count": th.zeros(1, device=dev), "ret_sum": th.zeros(1, device=dev), "len_sum": th.zeros(1, device=dev)}
         while self.num_timesteps < total_timesteps:
             out = eng.advance(slot_act, self.async_slice, lst, cnt)
             eng.observe_list(lst, cnt, stage)
             valid = (ar < cnt) & (lst >= 0)
             env = th.where(valid, lst, th.full_like(lst, N)).long()                  # row N: dump
             envc = env.clamp(max=N - 1)
-            self.replay_buffer.add_rows(valid & has_prev[env], prev_obs[env], stage, prev_act[env], out["reward"][envc].float(), out["done"][envc].float())
+            if her:
+                # the goals the reward of the finished macro step was computed with (robot_env.py:175-178): the object's final position and its
+                # projection on the target direction -- from info, not from the auto-reset goal outputs; the goals of the NEW decision point
+                # are the engine's goal outputs (reset goals after a done)
+                d = tdir[envc]
+                nag = out["object_position"][envc, :2].float()
+                ndg = ((nag * d).sum(-1, keepdim=True) / (d * d).sum(-1, keepdim=True)) * d
+                self.replay_buffer.add_rows(valid & has_prev[env], prev_obs[env], stage, prev_act[env], out["reward"][envc].float(), out["done"][envc].float(),
+                                            env=env, goals=(prev_ag[env], prev_dg[env], nag, ndg))
+                prev_ag.index_copy_(0, env, out["achieved_goal"][envc].float()); prev_dg.index_copy_(0, env, out["desired_goal"][envc].float())
+            else:
+                self.replay_buffer.add_rows(valid & has_prev[env], prev_obs[env], stage, prev_act[env], out["reward"][envc].float(), out["done"][envc].float())
+            # episode bookkeeping of the listed envs
+            stored = valid & has_prev[env]
+            r_now = th.where(stored, out["reward"][envc].float(), th.zeros(Ccap, device=dev)); d_now = stored & (out["done"][envc] > 0)
+            ep_ret.index_add_(0, env, r_now); ep_len.index_add_(0, env, stored.float())
+            self.ep_stats["count"] += d_now.sum(); self.ep_stats["ret_sum"] += (ep_ret[env] * d_now).sum(); self.ep_stats["len_sum"] += (ep_len[env] * d_now).sum()
+            keep = (~d_now).float(); ep_ret.index_copy_(0, env, ep_ret[env] * keep); ep_len.index_copy_(0, env, ep_len[env] * keep); ep_ret[N] = 0; ep_len[N] = 0
             if self.num_timesteps < self.learning_starts:
                 a = th.rand(Ccap, A, device=dev) * 2 - 1                              # warm-up: uniform actions
             else:

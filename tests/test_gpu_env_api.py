@@ -305,6 +305,42 @@ def test_sac_over_the_time_sliced_engine(torch):
     env.close()
 
 
+def test_sac_with_hindsight_replay_over_the_time_sliced_engine(torch):
+    """n1, the reference's HER branch (train_agent.py:57-79: HerReplayBuffer, n_sampled_goal 4, 'future', online sampling) on the schedule
+    the engine is fast on: the time-sliced collector fills a FlatHerReplayBuffer -- per-episode goal trajectories beside the flat ring --
+    and SAC trains on relabelled samples. Stored goals are the ones the step's reward was computed with (final object position and its
+    projection on the target direction); a relabelled sample carries a goal achieved later in the same episode and its reward moved by
+    exactly the e^-|dg - ag| swap (robot_env.py:268-271)."""
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import BatchedRobotEnv, default_config
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3 import SAC, GpuVecEnv, HerReplayBuffer, FlatHerReplayBuffer
+    from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
+    env = GpuVecEnv(BatchedRobotEnv(default_config(sim_env="/xmls/sand_ball_env.xml", time_horizon=4, her_buffer=True), n_envs=256, auto_reset=True))
+    model = SAC("MultiInputPolicy", env, buffer_size=8192, learning_starts=600, batch_size=128, seed=0, async_slice=48, async_capacity=128, async_budget_us=0,
+                replay_buffer_class=HerReplayBuffer, replay_buffer_kwargs=dict(n_sampled_goal=4, goal_selection_strategy="future", online_sampling=True, max_episode_length=4),
+                policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]))
+    rb = model.replay_buffer
+    assert isinstance(rb, FlatHerReplayBuffer)
+    model.learn(total_timesteps=2500)
+    n = rb.sync_size()
+    assert n >= 2500 and model._n_updates > 0 and np.isfinite(float(model.logger["critic_loss"]))
+    # stored goals: the desired goal of a step is the projection of its achieved goal on the target direction (1, 0): (x, 0)
+    nag, ndg = rb.next_achieved[:n], rb.next_desired[:n]
+    assert torch.allclose(ndg[:, 0], nag[:, 0], atol=1e-6) and float(ndg[:, 1].abs().max()) == 0.0
+    assert float(rb.dones[:n].mean()) > 0.15                                # 4-step episodes
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    b = rb.sample(4096, generator=g); rel = b["relabelled"]
+    assert 0.3 < float(rel.float().mean()) < 0.85                           # 0.8 of the rows whose episode is complete and still in the trajectory store
+    newg = b["obs"]["desired_goal"]; own = b["next_obs"]["achieved_goal"]
+    assert torch.equal(newg, b["next_obs"]["desired_goal"])
+    # the relabelled goal is an achieved goal of the same episode: of this very step, or of one of its (at most 3) successors
+    diff = (newg[rel] - own[rel]).abs().amax(1)
+    assert float((diff == 0).float().mean()) > 0.2 and float((diff > 0).float().mean()) > 0.2 and float(diff.max()) < 0.2
+    # reward moved by exactly the swap of the goal-dependent term
+    i_rewards = b["rewards"]
+    assert torch.isfinite(i_rewards).all() and float(i_rewards.abs().max()) < 12
+    env.close()
+
+
 def test_fused_first_layer_gradients_match_the_library_path(torch):
     """a17 in training: AugmentedNatureCNN's first layer through grip_conv1_u8 (f32 MFMA, custom autograd: _Conv1U8) against the tensor
     library's convolution + ReLU on the same uint8 observations. The layer in isolation under a linear loss (a ReLU sitting within 5e-8 of

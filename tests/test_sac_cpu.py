@@ -141,3 +141,67 @@ def test_flat_replay_ring_and_sac_over_a_scripted_time_sliced_engine():
     assert th.equal(no, o + 1)                              # next observation of a transition = that env's next decision point
     assert th.equal(r.long(), no % 40)                      # and the reward is the one reported when the env was listed again
     assert set((o // 40).tolist()) == set(range(6))         # every env contributes, on its own clock
+
+
+def test_flat_her_buffer_relabels_with_a_future_goal_of_the_same_episode():
+    """HER over the time-sliced collector (n1; train_agent.py:57-79: 'future', n_sampled_goal = 4): transitions of different envs arrive
+    interleaved and at arbitrary ring rows; a relabelled sample must take the goal achieved at a LATER step of the SAME episode of the SAME
+    env, only episodes that are complete are relabelled, the reward changes by exactly the swap of the e^-|dg - ag| term, and a recycled
+    trajectory slot (or a row of an open episode) is left alone."""
+    import torch as th
+    from mujoco_rl_manipulate_unknown_objects_amd import spaces
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3 import FlatHerReplayBuffer
+    osp = spaces.Dict({"observation": spaces.Box(0, 255, shape=(1, 2, 2), dtype=np.uint8)}); asp = spaces.Box(-1., 1., shape=(2,), dtype=np.float32)
+    N, C = 5, 4
+    rb = FlatHerReplayBuffer(4000, osp, asp, th.device("cpu"), n_envs=N, n_sampled_goal=4, max_episode_length=50, n_slots=1024)
+    g = th.Generator().manual_seed(0)
+    ep = [0] * N; k = [0] * N; length = [3 + 2 * e for e in range(N)]              # env e: episodes of 3 + 2 e steps
+    code = lambda e, j, s: float(e * 10000 + j * 100 + s)                          # goal achieved after step s of episode j of env e
+    rows_total = 0
+    for tick in range(400):
+        envs = th.randperm(N, generator=g)[:C]                                     # which envs finished a macro step this tick (any order)
+        mask = th.rand(C, generator=g) < 0.8
+        ag, dg, nag, ndg, done = th.zeros(C, 2), th.zeros(C, 2), th.zeros(C, 2), th.zeros(C, 2), th.zeros(C)
+        for r, e in enumerate(envs.tolist()):
+            if not mask[r]:
+                continue
+            nag[r, 0] = code(e, ep[e], k[e]); ndg[r, 0] = -1.0; ag[r, 0] = code(e, ep[e], k[e]) - 1; dg[r, 0] = -1.0
+            k[e] += 1
+            if k[e] == length[e]:
+                done[r] = 1.0; ep[e] += 1; k[e] = 0
+        obs = th.zeros(C, 1, 2, 2, dtype=th.uint8)
+        rb.add_rows(mask, obs, obs, th.zeros(C, 2), th.full((C,), 7.0), done, env=th.where(mask, envs, th.full_like(envs, N)), goals=(ag, dg, nag, ndg))
+        rows_total += int(mask.sum())
+    assert rb.sync_size() == rows_total < 4000
+    b = rb.sample(4096, generator=g)
+    rel = b["relabelled"]
+    assert 0.6 < rel.float().mean() < 0.85                                         # her_ratio 0.8 of the rows whose episode is complete
+    own = b["next_obs"]["achieved_goal"][:, 0]; new = b["obs"]["desired_goal"][:, 0]
+    e0, j0, s0 = (own // 10000).long(), ((own % 10000) // 100).long(), (own % 100).long()
+    e1, j1, s1 = (new // 10000).long(), ((new % 10000) // 100).long(), (new % 100).long()
+    assert th.equal(e0[rel], e1[rel]) and th.equal(j0[rel], j1[rel]) and (s1[rel] >= s0[rel]).all()
+    assert (s1[rel] < (3 + 2 * e0[rel])).all() and (s1[rel] > s0[rel]).any() and (s1[rel] == s0[rel]).any()
+    assert (new[~rel] == -1.0).all()                                               # untouched rows keep the stored desired goal
+    # reward: 7 - e^-|old dg - ag'| + e^-|new goal - ag'|
+    want = 7.0 - th.exp(-(own[rel] + 1.0).abs()) + th.exp(-(new[rel] - own[rel]).abs())
+    assert th.allclose(b["rewards"][rel], want, atol=1e-6) and (b["rewards"][~rel] == 7.0).all()
+    # rows of the episodes still open are never relabelled
+    open_rows = th.tensor([j0[i] == ep[int(e0[i])] for i in range(len(own))])
+    assert not rel[open_rows].any() and open_rows.any()
+    # recycling: with only 8 slots the early episodes' slots have been handed out again -- their rows must not be relabelled with foreign goals
+    rb2 = FlatHerReplayBuffer(4000, osp, asp, th.device("cpu"), n_envs=N, n_sampled_goal=4, max_episode_length=50, n_slots=8)
+    ep = [0] * N; k = [0] * N
+    for tick in range(400):
+        envs = th.arange(C); mask = th.ones(C, dtype=th.bool)
+        ag, dg, nag, ndg, done = th.zeros(C, 2), th.zeros(C, 2), th.zeros(C, 2), th.zeros(C, 2), th.zeros(C)
+        for r, e in enumerate(envs.tolist()):
+            nag[r, 0] = code(e, ep[e], k[e]); ndg[r, 0] = -1.0; k[e] += 1
+            if k[e] == length[e]:
+                done[r] = 1.0; ep[e] += 1; k[e] = 0
+        obs = th.zeros(C, 1, 2, 2, dtype=th.uint8)
+        rb2.add_rows(mask, obs, obs, th.zeros(C, 2), th.zeros(C), done, env=envs, goals=(ag, dg, nag, ndg))
+    rb2.sync_size()
+    b2 = rb2.sample(4096, generator=g); rel2 = b2["relabelled"]
+    own2 = b2["next_obs"]["achieved_goal"][:, 0]; new2 = b2["obs"]["desired_goal"][:, 0]
+    assert rel2.any() and th.equal((own2[rel2] // 100).long(), (new2[rel2] // 100).long())       # same env, same episode, always
+    assert (rel2.float().mean() < 0.2)                                             # most rows' slots are gone: left alone
