@@ -148,7 +148,7 @@ class ActorCriticPolicy(nn.Module):
         c = self._rollout_cache
         # stale copies are refreshed here too (train() followed by an evaluation, load_state_dict, a foreign optimizer step ...), except
         # inside a stream capture, where PPO has refreshed them before capturing and the graph must keep reading the same addresses
-        if c.get("stamp") != self._param_stamp() and not (obs.is_cuda and th.cuda.is_current_stream_capturing()):
+        if c.get("stamp") != self._param_stamp() and not (self.action_net.weight.is_cuda and th.cuda.is_current_stream_capturing()):
             self.refresh_rollout_cache()
         h = self.features_extractor.rollout_features(self._prep(obs))
         if h is None:                                               # not the observation layout the extractor's fast path handles
