@@ -638,7 +638,9 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
 #ifdef GRIP_STAMPS
                 stm.acc[11] += 1;               // env-substeps of this lane (lane 0 of each wave is reported)
 #endif
-                if (budget_ticks > 0 && wall_clock64() - t_start > budget_ticks) budget = 0;     // the wave's share of the tick is spent
+                // the wave's share of the tick is spent? (every step: looking only every fourth step saves a scalar memory round trip per step but
+                // lets the waves overrun the budget by different amounts -- the launch then waits for the latest: measured -4.6 %)
+                if (budget_ticks > 0 && wall_clock64() - t_start > budget_ticks) budget = 0;
                 // ---- post-step transitions
                 bool to_gripper = false, to_final = false, set56 = false;
                 float c56 = 0.f;                            // new value of ctrl[5] = ctrl[6] (knuckle motors) when a transition sets them
@@ -752,15 +754,16 @@ DEVI int group_of_block(const GroupArgs *__restrict__ groups, int ngroups, int b
 
 // out1 (use_out1 != 0): result arrays given with the call (grip_batch_step / _advance of a single batch) instead of the ones
 // bound to the set. slice <= 0: actions float32 [total envs, adim] (lock-step); slice > 0: [ngroups * seg_rows, adim].
-__global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_macro_step(const GroupArgs *__restrict__ groups, int ngroups, StepOutDev out1, int use_out1, const float *actions,
+__global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_macro_step(const GroupArgs *__restrict__ groups, int ngroups, const StepOutDev out1, int use_out1, const float *actions,
                                                               int seg_rows, int slice, long long budget_ticks, int lag) {
     const int g = group_of_block(groups, ngroups, (int)blockIdx.x);
     const GroupArgs &ga = groups[g];
     const int adim = ga.cfg.include_roll ? 6 : 5;
     const float *act = actions + (slice > 0 ? (size_t)g * seg_rows : (size_t)ga.env0) * adim;
-    StepOutDev out = ga.out;
-    if (use_out1) out = out1;
-    macro_step_body(ga.m, ga.cfg, ga.st, act, out, ga.reset_info, ga.xfrc_z, ga.mc, slice, slice > 0 ? ga.order : nullptr, budget_ticks, lag,
+    // the 16 result pointers are needed only when a macro step ends: handed on by address (the call's own arrays sit in the kernel-argument
+    // segment, the set's in the group record) and loaded there, instead of being selected here and kept in 32 registers for the whole launch
+    const StepOutDev *outp = use_out1 ? &out1 : &ga.out;
+    macro_step_body(ga.m, ga.cfg, ga.st, act, *outp, ga.reset_info, ga.xfrc_z, ga.mc, slice, slice > 0 ? ga.order : nullptr, budget_ticks, lag,
                     (int)blockIdx.x - ga.wg0);
 }
 
