@@ -121,7 +121,8 @@ int grip_batch_advance(GripBatch *b, const float *slot_actions_dev, int slice, i
                        int32_t *ready_list_dev, int32_t *ready_count_dev, void *stream);
 /* get_observation for the listed envs only: row r of obs_dev (uint8 [capacity,5,64,64]) = env list_dev[r], r < *count_dev.
  * records_dev != NULL: the same bytes are also written to row record_row_dev[0] + r of records_dev (a trainer's observation
- * store; the row base is read on the device so that a captured hipGraph can advance it). */
+ * store; the row base is read on the device so that a captured hipGraph can advance it). obs_dev may then be NULL: the
+ * observation is rendered once, into the record rows only (grip_conv1_u8_rows reads them there). */
 int grip_batch_observe_list(GripBatch *b, const int32_t *list_dev, const int32_t *count_dev, int capacity, uint8_t *obs_dev,
                             uint8_t *records_dev, const int64_t *record_row_dev, void *stream);
 
@@ -191,6 +192,10 @@ int grip_obs_preprocess(const uint8_t *obs_dev, int n, int channels, float *img_
  * Inference only; the update runs the same layer through the tensor library with autograd. */
 int grip_conv1_u8(const uint8_t *obs_dev, int n, int channels, const float *weight_dev, const int64_t *weight_strides, const float *bias_dev,
                   float *scratch_dev, float *out_nhwc_dev, float *other_dev, void *stream);
+/* The same on rows row0_dev[0] .. row0_dev[0] + n - 1 of obs_dev (row0_dev: int64 [1] in device memory, NULL = 0): the time-sliced trainer renders
+ * the observations of a tick once, straight into its record rows (grip_batch_observe_list with obs_dev = NULL), and the policy reads them there. */
+int grip_conv1_u8_rows(const uint8_t *obs_dev, const int64_t *row0_dev, int n, int channels, const float *weight_dev, const int64_t *weight_strides,
+                       const float *bias_dev, float *scratch_dev, float *out_nhwc_dev, float *other_dev, void *stream);
 
 /* Rollout-side second and third layers of AugmentedNatureCNN (models/feature_extractor.py:17-21) in one launch on the matrix cores
  * (v_mfma_f32_16x16x4_f32: fp32 products and sums): y1_nhwc_dev float32 [n, 15, 15, 32] (grip_conv1_u8's output) ->

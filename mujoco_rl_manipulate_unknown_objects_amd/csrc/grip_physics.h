@@ -112,7 +112,9 @@ __device__ unsigned long long g_dbg_cnt[16];   // 8..11: wave-level (first wave 
 // 24..31 wave trips by the number of Newton iterations the wave ran (max over its envs) 0..6, 7+
 __device__ unsigned long long g_dbg_hist[96];   // 64..71 gradient decade at the chosen start; 72 warm start taken; 73 solves; 74..76 hull contacts by cone zone (top, middle, bottom) at the start; 77..79 at the end; 80 hull contacts whose zone changed; 81..83 / 84..86 / 87 the same for floor contacts   // 32 + 8 k + b: after Newton iteration k + 1 (k = 0..3) the scaled gradient was in decade b (< 1e-7, 1e-7.., ..., >= 1e-1)
 #define DBG_HIST(i, n) atomicAdd(&g_dbg_hist[i], (unsigned long long)(n))
+#ifdef GRIP_HIST            // the per-step histograms (atomics from every env: they distort the phase timings, so they are their own build)
 #define HAVE_DBG_HIST 1
+#endif
 #elif defined(GRIP_MARKS)      // listing build only (hipcc -S -DGRIP_MARKS): phase boundaries as comments in the ISA, to count instructions per phase
 #define DBG_COUNT(i, n) do { } while (0)
 struct Stamps { int dummy; };

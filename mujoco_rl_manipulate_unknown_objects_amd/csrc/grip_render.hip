@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "grip_device.h"
+#include <atomic>
 
 int grip_fail(const char *msg);                     // grip_sim.hip: records the message grip_last_error() returns, yields -1
 static int launch_status(const char *what) {
@@ -118,6 +119,7 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
     __shared__ int wcnt[RTHREADS / 64];
     __shared__ float red[RTHREADS];
     __shared__ int redi[RTHREADS];
+    __shared__ __align__(16) uint8_t img[5 * RPIX];    // the observation is composed here and leaves in 16-byte stores, once per destination
     const int tid = threadIdx.x;
     if (tid < 7) frame_role(m, qpos, n, e, cfg.state_half, tid, fr);
     __syncthreads();
@@ -203,8 +205,8 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
     const Frames *frl = &fr;
     asm volatile("" : "+v"(frl));
     const int nch = cfg.full_observation ? 5 : 4;
-    uint8_t *o = obs + (size_t)blockIdx.x * nch * RPIX;
-    uint8_t *o2 = obs2 ? obs2 + (size_t)(row2[0] + blockIdx.x) * nch * RPIX : nullptr;
+    uint8_t *o = obs ? obs + (size_t)blockIdx.x * nch * RPIX : nullptr;        // either destination may be absent (the trainer renders straight
+    uint8_t *o2 = obs2 ? obs2 + (size_t)(row2[0] + blockIdx.x) * nch * RPIX : nullptr;   // into its record rows and reads them from there)
     const float tanh_ = tanf(0.5f * m.cam_fovy * 0.017453292519943295f);
     // tile of this thread: a wave covers 8 x 8 tiles = a square block of (8 TW)^2 pixels
     constexpr int WPR = RW / (8 * TW);          // waves per row of wave blocks
@@ -378,9 +380,7 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
     // the two pixels of a tile row leave as one 16-bit store per channel (the tile's column is even: 2-byte aligned)
     auto put2 = [&](int ch, int r, unsigned lo, unsigned hi) {
         const int px = (TW * ty + r) * RW + TW * tx;
-        const uint16_t v = (uint16_t)(lo | (hi << 8));
-        *reinterpret_cast<uint16_t *>(o + ch * RPIX + px) = v;
-        if (o2) *reinterpret_cast<uint16_t *>(o2 + ch * RPIX + px) = v;
+        *reinterpret_cast<uint16_t *>(img + ch * RPIX + px) = (uint16_t)(lo | (hi << 8));
     };
 #pragma unroll
     for (int r = 0; r < TW; r++) {
@@ -412,8 +412,15 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
     __syncthreads();
     if (tid == 0) {
         const int pg_ = GPTR(const int, pad_grasp)[e], pp_ = GPTR(const int, pad_pher)[e];
-        o[(nch - 1) * RPIX] = (uint8_t)pg_; o[(nch - 1) * RPIX + 1] = (uint8_t)pp_;
-        if (o2) { o2[(nch - 1) * RPIX] = (uint8_t)pg_; o2[(nch - 1) * RPIX + 1] = (uint8_t)pp_; }
+        img[(nch - 1) * RPIX] = (uint8_t)pg_; img[(nch - 1) * RPIX + 1] = (uint8_t)pp_;
+    }
+    __syncthreads();
+    // rows are nch x 4096 bytes from 16-byte aligned bases: 1280 (1024) 16-byte stores per destination, coalesced
+    const uint4 *src = reinterpret_cast<const uint4 *>(img);
+    for (int i = tid; i < nch * RPIX / 16; i += RTHREADS) {
+        const uint4 v = src[i];
+        if (o) reinterpret_cast<uint4 *>(o)[i] = v;
+        if (o2) reinterpret_cast<uint4 *>(o2)[i] = v;
     }
 }
 
@@ -434,6 +441,16 @@ __global__ void __launch_bounds__(RTHREADS, 8) k_observe(const RenderGroup *__re
 
 extern "C" int grip_render_launch(const RenderGroup *groups_dev, int ngroups, const int *list, const int *count, int nblocks, int nplanes_max,
                                   uint8_t *obs, uint8_t *obs2, const long long *row2, hipStream_t s) {
+    {   // static (image, reductions, frames: ~29 KB) + dynamic LDS (up to 41 KB of planes) passes 64 KB for the largest hulls: opt in, once per device
+        static std::atomic<unsigned long long> attr_set_mask{0ULL};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return -1;
+        const unsigned long long bit = 1ULL << (dev & 63);
+        if (!(attr_set_mask.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute((const void *)k_observe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((RMAXPL + NBOX * GN_HULL) * sizeof(float4))) != hipSuccess) return -1;
+            attr_set_mask.fetch_or(bit, std::memory_order_release);
+        }
+    }
     hipLaunchKernelGGL(k_observe, dim3(nblocks), dim3(RTHREADS), (size_t)(nplanes_max + NBOX * GN_HULL) * sizeof(float4), s, groups_dev, ngroups, list, count, obs, obs2, row2);
     return launch_status("grip_render_launch");
 }

@@ -1320,7 +1320,7 @@ extern "C" int grip_batch_render_camera(GripBatch *b, int env, const float *cam_
 }
 extern "C" int grip_batch_observe_list(GripBatch *b, const int32_t *list_dev, const int32_t *count_dev, int capacity, uint8_t *obs_dev,
                                        uint8_t *records_dev, const int64_t *record_row_dev, void *stream) {
-    if (!b || !obs_dev || !list_dev || !count_dev || capacity <= 0 || (records_dev && !record_row_dev)) return fail("grip_batch_observe_list: bad argument");
+    if (!b || (!obs_dev && !records_dev) || !list_dev || !count_dev || capacity <= 0 || (records_dev && !record_row_dev)) return fail("grip_batch_observe_list: bad argument");
     HIPCHK(hipSetDevice(b->device));
     if (grip_render_launch((const RenderGroup *)b->d_rself, 1, list_dev, count_dev, capacity, b->nplanes, obs_dev, records_dev, (const long long *)record_row_dev, (hipStream_t)stream)) return -1;
     return 0;
@@ -1434,7 +1434,7 @@ extern "C" int grip_batchset_observe(GripBatchSet *s, uint8_t *obs_dev, void *st
 
 extern "C" int grip_batchset_observe_list(GripBatchSet *s, const int32_t *list_dev, int capacity, uint8_t *obs_dev, uint8_t *records_dev,
                                           const int64_t *record_row_dev, void *stream) {
-    if (!s || !list_dev || !obs_dev || capacity <= 0 || (records_dev && !record_row_dev)) return fail("grip_batchset_observe_list: bad argument");
+    if (!s || !list_dev || (!obs_dev && !records_dev) || capacity <= 0 || (records_dev && !record_row_dev)) return fail("grip_batchset_observe_list: bad argument");
     HIPCHK(hipSetDevice(s->device));
     return grip_render_launch(s->d_rgroups, (int)s->b.size(), list_dev, nullptr, capacity, s->nplanes_max, obs_dev, records_dev, (const long long *)record_row_dev, (hipStream_t)stream);
 }

@@ -106,7 +106,7 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_set_flags", "grip_batch_substep", "grip_batch_debug_forward", "grip_batch_target_pose",
            "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward", "grip_obs_preprocess",
            "grip_batch_set_state_storage", "grip_batchset_create", "grip_batchset_destroy", "grip_batchset_refresh", "grip_batchset_num_envs",
-           "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list", "grip_conv1_u8", "grip_batch_render_camera", "grip_ppo_loss", "grip_conv23_prep", "grip_conv23"]
+           "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list", "grip_conv1_u8", "grip_conv1_u8_rows", "grip_batch_render_camera", "grip_ppo_loss", "grip_conv23_prep", "grip_conv23"]
 
 
 def lib():
@@ -160,6 +160,7 @@ def lib():
     L.grip_batchset_observe.argtypes = [vp, vp, vp]
     L.grip_batchset_observe_list.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp]
     L.grip_conv1_u8.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int64), vp, vp, vp, vp, vp]
+    L.grip_conv1_u8_rows.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int64), vp, vp, vp, vp, vp]
     L.grip_conv23_prep.argtypes = [vp, C.POINTER(C.c_int64), vp, C.POINTER(C.c_int64), vp, vp, vp]
     L.grip_conv23.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.grip_ppo_loss.argtypes = [vp] * 7 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float] + [vp] * 5
@@ -197,21 +198,47 @@ def obs_preprocess(obs):
     return img, other
 
 
+class RecordRows:
+    """`n` consecutive rows of a uint8 observation store [R, 5, 64, 64], starting at the row a DEVICE scalar holds (int64 [1]): what the
+    time-sliced trainer hands to the policy instead of a staging copy of the tick's observations -- the observation kernel renders them once,
+    into the record rows, and the first layer (conv1_u8) reads them there. Quacks like the tensor of those rows where the policy looks."""
+    dtype_name = "uint8"
+
+    def __init__(self, records, row0, n):
+        import torch
+        assert records.is_cuda and records.dtype == torch.uint8 and records.is_contiguous() and row0.dtype == torch.int64 and row0.is_cuda
+        self.records, self.row0, self.n = records, row0, int(n)
+        self.dtype, self.is_cuda, self.device = torch.uint8, True, records.device
+        self.shape = (self.n,) + tuple(records.shape[1:])
+        self.ndim = records.ndim
+
+    def contiguous(self):
+        return self
+
+    def materialize(self):
+        """the rows as an ordinary tensor (a host sync: for fallbacks and tests, never on the captured path)"""
+        r = int(self.row0.item())
+        return self.records[r:r + self.n]
+
+
 def conv1_u8(obs, weight, bias):
     """First layer of AugmentedNatureCNN for rollouts (grip_conv1_u8, csrc/grip_policy.hip): uint8 CUDA observations
     [n, 5, 64, 64] -> (relu(conv2d(obs[:, :4] / 255, weight, bias, stride 4)) as a channels-last float32 [n, 32, 15, 15]
     tensor, the two sensor-pad scalars / 255 as [n, 2]) in one launch on the matrix cores (f32 MFMA). No autograd."""
     import torch
+    rows = obs if isinstance(obs, RecordRows) else None
+    if rows is not None:
+        obs = rows.records
     assert obs.is_cuda and obs.dtype == torch.uint8 and obs.is_contiguous() and tuple(obs.shape[1:]) == (5, 64, 64)
     assert weight.dtype == torch.float32 and tuple(weight.shape) == (32, 4, 8, 8) and bias.dtype == torch.float32 and bias.is_contiguous()
-    n = int(obs.shape[0])
+    n = int(obs.shape[0]) if rows is None else rows.n
     out = torch.empty((n, 32, 15, 15), dtype=torch.float32, device=obs.device, memory_format=torch.channels_last)
     other = torch.empty((n, 2), dtype=torch.float32, device=obs.device)
     scratch = torch.empty(8192, dtype=torch.float32, device=obs.device)
     strides = (C.c_int64 * 4)(*weight.stride())
     stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
-    _chk(lib().grip_conv1_u8(C.c_void_p(obs.data_ptr()), n, 5, C.c_void_p(weight.data_ptr()), strides, C.c_void_p(bias.data_ptr()),
-                             C.c_void_p(scratch.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(other.data_ptr()), stream))
+    _chk(lib().grip_conv1_u8_rows(C.c_void_p(obs.data_ptr()), None if rows is None else C.c_void_p(rows.row0.data_ptr()), n, 5, C.c_void_p(weight.data_ptr()), strides,
+                                  C.c_void_p(bias.data_ptr()), C.c_void_p(scratch.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(other.data_ptr()), stream))
     return out, other
 
 
@@ -387,12 +414,14 @@ class Batch:
         """Render the listed envs into obs rows 0..count-1; with `records` (uint8 [R, C, 64, 64]) and `record_row` (int64 [1])
         also into records[record_row + r]."""
         cap = int(ready_list.numel())
-        if obs.dtype != self.torch.uint8 or not obs.is_contiguous() or obs.shape[0] < cap:
+        if obs is None and records is None:
+            raise GripError("observe_list needs obs rows, record rows, or both")
+        if obs is not None and (obs.dtype != self.torch.uint8 or not obs.is_contiguous() or obs.shape[0] < cap):
             raise GripError("obs must be contiguous uint8 [capacity, C, 64, 64]")
         rp = None if records is None else C.c_void_p(records.data_ptr())
         rr = None if record_row is None else C.c_void_p(record_row.data_ptr())
         _chk(lib().grip_batch_observe_list(self.ptr, C.c_void_p(ready_list.data_ptr()), C.c_void_p(ready_count.data_ptr()), cap,
-                                           C.c_void_p(obs.data_ptr()), rp, rr, self._stream()))
+                                           None if obs is None else C.c_void_p(obs.data_ptr()), rp, rr, self._stream()))
         return obs
 
     def add_intrinsic_reward(self, old_obs, new_obs, reward, old_rows=None, ready_list=None, ready_count=None):
@@ -597,11 +626,13 @@ class MixedBatch:
     def observe_list(self, ready_list, ready_count, obs, records=None, record_row=None):
         """Row r of obs (and of records from row record_row on) = observation of env ready_list[r]; holes are skipped."""
         cap = int(ready_list.numel())
-        if obs.dtype != self.torch.uint8 or not obs.is_contiguous() or obs.shape[0] < cap:
+        if obs is None and records is None:
+            raise GripError("observe_list needs obs rows, record rows, or both")
+        if obs is not None and (obs.dtype != self.torch.uint8 or not obs.is_contiguous() or obs.shape[0] < cap):
             raise GripError("obs must be contiguous uint8 [capacity, C, 64, 64]")
         rp = None if records is None else C.c_void_p(records.data_ptr())
         rr = None if record_row is None else C.c_void_p(record_row.data_ptr())
-        _chk(lib().grip_batchset_observe_list(self.ptr, C.c_void_p(ready_list.data_ptr()), cap, C.c_void_p(obs.data_ptr()), rp, rr, self._stream()))
+        _chk(lib().grip_batchset_observe_list(self.ptr, C.c_void_p(ready_list.data_ptr()), cap, None if obs is None else C.c_void_p(obs.data_ptr()), rp, rr, self._stream()))
         return obs
 
     def add_intrinsic_reward(self, *a, **k):

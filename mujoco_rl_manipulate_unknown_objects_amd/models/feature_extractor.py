@@ -86,7 +86,7 @@ class AugmentedNatureCNN(BaseFeaturesExtractor):
                 and not th.is_autocast_enabled()):
             return None
         from ..engine import conv1_u8
-        x, other = conv1_u8(obs.contiguous(), c0.weight, c0.bias)
+        x, other = conv1_u8(obs.contiguous(), c0.weight, c0.bias)      # (a tensor, or engine.RecordRows: the tick's record rows, read in place)
         if self._b23 is not None:                                   # both remaining convolutions + ReLUs as one f32-MFMA launch
             from ..engine import conv23
             x = conv23(x, self._b23[0], self.cnn[2].bias, self._b23[1], self.cnn[4].bias)

@@ -184,11 +184,19 @@ class AsyncRollout:
     def _decide(self, out, lst, cnt, obs_stage, slot_act, p):
         """Render the listed envs, run the policy on them, record the decisions; writes slot_act for the next start."""
         dual = getattr(self.eng, "batch", None) is not None       # the GPU engine writes the record rows itself
-        if dual:
+        im = getattr(self.eng, "im_reward", False)
+        # render ONCE, straight into the tick's record rows, when the policy's first layer can read them there (engine.RecordRows): no
+        # staging copy of the observations is written or read (the intrinsic reward still wants the staged rows)
+        rows_only = bool(dual and not im and self.fused and self.policy_parts_fn is not None and getattr(self.policy_parts_fn, "accepts_record_rows", lambda: False)())
+        if rows_only:
+            from ..engine import RecordRows
+            self.eng.observe_list(lst, cnt, None, self.obs, self.base_t)
+            obs_stage = RecordRows(self.obs, self.base_t, self.C)
+        elif dual:
             self.eng.observe_list(lst, cnt, obs_stage, self.obs, self.base_t)
         else:
             self.eng.observe_list(lst, cnt, obs_stage)
-        if getattr(self.eng, "im_reward", False):
+        if im:
             env = th.where((self.ar_c < cnt) & (lst >= 0), lst, self.N).long()
             self.eng.add_intrinsic_reward(self.obs, self.rec_of_env[env], obs_stage, lst, cnt, out["reward"])
         noise = log_std = None

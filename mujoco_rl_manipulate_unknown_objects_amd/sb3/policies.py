@@ -88,10 +88,17 @@ class ActorCriticPolicy(nn.Module):
         actions = mean if deterministic else mean + th.randn_like(mean) * th.exp(log_std)
         return actions, values, self._log_prob(mean, log_std, actions)
 
+    def accepts_record_rows(self):
+        """can forward_parts() take engine.RecordRows (the tick's observations read in place from the trainer's record rows)?"""
+        fe = self.features_extractor
+        return self._rollout_cache is not None and getattr(fe, "_wl_nhwc", None) is not None and getattr(self, "_fused_preprocess", False)
+
     def forward_parts(self, obs):
         """(mean, log_std, values): the Gaussian head left un-sampled, for callers that sample and score in a fused kernel."""
         if self._rollout_cache is not None and not th.is_grad_enabled():
             return self._forward_parts_merged(obs)
+        if hasattr(obs["observation"], "materialize"):
+            obs = {"observation": obs["observation"].materialize()}
         lp, lv = self._latents(obs)
         return self.action_net(lp).float(), self.log_std.float(), self.value_net(lv).float().squeeze(-1)
 
@@ -152,6 +159,8 @@ class ActorCriticPolicy(nn.Module):
             self.refresh_rollout_cache()
         h = self.features_extractor.rollout_features(self._prep(obs))
         if h is None:                                               # not the observation layout the extractor's fast path handles
+            if hasattr(obs["observation"], "materialize"):
+                obs = {"observation": obs["observation"].materialize()}
             lp, lv = self._latents(obs)
             return self.action_net(lp).float(), self.log_std.float(), self.value_net(lv).float().squeeze(-1)
         for W, b in zip(c["W"], c["b"]):

@@ -155,6 +155,7 @@ class PPO:
             def policy_parts_fn(obs_rows):
                 with th.no_grad(), self._ac():
                     return self.policy_rollout.forward_parts({"observation": obs_rows})
+            policy_parts_fn.accepts_record_rows = lambda: bool(getattr(self.policy_rollout, "accepts_record_rows", lambda: False)())
             parts = policy_parts_fn if hasattr(self.policy, "forward_parts") else None
             self._async = AsyncRollout(eng, policy_fn, policy_parts_fn=parts, target=n_steps * self.n_envs, capacity=min(cap, self.n_envs), slice_len=async_slice,
                                        gamma=gamma, gae_lambda=gae_lambda, action_low=env.action_space.low, action_high=env.action_space.high)

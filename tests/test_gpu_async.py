@@ -235,3 +235,46 @@ def test_fused_gaussian_head_matches_tensor_ops(engine, torch):
     assert torch.allclose(a["actions"][first][m], b["actions"][first][m], rtol=1e-5, atol=1e-5)
     assert torch.allclose(a["log_probs"][first][m], b["log_probs"][first][m], rtol=1e-5, atol=1e-4)
     assert torch.allclose(a["values"][first][m], b["values"][first][m], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_observations_rendered_once_into_the_record_rows():
+    """Decision phase of the time-sliced trainer: grip_batch_observe_list with obs_dev = NULL renders the listed envs ONLY into the trainer's
+    record rows (from the device-side row base), and grip_conv1_u8_rows reads them there: same bytes as the staged copy, same first-layer
+    output bit for bit, and the PPO tick takes that path (no staging write) when its policy can."""
+    import torch
+    from mujoco_rl_manipulate_unknown_objects_amd import engine
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import BatchedRobotEnv, default_config
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3 import PPO, GpuVecEnv
+    from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
+    n, cap = 96, 32
+    b = engine.Batch("sugar_cube", n, auto_reset=1)
+    lst = torch.full((cap,), -1, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    for _ in range(6):
+        b.advance(torch.rand(cap, 6, device="cuda", generator=g) * 2 - 1, 64, lst, cnt)
+    c = int(cnt.item()); assert c > 0
+    stage = torch.zeros(cap, 5, 64, 64, dtype=torch.uint8, device="cuda")
+    rec_a = torch.full((200, 5, 64, 64), 7, dtype=torch.uint8, device="cuda"); rec_b = rec_a.clone()
+    row = torch.tensor([61], dtype=torch.int64, device="cuda")
+    b.observe_list(lst, cnt, stage, rec_a, row)                  # both destinations
+    b.observe_list(lst, cnt, None, rec_b, row)                   # record rows only
+    torch.cuda.synchronize()
+    assert torch.equal(rec_a, rec_b) and torch.equal(rec_b[61:61 + c], stage[:c]) and (rec_b[:61] == 7).all() and (rec_b[61 + cap:] == 7).all()
+    assert int((stage[:c, :3] != 0).sum()) > 1000                # real pictures
+    w = torch.randn(32, 4, 8, 8, device="cuda"); bias = torch.randn(32, device="cuda")
+    y0, o0 = engine.conv1_u8(rec_b[61:61 + cap].contiguous(), w, bias)
+    y1, o1 = engine.conv1_u8(engine.RecordRows(rec_b, row, cap), w, bias)
+    assert torch.equal(y0, y1) and torch.equal(o0, o1)
+    b.close()
+    env = BatchedRobotEnv(default_config(sim_env="/xmls/sand_ball_env.xml"), n_envs=64, auto_reset=True)
+    model = PPO("MultiInputPolicy", GpuVecEnv(env), n_steps=2, batch_size=64, n_epochs=1, async_slice=32, async_capacity=32, async_budget_us=1000,
+                policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]))
+    assert model._async.policy_parts_fn.accepts_record_rows()
+    model._async.obs_stage.fill_(9)
+    model.collect_rollouts(); st = model.train(); torch.cuda.synchronize()
+    assert np.isfinite(float(st["loss"]))
+    assert (model._async.obs_stage == 9).all()                  # the staging rows were never written
+    rows = model._async.window_rows()
+    assert int((model._async.obs[rows][:, :3] != 0).sum()) > 1000   # the records hold the rendered observations
+    env.close()

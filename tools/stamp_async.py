@@ -1,4 +1,5 @@
-"""Diagnostic: whole-GPU per-phase cycle shares of the physics kernel in the time-sliced workload (random actions).
+"""Diagnostic: whole-GPU per-phase cycle shares of the physics kernel in the time-sliced workload (random actions). GRIP_STAMPS_LIB=hist
+(a -DGRIP_STAMPS -DGRIP_HIST build) adds per-step histograms (Newton iterations, contacts, cone zones); its timings are distorted by the atomics.
 Uses the -DGRIP_STAMPS build (libgrip_sim_stamps.so), never the shipped library."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
