@@ -61,10 +61,23 @@ DEVI int wg_env_slot(bool &active) {
 #define ES_QFS (ES_WARM + 16)           // qfrc_smooth[13] of this step (16), dense block -> integrator
 #define ES_QS (ES_QFS + 16)             // qacc_smooth[13] of this step (16), dense block -> solver
 #define ES_MAC (ES_QS + 16)             // macro step: target[5], init_q[5], open_close, tq, init_obj[3] (16; same order as the suspended record MCF)
-#define ENV_FLOATS (ES_MAC + 16)
+// ... and its integer words, the suspended record's order first (phase is kept in a register: the step loop turns on it):
+//   [0] -, [1] cnt, [2] nsub, [3] grasped, [4] flags (bit 0 reached_target, bit 1 reached_initial), [5] fault bits,
+//   [8] Newton iterations of this slice, [9] steps of this slice, [10] episode_step, [11] status, [12] gripper_open
+#define ES_MACI (ES_MAC + 16)
+#define ENV_FLOATS (ES_MACI + 16)
+enum { MI_CNT = 1, MI_NSUB = 2, MI_GRASPED = 3, MI_FLAGS = 4, MI_FAULT = 5, MI_SUMIT = 8, MI_NSLICE = 9, MI_EPSTEP = 10, MI_STATUS = 11, MI_GOPEN = 12 };
+#define MI(cx, i) (reinterpret_cast<int *>((cx).envl + ES_MACI)[i])
 // what the constraint rows need of the kinematics (pe, a4, pk[2], ak[2], po, Ro: 30 floats): kinematics() -> make_constraints(). It sits in the
 // last two Hessian-vector slots of the LAST contact, which nobody writes before hessian_vectors() of the following solve.
 #define ES_KIN (EF_U + (G_MAXC - 1) * 6 * U_STRIDE + 4 * U_STRIDE)
+// The narrow phase's portal memory (3 vertex-pair ids + 3 query directions = 12 words per hull-pair lane, lanes 0..10): in the Hessian-vector
+// slots of contacts 12 and 13 (rows 0..3 of slot 13: its rows 4, 5 hold ES_KIN), which the solver touches only when an env has 13 or 14
+// contacts -- collide() then forgets the portals (has = 0) and the next step starts them cold, exactly as a fresh macro step does.
+#define ES_PORTAL (EF_U + (G_MAXC - 2) * 6 * U_STRIDE)
+#define PORTAL_WORDS 12
+#define PORTAL_SAFE_NCON (G_MAXC - 2)
+static_assert(ES_PORTAL + 11 * PORTAL_WORDS <= ES_KIN && ES_PORTAL % 4 == 0, "portal memory must fit below ES_KIN");
 // the integrator's exchange vector (qfrc_smooth + J^T f, one component per dof lane): the staging area is free once the solve is over
 #define ES_ACC EF_STAGE
 // The Newton step's linear system, gathered so that EVERY lane holds all of it: row r of H at EF_H + 16 r (13 entries), the negative
@@ -235,6 +248,11 @@ DEVI Ctx stage_tables(const DevModel &m, float *lds) {
     bool act_; c.envl = lds + LDS_ENV_BASE(m.hull_words) + wg_env_slot(act_) * ENV_FLOATS;
     return c;
 }
+
+// fault bits of the env (1 diverged, 2 contact overflow, 4 Newton iteration limit): a word of the env's LDS region, OR-ed by the lanes that see
+// the condition (the env's 16 lanes always agree)
+DEVI void env_fault_or(const Ctx &cx, int bits) { MI(cx, MI_FAULT) |= bits; }
+DEVI int env_fault(const Ctx &cx) { return MI(cx, MI_FAULT); }
 
 // ---------------------------------------------------------------- kinematics (redundant in the 16 lanes)
 DEVI void store_frame(float *envl, int g, V3 p, const M3 &R) {
@@ -806,7 +824,7 @@ DEVI V3 find_pos(const Sup &p0, const Sup &p1, const Sup &p2, const Sup &p3) {
 // 1-3 trips instead of 3 discovery + ~8 refinement trips. The converged facet is the same to the 1e-6 tolerance; the path is
 // not, so results differ from a cold start at the 1e-6 m level over tens of steps (tests/test_gpu_parity.py).
 #ifndef GRIP_COLD_PORTAL
-struct PairMemo { V3 sep; int h1, h2; int has; int pi[3]; V3 pd[3]; };      // + the last converged portal: vertex pairs and query directions
+struct PairMemo { V3 sep; int h1, h2; int has; };      // has: the last converged portal (vertex pairs and query directions) is in the lane's ES_PORTAL words
 #else
 struct PairMemo { V3 sep; int h1, h2; };
 #endif
@@ -827,7 +845,7 @@ struct Contact {
 // support <= 0). Bodies move little in 2 ms, so the next call first tests that one direction (phase 6, one support pair) and
 // usually is done -- the exact separating-axis argument MPR itself ends with, so no result changes; only when it fails does
 // the portal search start from scratch.
-DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, PairMemo &memo, Stamps &st) {
+DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, PairMemo &memo, Stamps &st) {
     V3 &sep = memo.sep;
     const float EPS2 = 1e-12f, EPSD = 1e-10f;
     const float infl = 0.5f * m.margin;
@@ -880,13 +898,18 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
             if (phase < 0) memo.has = 0;
             if (phase == 0 && memo.has) {           // rebuild the portal the last step converged to at the new poses; use it if it still holds the origin ray
                 Sup w[3];
+                int mpi[3]; V3 mpd[3];
+                {   const float4 *pm = reinterpret_cast<const float4 *>(cx.envl + ES_PORTAL + min(cx.sub, 10) * PORTAL_WORDS);
+                    const float4 m1 = pm[0], m2 = pm[1], m3 = pm[2];
+                    mpi[0] = __float_as_int(m1.x); mpi[1] = __float_as_int(m1.y); mpi[2] = __float_as_int(m1.z);
+                    mpd[0] = v3(m1.w, m2.x, m2.y); mpd[1] = v3(m2.z, m2.w, m3.x); mpd[2] = v3(m3.y, m3.z, m3.w); }
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    const int i1 = memo.pi[k] & 0xffff, i2 = memo.pi[k] >> 16;
+                    const int i1 = mpi[k] & 0xffff, i2 = mpi[k] >> 16;
                     const float *a1 = T.v + 4 * (base1 + i1), *a2 = T.v + 4 * (base2 + i2);
-                    w[k].v1 = p1 + mulv(R1, v3(a1[0], a1[1], a1[2])) + memo.pd[k] * infl;
-                    w[k].v2 = p2 + mulv(R2, v3(a2[0], a2[1], a2[2])) - memo.pd[k] * infl;
-                    w[k].v = w[k].v1 - w[k].v2; w[k].id = memo.pi[k]; w[k].qd = memo.pd[k];
+                    w[k].v1 = p1 + mulv(R1, v3(a1[0], a1[1], a1[2])) + mpd[k] * infl;
+                    w[k].v2 = p2 + mulv(R2, v3(a2[0], a2[1], a2[2])) - mpd[k] * infl;
+                    w[k].v = w[k].v1 - w[k].v2; w[k].id = mpi[k]; w[k].qd = mpd[k];
                 }
                 V3 nn = cross(w[1].v - w[0].v, w[2].v - w[0].v);
                 const float n2 = dot(nn, nn);
@@ -1027,7 +1050,10 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
                             depth = sqrtf(d2); nrm = depth < 1e-9f ? v3(0, 0, 0) : normalized(w);
                             pos = find_pos(s0, s1, s2, s3); hit = true;
 #ifndef GRIP_COLD_PORTAL
-                            memo.has = 1; memo.pi[0] = s1.id; memo.pi[1] = s2.id; memo.pi[2] = s3.id; memo.pd[0] = s1.qd; memo.pd[1] = s2.qd; memo.pd[2] = s3.qd;
+                            memo.has = 1;
+                            {   float4 *pm = reinterpret_cast<float4 *>(cx.envl + ES_PORTAL + min(cx.sub, 10) * PORTAL_WORDS);
+                                pm[0] = make_float4(__int_as_float(s1.id), __int_as_float(s2.id), __int_as_float(s3.id), s1.qd.x);
+                                pm[1] = make_float4(s1.qd.y, s1.qd.z, s2.qd.x, s2.qd.y); pm[2] = make_float4(s2.qd.z, s3.qd.x, s3.qd.y, s3.qd.z); }
 #endif
                         } else {
                             expand_portal(s0, s1, s2, s3, s);
@@ -1074,7 +1100,10 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, int &fault, Pai
             }
         }
     }
-    if (total > G_MAXC) { fault |= 2; total = G_MAXC; }
+    if (total > G_MAXC) { env_fault_or(cx, 2); total = G_MAXC; }
+#ifndef GRIP_COLD_PORTAL
+    if (total > PORTAL_SAFE_NCON) memo.has = 0;          // the solver is about to use the slots the portals live in: forget them (next step starts cold)
+#endif
     wave_sync();
     // lane c takes contact c
     {   const float *st = cx.envl + EF_STAGE + min(cx.sub, G_MAXC - 1) * ST_STRIDE;
@@ -1447,7 +1476,7 @@ DEVI void cone_sel(Cone &d, bool take, const Cone &s) {
 // pricing just evaluated), then the new point is priced: one pricing per iteration, none repeated. All control flow depends only on
 // all-reduced values, so the 16 lanes of an env always agree.
 DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Contact &c, bool live, int ncon,
-                       float &xi_out, float &jtfi_out, int &fault, int &iters, Stamps &st, float *dbgH = nullptr) {
+                       float &xi_out, float &jtfi_out, int &iters, Stamps &st, float *dbgH = nullptr) {
     const float lsgn = lc.lsgn, lD = lc.lD, laref = lc.laref, qsi = lc.qsi, warmi = lc.warmi, Md_w = lc.Md_w;
     const float scale = 1.0f / (m.meaninertia * 13.f);
     const float tol = fmaxf(m.tolerance, NEWTON_TOL);       // fp32 noise floor of the scaled gradient is ~1e-6
@@ -1517,6 +1546,9 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
 #pragma unroll
                     for (int j = 0; j < 13; j++) dbgH[cx.sub * 13 + j] = row[j];
                 }
+                // (gathered and factorised redundantly like the blocks: on a block-diagonal H its arithmetic is that of the block path plus exact
+                // zeros, so an uncoupled env gets the same bits whether or not a wave-mate forces the full system -- results stay independent
+                // of who shares the wave; the row-distributed Cholesky would save registers on this rare path but sums in another order)
                 float p[13];
                 gathered_solve<0>(cx, row, gi, p);
 #pragma unroll
@@ -1615,7 +1647,7 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
 #ifdef HAVE_DBG_HIST
                 if (cx.sub == 0 && iters <= 4) { const float sg = scale * sqrtf(g2); int b = 0; for (float t = 1e-7f; b < 7 && sg >= t; t *= 10.f) b++; DBG_HIST(32 + 8 * (iters - 1) + b, 1); }
 #endif
-                if (!stop && iters >= NEWTON_MAXIT) { stop = true; fault |= 4; }
+                if (!stop && iters >= NEWTON_MAXIT) { stop = true; env_fault_or(cx, 4); }
                 done = stop;
                 STAMP(st, 6);
             }
@@ -1691,18 +1723,19 @@ DEVI void forward_dense(const DevModel &m, const Ctx &cx, const Kin &k, const fl
 DEVI void env_lds_init(const Ctx &cx) {
     float *M = cx.envl + EF_M;
     for (int i = cx.sub; i < 169; i += KL) M[i] = 0.f;
+    MI(cx, cx.sub) = 0;                                   // the macro step's integer words, fault bits included
     wave_sync();
 }
 
 // dynamics stage up to qacc: constraints + Newton solve. Lane i < 13 returns component i of qacc and of the constraint force J^T f.
-DEVI void forward_acc(const DevModel &m, const Ctx &cx, Contact &con, int ncon, int &fault, float &qacci, float &jtfi, int &iters, Stamps &st, float *dbgH = nullptr) {
+DEVI void forward_acc(const DevModel &m, const Ctx &cx, Contact &con, int ncon, float &qacci, float &jtfi, int &iters, Stamps &st, float *dbgH = nullptr) {
     LaneCon lc;
     make_constraints(m, cx, con, ncon, lc);
     wave_sync();
     STAMP(st, 3);
     qacci = lc.qsi; jtfi = 0.f; iters = 0;
     if (__any(lc.constrained)) {
-        if (lc.constrained) solve_newton(m, cx, lc, con, cx.sub < ncon, ncon, qacci, jtfi, fault, iters, st, dbgH);
+        if (lc.constrained) solve_newton(m, cx, lc, con, cx.sub < ncon, ncon, qacci, jtfi, iters, st, dbgH);
     }
 #ifdef HAVE_DBG_HIST
     if (cx.sub == 0) {
@@ -1725,7 +1758,7 @@ DEVI void forward_acc(const DevModel &m, const Ctx &cx, Contact &con, int ncon, 
 // semi-implicit Euler with implicit joint damping: (M + h D) a' = qfrc_smooth + J^T f   (mj_Euler). The object block has
 // no damping, so a' = qacc there. The dof lanes hand their components over through LDS (new warm start = qacc, and qfrc_smooth + J^T f),
 // every lane integrates the whole state redundantly, lane 0 stores it. qnew: the gripper's new joint positions (control hooks).
-DEVI void integrate(const DevModel &m, const Ctx &cx, float qacci, float jtfi, int &fault, float (&qnew)[7], Stamps &st) {
+DEVI void integrate(const DevModel &m, const Ctx &cx, float qacci, float jtfi, float (&qnew)[7], Stamps &st) {
     float *S = cx.envl;
     const float h = m.timestep;
     if (cx.sub < 13) { S[ES_WARM + cx.sub] = qacci; S[ES_ACC + cx.sub] = S[ES_QFS + cx.sub] + jtfi; }
@@ -1783,7 +1816,7 @@ DEVI void integrate(const DevModel &m, const Ctx &cx, float qacci, float jtfi, i
     for (int i = 0; i < 14; i++) bad |= !(fabsf(qpos[i]) < 1e6f);
 #pragma unroll
     for (int i = 0; i < 13; i++) bad |= !(fabsf(qvel[i]) < 1e6f);
-    if (bad) fault |= 1;
+    if (bad) env_fault_or(cx, 1);
     if (cx.sub == 0) { lds_st<14>(S + ES_QPOS, qpos); lds_st<13>(S + ES_QVEL, qvel); }
 #pragma unroll
     for (int i = 0; i < 7; i++) qnew[i] = qpos[i];
@@ -1792,22 +1825,22 @@ DEVI void integrate(const DevModel &m, const Ctx &cx, float qacci, float jtfi, i
 }
 
 // dynamics + integration of one physics.step(); kinematics, forward_dense and collide must have run on the current state
-DEVI void physics_advance(const DevModel &m, const Ctx &cx, Contact &con, int ncon, int &fault, Stamps &st, float (&qnew)[7], int *newton_iters = nullptr) {
+DEVI void physics_advance(const DevModel &m, const Ctx &cx, Contact &con, int ncon, Stamps &st, float (&qnew)[7], int *newton_iters = nullptr) {
     float qacci, jtfi; int iters;
-    forward_acc(m, cx, con, ncon, fault, qacci, jtfi, iters, st);
+    forward_acc(m, cx, con, ncon, qacci, jtfi, iters, st);
     if (newton_iters) *newton_iters = iters;
-    integrate(m, cx, qacci, jtfi, fault, qnew, st);
+    integrate(m, cx, qacci, jtfi, qnew, st);
 }
 
 // one whole physics.step() on the LDS state with the stored controls (k_substep, k_reset's position stage uses the first half)
-DEVI void physics_step(const DevModel &m, const Ctx &cx, float xfrc_z, Contact &con, int &ncon, int &fault, PairMemo &memo, Stamps &st) {
+DEVI void physics_step(const DevModel &m, const Ctx &cx, float xfrc_z, Contact &con, int &ncon, PairMemo &memo, Stamps &st) {
     float qpos[14]; Kin k;
     forward_kin(m, cx, qpos, k);
     STAMP(st, 0);
     float ctrl[8]; lds_ld<8>(cx.envl + ES_CTRL, ctrl);
     forward_dense(m, cx, k, ctrl, xfrc_z, nullptr, st);
-    ncon = collide(m, cx, con, fault, memo, st);
+    ncon = collide(m, cx, con, memo, st);
     STAMP(st, 1);
     float qn[7];
-    physics_advance(m, cx, con, ncon, fault, st, qn);
+    physics_advance(m, cx, con, ncon, st, qn);
 }

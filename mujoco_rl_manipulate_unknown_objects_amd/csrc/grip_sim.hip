@@ -300,6 +300,7 @@ struct MacroCtx { int *ints; float *flts; int *astate; int *slot; int *heavy; in
 #define MCI(mc, f, e) (mc).ints[(size_t)(e) * MC_NINT_PAD + (f)]
 #define MCF(mc, f, e) (mc).flts[(size_t)(e) * MC_NFLT_PAD + (f)]
 enum { MC_PHASE = 0, MC_CNT, MC_NSUB, MC_GRASPED, MC_FLAGS, MC_FAULT, MC_NINT };
+static_assert(MC_CNT == MI_CNT && MC_NSUB == MI_NSUB && MC_GRASPED == MI_GRASPED && MC_FLAGS == MI_FLAGS && MC_FAULT == MI_FAULT, "suspended record = layout of ES_MACI");
 enum { MC_TARGET = 0, MC_INITQ = 5, MC_OPENCLOSE = 10, MC_TQ = 11, MC_INITOBJ = 12, MC_NFLT = 15 };
 static_assert(MC_NINT <= MC_NINT_PAD && MC_NFLT <= MC_NFLT_PAD, "suspended-context record too small");
 
@@ -412,7 +413,7 @@ enum { PH_MOVE = 0, PH_RETURN, PH_OPEN, PH_CLOSE, PH_FINAL, PH_DONE };
 // ------------------------------------------------------------------------------------------------
 extern __shared__ float lds_dyn[];
 #ifndef GRIP_COLD_PORTAL
-#define PAIRMEMO_EXTRA_INIT(m) (m).has = 0; for (int k_ = 0; k_ < 3; k_++) { (m).pi[k_] = 0; (m).pd[k_] = v3(0, 0, 1); }
+#define PAIRMEMO_EXTRA_INIT(m) (m).has = 0;
 #else
 #define PAIRMEMO_EXTRA_INIT(m)
 #endif
@@ -434,11 +435,12 @@ __global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_reset(const D
     env_lds_init(cx);
     if (cx.sub == 0) reset_state(m, cx);
     wave_sync();
-    Kin k; Contact con; int ncon = 0, fault = 0;
+    Kin k; Contact con; int ncon = 0;
     PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1; PAIRMEMO_EXTRA_INIT(sep)
     float q0[14];
     forward_kin(m, cx, q0, k);
-    ncon = collide(m, cx, con, fault, sep, stm);
+    ncon = collide(m, cx, con, sep, stm);
+    const int fault = env_fault(cx);
     int grasp = check_grasp(cx, con, ncon), pher = pheromone_level(k.pe, cfg);
     if (blockIdx.x == 0 && threadIdx.x == 0 && reset_info) { reset_info[0] = (float)grasp; reset_info[1] = (float)pher; reset_info[2] = k.po.x; reset_info[3] = k.po.y; }
     st_state(st, e, cx, doit);
@@ -476,27 +478,27 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
     float *S = cx.envl;
     env_lds_init(cx);
     ld_state(st, e, cx);
-    int episode_step = st.episode_step[e], status = st.status[e], gripper_open = st.gripper_open[e];
     const int adim = cfg.include_roll ? 6 : 5;
 
-    Contact con; int ncon = 0, fault = 0;
-    int phase = valid ? PH_MOVE : PH_DONE, cnt = 0, nsub = 0, grasped = 0;
-    bool reached_target = false, reached_initial = false, first = true;
+    // What the macro step carries lives in the env's LDS region (ES_MAC floats, ES_MACI integers); registers keep what the loop turns on:
+    // phase, the step budget, the "first step" flag.
+    Contact con; int ncon = 0;
+    int phase = valid ? PH_MOVE : PH_DONE;
+    bool first = true;
     size_t arow = (size_t)e;
+    if (cx.sub == 0) { MI(cx, MI_EPSTEP) = st.episode_step[e]; MI(cx, MI_STATUS) = st.status[e]; MI(cx, MI_GOPEN) = st.gripper_open[e]; }
     if (sliced && valid) {
         if (mc.astate[e] != 0) {                        // waiting: start only when the last compaction gave this env a slot
             int sl = mc.slot[e];
             if (sl >= 0 && mc.gen[e] <= mc.tick[0] - lag) arow = (size_t)sl; else phase = PH_DONE;
         } else {                                        // in flight: resume
-            phase = MCI(mc, MC_PHASE, e); cnt = MCI(mc, MC_CNT, e); nsub = MCI(mc, MC_NSUB, e);
-            grasped = MCI(mc, MC_GRASPED, e); fault = MCI(mc, MC_FAULT, e);
-            int fl = MCI(mc, MC_FLAGS, e);
-            reached_target = fl & 1; reached_initial = fl & 2; first = false;
+            phase = MCI(mc, MC_PHASE, e); first = false;
+            if (cx.sub >= 1 && cx.sub < MC_NINT) MI(cx, cx.sub) = MCI(mc, cx.sub, e);   // cnt, nsub, grasped, flags, fault: the record has the layout of ES_MACI
             if (cx.sub < MC_NFLT) S[ES_MAC + cx.sub] = MCF(mc, cx.sub, e);         // targets etc.: the record has the layout of ES_MAC
         }
     }
     wave_sync();
-    int budget = sliced ? slice : 0x7fffffff, last_iters = 0, sum_iters = 0, nsub_slice = 0;
+    int budget = sliced ? slice : 0x7fffffff;
     PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1; PAIRMEMO_EXTRA_INIT(sep)   // collide()'s per-lane memory of its pair's separating direction
 #ifndef GRIP_COLD_PORTAL
     // the portal memory lives as long as the macro step: a resumed env gets it back, so that the result does not depend on where
@@ -507,9 +509,8 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
         sep.has = w0 & 1; sep.h1 = ((w0 >> 2) & 0xfff) - 1; sep.h2 = ((w0 >> 14) & 0xfff) - 1;
         if (w0 & 2) sep.sep = v3(m0.y, m0.z, m0.w);
         if (sep.has) {                                      // only lanes whose pair was in contact carry more than the first block
-            const float4 m1 = *MEMO4(mc, e, 1, cx.sub), m2 = *MEMO4(mc, e, 2, cx.sub), m3 = *MEMO4(mc, e, 3, cx.sub);
-            sep.pi[0] = __float_as_int(m1.x); sep.pi[1] = __float_as_int(m1.y); sep.pi[2] = __float_as_int(m1.z);
-            sep.pd[0] = v3(m1.w, m2.x, m2.y); sep.pd[1] = v3(m2.z, m2.w, m3.x); sep.pd[2] = v3(m3.y, m3.z, m3.w);
+            float4 *pm = reinterpret_cast<float4 *>(S + ES_PORTAL + min(cx.sub, 10) * PORTAL_WORDS);      // (only hull-pair lanes 0..10 ever have a portal)
+            pm[0] = *MEMO4(mc, e, 1, cx.sub); pm[1] = *MEMO4(mc, e, 2, cx.sub); pm[2] = *MEMO4(mc, e, 3, cx.sub);
         }
     }
 #endif
@@ -574,7 +575,7 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
                     forward_dense(m, cx, k, ctrl, xfrc_z, nullptr, stm);
                 }
             }
-            ncon = collide(m, cx, con, fault, sep, stm);       // contacts as check_grasp sees them
+            ncon = collide(m, cx, con, sep, stm);       // contacts as check_grasp sees them
             STAMP(stm, 1);
             if (phase == PH_FINAL) {
                 // ---- robot_env.py:170-241 on the final state
@@ -582,6 +583,9 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
                 V3 fo = kc.po, fe = kc.pe;
                 V3 init_obj = v3(S[ES_MAC + MC_INITOBJ], S[ES_MAC + MC_INITOBJ + 1], S[ES_MAC + MC_INITOBJ + 2]);
                 float dxy = sqrtf((fo.x - fe.x) * (fo.x - fe.x) + (fo.y - fe.y) * (fo.y - fe.y));
+                int status = MI(cx, MI_STATUS), gripper_open = MI(cx, MI_GOPEN), episode_step = MI(cx, MI_EPSTEP), fault = MI(cx, MI_FAULT);
+                const int grasped = MI(cx, MI_GRASPED), flags = MI(cx, MI_FLAGS), nsub = MI(cx, MI_NSUB);
+                const bool reached_target = flags & 1, reached_initial = flags & 2;
                 if (dxy > 1.f) status = 1;
                 float p1 = project_dir(fo.x, fo.y, cfg);
                 float dgx = p1 * cfg.dir_x, dgy = p1 * cfg.dir_y;
@@ -631,10 +635,13 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
                 }
                 phase = PH_DONE;
             } else {
-                if (phase == PH_CLOSE) grasped = check_grasp(cx, con, ncon);       // robot_env.py:155, before the step
-                float qn[7];
-                physics_advance(m, cx, con, ncon, fault, stm, qn, &last_iters);
-                nsub++; cnt++; budget--; sum_iters += last_iters; nsub_slice++;
+                int grasped = 0;
+                if (phase == PH_CLOSE) { grasped = check_grasp(cx, con, ncon); if (cx.sub == 0) MI(cx, MI_GRASPED) = grasped; }   // robot_env.py:155, before the step
+                float qn[7]; int last_iters = 0;
+                physics_advance(m, cx, con, ncon, stm, qn, &last_iters);
+                const int cnt = MI(cx, MI_CNT) + 1;
+                if (cx.sub == 0) { MI(cx, MI_CNT) = cnt; MI(cx, MI_NSUB) += 1; MI(cx, MI_SUMIT) += last_iters; MI(cx, MI_NSLICE) += 1; }
+                budget--;
 #ifdef GRIP_STAMPS
                 stm.acc[11] += 1;               // env-substeps of this lane (lane 0 of each wave is reported)
 #endif
@@ -642,7 +649,7 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
                 // lets the waves overrun the budget by different amounts -- the launch then waits for the latest: measured -4.6 %)
                 if (budget_ticks > 0 && wall_clock64() - t_start > budget_ticks) budget = 0;
                 // ---- post-step transitions
-                bool to_gripper = false, to_final = false, set56 = false;
+                bool to_gripper = false, to_final = false, set56 = false, zero_cnt = false;
                 float c56 = 0.f;                            // new value of ctrl[5] = ctrl[6] (knuckle motors) when a transition sets them
                 if (phase == PH_MOVE || phase == PH_RETURN) {
                     float tg[8]; lds_ld<8>(S + ES_MAC + (phase == PH_RETURN ? MC_INITQ : MC_TARGET) / 4 * 4, tg);
@@ -654,35 +661,39 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
                     if (reached && cx.sub == 0) {                       // ctrl[0..4] = 0
                         *reinterpret_cast<float4 *>(S + ES_CTRL) = make_float4(0.f, 0.f, 0.f, 0.f); S[ES_CTRL + 4] = 0.f;
                     }
+                    const int flags = MI(cx, MI_FLAGS);
                     if (phase == PH_MOVE) {
-                        if (reached) reached_target = true;
+                        if (reached && cx.sub == 0) MI(cx, MI_FLAGS) = flags | 1;      // reached_target
                         if (cnt == cfg.max_steps) {                     // step_limit == 0 (:112), also when reached on the last try (Q5)
-                            phase = PH_RETURN; cnt = 0;                 // (the RETURN loop steers towards init_q: MC_INITQ of ES_MAC)
+                            phase = PH_RETURN; zero_cnt = true;         // (the RETURN loop steers towards init_q: MC_INITQ of ES_MAC)
                         } else if (reached) to_gripper = true;
                     } else {
-                        if (reached) reached_initial = true;
-                        if (reached || cnt == cfg.max_steps) { if (reached_target) to_gripper = true; else to_final = true; }
+                        if (reached && cx.sub == 0) MI(cx, MI_FLAGS) = flags | 2;      // reached_initial
+                        if (reached || cnt == cfg.max_steps) { if (flags & 1) to_gripper = true; else to_final = true; }
                     }
                 } else if (phase == PH_OPEN) {
                     const float tq = S[ES_MAC + MC_TQ];
                     bool stop = delta_pre < cfg.grasp_tolerance || (qn[5] > tq && qn[6] > tq);
-                    if (stop) gripper_open = 1;
+                    if (stop && cx.sub == 0) MI(cx, MI_GOPEN) = 1;
                     if (stop || cnt == cfg.max_steps) { c56 = 0.f; set56 = true; to_final = true; }
                 } else {   // PH_CLOSE
                     bool stop = delta_pre < cfg.grasp_tolerance || grasped == 3;
-                    if (stop) gripper_open = 0;
+                    if (stop && cx.sub == 0) MI(cx, MI_GOPEN) = 0;
                     if (stop || cnt == cfg.max_steps) { c56 = 0.f; set56 = true; to_final = true; }
                 }
                 if (to_gripper) {
                     const float open_close = S[ES_MAC + MC_OPENCLOSE];
+                    const int gripper_open = MI(cx, MI_GOPEN);
                     float tq = 0.f; bool set_tq = false;
-                    if (open_close > 0.f && !gripper_open) { phase = PH_OPEN; cnt = 0; tq = 0.4f; set_tq = true; c56 = 0.5f; set56 = true; }
-                    else if (open_close < 0.f && gripper_open) { phase = PH_CLOSE; cnt = 0; tq = -0.4f; set_tq = true; c56 = -1.f; set56 = true; }
+                    if (open_close > 0.f && !gripper_open) { phase = PH_OPEN; zero_cnt = true; tq = 0.4f; set_tq = true; c56 = 0.5f; set56 = true; }
+                    else if (open_close < 0.f && gripper_open) { phase = PH_CLOSE; zero_cnt = true; tq = -0.4f; set_tq = true; c56 = -1.f; set56 = true; }
                     else to_final = true;
                     if (set_tq && cx.sub == 0) S[ES_MAC + MC_TQ] = tq;
                 }
+                if (zero_cnt && cx.sub == 0) MI(cx, MI_CNT) = 0;
                 if (to_final) {
-                    if (!reached_target && !reached_initial) status = 1;       // robot_env.py:130-132
+                    const int flags = MI(cx, MI_FLAGS);
+                    if (!(flags & 3) && cx.sub == 0) MI(cx, MI_STATUS) = 1;       // robot_env.py:130-132: neither the target nor the initial pose reached
                     phase = PH_FINAL;
                 }
                 if (set56 && cx.sub == 0) { S[ES_CTRL + 5] = c56; S[ES_CTRL + 6] = c56; }
@@ -697,19 +708,9 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
         // cost estimate of this env's next physics.step(), in units of roughly half a plain step: Newton iterations of the
         // last solve plus 1.5 per hull-hull contact (MPR refinement); k_compact sorts the work order by it
         int hv = __popc(group_bits(__ballot(cx.sub < ncon && con.g1 != 0), cx.lane));
+        const int sum_iters = MI(cx, MI_SUMIT), nsub_slice = MI(cx, MI_NSLICE);
         // (twice the mean Newton iteration count of this slice: single steps alternate between 1 and 2 iterations)
-#ifndef HEAVY_KEY
-#define HEAVY_KEY 0
-#endif
-        if (writer && nsub_slice > 0) {
-            int key;
-            if (HEAVY_KEY == 0) key = (2 * sum_iters + nsub_slice / 2) / nsub_slice + 3 * min(hv, 3);
-            else if (HEAVY_KEY == 1) key = (4 * sum_iters + nsub_slice / 2) / nsub_slice;                       // Newton iterations only, finer
-            else if (HEAVY_KEY == 2) key = (4 * sum_iters + nsub_slice / 2) / nsub_slice + (hv > 1 ? 4 : 0);
-            else if (HEAVY_KEY == 3) key = 2 * min(last_iters, 5) + ((2 * sum_iters + nsub_slice / 2) / nsub_slice > 4 ? 1 : 0);   // the last step's count first
-            else key = (3 * sum_iters + nsub_slice / 2) / nsub_slice + min(last_iters, 3);
-            mc.heavy[e] = min(CP_CLASSES - 2, key);
-        }
+        if (writer && nsub_slice > 0) mc.heavy[e] = min(CP_CLASSES - 2, (2 * sum_iters + nsub_slice / 2) / nsub_slice + 3 * min(hv, 3));
     }
 #ifndef GRIP_COLD_PORTAL
     if (sliced && valid && phase != PH_DONE) {              // every lane parks its pair's portal memory (the flag; the portal if there is one)
@@ -717,21 +718,19 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
         const int w0 = (sep.has & 1) | (has_sep ? 2 : 0) | (((sep.h1 + 1) & 0xfff) << 2) | (((sep.h2 + 1) & 0xfff) << 14);
         *MEMO4(mc, e, 0, cx.sub) = make_float4(__int_as_float(w0), sep.sep.x, sep.sep.y, sep.sep.z);     // the direction is read back only under its flag
         if (sep.has) {
-            *MEMO4(mc, e, 1, cx.sub) = make_float4(__int_as_float(sep.pi[0]), __int_as_float(sep.pi[1]), __int_as_float(sep.pi[2]), sep.pd[0].x);
-            *MEMO4(mc, e, 2, cx.sub) = make_float4(sep.pd[0].y, sep.pd[0].z, sep.pd[1].x, sep.pd[1].y);
-            *MEMO4(mc, e, 3, cx.sub) = make_float4(sep.pd[1].z, sep.pd[2].x, sep.pd[2].y, sep.pd[2].z);
+            const float4 *pm = reinterpret_cast<const float4 *>(S + ES_PORTAL + min(cx.sub, 10) * PORTAL_WORDS);
+            *MEMO4(mc, e, 1, cx.sub) = pm[0]; *MEMO4(mc, e, 2, cx.sub) = pm[1]; *MEMO4(mc, e, 3, cx.sub) = pm[2];
         }
     }
 #endif
     if (sliced && phase != PH_DONE) {                       // out of budget mid-step: suspend
         st_state(st, e, cx, valid);
         if (valid && cx.sub < MC_NFLT) MCF(mc, cx.sub, e) = S[ES_MAC + cx.sub];
+        if (valid && cx.sub >= 1 && cx.sub < MC_NINT) MCI(mc, cx.sub, e) = MI(cx, cx.sub);      // cnt, nsub, grasped, flags, fault
         if (writer) {
-            st.status[e] = status; st.gripper_open[e] = gripper_open;
+            st.status[e] = MI(cx, MI_STATUS); st.gripper_open[e] = MI(cx, MI_GOPEN);
             mc.astate[e] = 0;
-            MCI(mc, MC_PHASE, e) = phase; MCI(mc, MC_CNT, e) = cnt; MCI(mc, MC_NSUB, e) = nsub;
-            MCI(mc, MC_GRASPED, e) = grasped; MCI(mc, MC_FAULT, e) = fault;
-            MCI(mc, MC_FLAGS, e) = (reached_target ? 1 : 0) | (reached_initial ? 2 : 0);
+            MCI(mc, MC_PHASE, e) = phase;
         }
     }
 }
@@ -881,11 +880,11 @@ __global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_substep(const
     if (e >= st.n) e = st.n - 1;          // (idle rows of a 2-env wave mirror the env of the row 32 lanes below: same reads, no writes)
     env_lds_init(cx);
     ld_state(st, e, cx);
-    Contact con; int ncon = 0, fault = 0;
+    Contact con; int ncon = 0;
     PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1; PAIRMEMO_EXTRA_INIT(sep)
-    for (int i = 0; i < nsteps; i++) physics_step(m, cx, xfrc_z, con, ncon, fault, sep, stm);
+    for (int i = 0; i < nsteps; i++) physics_step(m, cx, xfrc_z, con, ncon, sep, stm);
     st_state(st, e, cx, valid);
-    if (valid && cx.sub == 0 && fault_out) fault_out[e] = fault;
+    if (valid && cx.sub == 0 && fault_out) fault_out[e] = env_fault(cx);
 #ifdef GRIP_STAMPS
     if (blockIdx.x == 0 && threadIdx.x == 0) for (int i = 0; i < NSTAMP; i++) g_stamp_acc[i] = stm.acc[i];
 #endif
@@ -900,19 +899,19 @@ __global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_debug_forward
     if (e >= st.n) e = st.n - 1;          // (idle rows of a 2-env wave mirror the env of the row 32 lanes below: same reads, no writes)
     env_lds_init(cx);
     ld_state(st, e, cx);
-    Kin k; Contact con; int ncon = 0, fault = 0, iters = 0;
+    Kin k; Contact con; int ncon = 0, iters = 0;
     PairMemo sep; sep.sep = v3(0, 0, 0); sep.h1 = sep.h2 = -1; PAIRMEMO_EXTRA_INIT(sep)
     float q0[14], bias[13], ctrl[8];
     forward_kin(m, cx, q0, k);
     lds_ld<8>(cx.envl + ES_CTRL, ctrl);
     forward_dense(m, cx, k, ctrl, xfrc_z, bias, stm);
-    ncon = collide(m, cx, con, fault, sep, stm);
+    ncon = collide(m, cx, con, sep, stm);
     float gpos[18];                             // geom frame origins, read now: the solver reuses the frames' LDS area (EF_H)
     for (int g = 1; g <= 6; g++) { V3 p; M3 R; load_frame(cx.envl, g, p, R); gpos[3 * (g - 1)] = p.x; gpos[3 * (g - 1) + 1] = p.y; gpos[3 * (g - 1) + 2] = p.z; }
     float qs[13]; lds_ld<13>(cx.envl + ES_QS, qs);
     wave_sync();
     float qacci, jtfi, qacc[13];
-    forward_acc(m, cx, con, ncon, fault, qacci, jtfi, iters, stm, getenv_dbgH ? M_out + (size_t)e * 169 : nullptr);
+    forward_acc(m, cx, con, ncon, qacci, jtfi, iters, stm, getenv_dbgH ? M_out + (size_t)e * 169 : nullptr);
     gather13(qacci, qacc);
     if (!valid) return;
     if (cx.sub < G_MAXC) {                      // lane c reports contact c

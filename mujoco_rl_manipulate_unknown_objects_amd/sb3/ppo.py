@@ -314,8 +314,12 @@ class PPO:
     def _minibatch_update(self, src, idx):
         """One optimiser step. Eager on CPU; on a GPU two captured graphs with the (eager) gradient all-reduce between them."""
         if self.graph_update and (self._upd is None or self._upd.get("fwd") is None) and self.miopen_find:
-            with th.backends.cudnn.flags(enabled=th.backends.cudnn.enabled, benchmark=True):     # find mode for the eager steps and the capture only
+            prev = th.backends.cudnn.benchmark                   # find mode for the eager steps and the capture only
+            th.backends.cudnn.benchmark = True
+            try:
                 return self._minibatch_update_impl(src, idx)
+            finally:
+                th.backends.cudnn.benchmark = prev
         return self._minibatch_update_impl(src, idx)
 
     def _minibatch_update_impl(self, src, idx):
