@@ -377,7 +377,7 @@ def main():
             # passes of THIS command at THIS configuration (profiles/r03_pmc_summary.json: separate passes, gfx950 FETCH_SIZE
             # correction) and are attached only when the run is that configuration; otherwise traffic stays null.
             try:
-                pmj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
+                pmj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")))
                 same_cfg = (pmj.get("config") == {"object": a.object, "envs": a.envs, "state_dtype": a.state_dtype, "mixed": bool(a.mixed)})
                 pm = pmj["kernels"]["k_macro_step"]
                 if same_cfg and not a.lockstep:
