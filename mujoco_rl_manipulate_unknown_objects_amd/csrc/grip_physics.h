@@ -196,6 +196,11 @@ struct Ctx {
     Tables T;
 };
 
+// The lane's index inside its env as a value the optimiser cannot trace back to threadIdx: an address formed from it (slot, row, state word)
+// is then computed where it is used -- two integer instructions -- instead of being hoisted out of the step loop and kept in a register for the
+// whole launch (a dozen such addresses were the kernel's last spilled registers).
+DEVI int local_sub(const Ctx &cx) { int s_ = cx.sub; asm volatile("" : "+v"(s_)); return s_; }
+
 constexpr DEVI int pidx(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
 // N floats of a 16-byte aligned LDS vector (padded to a multiple of 4) into registers: ceil(N / 4) ds_read_b128, all lanes of an env read
@@ -622,9 +627,10 @@ DEVI void gathered_solve(const Ctx &cx, const float (&row)[13], float gi, float 
 // loads) and returns the block's part of the Newton direction in x (x[6] = 0 in the object block).
 DEVI void gathered_solve_block(const Ctx &cx, const float (&row)[7], float gi, float (&x)[7]) {
     float4 *H4 = reinterpret_cast<float4 *>(cx.envl + EF_H);
-    if (cx.sub < 13) { H4[2 * cx.sub] = make_float4(row[0], row[1], row[2], row[3]); H4[2 * cx.sub + 1] = make_float4(row[4], row[5], row[6], -gi); }
+    const int lsub = local_sub(cx);
+    if (lsub < 13) { H4[2 * lsub] = make_float4(row[0], row[1], row[2], row[3]); H4[2 * lsub + 1] = make_float4(row[4], row[5], row[6], -gi); }
     wave_sync();
-    const bool grip = cx.sub < 7;
+    const bool grip = lsub < 7;
     const int base = grip ? 0 : 7;
     float A[28];
 #pragma unroll
@@ -899,7 +905,7 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, PairMemo &memo,
             if (phase == 0 && memo.has) {           // rebuild the portal the last step converged to at the new poses; use it if it still holds the origin ray
                 Sup w[3];
                 int mpi[3]; V3 mpd[3];
-                {   const float4 *pm = reinterpret_cast<const float4 *>(cx.envl + ES_PORTAL + min(cx.sub, 10) * PORTAL_WORDS);
+                {   const float4 *pm = reinterpret_cast<const float4 *>(cx.envl + ES_PORTAL + min(local_sub(cx), 10) * PORTAL_WORDS);
                     const float4 m1 = pm[0], m2 = pm[1], m3 = pm[2];
                     mpi[0] = __float_as_int(m1.x); mpi[1] = __float_as_int(m1.y); mpi[2] = __float_as_int(m1.z);
                     mpd[0] = v3(m1.w, m2.x, m2.y); mpd[1] = v3(m2.z, m2.w, m3.x); mpd[2] = v3(m3.y, m3.z, m3.w); }
@@ -1051,7 +1057,7 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, PairMemo &memo,
                             pos = find_pos(s0, s1, s2, s3); hit = true;
 #ifndef GRIP_COLD_PORTAL
                             memo.has = 1;
-                            {   float4 *pm = reinterpret_cast<float4 *>(cx.envl + ES_PORTAL + min(cx.sub, 10) * PORTAL_WORDS);
+                            {   float4 *pm = reinterpret_cast<float4 *>(cx.envl + ES_PORTAL + min(local_sub(cx), 10) * PORTAL_WORDS);
                                 pm[0] = make_float4(__int_as_float(s1.id), __int_as_float(s2.id), __int_as_float(s3.id), s1.qd.x);
                                 pm[1] = make_float4(s1.qd.y, s1.qd.z, s2.qd.x, s2.qd.y); pm[2] = make_float4(s2.qd.z, s3.qd.x, s3.qd.y, s3.qd.z); }
 #endif
@@ -1204,7 +1210,7 @@ DEVI float row_dot(const float (&row)[13], const float (&v)[13]) {
 // its velocity (-> aref) and its two start residuals. State comes from the env's LDS vectors, the kinematics from ES_KIN.
 DEVI void make_constraints(const DevModel &m, const Ctx &cx, Contact &c, int ncon, LaneCon &lc) {
     float *S = cx.envl;
-    const int sub = cx.sub;
+    const int sub = local_sub(cx);
     const bool live = sub < ncon;
     {   const int j = min(sub, 6);
         const float qj = S[ES_QPOS + j], vj = S[ES_QVEL + j];
@@ -1300,7 +1306,7 @@ DEVI float price_constraints(const DevModel &m, const Ctx &cx, float lsgn, float
     cn.cost = 0.f; cn.ka = 0.f; cn.kb = 0.f;
     if (live) {
         cone_eval(c.jar, c.D0, m.impratio, c.fs, c.ft, cn);
-        *reinterpret_cast<float4 *>(cx.envl + EF_FORCE + 4 * cx.sub) = make_float4(-cn.grad[0], -cn.grad[1], -cn.grad[2], -cn.grad[3]);
+        *reinterpret_cast<float4 *>(cx.envl + EF_FORCE + 4 * local_sub(cx)) = make_float4(-cn.grad[0], -cn.grad[1], -cn.grad[2], -cn.grad[3]);
     }
     float cost = cn.cost;
     // joint limit owned by this lane (lanes 0..6): J = sgn at dof `sub`
@@ -1310,7 +1316,7 @@ DEVI float price_constraints(const DevModel &m, const Ctx &cx, float lsgn, float
     cost += lact ? 0.5f * lD * ljar * ljar : 0.f;
     hdiag = lact ? lD : 0.f;
     wave_sync();
-    const int isub = UPOS(min(cx.sub, 12));
+    const int isub = UPOS(min(local_sub(cx), 12));
     for (int k = 0; k < ncon; k++) {
         const float4 f = *reinterpret_cast<const float4 *>(cx.envl + EF_FORCE + 4 * k);
         const float *u = cx.envl + EF_U + k * 6 * U_STRIDE + isub;
@@ -1325,7 +1331,7 @@ DEVI float price_constraints(const DevModel &m, const Ctx &cx, float lsgn, float
 // assembles its own row of H (assemble_rows). The rows are re-read from the lane's own slots, four columns at a time.
 DEVI void hessian_vectors(const Ctx &cx, bool live, const Cone &cn) {
     if (!live) return;
-    float *Uf = cx.envl + EF_U + cx.sub * 6 * U_STRIDE;
+    float *Uf = cx.envl + EF_U + local_sub(cx) * 6 * U_STRIDE;
     float4 *U = reinterpret_cast<float4 *>(Uf);
 #pragma unroll
     for (int r = 0; r < 4; r++) { Uf[r * U_STRIDE + 7] = cn.w[r]; Uf[r * U_STRIDE + 15] = cn.w[r]; }
@@ -1348,7 +1354,7 @@ DEVI void hessian_vectors(const Ctx &cx, bool live, const Cone &cn) {
 // weight / padding positions, so the products there vanish)
 DEVI void contact_jp(const Ctx &cx, bool live, float (&jv)[4]) {
     if (!live) return;
-    const float4 *U = reinterpret_cast<const float4 *>(cx.envl + EF_U + cx.sub * 6 * U_STRIDE);
+    const float4 *U = reinterpret_cast<const float4 *>(cx.envl + EF_U + local_sub(cx) * 6 * U_STRIDE);
     const float4 *P = reinterpret_cast<const float4 *>(cx.envl + EF_P);
     const float4 p0 = P[0], p1 = P[1], p2 = P[2], p3 = P[3];
 #pragma unroll
@@ -1392,7 +1398,7 @@ DEVI void assemble_rows(const Ctx &cx, int ncon, float hdiag, float (&row)[13]) 
 DEVI void assemble_rows_block(const Ctx &cx, int ncon, const float (&mrow7)[7], float hdiag, float (&row)[7]) {
 #pragma unroll
     for (int j = 0; j < 7; j++) row[j] = mrow7[j];
-    const int isub = UPOS(min(cx.sub, 12)), half = cx.sub < 7 ? 0 : 2;
+    const int lsub = local_sub(cx), isub = UPOS(min(lsub, 12)), half = lsub < 7 ? 0 : 2;
     const float *U = cx.envl + EF_U;
 #pragma unroll 4
     for (int s = 0; s < 6 * ncon; s++) {
@@ -1440,8 +1446,8 @@ DEVI void price_two_starts(const DevModel &m, const Ctx &cx, float lsgn, float l
     if (live) {
         cone_eval(jar_s, c.D0, m.impratio, c.fs, c.ft, cn_s);
         cone_eval(jar_w, c.D0, m.impratio, c.fs, c.ft, cn_w);
-        *reinterpret_cast<float4 *>(cx.envl + EF_FORCE + 4 * cx.sub) = make_float4(-cn_s.grad[0], -cn_s.grad[1], -cn_s.grad[2], -cn_s.grad[3]);
-        *reinterpret_cast<float4 *>(cx.envl + EF_FORCE2 + 4 * cx.sub) = make_float4(-cn_w.grad[0], -cn_w.grad[1], -cn_w.grad[2], -cn_w.grad[3]);
+        *reinterpret_cast<float4 *>(cx.envl + EF_FORCE + 4 * local_sub(cx)) = make_float4(-cn_s.grad[0], -cn_s.grad[1], -cn_s.grad[2], -cn_s.grad[3]);
+        *reinterpret_cast<float4 *>(cx.envl + EF_FORCE2 + 4 * local_sub(cx)) = make_float4(-cn_w.grad[0], -cn_w.grad[1], -cn_w.grad[2], -cn_w.grad[3]);
     }
     lc_s = cn_s.cost; lc_w = cn_w.cost;
     {   float lj = lsgn * xs - laref; bool la = lsgn != 0.f && lj < 0.f;
@@ -1449,7 +1455,7 @@ DEVI void price_two_starts(const DevModel &m, const Ctx &cx, float lsgn, float l
     {   float lj = lsgn * xw - laref; bool la = lsgn != 0.f && lj < 0.f;
         jt_w = la ? -lD * lj * lsgn : 0.f; lc_w += la ? 0.5f * lD * lj * lj : 0.f; hd_w = la ? lD : 0.f; }
     wave_sync();
-    const int isub = UPOS(min(cx.sub, 12));
+    const int isub = UPOS(min(local_sub(cx), 12));
     for (int k = 0; k < ncon; k++) {
         const float4 f = *reinterpret_cast<const float4 *>(cx.envl + EF_FORCE + 4 * k);
         const float4 g = *reinterpret_cast<const float4 *>(cx.envl + EF_FORCE2 + 4 * k);
@@ -1482,7 +1488,8 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
     const float tol = fmaxf(m.tolerance, NEWTON_TOL);       // fp32 noise floor of the scaled gradient is ~1e-6
     // this lane's row of the (always block-diagonal) mass matrix, the seven entries of its own block
     float mrow[7];
-    {   const float *M = cx.envl + EF_M + min(cx.sub, 12) * 13 + (cx.sub < 7 ? 0 : 7);
+    {   const int lsub = local_sub(cx);
+        const float *M = cx.envl + EF_M + min(lsub, 12) * 13 + (lsub < 7 ? 0 : 7);
 #pragma unroll
         for (int j = 0; j < 7; j++) mrow[j] = (cx.sub < 13 && (j < 6 || cx.sub < 7)) ? M[min(j, cx.sub < 7 ? 6 : 5)] : 0.f;
     }
@@ -1761,7 +1768,8 @@ DEVI void forward_acc(const DevModel &m, const Ctx &cx, Contact &con, int ncon, 
 DEVI void integrate(const DevModel &m, const Ctx &cx, float qacci, float jtfi, float (&qnew)[7], Stamps &st) {
     float *S = cx.envl;
     const float h = m.timestep;
-    if (cx.sub < 13) { S[ES_WARM + cx.sub] = qacci; S[ES_ACC + cx.sub] = S[ES_QFS + cx.sub] + jtfi; }
+    {   const int lsub = local_sub(cx);
+        if (lsub < 13) { S[ES_WARM + lsub] = qacci; S[ES_ACC + lsub] = S[ES_QFS + lsub] + jtfi; } }
     wave_sync();
     float acc[13], qacc[13];
     lds_ld<13>(S + ES_ACC, acc); lds_ld<13>(S + ES_WARM, qacc);

@@ -526,7 +526,8 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
             // get a budget of their own; a workgroup that is merely placed a little late still ends with the launch
             if (now - t0v > (unsigned long long)(budget_ticks / 2)) t0v = now;
         }
-        t0v = __shfl(t0v, 0);
+        // wave-uniform: keep it in scalar registers
+        t0v = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(t0v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(t0v & 0xffffffffULL));
     }
     const long long t_start = (long long)t0v;
 
@@ -579,6 +580,7 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
             STAMP(stm, 1);
             if (phase == PH_FINAL) {
                 // ---- robot_env.py:170-241 on the final state
+                int ef = e; asm volatile("" : "+v"(ef));         // the result addresses are formed here, not before the loop (and kept)
                 KinC kc; kinc_load(S, kc);
                 V3 fo = kc.po, fe = kc.pe;
                 V3 init_obj = v3(S[ES_MAC + MC_INITOBJ], S[ES_MAC + MC_INITOBJ + 1], S[ES_MAC + MC_INITOBJ + 2]);
@@ -604,20 +606,20 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
                 episode_step += 1;
                 int pg = check_grasp(cx, con, ncon), ph = pheromone_level(fe, cfg);
                 if (writer) {
-                    if (out.reward) out.reward[e] = reward;
-                    if (out.done) out.done[e] = (uint8_t)done;
-                    if (out.status) out.status[e] = status;
-                    if (out.episode_step) out.episode_step[e] = episode_step;
-                    if (out.gripper_open) out.gripper_open[e] = gripper_open;
-                    if (out.object_grasped) out.object_grasped[e] = grasped;
-                    if (out.position_reached) out.position_reached[e] = (reached_target ? 1 : 0) | (reached_initial ? 2 : 0) | ((!reached_target && !reached_initial) ? 4 : 0);
-                    if (out.total_distance) out.total_distance[e] = sqrtf((fo.x - init_obj.x) * (fo.x - init_obj.x) + (fo.y - init_obj.y) * (fo.y - init_obj.y));
-                    if (out.line_distance) out.line_distance[e] = line;
-                    if (out.gripper_position) { out.gripper_position[3 * e] = fe.x; out.gripper_position[3 * e + 1] = fe.y; out.gripper_position[3 * e + 2] = fe.z; }
-                    if (out.object_position) { out.object_position[3 * e] = fo.x; out.object_position[3 * e + 1] = fo.y; out.object_position[3 * e + 2] = fo.z; }
-                    if (out.init_obj_pos) { out.init_obj_pos[3 * e] = init_obj.x; out.init_obj_pos[3 * e + 1] = init_obj.y; out.init_obj_pos[3 * e + 2] = init_obj.z; }
-                    if (out.n_substeps) out.n_substeps[e] = nsub;
-                    if (out.fault) out.fault[e] = fault;
+                    if (out.reward) out.reward[ef] = reward;
+                    if (out.done) out.done[ef] = (uint8_t)done;
+                    if (out.status) out.status[ef] = status;
+                    if (out.episode_step) out.episode_step[ef] = episode_step;
+                    if (out.gripper_open) out.gripper_open[ef] = gripper_open;
+                    if (out.object_grasped) out.object_grasped[ef] = grasped;
+                    if (out.position_reached) out.position_reached[ef] = (reached_target ? 1 : 0) | (reached_initial ? 2 : 0) | ((!reached_target && !reached_initial) ? 4 : 0);
+                    if (out.total_distance) out.total_distance[ef] = sqrtf((fo.x - init_obj.x) * (fo.x - init_obj.x) + (fo.y - init_obj.y) * (fo.y - init_obj.y));
+                    if (out.line_distance) out.line_distance[ef] = line;
+                    if (out.gripper_position) { out.gripper_position[3 * ef] = fe.x; out.gripper_position[3 * ef + 1] = fe.y; out.gripper_position[3 * ef + 2] = fe.z; }
+                    if (out.object_position) { out.object_position[3 * ef] = fo.x; out.object_position[3 * ef + 1] = fo.y; out.object_position[3 * ef + 2] = fo.z; }
+                    if (out.init_obj_pos) { out.init_obj_pos[3 * ef] = init_obj.x; out.init_obj_pos[3 * ef + 1] = init_obj.y; out.init_obj_pos[3 * ef + 2] = init_obj.z; }
+                    if (out.n_substeps) out.n_substeps[ef] = nsub;
+                    if (out.fault) out.fault[ef] = fault;
                 }
                 float agx = fo.x, agy = fo.y;
                 if (done && (cfg.auto_reset || diverged)) {
@@ -625,13 +627,13 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
                     episode_step = 0; status = 0; gripper_open = 1;
                     pg = (int)reset_info[0]; ph = (int)reset_info[1]; agx = reset_info[2]; agy = reset_info[3]; dgx = cfg.dir_x; dgy = cfg.dir_y;
                 }
-                st_state(st, e, cx, valid);
+                st_state(st, ef, cx, valid);
                 if (writer) {
-                    if (out.achieved_goal) { out.achieved_goal[2 * e] = agx; out.achieved_goal[2 * e + 1] = agy; }
-                    if (out.desired_goal) { out.desired_goal[2 * e] = dgx; out.desired_goal[2 * e + 1] = dgy; }
-                    st.pad_grasp[e] = pg; st.pad_pher[e] = ph;
-                    st.episode_step[e] = episode_step; st.status[e] = status; st.gripper_open[e] = gripper_open;
-                    if (mc.astate) { mc.astate[e] = 1; mc.slot[e] = -1; }
+                    if (out.achieved_goal) { out.achieved_goal[2 * ef] = agx; out.achieved_goal[2 * ef + 1] = agy; }
+                    if (out.desired_goal) { out.desired_goal[2 * ef] = dgx; out.desired_goal[2 * ef + 1] = dgy; }
+                    st.pad_grasp[ef] = pg; st.pad_pher[ef] = ph;
+                    st.episode_step[ef] = episode_step; st.status[ef] = status; st.gripper_open[ef] = gripper_open;
+                    if (mc.astate) { mc.astate[ef] = 1; mc.slot[ef] = -1; }
                 }
                 phase = PH_DONE;
             } else {
@@ -659,7 +661,8 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
                     for (int i = 0; i < 5; i++) dmax = fmaxf(dmax, fabsf(qn[i] - (o ? tg[i + 1] : tg[i])));
                     bool reached = dmax < cfg.pos_tolerance;            // post-step qpos (quirk Q4)
                     if (reached && cx.sub == 0) {                       // ctrl[0..4] = 0
-                        *reinterpret_cast<float4 *>(S + ES_CTRL) = make_float4(0.f, 0.f, 0.f, 0.f); S[ES_CTRL + 4] = 0.f;
+                        float z = 0.f; asm volatile("" : "+v"(z));      // (a zero made here: a hoisted constant vector was being kept -- spilled -- across the loop)
+                        *reinterpret_cast<float4 *>(S + ES_CTRL) = make_float4(z, z, z, z); S[ES_CTRL + 4] = z;
                     }
                     const int flags = MI(cx, MI_FLAGS);
                     if (phase == PH_MOVE) {
@@ -704,33 +707,34 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
 #ifdef GRIP_STAMPS
     if (cx.lane == 0) for (int i = 0; i < NSTAMP; i++) atomicAdd(&g_stamp_acc[i], stm.acc[i]);      // whole-GPU phase totals (diagnostic build)
 #endif
+    int ee = e; asm volatile("" : "+v"(ee));                 // (the suspend addresses are formed here, after the loop)
     if (sliced) {
         // cost estimate of this env's next physics.step(), in units of roughly half a plain step: Newton iterations of the
         // last solve plus 1.5 per hull-hull contact (MPR refinement); k_compact sorts the work order by it
         int hv = __popc(group_bits(__ballot(cx.sub < ncon && con.g1 != 0), cx.lane));
         const int sum_iters = MI(cx, MI_SUMIT), nsub_slice = MI(cx, MI_NSLICE);
         // (twice the mean Newton iteration count of this slice: single steps alternate between 1 and 2 iterations)
-        if (writer && nsub_slice > 0) mc.heavy[e] = min(CP_CLASSES - 2, (2 * sum_iters + nsub_slice / 2) / nsub_slice + 3 * min(hv, 3));
+        if (writer && nsub_slice > 0) mc.heavy[ee] = min(CP_CLASSES - 2, (2 * sum_iters + nsub_slice / 2) / nsub_slice + 3 * min(hv, 3));
     }
 #ifndef GRIP_COLD_PORTAL
     if (sliced && valid && phase != PH_DONE) {              // every lane parks its pair's portal memory (the flag; the portal if there is one)
         const bool has_sep = dot(sep.sep, sep.sep) > 0.5f;
         const int w0 = (sep.has & 1) | (has_sep ? 2 : 0) | (((sep.h1 + 1) & 0xfff) << 2) | (((sep.h2 + 1) & 0xfff) << 14);
-        *MEMO4(mc, e, 0, cx.sub) = make_float4(__int_as_float(w0), sep.sep.x, sep.sep.y, sep.sep.z);     // the direction is read back only under its flag
+        *MEMO4(mc, ee, 0, cx.sub) = make_float4(__int_as_float(w0), sep.sep.x, sep.sep.y, sep.sep.z);     // the direction is read back only under its flag
         if (sep.has) {
             const float4 *pm = reinterpret_cast<const float4 *>(S + ES_PORTAL + min(cx.sub, 10) * PORTAL_WORDS);
-            *MEMO4(mc, e, 1, cx.sub) = pm[0]; *MEMO4(mc, e, 2, cx.sub) = pm[1]; *MEMO4(mc, e, 3, cx.sub) = pm[2];
+            *MEMO4(mc, ee, 1, cx.sub) = pm[0]; *MEMO4(mc, ee, 2, cx.sub) = pm[1]; *MEMO4(mc, ee, 3, cx.sub) = pm[2];
         }
     }
 #endif
     if (sliced && phase != PH_DONE) {                       // out of budget mid-step: suspend
-        st_state(st, e, cx, valid);
-        if (valid && cx.sub < MC_NFLT) MCF(mc, cx.sub, e) = S[ES_MAC + cx.sub];
-        if (valid && cx.sub >= 1 && cx.sub < MC_NINT) MCI(mc, cx.sub, e) = MI(cx, cx.sub);      // cnt, nsub, grasped, flags, fault
+        st_state(st, ee, cx, valid);
+        if (valid && cx.sub < MC_NFLT) MCF(mc, cx.sub, ee) = S[ES_MAC + cx.sub];
+        if (valid && cx.sub >= 1 && cx.sub < MC_NINT) MCI(mc, cx.sub, ee) = MI(cx, cx.sub);      // cnt, nsub, grasped, flags, fault
         if (writer) {
-            st.status[e] = MI(cx, MI_STATUS); st.gripper_open[e] = MI(cx, MI_GOPEN);
-            mc.astate[e] = 0;
-            MCI(mc, MC_PHASE, e) = phase;
+            st.status[ee] = MI(cx, MI_STATUS); st.gripper_open[ee] = MI(cx, MI_GOPEN);
+            mc.astate[ee] = 0;
+            MCI(mc, MC_PHASE, ee) = phase;
         }
     }
 }
