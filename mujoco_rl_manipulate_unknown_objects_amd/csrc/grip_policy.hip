@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) k_conv1_prep(const float *__restrict__ w,
 
 // row0 != NULL: image b is row row0[0] + b of obs (the trainer's record rows of this tick: the observation kernel renders straight into them)
 __global__ void __launch_bounds__(256) k_conv1_u8(const uint8_t *__restrict__ obs, const long long *__restrict__ row0, int n_img, int channels, const float *__restrict__ Bg,
-                                                  const float *__restrict__ bias, float *__restrict__ out, float *__restrict__ other) {
+                                                  const float *__restrict__ bias, float *__restrict__ out, float *__restrict__ other, uint32_t *__restrict__ mask) {
     __shared__ __attribute__((aligned(16))) uint8_t img[C1_IN * C1_HW * C1_HW];
     __shared__ __attribute__((aligned(16))) float B[C1_KDIM * C1_OUT];
     const int tid = threadIdx.x;
@@ -100,27 +100,36 @@ __global__ void __launch_bounds__(256) k_conv1_u8(const uint8_t *__restrict__ ob
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int p = (wave + 4 * t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (p < C1_POS) out[((size_t)b * C1_POS + p) * C1_OUT + m] = fmaxf(acc[t][r] + bn, 0.f);
+            const float v = acc[t][r] + bn;
+            if (p < C1_POS) out[((size_t)b * C1_POS + p) * C1_OUT + m] = fmaxf(v, 0.f);
+            if (mask) {                                                 // training: bit c of word (image, position) = channel c is active (the backward's ReLU mask)
+                const unsigned long long bal = __ballot(v > 0.f);
+                if (m == 0 && p < C1_POS) mask[(size_t)b * C1_POS + p] = half ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+            }
         }
     }
   }
 }
 
+extern "C" int grip_conv1_u8_train(const uint8_t *obs_dev, const int64_t *row0_dev, int n, int channels, const float *weight_dev, const int64_t *weight_strides,
+                                   const float *bias_dev, float *scratch_dev, float *out_nhwc_dev, float *other_dev, uint32_t *mask_dev, void *stream);
 extern "C" int grip_conv1_u8_rows(const uint8_t *obs_dev, const int64_t *row0_dev, int n, int channels, const float *weight_dev, const int64_t *weight_strides,
-                                  const float *bias_dev, float *scratch_dev, float *out_nhwc_dev, float *other_dev, void *stream);
+                                  const float *bias_dev, float *scratch_dev, float *out_nhwc_dev, float *other_dev, void *stream) {
+    return grip_conv1_u8_train(obs_dev, row0_dev, n, channels, weight_dev, weight_strides, bias_dev, scratch_dev, out_nhwc_dev, other_dev, nullptr, stream);
+}
 extern "C" int grip_conv1_u8(const uint8_t *obs_dev, int n, int channels, const float *weight_dev, const int64_t *weight_strides, const float *bias_dev,
                              float *scratch_dev, float *out_nhwc_dev, float *other_dev, void *stream) {
     return grip_conv1_u8_rows(obs_dev, nullptr, n, channels, weight_dev, weight_strides, bias_dev, scratch_dev, out_nhwc_dev, other_dev, stream);
 }
-extern "C" int grip_conv1_u8_rows(const uint8_t *obs_dev, const int64_t *row0_dev, int n, int channels, const float *weight_dev, const int64_t *weight_strides,
-                                  const float *bias_dev, float *scratch_dev, float *out_nhwc_dev, float *other_dev, void *stream) {
+extern "C" int grip_conv1_u8_train(const uint8_t *obs_dev, const int64_t *row0_dev, int n, int channels, const float *weight_dev, const int64_t *weight_strides,
+                                   const float *bias_dev, float *scratch_dev, float *out_nhwc_dev, float *other_dev, uint32_t *mask_dev, void *stream) {
     if (!obs_dev || !weight_dev || !weight_strides || !bias_dev || !scratch_dev || !out_nhwc_dev || !other_dev || n <= 0 || channels != C1_IN + 1)
         return grip_fail("grip_conv1_u8: need uint8 [n, 5, 64, 64] observations, Conv2d(4, 32, 8, 4) weights and bias, a 32 KB scratch and the two outputs");
     hipLaunchKernelGGL(k_conv1_prep, dim3(C1_KDIM * C1_OUT / 256), dim3(256), 0, (hipStream_t)stream, weight_dev, (long long)weight_strides[0], (long long)weight_strides[1],
                        (long long)weight_strides[2], (long long)weight_strides[3], scratch_dev);
     const int resident = 256 * 3;                               // 48 KB of LDS per workgroup: three per CU
     const int per_wg = (n + resident - 1) / resident, grid = (n + per_wg - 1) / per_wg;
-    hipLaunchKernelGGL(k_conv1_u8, dim3(grid), dim3(256), 0, (hipStream_t)stream, obs_dev, (const long long *)row0_dev, n, channels, (const float *)scratch_dev, bias_dev, out_nhwc_dev, other_dev);
+    hipLaunchKernelGGL(k_conv1_u8, dim3(grid), dim3(256), 0, (hipStream_t)stream, obs_dev, (const long long *)row0_dev, n, channels, (const float *)scratch_dev, bias_dev, out_nhwc_dev, other_dev, mask_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { char buf[160]; snprintf(buf, sizeof buf, "grip_conv1_u8: %s", hipGetErrorString(e)); return grip_fail(buf); }
     return 0;
@@ -256,7 +265,8 @@ __global__ void __launch_bounds__(256) k_conv23_prep(const float *__restrict__ w
 }
 
 __global__ void __launch_bounds__(256) k_conv23(const float *__restrict__ y1, int n_img, const float *__restrict__ B2, const float *__restrict__ bias2,
-                                                const float *__restrict__ B3, const float *__restrict__ bias3, float *__restrict__ out) {
+                                                const float *__restrict__ B3, const float *__restrict__ bias3, float *__restrict__ out, float *__restrict__ y2_out,
+                                                uint16_t *__restrict__ mask2, uint16_t *__restrict__ mask3) {
     extern __shared__ __attribute__((aligned(16))) float c2_lds[];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r16 = l & 15, kq = l >> 4;
     const int img0 = blockIdx.x * C2_G, nimg = min(C2_G, n_img - img0);
@@ -328,7 +338,15 @@ __global__ void __launch_bounds__(256) k_conv23(const float *__restrict__ y1, in
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int m = t * 16 + 4 * kq + r;                    // = g * 36 + position
-                c2_lds[m * C2_PS2 + ncol] = fmaxf(acc[t][r] + bn, 0.f);
+                const float v = fmaxf(acc[t][r] + bn, 0.f);
+                c2_lds[m * C2_PS2 + ncol] = v;
+                if (y2_out) {                                         // training: the activation for the weight gradient, and its ReLU mask -- bit c of the 64-bit word
+                    const unsigned long long bal = __ballot(v > 0.f);  // (image, position) = channel c is active; this wave's 16 channels are one uint16 of it
+                    if (m < nimg * 36) {
+                        y2_out[((size_t)img0 * 36 + m) * 64 + ncol] = v;
+                        if (r16 == 0) mask2[((size_t)img0 * 36 + m) * 4 + w] = (uint16_t)(bal >> (16 * kq));
+                    }
+                }
             }
         }
     }
@@ -377,7 +395,14 @@ __global__ void __launch_bounds__(256) k_conv23(const float *__restrict__ y1, in
         for (int g = 0; g < C2_G; g++) {
             if (g < nimg) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) out[((size_t)(img0 + g) * 16 + 4 * kq + r) * 64 + ncol] = fmaxf(acc3[g][r] + bn, 0.f);
+                for (int r = 0; r < 4; r++) {
+                    const float v = fmaxf(acc3[g][r] + bn, 0.f);
+                    out[((size_t)(img0 + g) * 16 + 4 * kq + r) * 64 + ncol] = v;
+                    if (mask3) {
+                        const unsigned long long bal = __ballot(v > 0.f);
+                        if (r16 == 0) mask3[((size_t)(img0 + g) * 16 + 4 * kq + r) * 4 + w] = (uint16_t)(bal >> (16 * kq));
+                    }
+                }
             }
         }
     }
@@ -394,8 +419,16 @@ extern "C" int grip_conv23_prep(const float *w2_dev, const int64_t *w2_strides, 
     return 0;
 }
 
+extern "C" int grip_conv23_train(const float *y1_nhwc_dev, int n, const float *b2_mat_dev, const float *bias2_dev, const float *b3_mat_dev, const float *bias3_dev,
+                                 float *out_nhwc_dev, float *y2_nhwc_dev, uint64_t *mask2_dev, uint64_t *mask3_dev, void *stream);
 extern "C" int grip_conv23(const float *y1_nhwc_dev, int n, const float *b2_mat_dev, const float *bias2_dev, const float *b3_mat_dev, const float *bias3_dev,
                            float *out_nhwc_dev, void *stream) {
+    return grip_conv23_train(y1_nhwc_dev, n, b2_mat_dev, bias2_dev, b3_mat_dev, bias3_dev, out_nhwc_dev, nullptr, nullptr, nullptr, stream);
+}
+extern "C" int grip_conv23_train(const float *y1_nhwc_dev, int n, const float *b2_mat_dev, const float *bias2_dev, const float *b3_mat_dev, const float *bias3_dev,
+                                 float *out_nhwc_dev, float *y2_nhwc_dev, uint64_t *mask2_dev, uint64_t *mask3_dev, void *stream) {
+    if ((y2_nhwc_dev != nullptr) != (mask2_dev != nullptr) || (y2_nhwc_dev != nullptr) != (mask3_dev != nullptr))
+        return grip_fail("grip_conv23_train: the training outputs (y2, mask2, mask3) come together or not at all");
     if (!y1_nhwc_dev || !b2_mat_dev || !bias2_dev || !b3_mat_dev || !bias3_dev || !out_nhwc_dev || n <= 0)
         return grip_fail("grip_conv23: need y1 [n, 15, 15, 32], the two weight matrices of grip_conv23_prep, both biases and the output [n, 4, 4, 64]");
     const size_t lds = (size_t)C2_LDS_FLOATS * sizeof(float);
@@ -409,7 +442,8 @@ extern "C" int grip_conv23(const float *y1_nhwc_dev, int n, const float *b2_mat_
             attr_set_mask.fetch_or(bit, std::memory_order_release);
         }
     }
-    hipLaunchKernelGGL(k_conv23, dim3((n + C2_G - 1) / C2_G), dim3(256), lds, (hipStream_t)stream, y1_nhwc_dev, n, b2_mat_dev, bias2_dev, b3_mat_dev, bias3_dev, out_nhwc_dev);
+    hipLaunchKernelGGL(k_conv23, dim3((n + C2_G - 1) / C2_G), dim3(256), lds, (hipStream_t)stream, y1_nhwc_dev, n, b2_mat_dev, bias2_dev, b3_mat_dev, bias3_dev, out_nhwc_dev, y2_nhwc_dev,
+                       (uint16_t *)mask2_dev, (uint16_t *)mask3_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { char buf[160]; snprintf(buf, sizeof buf, "grip_conv23: %s", hipGetErrorString(e)); return grip_fail(buf); }
     return 0;

@@ -1,0 +1,372 @@
+// grip_train.hip -- backward pass of AugmentedNatureCNN's three convolutions (reference models/feature_extractor.py:14-22) for the PPO / SAC
+// update, on the matrix cores in exact fp32 (v_mfma_f32_16x16x4_f32 / v_mfma_f32_32x32x2_f32: fp32 products, fp32 sums -- the arithmetic of
+// the tensor library's fp32 path up to the order of summation).
+//
+// As tensor-library calls the backward of the trunk is, per 4096-sample minibatch on MI355X: data gradients 109 + 306 us (the stride-2 4 x 4
+// layer at 32 TFLOP/s), weight gradients 55 + 93 + 211 us, three ReLU-mask passes (16 + 16 + 49 us), three bias-gradient reductions
+// (14 + 18 + 39 us), a uint8 -> float image pass for the first layer's weight gradient (67 us) and ~40 us of zero-fills: ~1.0 ms of the
+// update's 2.0 ms. Here:
+//   k_conv23_dgrad     g3 (gradient at the third layer's ReLU output) -> masked g3, masked g2, masked g1 in ONE launch: both data gradients as
+//                      scatter GEMMs whose column blocks are summed into an LDS tile, g2 never leaving LDS between the layers, the three ReLU
+//                      masks folded into the loads / stores.
+//   k_conv1_wgrad_u8   first layer's weight + bias gradient straight from the uint8 observation (no float image).
+//   k_conv2_wgrad, k_conv3_wgrad   weight + bias gradients of the other two layers.
+//   k_wgrad_reduce     the workgroups' partial sums -> the gradient tensors (deterministic: fixed order, no atomics).
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <stdint.h>
+#include <cstdio>
+
+int grip_fail(const char *msg);                     // grip_sim.hip
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_trunk_bwd. Shapes (NHWC): y1 [n, 15, 15, 32], y2 [n, 6, 6, 64], y3 [n, 4, 4, 64] (post-ReLU activations of the forward), g3 [n, 4, 4, 64] = d loss / d y3,
+// obs uint8 [n, 5, 64, 64]. Weights as the forward's GEMM operands (grip_conv23_prep): B3[(ky, kx, ci)][co] (576 x 64), B2[(ky, kx, ci)][co] (512 x 64).
+//   g3m = g3 * (y3 > 0)
+//   col3[(img, oy, ox)][(ky, kx, ci)] = sum_co g3m[img, oy, ox, co] * w3[co, ci, ky, kx];  g2[img, oy + ky, ox + kx, ci] += col3;  g2m = g2 * (y2 > 0)
+//   col2[(img, oy, ox)][(ky, kx, ci)] = sum_co g2m[img, oy, ox, co] * w2[co, ci, ky, kx];  g1[img, 2 oy + ky, 2 ox + kx, ci] += col2;  g1m = g1 * (y1 > 0)
+//   dW1[(ci, ky, kx)][co] += sum_(oy, ox) obs[img, ci, 4 oy + ky, 4 ox + kx] * g1m[img, oy, ox, co];  db1[co] += sum g1m        (dW1 / 255 in the reduction)
+// Persistent workgroups (4 waves) walk groups of DG = 2 images, two workgroups per CU (one stages / masks while the other's MFMAs run).
+// The data-gradient GEMMs: M = (image, position) rows, K = 64 output channels, N = (ky, kx, ci) columns; the A operand (the masked gradient tile) sits in
+// registers for the whole GEMM, the weights come from L2 (16 floats per lane and 16-column block, requested one block ahead). The reduction index is
+// permuted -- k-step j of an instruction pairs co = 16 (l >> 4) + j -- so that a lane's 16 operand values are contiguous in memory (b128 reads) in both A
+// and B; a sum does not care. After the 16 k-steps of a column block its 16 x 16 tile is ADDED into the LDS tile of the layer below, software-pipelined: the
+// reads of the old values go out before the first half of the NEXT block's MFMAs, the adds and writes sit between its halves (an add pass issued on its own
+// costs 60 cycles per word: 65 us of the first version's 225). No atomics: in GEMM 1 wave w owns input channels 16 w .. 16 w + 15 of every tap; in GEMM 2
+// wave w owns the taps of one parity class (ky & 1, kx & 1) = (w >> 1, w & 1), whose target pixels have that parity -- waves never touch the same word,
+// within a wave one block's rows are distinct pixels and blocks follow in program order.
+// The first layer's weight gradient never sees g1 in memory: the masked tile stays in LDS and is the B operand of v_mfma_f32_32x32x2_f32 against the
+// image bytes (A, converted on the fly; the planes of one image take the place of the dead g2 tile): M = 256 patch elements (wave w = plane w, two 32-row
+// tiles = ky 0..3 / 4..7), N = 32 channels, K = 225 positions per image, accumulated in registers over all of the workgroup's images.
+#define DG 2
+#define D_PS1 34                            // floats per g1 pixel in LDS
+#define D_PS2 68                            // floats per g2 / g3 row in LDS
+#define D_T1 (DG * 225 * D_PS1)             // g1 tile; the g3 tile (DG * 16 * D_PS2 floats) lives in its first part until GEMM 1 has its operands
+#define D_T2 (DG * 36 * D_PS2)              // g2 tile; later the four 64 x 64 byte planes of one image (16 KB of its 19.1)
+#define D_LDS_FLOATS (D_T1 + D_T2)
+#define TB_PART (256 * 32 + 32)             // floats of a workgroup's partial sums: dW1 as [(ci, ky, kx)][co], then db1[co]
+
+// MT row tiles x NB column blocks. The lane's A operand of tile t and k-steps 4 q .. 4 q + 3 is the float4 at TA[arow[t] + 4 q] (row t * 16 + (l & 15), co = 16 (l >> 4) + 4 q ..),
+// read again for every column block (20 b128 reads per 80 MFMAs) rather than held (80 registers); bofs(nb) = float offset of the block's weights from Bp;
+// tgt(nb, t, r) = LDS word (index into T) the lane's accumulator element r of tile t is added to, if live(t). The adds of block nb are pipelined into block
+// nb + 1: the old sums are requested before its MFMAs, added and written back between its first and second k-quarter (ds_add_f32 would need no registers,
+// but executes at a few lanes per cycle: 3x the whole kernel's time).
+// A later block's reads see words OTHER LANES of the wave wrote in an earlier one: the hardware executes a wave's LDS instructions in order, but to the
+// compiler those are different threads -- wave_order() keeps it from moving reads above earlier writes.
+__device__ __forceinline__ void wave_order() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+template <int MT, int NB, class BOfs, class Tgt, class Live>
+__device__ __forceinline__ void scatter_gemm(const float *TA, const int (&arow)[MT], const float *__restrict__ Bp, float *T, BOfs bofs, Tgt tgt, Live live) {
+    float4 bn[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) bn[q] = *reinterpret_cast<const float4 *>(Bp + bofs(0) + 4 * q);
+    f32x4 prev[MT];
+#pragma unroll
+    for (int nb = 0; nb <= NB; nb++) {
+        float4 b[4], aq[MT];
+        float old[MT][4];
+        if (nb < NB) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) b[q] = bn[q];
+            if (nb + 1 < NB) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) bn[q] = *reinterpret_cast<const float4 *>(Bp + bofs(nb + 1) + 4 * q);
+            }
+#pragma unroll
+            for (int t = 0; t < MT; t++) aq[t] = *reinterpret_cast<const float4 *>(TA + arow[t]);
+        }
+        if (nb > 0) {
+#pragma unroll
+            for (int t = 0; t < MT; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) old[t][r] = T[tgt(nb - 1, t, r)];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // the requests (next block's weights, first operands, old sums) stay above the MFMAs: the scheduler would sink them to their uses
+        f32x4 acc[MT];
+#pragma unroll
+        for (int t = 0; t < MT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (nb < NB) {
+                if (q > 0) {                    // (not double-buffered: 20 registers this kernel does not have; the co-resident workgroup's wave covers the LDS latency)
+#pragma unroll
+                    for (int t = 0; t < MT; t++) aq[t] = *reinterpret_cast<const float4 *>(TA + arow[t] + 4 * q);
+                }
+#pragma unroll
+                for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[t].x, b[q].x, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[t].y, b[q].y, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[t].z, b[q].z, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[t].w, b[q].w, acc[t], 0, 0, 0);
+            }
+            if (q == 0 && nb > 0) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < MT; t++)
+                    if (live(t)) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) T[tgt(nb - 1, t, r)] = old[t][r] + prev[t][r];
+                    }
+                wave_order();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (nb < NB) {
+#pragma unroll
+            for (int t = 0; t < MT; t++) prev[t] = acc[t];
+        }
+    }
+}
+
+__device__ __forceinline__ float4 relu_mask(float4 y, float4 v) { return make_float4(y.x > 0.f ? v.x : 0.f, y.y > 0.f ? v.y : 0.f, y.z > 0.f ? v.z : 0.f, y.w > 0.f ? v.w : 0.f); }
+
+__device__ __forceinline__ float4 bit_mask(unsigned bits, float4 v) { return make_float4(bits & 1u ? v.x : 0.f, bits & 2u ? v.y : 0.f, bits & 4u ? v.z : 0.f, bits & 8u ? v.w : 0.f); }
+
+struct GroupIn { float4 g3[2]; unsigned m3[2]; unsigned long long m2; unsigned m1[2]; };     // a thread's share of a group's gradient tile and ReLU masks
+
+__device__ __forceinline__ void group_in_load(GroupIn &gi, int tl, int img0, int nimg, const float *__restrict__ g3, const uint16_t *__restrict__ m3h,
+                                              const unsigned long long *__restrict__ m2, const uint32_t *__restrict__ m1) {
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int i = tl + 256 * u, row = i >> 4, c4 = (i & 15) * 4;
+        gi.g3[u] = make_float4(0.f, 0.f, 0.f, 0.f); gi.m3[u] = 0u;
+        if ((row >> 4) < nimg) {
+            gi.g3[u] = *reinterpret_cast<const float4 *>(g3 + ((size_t)img0 * 16 + row) * 64 + c4);
+            gi.m3[u] = (unsigned)m3h[((size_t)img0 * 16 + row) * 4 + (c4 >> 4)] >> (c4 & 15);
+        }
+        const int pj = tl + 256 * u;
+        gi.m1[u] = pj < nimg * 225 ? m1[(size_t)img0 * 225 + pj] : 0u;
+    }
+    gi.m2 = tl < nimg * 36 ? m2[(size_t)img0 * 36 + tl] : 0ULL;
+}
+
+__global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ g3, const uint64_t *__restrict__ m3, const uint64_t *__restrict__ m2, const uint32_t *__restrict__ m1,
+                                                      const uint8_t *__restrict__ obs, int channels, const float *__restrict__ B3, const float *__restrict__ B2, int n_img,
+                                                      float *__restrict__ g3m_out, float *__restrict__ g2m_out, float *__restrict__ g1m_out, float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float d_lds[];
+    float *T1 = d_lds, *T2 = d_lds + D_T1, *T3 = d_lds;
+    uint8_t *U = reinterpret_cast<uint8_t *>(T2);
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r16 = l & 15, kq = l >> 4;
+    const int half = l >> 5, m32 = l & 31;                               // lane roles in the 32 x 32 x 2 instruction
+    f32x16 cw[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) cw[t][r] = 0.f;
+    float bsum = 0.f;
+    const int ngroups = (n_img + DG - 1) / DG;
+    GroupIn gi;
+    if ((int)blockIdx.x < ngroups) group_in_load(gi, tid, blockIdx.x * DG, min(DG, n_img - (int)blockIdx.x * DG), g3, reinterpret_cast<const uint16_t *>(m3),
+                                                 reinterpret_cast<const unsigned long long *>(m2), m1);
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int img0 = grp * DG, nimg = min(DG, n_img - img0);
+    // the weights are the same for every group: hidden from the optimiser, which would otherwise hoist all 68 float4 loads per lane out of this loop (and spill them)
+    const float *B3g = B3, *B2g = B2;
+    asm volatile("" : "+s"(B3g), "+s"(B2g));
+    int tl = tid;                                                           // likewise the staging passes' per-thread indices (all functions of tid): recomputed, not kept
+    asm volatile("" : "+v"(tl));
+    // ---- g3m = g3 * mask3 -> T3 (and memory: the third layer's weight gradient reads it); zero T2
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int i = tl + 256 * u, row = i >> 4, c4 = (i & 15) * 4;
+        const float4 v = bit_mask(gi.m3[u], gi.g3[u]);
+        if (g3m_out && (row >> 4) < nimg) *reinterpret_cast<float4 *>(g3m_out + ((size_t)img0 * 16 + row) * 64 + c4) = v;
+        *reinterpret_cast<float4 *>(T3 + row * D_PS2 + c4) = v;
+    }
+#pragma unroll 1
+    for (int i = tl; i < D_T2 / 4; i += 256) reinterpret_cast<float4 *>(T2)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (tl < DG * 36) *reinterpret_cast<unsigned long long *>(T2 + tl * D_PS2 + 64) = gi.m2;      // the rows' ReLU masks ride in their padding words (the GEMMs never touch them)
+    // ---- GEMM 1: rows (image t, position r16 = oy * 4 + ox), 9 column blocks (taps) of this wave's 16 input channels
+    {
+        int arow[DG];
+#pragma unroll
+        for (int t = 0; t < DG; t++) arow[t] = (t * 16 + r16) * D_PS2 + 16 * kq;
+        const int tb = kq * 6 * D_PS2 + 16 * w + r16;                      // the lane holds rows 4 kq + r: (oy, ox) = (kq, r)
+        scatter_gemm<DG, 9>(T3, arow, B3g + (size_t)(16 * w + r16) * 64 + 16 * kq, T2,
+                            [](int c) { return c * 4096; },                  // column n = c * 64 + 16 w + r16
+                            [&](int c, int t, int r) { return tb + (t * 36 + (c / 3) * 6 + r + (c % 3)) * D_PS2; }, [](int) { return true; });
+    }
+    __syncthreads();                                                        // T2 complete, T3 no longer needed
+    // ---- g2m = g2 * mask2: to memory (the second layer's weight gradient reads it) and back into T2 as GEMM 2's operand; zero T1
+#pragma unroll
+    for (int u = 0; u < 5; u++) {
+        const int i = tl + 256 * u, row = i >> 4, c4 = (i & 15) * 4;
+        if (i < DG * 36 * 16) {
+            const unsigned bits = reinterpret_cast<const unsigned *>(T2)[row * D_PS2 + 64 + (c4 >> 5)] >> (c4 & 31);
+            const float4 v = bit_mask(bits, *reinterpret_cast<float4 *>(T2 + row * D_PS2 + c4));
+            *reinterpret_cast<float4 *>(T2 + row * D_PS2 + c4) = v;
+            if (row < nimg * 36) *reinterpret_cast<float4 *>(g2m_out + ((size_t)img0 * 36 + row) * 64 + c4) = v;
+        }
+    }
+#pragma unroll 1
+    for (int i = tl; i < D_T1 / 4; i += 256) reinterpret_cast<float4 *>(T1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+        if (tl + 256 * u < DG * 225) reinterpret_cast<unsigned *>(T1)[(tl + 256 * u) * D_PS1 + 32] = gi.m1[u];
+    // ---- GEMM 2: rows m = image * 36 + position (72 = 4.5 tiles: the last half tile is padding, computed from a clamped row and dropped), 8 column
+    // blocks = this wave's 4 taps x 2 channel halves
+    {
+        int arow[5], base[5][4];
+        const int py = w >> 1, px = w & 1;
+#pragma unroll
+        for (int t = 0; t < 5; t++) {
+            arow[t] = min(t * 16 + r16, DG * 36 - 1) * D_PS2 + 16 * kq;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {               // (the wave's parity offset goes into the base: what is left per block is a compile-time constant, i.e. an instruction offset)
+                const int mo = min(t * 16 + 4 * kq + r, DG * 36 - 1), g = mo / 36, p = mo - g * 36, oy = p / 6, ox = p - oy * 6;
+                base[t][r] = (g * 225 + (2 * oy + py) * 15 + 2 * ox + px) * D_PS1 + r16;
+            }
+        }
+        const bool pad_ok = kq < 2;                     // tile 4: rows 64 + 4 kq + r exist for kq < 2 only
+        // column block nt: tap (ky, kx) = (py + 2 (nt >> 2), px + 2 ((nt >> 1) & 1)), channel half nt & 1; n = (ky * 4 + kx) * 32 + 16 (nt & 1) + r16
+        scatter_gemm<5, 8>(T2, arow, B2g + (size_t)((py * 4 + px) * 32 + r16) * 64 + 16 * kq, T1,
+                           [](int nt) { return (((nt >> 2) * 8 + 2 * ((nt >> 1) & 1)) * 32 + 16 * (nt & 1)) * 64; },
+                           [&](int nt, int t, int r) { return base[t][r] + ((nt >> 2) * 30 + 2 * ((nt >> 1) & 1)) * D_PS1 + 16 * (nt & 1); },
+                           [&](int t) { return t < 4 || pad_ok; });
+    }
+    __syncthreads();                                                        // T1 complete, T2 free
+    // ---- g1m = g1 * mask1, in place (and to memory when asked for), while the first image's byte planes are on their way (to registers, then U = T2's space)
+    uint4 pa = make_uint4(0, 0, 0, 0), pb = pa, pc = pa, pd = pa;            // (scalars: as an array the four land in scratch memory)
+    if (obs) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(obs + (size_t)img0 * channels * 4096) + tl;
+        pa = src[0]; pb = src[256]; pc = src[512]; pd = src[768];
+    }
+#pragma unroll 2
+    for (int i = tl; i < DG * 225 * 8; i += 256) {
+        const int pix = i >> 3, c4 = (i & 7) * 4;
+        float2 *tp = reinterpret_cast<float2 *>(T1 + pix * D_PS1 + c4);
+        const float2 v0 = tp[0], v1 = tp[1];
+        const float4 v = bit_mask(reinterpret_cast<const unsigned *>(T1)[pix * D_PS1 + 32] >> c4, make_float4(v0.x, v0.y, v1.x, v1.y));
+        tp[0] = make_float2(v.x, v.y); tp[1] = make_float2(v.z, v.w);
+        if (g1m_out && i < nimg * 225 * 8) *reinterpret_cast<float4 *>(g1m_out + (size_t)img0 * 7200 + (size_t)i * 4) = v;
+    }
+    const int gnext = grp + gridDim.x;
+    auto next_group = [&]() {
+        if (gnext < ngroups)
+            group_in_load(gi, tl, gnext * DG, min(DG, n_img - gnext * DG), g3, reinterpret_cast<const uint16_t *>(m3), reinterpret_cast<const unsigned long long *>(m2), m1);
+    };
+    // K loop over an image's 225 positions, two per instruction: pos = 2 j + half
+    auto wgrad_image = [&](int g) {
+        const uint8_t *ap = U + w * 4096 + (m32 >> 3) * 64 + (m32 & 7);        // + (4 oy) * 64 + 4 ox; second tile (ky + 4): + 256
+        const float *bp = T1 + g * 225 * D_PS1 + m32;
+        int pos = half, oy = 0, ox = half;
+        asm volatile("" : "+v"(pos), "+v"(oy), "+v"(ox));                    // (or the whole 113-step address sequence is computed once, outside the group loop, and spilled)
+        float a0n = (float)ap[4 * ox], a1n = (float)ap[4 * ox + 256], bnx = bp[pos * D_PS1];
+#ifdef EXP_NOWGRAD
+        if (n_img < 0)
+#endif
+#pragma unroll 1
+        for (int j = 0; j < 113; j++) {
+            const float a0 = a0n, a1 = a1n, b = bnx;
+            pos += 2; ox += 2;
+            if (ox >= 15) { ox -= 15; oy++; }
+            const bool valid = pos < 225;
+            const int off = valid ? oy * 256 + 4 * ox : 0;
+            a0n = (float)ap[off]; a1n = (float)ap[off + 256];
+            bnx = valid ? bp[pos * D_PS1] : 0.f;
+            bsum += b;
+            cw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, cw[0], 0, 0, 0);
+            cw[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, cw[1], 0, 0, 0);
+        }
+    };
+    if (obs) {
+        uint4 *Uq = reinterpret_cast<uint4 *>(U) + tl;
+        Uq[0] = pa; Uq[256] = pb; Uq[512] = pc; Uq[768] = pd;
+        __syncthreads();
+        // requests that fly during the K loop (it issues none of its own): the second image's planes, or the next group's gradient tile and masks
+        if (nimg > 1) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(obs + (size_t)(img0 + 1) * channels * 4096) + tl;
+            pa = src[0]; pb = src[256]; pc = src[512]; pd = src[768];
+        } else next_group();
+        wgrad_image(0);
+        if (nimg > 1) {
+            __syncthreads();                                                // every wave is done with the first image's planes
+            Uq[0] = pa; Uq[256] = pb; Uq[512] = pc; Uq[768] = pd;
+            __syncthreads();
+            next_group();
+            wgrad_image(1);
+        }
+    } else next_group();
+    __syncthreads();                                                        // before the next group's staging
+  }
+    if (part) {
+        float *P = part + (size_t)blockIdx.x * TB_PART;
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;          // = ky_local * 8 + kx of tile t
+                P[(w * 64 + t * 32 + row) * 32 + m32] = cw[t][r];
+            }
+        bsum += __shfl_xor(bsum, 32);
+        if (w == 0 && l < 32) P[256 * 32 + l] = bsum;
+    }
+}
+
+// dW1[co][ci][ky][kx] = sum over the workgroups' partials / 255 (the forward multiplies bytes by w / 255), db1[co] = sum: 32 outputs per block,
+// 8 slices of the partials each, added in a fixed order
+__global__ void __launch_bounds__(256) k_wgrad1_reduce(const float *__restrict__ part, int nparts, float *__restrict__ gw, long long so, long long sc, long long sy, long long sx,
+                                                        float *__restrict__ gb) {
+    __shared__ float red[8][32];
+    const int o = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
+    float s = 0.f;
+    for (int p = sl; p < nparts; p += 8) s += part[(size_t)p * TB_PART + o];
+    red[sl][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (sl == 0) {
+        float t = red[0][threadIdx.x];
+#pragma unroll
+        for (int i = 1; i < 8; i++) t += red[i][threadIdx.x];
+        if (o < 256 * 32) {
+            const int mm = o >> 5, co = o & 31, ci = mm >> 6, ky = (mm >> 3) & 7, kx = mm & 7;
+            gw[co * so + ci * sc + ky * sy + kx * sx] = t * (1.0f / 255.0f);
+        } else gb[o - 256 * 32] = t;
+    }
+}
+
+static int set_dyn_lds(const void *fn, size_t bytes, std::atomic<unsigned long long> &mask, const char *who) {
+    // the dynamic-LDS opt-in is a per-DEVICE function attribute: remember it per device (a process may drive several GPUs, from several threads)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return grip_fail("grip_train: no current device");
+    const unsigned long long bit = 1ULL << (dev & 63);
+    if (!(mask.load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) { char buf[96]; snprintf(buf, sizeof buf, "%s: cannot reserve LDS", who); return grip_fail(buf); }
+        mask.fetch_or(bit, std::memory_order_release);
+    }
+    return 0;
+}
+
+static int launch_check(const char *who) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { char buf[160]; snprintf(buf, sizeof buf, "%s: %s", who, hipGetErrorString(e)); return grip_fail(buf); }
+    return 0;
+}
+
+extern "C" int grip_trunk_backward_parts(int n) { const int groups = (n + DG - 1) / DG; return groups < 512 ? groups : 512; }
+
+extern "C" int grip_trunk_backward(const float *g3_dev, const uint64_t *mask3_dev, const uint64_t *mask2_dev, const uint32_t *mask1_dev, const uint8_t *obs_dev, int channels,
+                                   const float *b3_mat_dev, const float *b2_mat_dev, int n, float *g3m_dev, float *g2m_dev, float *g1m_dev, float *partials_dev,
+                                   float *grad_w1_dev, const int64_t *grad_w1_strides, float *grad_b1_dev, void *stream) {
+    if (!g3_dev || !mask3_dev || !mask2_dev || !mask1_dev || !b3_mat_dev || !b2_mat_dev || !g2m_dev || n <= 0)
+        return grip_fail("grip_trunk_backward: need g3 [n, 4, 4, 64], the three ReLU masks of the training forward (grip_conv1_u8_train, grip_conv23_train), the two weight "
+                         "matrices of grip_conv23_prep and the output g2m");
+    if (obs_dev && (channels != 5 || !partials_dev || !grad_w1_dev || !grad_w1_strides || !grad_b1_dev))
+        return grip_fail("grip_trunk_backward: with observations (uint8 [n, 5, 64, 64]) the partial-sum scratch (grip_trunk_backward_parts(n) x 8224 floats) and the "
+                         "first layer's gradient outputs are needed");
+    if (!obs_dev && !g1m_dev) return grip_fail("grip_trunk_backward: nothing to do with the first layer's gradient (neither observations nor g1m)");
+    static std::atomic<unsigned long long> mask{0ULL};
+    const size_t lds = (size_t)D_LDS_FLOATS * sizeof(float);
+    if (set_dyn_lds((const void *)k_trunk_bwd, lds, mask, "grip_trunk_backward")) return -1;
+    const int parts = grip_trunk_backward_parts(n);
+    hipLaunchKernelGGL(k_trunk_bwd, dim3(parts), dim3(256), lds, (hipStream_t)stream, g3_dev, mask3_dev, mask2_dev, mask1_dev, obs_dev, channels, b3_mat_dev, b2_mat_dev, n, g3m_dev, g2m_dev,
+                       g1m_dev, obs_dev ? partials_dev : (float *)nullptr);
+    if (obs_dev)
+        hipLaunchKernelGGL(k_wgrad1_reduce, dim3(TB_PART / 32), dim3(256), 0, (hipStream_t)stream, (const float *)partials_dev, parts, grad_w1_dev, (long long)grad_w1_strides[0],
+                           (long long)grad_w1_strides[1], (long long)grad_w1_strides[2], (long long)grad_w1_strides[3], grad_b1_dev);
+    return launch_check("grip_trunk_backward");
+}

@@ -46,7 +46,7 @@ def build_library(force=False, verbose=False):
         cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-fno-strict-aliasing", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
                "-fgpu-flush-denormals-to-zero", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-shared", "-fPIC"] + extra + ["-o", tmp,
                os.path.join(CSRC, "grip_sim.hip"), os.path.join(CSRC, "grip_render.hip"), os.path.join(CSRC, "grip_rollout.hip"),
-               os.path.join(CSRC, "grip_policy.hip")]
+               os.path.join(CSRC, "grip_policy.hip"), os.path.join(CSRC, "grip_train.hip")]
         procs.append((path, tmp, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
     for path, tmp, pr in procs:                                  # the two builds run side by side
         out, err = pr.communicate()
@@ -106,7 +106,8 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_set_flags", "grip_batch_substep", "grip_batch_debug_forward", "grip_batch_target_pose",
            "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward", "grip_obs_preprocess",
            "grip_batch_set_state_storage", "grip_batchset_create", "grip_batchset_destroy", "grip_batchset_refresh", "grip_batchset_num_envs",
-           "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list", "grip_conv1_u8", "grip_conv1_u8_rows", "grip_batch_render_camera", "grip_ppo_loss", "grip_conv23_prep", "grip_conv23"]
+           "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list", "grip_conv1_u8", "grip_conv1_u8_rows", "grip_batch_render_camera", "grip_ppo_loss", "grip_conv23_prep", "grip_conv23",
+           "grip_trunk_backward", "grip_trunk_backward_parts", "grip_conv1_u8_train", "grip_conv23_train"]
 
 
 def lib():
@@ -163,6 +164,10 @@ def lib():
     L.grip_conv1_u8_rows.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int64), vp, vp, vp, vp, vp]
     L.grip_conv23_prep.argtypes = [vp, C.POINTER(C.c_int64), vp, C.POINTER(C.c_int64), vp, vp, vp]
     L.grip_conv23.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.grip_conv23_train.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.grip_conv1_u8_train.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int64), vp, vp, vp, vp, vp, vp]
+    L.grip_trunk_backward.argtypes = [vp] * 5 + [C.c_int, vp, vp, C.c_int] + [vp] * 5 + [C.POINTER(C.c_int64), vp, vp]
+    L.grip_trunk_backward_parts.argtypes = [C.c_int]
     L.grip_ppo_loss.argtypes = [vp] * 7 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float] + [vp] * 5
     L.grip_batch_render_camera.argtypes = [vp, C.c_int, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp]
     L.grip_rollout_tick.argtypes = [vp, vp]
@@ -221,7 +226,7 @@ class RecordRows:
         return self.records[r:r + self.n]
 
 
-def conv1_u8(obs, weight, bias):
+def conv1_u8(obs, weight, bias, with_mask=False):
     """First layer of AugmentedNatureCNN for rollouts (grip_conv1_u8, csrc/grip_policy.hip): uint8 CUDA observations
     [n, 5, 64, 64] -> (relu(conv2d(obs[:, :4] / 255, weight, bias, stride 4)) as a channels-last float32 [n, 32, 15, 15]
     tensor, the two sensor-pad scalars / 255 as [n, 2]) in one launch on the matrix cores (f32 MFMA). No autograd."""
@@ -237,9 +242,12 @@ def conv1_u8(obs, weight, bias):
     scratch = torch.empty(8192, dtype=torch.float32, device=obs.device)
     strides = (C.c_int64 * 4)(*weight.stride())
     stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
-    _chk(lib().grip_conv1_u8_rows(C.c_void_p(obs.data_ptr()), None if rows is None else C.c_void_p(rows.row0.data_ptr()), n, 5, C.c_void_p(weight.data_ptr()), strides,
-                                  C.c_void_p(bias.data_ptr()), C.c_void_p(scratch.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(other.data_ptr()), stream))
-    return out, other
+    # with_mask (the update's forward): also the layer's ReLU mask, int32 [n, 225], bit c of word (image, position) = channel c is active
+    mask = torch.empty((n, 225), dtype=torch.int32, device=obs.device) if with_mask else None
+    _chk(lib().grip_conv1_u8_train(C.c_void_p(obs.data_ptr()), None if rows is None else C.c_void_p(rows.row0.data_ptr()), n, 5, C.c_void_p(weight.data_ptr()), strides,
+                                   C.c_void_p(bias.data_ptr()), C.c_void_p(scratch.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(other.data_ptr()),
+                                   None if mask is None else C.c_void_p(mask.data_ptr()), stream))
+    return (out, other, mask) if with_mask else (out, other)
 
 
 def conv23_prep(w2, w3, b2_mat=None, b3_mat=None):
@@ -255,7 +263,7 @@ def conv23_prep(w2, w3, b2_mat=None, b3_mat=None):
     return b2_mat, b3_mat
 
 
-def conv23(y1, b2_mat, bias2, b3_mat, bias3):
+def conv23(y1, b2_mat, bias2, b3_mat, bias3, train=False):
     """relu(conv3(relu(conv2(y1)))) of AugmentedNatureCNN for rollouts in one launch (grip_conv23, csrc/grip_policy.hip): y1 = conv1_u8's
     channels-last float32 [n, 32, 15, 15] -> channels-last float32 [n, 64, 4, 4]. No autograd."""
     import torch
@@ -264,9 +272,49 @@ def conv23(y1, b2_mat, bias2, b3_mat, bias3):
     assert tuple(b2_mat.shape) == (512, 64) and tuple(b3_mat.shape) == (576, 64) and bias2.is_contiguous() and bias3.is_contiguous()
     out = torch.empty((n, 64, 4, 4), dtype=torch.float32, device=y1.device, memory_format=torch.channels_last)
     stream = C.c_void_p(torch.cuda.current_stream(y1.device).cuda_stream)
-    _chk(lib().grip_conv23(C.c_void_p(y1.data_ptr()), n, C.c_void_p(b2_mat.data_ptr()), C.c_void_p(bias2.data_ptr()), C.c_void_p(b3_mat.data_ptr()),
-                           C.c_void_p(bias3.data_ptr()), C.c_void_p(out.data_ptr()), stream))
-    return out
+    # train (the update's forward): also y2 (channels-last [n, 64, 6, 6]) and the two layers' ReLU masks, int64 [n, 36] / [n, 16], bit c = channel c is active
+    y2 = torch.empty((n, 64, 6, 6), dtype=torch.float32, device=y1.device, memory_format=torch.channels_last) if train else None
+    m2 = torch.empty((n, 36), dtype=torch.int64, device=y1.device) if train else None
+    m3 = torch.empty((n, 16), dtype=torch.int64, device=y1.device) if train else None
+    vp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    _chk(lib().grip_conv23_train(C.c_void_p(y1.data_ptr()), n, C.c_void_p(b2_mat.data_ptr()), C.c_void_p(bias2.data_ptr()), C.c_void_p(b3_mat.data_ptr()),
+                                 C.c_void_p(bias3.data_ptr()), C.c_void_p(out.data_ptr()), vp(y2), vp(m2), vp(m3), stream))
+    return (out, y2, m2, m3) if train else out
+
+
+def _nhwc(t, c, hw):
+    import torch
+    return t.is_cuda and t.dtype == torch.float32 and tuple(t.shape[1:]) == (c, hw, hw) and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def trunk_backward(g3, mask3, mask2, mask1, obs, b3_mat, b2_mat, w1=None, want_g1m=False):
+    """Backward of AugmentedNatureCNN's convolutions below the third layer's output, one launch (grip_trunk_backward, csrc/grip_train.hip):
+    g3 = d loss / d y3 (channels-last float32 [n, 64, 4, 4]), the ReLU masks of the training forward (conv23(train=True): mask3 int64 [n, 16], mask2
+    int64 [n, 36]; conv1_u8(with_mask=True): mask1 int32 [n, 225]), the weight matrices of conv23_prep, the uint8 observations [n, 5, 64, 64] (None:
+    no first-layer weight gradient) and the first layer's weight (for the gradient's shape and strides) -> (g3 * mask3, d loss / d conv2's
+    pre-activation, d loss / d w1, d loss / d b1, d loss / d conv1's pre-activation or None), the data gradients channels-last."""
+    import torch
+    n = int(g3.shape[0])
+    assert _nhwc(g3, 64, 4)
+    for m, shape, dt in ((mask3, (n, 16), torch.int64), (mask2, (n, 36), torch.int64), (mask1, (n, 225), torch.int32)):
+        assert m.is_cuda and m.dtype == dt and tuple(m.shape) == shape and m.is_contiguous()
+    assert tuple(b2_mat.shape) == (512, 64) and tuple(b3_mat.shape) == (576, 64) and b2_mat.is_contiguous() and b3_mat.is_contiguous()
+    g3m = torch.empty_like(g3)
+    g2m = torch.empty((n, 64, 6, 6), dtype=torch.float32, device=g3.device, memory_format=torch.channels_last)
+    g1m = torch.empty((n, 32, 15, 15), dtype=torch.float32, device=g3.device, memory_format=torch.channels_last) if want_g1m or obs is None else None
+    gw = gb = part = None
+    vp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    strides = None
+    if obs is not None:
+        assert obs.is_cuda and obs.dtype == torch.uint8 and obs.is_contiguous() and tuple(obs.shape) == (n, 5, 64, 64)
+        assert w1 is not None and tuple(w1.shape) == (32, 4, 8, 8) and w1.dtype == torch.float32
+        gw = torch.empty_like(w1); gb = torch.empty(32, dtype=torch.float32, device=g3.device)
+        part = torch.empty((int(lib().grip_trunk_backward_parts(n)), 8224), dtype=torch.float32, device=g3.device)
+        strides = (C.c_int64 * 4)(*gw.stride())
+    stream = C.c_void_p(torch.cuda.current_stream(g3.device).cuda_stream)
+    _chk(lib().grip_trunk_backward(vp(g3), vp(mask3), vp(mask2), vp(mask1), vp(obs), 5, vp(b3_mat), vp(b2_mat), n, vp(g3m), vp(g2m), vp(g1m), vp(part), vp(gw), strides,
+                                   vp(gb), stream))
+    return g3m, g2m, gw, gb, g1m
 
 
 def ppo_loss(mean, log_std, values, actions, old_log_prob, advantages, returns, clip_range, ent_coef, vf_coef):

@@ -367,6 +367,7 @@ def test_fused_first_layer_gradients_match_the_library_path(torch):
     assert torch.equal(other, obs[:, 4, 0, :2].float() / 255.0)
     assert (gwa - gwb).abs().max() < 1e-4 * gwb.abs().max() and (gba - gbb).abs().max() < 1e-4 * gbb.abs().max()
     feats = {}
+    net.fused_trunk_training = False                   # (the all-layers path has its own test: tests/test_gpu_train_kernels.py)
     for fused in (True, False):
         net.fused_first_layer_training = fused
         feats[fused] = net({"observation": obs}).detach()

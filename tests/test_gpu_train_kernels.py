@@ -1,0 +1,104 @@
+"""Hand-written backward of AugmentedNatureCNN's convolutions (csrc/grip_train.hip) against the tensor library's fp32 autograd on the same
+inputs (reference models/feature_extractor.py:14-22 trained by stable_baselines3 in fp32). Tolerances: both sides sum fp32 products of the same
+operands in different orders, over up to 576 (data gradients) / 4096 x 225 (weight gradients) terms."""
+import pytest
+import torch as th
+
+pytestmark = pytest.mark.gpu
+
+
+def _trunk(n, seed=0):
+    g = th.Generator(device="cuda").manual_seed(seed)
+    dev = "cuda"
+    y1 = th.relu(th.randn(n, 32, 15, 15, device=dev, generator=g)).contiguous(memory_format=th.channels_last)
+    w2 = (th.randn(64, 32, 4, 4, device=dev, generator=g) * 0.05).contiguous(memory_format=th.channels_last)
+    w3 = (th.randn(64, 64, 3, 3, device=dev, generator=g) * 0.05).contiguous(memory_format=th.channels_last)
+    b2 = th.randn(64, device=dev, generator=g) * 0.1
+    b3 = th.randn(64, device=dev, generator=g) * 0.1
+    return y1, w2, b2, w3, b3, g
+
+
+def _reference(n, seed):
+    """fp32 autograd through the three layers on a random uint8 observation: everything the kernels are compared with"""
+    y1_, w2, b2, w3, b3, g = _trunk(1, seed)
+    obs = th.randint(0, 256, (n, 5, 64, 64), device="cuda", dtype=th.uint8, generator=g)
+    w1 = (th.randn(32, 4, 8, 8, device="cuda", generator=g) * 0.05).contiguous(memory_format=th.channels_last).requires_grad_(True)
+    b1 = (th.randn(32, device="cuda", generator=g) * 0.1).requires_grad_(True)
+    x = (obs[:, :4].float() / 255.0).contiguous(memory_format=th.channels_last)
+    p1 = th.nn.functional.conv2d(x, w1, b1, stride=4); y1 = th.relu(p1)
+    p2 = th.nn.functional.conv2d(y1, w2, b2, stride=2); y2 = th.relu(p2)
+    p3 = th.nn.functional.conv2d(y2, w3, b3); y3 = th.relu(p3)
+    g3 = th.randn(y3.shape, device="cuda", generator=g).contiguous(memory_format=th.channels_last)
+    for t in (p1, p2, p3): t.retain_grad()
+    y3.backward(g3)
+    cl = lambda t: t.detach().contiguous(memory_format=th.channels_last)
+    return dict(obs=obs, w1=w1, b1=b1, b2=b2, b3=b3, w2=w2, w3=w3, y1=cl(y1), y2=cl(y2), y3=cl(y3), g3=g3, g3m=cl(p3.grad), g2m=cl(p2.grad), g1m=cl(p1.grad), gw1=w1.grad, gb1=b1.grad)
+
+
+def _close(a, b, rel):
+    err = (a - b).abs().max().item()
+    assert err <= rel * max(1.0, b.abs().max().item()), (err, b.abs().max().item())
+
+
+def _bits(mask, nbits):
+    """[n, P] integer words -> bool [n, nbits, P]"""
+    sh = th.arange(nbits, device=mask.device, dtype=mask.dtype).view(1, nbits, 1)
+    return ((mask.unsqueeze(1) >> sh) & 1).bool()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 64, 257, 1031])
+def test_trunk_backward_matches_autograd(n):
+    from mujoco_rl_manipulate_unknown_objects_amd.engine import conv23_prep, conv1_u8, conv23, trunk_backward
+    R = _reference(n, seed=n)
+    b2m, b3m = conv23_prep(R["w2"], R["w3"])
+    # the training forward: activations as the tensor library's, masks = their signs
+    y1, other, m1 = conv1_u8(R["obs"], R["w1"].detach(), R["b1"].detach(), with_mask=True)
+    y3, y2, m2, m3 = conv23(y1, b2m, R["b2"], b3m, R["b3"], train=True)
+    th.cuda.synchronize()
+    _close(y1, R["y1"], 1e-5); _close(y2, R["y2"], 1e-5); _close(y3, R["y3"], 1e-5)
+    assert th.equal(_bits(m1, 32).view(n, 32, 15, 15), y1 > 0) and th.equal(_bits(m2, 64).view(n, 64, 6, 6), y2 > 0) and th.equal(_bits(m3, 64).view(n, 64, 4, 4), y3 > 0)
+    # masks of the REFERENCE activations for the comparison of the gradients (a pre-activation within rounding of zero may flip between the two forwards)
+    pack = lambda y, dt: (((y.flatten(2) > 0).to(dt)) << th.arange(y.shape[1], device="cuda", dtype=dt).view(1, -1, 1)).sum(1).contiguous()
+    m1r, m2r, m3r = pack(R["y1"], th.int64).to(th.int32), pack(R["y2"], th.int64), pack(R["y3"], th.int64)
+    g3m, g2m, gw, gb, g1m = trunk_backward(R["g3"], m3r, m2r, m1r, R["obs"], b3m, b2m, R["w1"].detach(), want_g1m=True)
+    th.cuda.synchronize()
+    assert th.equal(g3m, R["g3m"])                                       # a mask: exact
+    _close(g2m, R["g2m"], 2e-5); _close(g1m, R["g1m"], 2e-5)
+    assert ((g2m == 0) == (R["g2m"] == 0)).float().mean().item() > 0.999 and ((g1m == 0) == (R["g1m"] == 0)).float().mean().item() > 0.999       # same masks
+    assert gw.stride() == R["w1"].stride()
+    _close(gw, R["gw1"], 1e-4); _close(gb, R["gb1"], 1e-4)               # sums over n x 225 positions
+    # without the on-chip consumer: data gradients only, same values; and run-to-run bit-identical
+    a = trunk_backward(R["g3"], m3r, m2r, m1r, None, b3m, b2m)
+    assert th.equal(a[1], g2m) and th.equal(a[4], g1m) and a[2] is None
+    b = trunk_backward(R["g3"], m3r, m2r, m1r, R["obs"], b3m, b2m, R["w1"].detach())
+    assert th.equal(b[2], gw) and th.equal(b[3], gb) and b[4] is None
+
+
+def test_extractor_trains_the_same_through_the_fused_trunk():
+    """AugmentedNatureCNN.forward under autograd: the hand-written trunk (_CnnTrunk + the NHWC linear layer) against the tensor library's modules on
+    the same parameters and uint8 observations -- features to 2e-5, every parameter's gradient under a random linear loss to 2e-4 of its largest
+    entry (sums over 4096 x up to 225 positions in different orders; a ReLU within rounding of zero may flip between the two forwards)."""
+    import numpy as np
+    from mujoco_rl_manipulate_unknown_objects_amd import spaces
+    from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
+    osp = spaces.Dict({"observation": spaces.Box(0, 255, shape=(5, 64, 64), dtype=np.uint8)})
+    th.manual_seed(0)
+    net = AugmentedNatureCNN(osp).cuda().to(memory_format=th.channels_last)
+    with th.no_grad():
+        for p in net.parameters():
+            if p.ndim == 1:
+                p.add_(0.05 * th.randn_like(p))
+    obs = th.randint(0, 256, (520, 5, 64, 64), dtype=th.uint8, device="cuda")
+    G = th.randn(520, 514, device="cuda")
+    out, grads = {}, {}
+    for fused in (True, False):
+        net.fused_trunk_training = fused; net.fused_first_layer_training = False
+        net.zero_grad(set_to_none=True)
+        f = net({"observation": obs})
+        (f * G).sum().backward()
+        out[fused] = f.detach(); grads[fused] = {k: p.grad.clone() for k, p in net.named_parameters()}
+    _close(out[True], out[False], 2e-5)
+    for k in grads[False]:
+        assert grads[True][k].shape == grads[False][k].shape and grads[True][k].stride() == grads[False][k].stride(), k
+        err = (grads[True][k] - grads[False][k]).abs().max().item()
+        assert err <= 2e-4 * grads[False][k].abs().max().item(), (k, err, grads[False][k].abs().max().item())
