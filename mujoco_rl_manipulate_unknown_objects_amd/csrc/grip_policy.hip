@@ -10,8 +10,8 @@
 // A workgroup (4 waves) per image at a time. LDS: the image's four 64 x 64 uint8 planes (16 KB) and the
 // weights as B[k][n] f32, already divided by 255 (32 KB). Wave w owns the 32-position tiles w and w + 4 (two independent accumulators; positions
 // 225..255 of the last tile are padding). Per (ci, ky) a lane reads the 8 bytes of its position's kernel row once
-// (two ds_read_b32, 4-byte aligned because the stride is 4) and converts the four bytes of its k-half with
-// v_cvt_f32_ubyte; lanes 0-31 / 32-63 read consecutive 128-byte rows of B: conflict-free.
+// (one ds_read_b32 of its k-half's word, 4-byte aligned because the stride is 4) and converts its four bytes with
+// v_cvt_f32_ubyte0..3; lanes 0-31 / 32-63 read 128-byte rows of B.
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <stdint.h>
@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256) k_conv1_prep(const float *__restrict__ w,
 }
 
 // row0 != NULL: image b is row row0[0] + b of obs (the trainer's record rows of this tick: the observation kernel renders straight into them)
-__global__ void __launch_bounds__(256) k_conv1_u8(const uint8_t *__restrict__ obs, const long long *__restrict__ row0, int n_img, int channels, const float *__restrict__ Bg,
+__global__ void __launch_bounds__(256, 3) k_conv1_u8(const uint8_t *__restrict__ obs, const long long *__restrict__ row0, int n_img, int channels, const float *__restrict__ Bg,
                                                   const float *__restrict__ bias, float *__restrict__ out, float *__restrict__ other, uint32_t *__restrict__ mask) {
     __shared__ __attribute__((aligned(16))) uint8_t img[C1_IN * C1_HW * C1_HW];
     __shared__ __attribute__((aligned(16))) float B[C1_KDIM * C1_OUT];
@@ -73,27 +73,42 @@ __global__ void __launch_bounds__(256) k_conv1_u8(const uint8_t *__restrict__ ob
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
     const unsigned *img32 = reinterpret_cast<const unsigned *>(img);
-#pragma unroll 4
+    // the instruction's two k values are kx = j (lanes 0-31) and kx = j + 4 (lanes 32-63): a lane needs ONE word of its position's kernel row, and the byte it
+    // converts is a compile-time index (v_cvt_f32_ubyte{j}: one VALU instruction per MFMA -- VALU instructions are not free next to MFMAs, they take issue
+    // cycles of the same SIMD: tools/hiptests/t_mfma_peak.hip). The operands of row r + 1 are requested before the eight MFMAs of row r (left to itself the
+    // scheduler reads each B pair right before its use, and every second MFMA waits a full LDS latency).
+    unsigned aw[2];
+    float bw[4];
+    const float *Bh = B + 4 * half * C1_OUT + m;
+#pragma unroll
+    for (int t = 0; t < 2; t++) aw[t] = img32[(base[t] >> 2) + half];
+#pragma unroll
+    for (int j = 0; j < 4; j++) bw[j] = Bh[j * C1_OUT];
+#pragma unroll 2
     for (int row = 0; row < C1_IN * C1_K; row++) {                // (ci, ky)
-        const int ci = row >> 3, ky = row & 7;
-        unsigned a0[2], a1[2];
+        const int rn = min(row + 1, C1_IN * C1_K - 1), ci = rn >> 3, ky = rn & 7;
+        unsigned an[2];
+        float bnx[4];
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const int off = (ci * C1_HW * C1_HW + ky * C1_HW + base[t]) >> 2;
-            a0[t] = img32[off]; a1[t] = img32[off + 1];                 // kx 0..3, 4..7
-        }
-        const float *Bk = B + (row * 8 + half) * C1_OUT + m;
+        for (int t = 0; t < 2; t++) an[t] = img32[((ci * C1_HW * C1_HW + ky * C1_HW + base[t]) >> 2) + half];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {                                   // k = row * 8 + 2 j + half
-            const float bv = Bk[2 * j * C1_OUT];
-            const int kx = 2 * j + half;
+        for (int j = 0; j < 4; j++) bnx[j] = Bh[(rn * 8 + j) * C1_OUT];
+        __builtin_amdgcn_sched_barrier(0);
+        float av[2][4];                                                 // conversions first, then the eight MFMAs back to back (167 us against 175 interleaved, 4096 images)
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const unsigned word = kx < 4 ? a0[t] : a1[t];
-                const float av = ubyte_f32(word, kx & 3);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-            }
-        }
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int t = 0; t < 2; t++) av[t][j] = ubyte_f32(aw[t], j);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; j++)                                     // k = row * 8 + j + 4 half
+#pragma unroll
+            for (int t = 0; t < 2; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][j], bw[j], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; t++) aw[t] = an[t];
+#pragma unroll
+        for (int j = 0; j < 4; j++) bw[j] = bnx[j];
     }
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -127,8 +142,10 @@ extern "C" int grip_conv1_u8_train(const uint8_t *obs_dev, const int64_t *row0_d
         return grip_fail("grip_conv1_u8: need uint8 [n, 5, 64, 64] observations, Conv2d(4, 32, 8, 4) weights and bias, a 32 KB scratch and the two outputs");
     hipLaunchKernelGGL(k_conv1_prep, dim3(C1_KDIM * C1_OUT / 256), dim3(256), 0, (hipStream_t)stream, weight_dev, (long long)weight_strides[0], (long long)weight_strides[1],
                        (long long)weight_strides[2], (long long)weight_strides[3], scratch_dev);
-    const int resident = 256 * 3;                               // 48 KB of LDS per workgroup: three per CU
-    const int per_wg = (n + resident - 1) / resident, grid = (n + per_wg - 1) / per_wg;
+    // 48 KB of LDS per workgroup: three per CU, 768 on the chip. Workgroup i takes images i, i + grid, ...: with all 768 launched a CU's three (i, i + 256,
+    // i + 512 under round-robin placement) share the remainder evenly -- sizing the grid for equal counts per WORKGROUP (683 x 6 for 4096 images) left a
+    // third of the CUs with two workgroups and the rest with three, 12 % off the balanced time
+    const int grid = n < 768 ? n : 768;
     hipLaunchKernelGGL(k_conv1_u8, dim3(grid), dim3(256), 0, (hipStream_t)stream, obs_dev, (const long long *)row0_dev, n, channels, (const float *)scratch_dev, bias_dev, out_nhwc_dev, other_dev, mask_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { char buf[160]; snprintf(buf, sizeof buf, "grip_conv1_u8: %s", hipGetErrorString(e)); return grip_fail(buf); }

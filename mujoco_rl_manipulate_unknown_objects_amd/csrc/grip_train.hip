@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ 
     for (int t = 0; t < 2; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) cw[t][r] = 0.f;
-    float bsum = 0.f;
+    float4 bs4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int ngroups = (n_img + DG - 1) / DG;
     GroupIn gi;
     if ((int)blockIdx.x < ngroups) group_in_load(gi, tid, blockIdx.x * DG, min(DG, n_img - (int)blockIdx.x * DG), g3, reinterpret_cast<const uint16_t *>(m3),
@@ -243,6 +243,7 @@ __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ 
         const float2 v0 = tp[0], v1 = tp[1];
         const float4 v = bit_mask(reinterpret_cast<const unsigned *>(T1)[pix * D_PS1 + 32] >> c4, make_float4(v0.x, v0.y, v1.x, v1.y));
         tp[0] = make_float2(v.x, v.y); tp[1] = make_float2(v.z, v.w);
+        bs4.x += v.x; bs4.y += v.y; bs4.z += v.z; bs4.w += v.w;             // db1: the thread's four channels (c4 is the same in every pass: 256 % 8 == 0)
         if (g1m_out && i < nimg * 225 * 8) *reinterpret_cast<float4 *>(g1m_out + (size_t)img0 * 7200 + (size_t)i * 4) = v;
     }
     const int gnext = grp + gridDim.x;
@@ -250,28 +251,30 @@ __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ 
         if (gnext < ngroups)
             group_in_load(gi, tl, gnext * DG, min(DG, n_img - gnext * DG), g3, reinterpret_cast<const uint16_t *>(m3), reinterpret_cast<const unsigned long long *>(m2), m1);
     };
-    // K loop over an image's 225 positions, two per instruction: pos = 2 j + half
+    // K loop over an image's 225 positions, two per instruction: lanes 0..31 walk rows 0..7, lanes 32..63 rows 8..15 (row 15 does not exist: its B operand
+    // is forced to zero; 120 k-steps instead of 113, but every address is the row base plus an instruction offset -- with positions 2 j and 2 j + 1 in
+    // the two halves the (oy, ox) bookkeeping was a dozen dependent VALU instructions per k-step, and the loop ran at 70 % of the MFMA rate)
     auto wgrad_image = [&](int g) {
-        const uint8_t *ap = U + w * 4096 + (m32 >> 3) * 64 + (m32 & 7);        // + (4 oy) * 64 + 4 ox; second tile (ky + 4): + 256
-        const float *bp = T1 + g * 225 * D_PS1 + m32;
-        int pos = half, oy = 0, ox = half;
-        asm volatile("" : "+v"(pos), "+v"(oy), "+v"(ox));                    // (or the whole 113-step address sequence is computed once, outside the group loop, and spilled)
-        float a0n = (float)ap[4 * ox], a1n = (float)ap[4 * ox + 256], bnx = bp[pos * D_PS1];
+        const uint8_t *ap = U + w * 4096 + (m32 >> 3) * 64 + (m32 & 7) + half * 8 * 256;      // + oy * 256 + 4 ox; second tile (ky + 4): + 256
+        const float *bp = T1 + (g * 225 + half * 8 * 15) * D_PS1 + m32;
 #ifdef EXP_NOWGRAD
         if (n_img < 0)
 #endif
 #pragma unroll 1
-        for (int j = 0; j < 113; j++) {
-            const float a0 = a0n, a1 = a1n, b = bnx;
-            pos += 2; ox += 2;
-            if (ox >= 15) { ox -= 15; oy++; }
-            const bool valid = pos < 225;
-            const int off = valid ? oy * 256 + 4 * ox : 0;
-            a0n = (float)ap[off]; a1n = (float)ap[off + 256];
-            bnx = valid ? bp[pos * D_PS1] : 0.f;
-            bsum += b;
-            cw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, cw[0], 0, 0, 0);
-            cw[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, cw[1], 0, 0, 0);
+        for (int ro = 0; ro < 7; ro++) {
+#pragma unroll
+            for (int ox = 0; ox < 15; ox++) {
+                const float b = bp[ox * D_PS1];
+                cw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)ap[4 * ox], b, cw[0], 0, 0, 0);
+                cw[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)ap[4 * ox + 256], b, cw[1], 0, 0, 0);
+            }
+            ap += 256; bp += 15 * D_PS1;
+        }
+#pragma unroll
+        for (int ox = 0; ox < 15; ox++) {                                   // rows 7 | 15: the upper half's row does not exist
+            const float b = half ? 0.f : bp[ox * D_PS1];
+            cw[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)ap[4 * ox], b, cw[0], 0, 0, 0);
+            cw[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)ap[4 * ox + 256], b, cw[1], 0, 0, 0);
         }
     };
     if (obs) {
@@ -303,8 +306,15 @@ __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ 
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * half;          // = ky_local * 8 + kx of tile t
                 P[(w * 64 + t * 32 + row) * 32 + m32] = cw[t][r];
             }
-        bsum += __shfl_xor(bsum, 32);
-        if (w == 0 && l < 32) P[256 * 32 + l] = bsum;
+        // db1: thread tid holds channels 4 (tid & 7) .. + 3 summed over its pixels: 32 threads per channel group, added in a fixed order through LDS
+        __syncthreads();
+        *reinterpret_cast<float4 *>(d_lds + tid * 4) = bs4;
+        __syncthreads();
+        if (tid < 32) {
+            float t = 0.f;
+            for (int k = 0; k < 32; k++) t += d_lds[((tid >> 2) + 8 * k) * 4 + (tid & 3)];
+            P[256 * 32 + tid] = t;
+        }
     }
 }
 

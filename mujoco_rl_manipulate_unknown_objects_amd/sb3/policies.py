@@ -70,9 +70,34 @@ class ActorCriticPolicy(nn.Module):
                 o = o / 255.0
         return {"observation": o}
 
+    # the update's forward with the two MLPs as ONE chain (autograd through it): first layers = one GEMM on the shared features with the weights
+    # concatenated, deeper layers = a batch-of-two GEMM; backward likewise (one weight-gradient GEMM, one input-gradient GEMM and one bias sum per
+    # layer instead of two). The same fp32 sums as the separate modules; [4096 x 256] x [256 x 256] GEMMs alone fill a quarter of the chip.
+    merged_heads_training = True
+
+    def _merged_ok(self):
+        ok = getattr(self, "_merged_ok_cache", None)
+        if ok is None:
+            pl = [m for m in self.policy_net if isinstance(m, nn.Linear)]; vl = [m for m in self.value_net_mlp if isinstance(m, nn.Linear)]
+            ok = (self.vf_features_extractor is None and len(pl) == len(vl) >= 1 and all(a.weight.shape == b.weight.shape for a, b in zip(pl, vl))
+                  and all(isinstance(m, (nn.Linear, nn.Tanh)) for m in list(self.policy_net) + list(self.value_net_mlp))
+                  and len(list(self.policy_net)) == 2 * len(pl) and len(list(self.value_net_mlp)) == 2 * len(vl))
+            self._merged_ok_cache = (pl, vl) if ok else False
+            ok = self._merged_ok_cache
+        return ok
+
     def _latents(self, obs):
         p = self._prep(obs)
         f = self.features_extractor(p)
+        m = self._merged_ok() if (self.merged_heads_training and th.is_grad_enabled() and f.is_cuda) else False
+        if m:
+            pl, vl = m
+            h = th.tanh(th.addmm(th.cat((pl[0].bias, vl[0].bias)), f, th.cat((pl[0].weight, vl[0].weight)).t()))      # [n, 2 o]
+            n, o = h.shape[0], pl[0].weight.shape[0]
+            hb = h.view(n, 2, o).transpose(0, 1)                                                                         # [2, n, o], a view
+            for a, b in zip(pl[1:], vl[1:]):
+                hb = th.tanh(th.baddbmm(th.stack((a.bias, b.bias)).unsqueeze(1), hb, th.stack((a.weight, b.weight)).transpose(1, 2)))
+            return hb[0], hb[1]
         fv = f if self.vf_features_extractor is None else self.vf_features_extractor(p)
         return self.policy_net(f), self.value_net_mlp(fv)
 

@@ -102,3 +102,37 @@ def test_extractor_trains_the_same_through_the_fused_trunk():
         assert grads[True][k].shape == grads[False][k].shape and grads[True][k].stride() == grads[False][k].stride(), k
         err = (grads[True][k] - grads[False][k]).abs().max().item()
         assert err <= 2e-4 * grads[False][k].abs().max().item(), (k, err, grads[False][k].abs().max().item())
+
+
+def test_merged_heads_training_gradients_match_the_separate_modules():
+    """ActorCriticPolicy's update forward with the policy | value MLPs as one chain (cat / batch-of-two GEMMs under autograd) against the separate
+    modules: outputs to 2e-5, every parameter's gradient under a random linear loss to 2e-4 of its largest entry (fp32 both ways, sums re-associated)."""
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3.policies import ActorCriticPolicy
+    from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.controller.sensor import RGBDSensor
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.controller.actuator import Actuator
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import default_config
+    cfg = default_config()
+    th.manual_seed(5)
+    pol = ActorCriticPolicy(RGBDSensor(config=cfg).setup_observation_space(), Actuator(config=cfg).setup_action_space(),
+                            features_extractor_class=AugmentedNatureCNN, net_arch=[256, 256]).cuda().to(memory_format=th.channels_last)
+    with th.no_grad():
+        for p in pol.parameters():
+            if p.ndim == 1:
+                p.add_(0.1 * th.randn_like(p))
+        pol.action_net.weight.mul_(30.0)
+    assert pol._merged_ok()
+    obs = {"observation": th.randint(0, 256, (300, 5, 64, 64), dtype=th.uint8, device="cuda")}
+    Gm, Gv = th.randn(300, pol.action_dim, device="cuda"), th.randn(300, device="cuda")
+    out, grads = {}, {}
+    for merged in (True, False):
+        pol.merged_heads_training = merged
+        pol.zero_grad(set_to_none=True)
+        mean, log_std, values = pol.forward_parts(obs)
+        ((mean * Gm).sum() + (values * Gv).sum()).backward()
+        out[merged] = (mean.detach(), values.detach()); grads[merged] = {k: p.grad.clone() for k, p in pol.named_parameters() if p.grad is not None}
+    _close(out[True][0], out[False][0], 2e-5); _close(out[True][1], out[False][1], 2e-5)
+    assert grads[True].keys() == grads[False].keys()
+    for k in grads[False]:
+        err = (grads[True][k] - grads[False][k]).abs().max().item()
+        assert err <= 2e-4 * max(grads[False][k].abs().max().item(), 1e-6), (k, err, grads[False][k].abs().max().item())

@@ -8,13 +8,14 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_INSTS_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_WAVES"; do
   tag=$(echo $set | cut -d' ' -f1-2 | tr ' ' '_')
   rm -rf /tmp/pmc_tr
-  rocprofv3 --pmc $set --kernel-include-regex 'k_trunk_bwd' --output-format csv -d /tmp/pmc_tr -o p -- python3 tools/train_kernels_bench.py > gpurun_out/pmc_train/run_$tag.log 2> gpurun_out/pmc_train/err_$tag.log || { tail -5 gpurun_out/pmc_train/err_$tag.log; continue; }
+  rocprofv3 --pmc $set --kernel-include-regex "${1:-k_trunk_bwd}" --output-format csv -d /tmp/pmc_tr -o p -- python3 tools/train_kernels_bench.py > gpurun_out/pmc_train/run_$tag.log 2> gpurun_out/pmc_train/err_$tag.log || { tail -5 gpurun_out/pmc_train/err_$tag.log; continue; }
   f=$(find /tmp/pmc_tr -name '*counter_collection.csv' | head -1)
   python3 - "$f" <<'PY'
 import csv, sys, collections
 agg = collections.Counter(); n = collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
-    agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
-for k, v in sorted(agg.items()): print(k, v / n[k], "per launch over", n[k])
+    key = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
+    agg[key] += float(r["Counter_Value"]); n[key] += 1
+for k, v in sorted(agg.items()): print(k[0], k[1], v / n[k], "per launch over", n[k])
 PY
 done
