@@ -201,8 +201,8 @@ int grip_conv1_u8_rows(const uint8_t *obs_dev, const int64_t *row0_dev, int n, i
  * (v_mfma_f32_16x16x4_f32: fp32 products and sums): y1_nhwc_dev float32 [n, 15, 15, 32] (grip_conv1_u8's output) ->
  * out_nhwc_dev float32 [n, 4, 4, 64] = relu(conv2d(relu(conv2d(y1, w2, b2, stride 2)), w3, b3, stride 1)), i.e. a channels-last
  * [n, 64, 4, 4] tensor. The weights are passed as the GEMMs' B matrices, which grip_conv23_prep writes from w2 float32 [64, 32, 4, 4]
- * and w3 float32 [64, 64, 3, 3] (element strides w*_strides[4], any layout) into b2_mat_dev (512 x 64 floats) and b3_mat_dev
- * (576 x 64 floats): call it again whenever the weights change. Inference only. */
+ * and w3 float32 [64, 64, 3, 3] (element strides w*_strides[4], any layout) into b2_mat_dev (2 x 512 x 64 floats: the matrix k-major, then
+ * channel-major) and b3_mat_dev (2 x 576 x 64 floats): call it again whenever the weights change. No autograd (the update's variant: grip_conv23_train). */
 int grip_conv23_prep(const float *w2_dev, const int64_t *w2_strides, const float *w3_dev, const int64_t *w3_strides, float *b2_mat_dev, float *b3_mat_dev,
                      void *stream);
 int grip_conv23(const float *y1_nhwc_dev, int n, const float *b2_mat_dev, const float *bias2_dev, const float *b3_mat_dev, const float *bias3_dev,
@@ -224,12 +224,13 @@ int grip_conv23_train(const float *y1_nhwc_dev, int n, const float *b2_mat_dev, 
  * be NULL) and g2m_dev [n, 6, 6, 64] = d loss / d (second layer's pre-activation) -- the operands of those layers' weight gradients; g1m_dev
  * [n, 15, 15, 32] = d loss / d (first layer's pre-activation) (may be NULL when obs_dev is given: the tile is consumed on chip); grad_w1_dev =
  * d loss / d w1 as float32 [32, 4, 8, 8] with element strides grad_w1_strides[4] (w.r.t. the weight that multiplies obs / 255), grad_b1_dev [32].
- * partials_dev: scratch of grip_trunk_backward_parts(n) x 8224 floats. fp32 products and sums on the matrix cores; sums in a fixed order (no
+ * With obs_dev also the other two layers' bias gradients, grad_b2_dev [64] and grad_b3_dev [64] (sums of g2m / g3m; either may be NULL).
+ * partials_dev: scratch of grip_trunk_backward_parts(n) x 8352 floats. fp32 products and sums on the matrix cores; sums in a fixed order (no
  * atomics): bit-identical from run to run. */
 int grip_trunk_backward_parts(int n);
 int grip_trunk_backward(const float *g3_dev, const uint64_t *mask3_dev, const uint64_t *mask2_dev, const uint32_t *mask1_dev, const uint8_t *obs_dev, int channels,
                         const float *b3_mat_dev, const float *b2_mat_dev, int n, float *g3m_dev, float *g2m_dev, float *g1m_dev, float *partials_dev,
-                        float *grad_w1_dev, const int64_t *grad_w1_strides, float *grad_b1_dev, void *stream);
+                        float *grad_w1_dev, const int64_t *grad_w1_strides, float *grad_b1_dev, float *grad_b2_dev, float *grad_b3_dev, void *stream);
 
 /* PPO's clipped-surrogate loss of one minibatch and its gradients in one launch (the update stable_baselines3's PPO.train runs for the
  * reference's train_agent.py:33-47: advantages normalised per minibatch, clip_range, no value clipping, diagonal Gaussian with a

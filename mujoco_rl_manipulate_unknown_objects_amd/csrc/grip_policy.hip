@@ -249,114 +249,123 @@ extern "C" int grip_ppo_loss(const float *mean_dev, const float *log_std_dev, co
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Rollout-side second and third layers of AugmentedNatureCNN (models/feature_extractor.py:17-21) in one launch:
+// Second and third layers of AugmentedNatureCNN (models/feature_extractor.py:17-21) in one launch:
 //   y2 = relu(conv2d(y1, w2, b2, stride 2)),  y1 [n, 15, 15, 32] NHWC (what k_conv1_u8 writes), w2 [64, 32, 4, 4]  -> [n, 6, 6, 64]
 //   y3 = relu(conv2d(y2, w3, b3, stride 1)),                                               w3 [64, 64, 3, 3]  -> [n, 4, 4, 64] NHWC
-// as two implicit GEMMs on v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulation), y2 never leaving LDS. As tensor-library calls
-// the pair is two implicit-GEMM launches plus bias and ReLU passes, 97 us per 1024 images; this kernel: one workgroup (4 waves) per
-// C2_G = 4 images -- GEMM 1: M = 144 (image, oy, ox) rows = 9 tiles of 16, N = 64, K = 4 x 4 x 32 = 512; GEMM 2: M = 64 = 4 tiles (one per image), N = 64,
-// K = 3 x 3 x 64 = 576. Wave w owns output channels 16 w .. 16 w + 15 and every M tile (9, then 4 independent accumulators: the 40-cycle
-// dependent latency of the instruction never shows). A comes from LDS: a lane's row (l & 15) fixes a pixel base, its k (l >> 4) a channel
-// offset; pixel strides of 34 / 68 floats spread the 64 lanes of a read over all banks. B comes straight from global memory (the weights
-// as B[k][n], k = (ky, kx, ci), 275 KB for both layers: L2-resident, rewritten by grip_conv23_prep whenever the weights change), one
-// dword per lane and k-step, fetched one (ky, kx) block = 8 or 16 k-steps ahead of its use.
+// as two implicit GEMMs on v_mfma_f32_16x16x4_f32 (exact f32 products, f32 accumulation), y2 staying in LDS between them. As tensor-library calls
+// the pair is two implicit-GEMM launches plus bias and ReLU passes. A workgroup (4 waves) per C2_G = 2 images, two workgroups per CU (one loads
+// while the other's MFMAs run) -- GEMM 1: M = 72 (image, oy, ox) rows = 4.5 tiles of 16, N = 64, K = 4 x 4 x 32 = 512; GEMM 2: M = 32 = 2 tiles (one per image),
+// N = 64, K = 3 x 3 x 64 = 576. Wave w owns output channels 16 w .. 16 w + 15 and every M tile. Operand traffic is what an fp32 MFMA kernel is priced by
+// (every LDS / VALU instruction next to an MFMA takes issue cycles of the same SIMD: tools/hiptests/t_mfma_peak.hip), so the reduction index is permuted:
+// within a (ky, kx) block the k-step j of an instruction pairs input channels ci = C (l >> 4) + j (C = 8 or 16 per lane) -- a lane's A values of a block
+// are then contiguous in LDS (b128 reads, one per four MFMAs) and its B values contiguous in the weights stored as Bt[co][k] (two or four 16-byte loads per
+// block from L2, requested one block ahead). The first version read one dword per MFMA for each operand: 197 us per 4096 images against 92 of MFMA time.
+// Training (y2_out != NULL): also y2 and both layers' ReLU masks as bits.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define C2_G 4
-#define C2_PS1 34                       // floats per y1 pixel in LDS (32 channels + 2: row stride 2 pixels = 68 floats = 4 banks)
+#define C2_G 2
+#define C2_PS1 36                       // floats per y1 pixel in LDS (32 channels + 4: 16-byte aligned rows)
 #define C2_PS2 68                       // floats per y2 pixel in LDS (64 channels + 4)
 #define C2_LDS_FLOATS (C2_G * 225 * C2_PS1)         // y1 of the group; y2 (C2_G * 36 * C2_PS2 floats) reuses the space once GEMM 1 is done
 
-// B2[k][n] = w2[n][ci][ky][kx], k = (ky * 4 + kx) * 32 + ci;  B3[k][n] = w3[n][ci][ky][kx], k = (ky * 3 + kx) * 64 + ci  (element strides given)
+// Both layouts of both weight matrices, k = (ky, kx, ci): B2[k][n] (512 x 64, what the backward's scatter GEMMs read) then B2t[n][k] (64 x 512, the forward's);
+// B3[k][n] (576 x 64) then B3t[n][k] (64 x 576)  (element strides of the weight tensors given)
 __global__ void __launch_bounds__(256) k_conv23_prep(const float *__restrict__ w2, long long s2o, long long s2c, long long s2y, long long s2x,
                                                      const float *__restrict__ w3, long long s3o, long long s3c, long long s3y, long long s3x,
                                                      float *__restrict__ B2, float *__restrict__ B3) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < 512 * 64) {
         const int n = i & 63, k = i >> 6, ci = k & 31, kx = (k >> 5) & 3, ky = k >> 7;
-        B2[i] = w2[n * s2o + ci * s2c + ky * s2y + kx * s2x];
+        const float v = w2[n * s2o + ci * s2c + ky * s2y + kx * s2x];
+        B2[i] = v; B2[512 * 64 + n * 512 + k] = v;
     }
     if (i < 576 * 64) {
         const int n = i & 63, k = i >> 6, ci = k & 63, kk = k >> 6, kx = kk % 3, ky = kk / 3;
-        B3[i] = w3[n * s3o + ci * s3c + ky * s3y + kx * s3x];
+        const float v = w3[n * s3o + ci * s3c + ky * s3y + kx * s3x];
+        B3[i] = v; B3[576 * 64 + n * 576 + k] = v;
     }
 }
 
-__global__ void __launch_bounds__(256) k_conv23(const float *__restrict__ y1, int n_img, const float *__restrict__ B2, const float *__restrict__ bias2,
-                                                const float *__restrict__ B3, const float *__restrict__ bias3, float *__restrict__ out, float *__restrict__ y2_out,
-                                                uint16_t *__restrict__ mask2, uint16_t *__restrict__ mask3) {
+// one implicit GEMM of the pair: MT row tiles, NBLK (ky, kx) blocks of 4 Q k-steps; the lane's A values of tile t and block c start at lds[abase[t] + aoff(c)]
+// (4 Q contiguous floats), its B values at Bt[c * 16 Q] (4 Q contiguous floats); quarter-blocks of four k-steps, the next quarter's A read while this one's MFMAs issue
+template <int MT, int NBLK, int Q, class AOff>
+__device__ __forceinline__ void conv_gemm(const float *lds, const int (&abase)[MT], const float *__restrict__ Bt, f32x4 (&acc)[MT], AOff aoff) {
+    float4 bcur[Q], bnext[Q], acur[MT], an[MT];
+#pragma unroll
+    for (int q = 0; q < Q; q++) bcur[q] = *reinterpret_cast<const float4 *>(Bt + 4 * q);
+#pragma unroll
+    for (int t = 0; t < MT; t++) acur[t] = *reinterpret_cast<const float4 *>(lds + abase[t] + aoff(0));
+#pragma unroll
+    for (int c = 0; c < NBLK; c++) {
+        const int cn = c + 1 < NBLK ? c + 1 : c;
+#pragma unroll
+        for (int q = 0; q < Q; q++) bnext[q] = *reinterpret_cast<const float4 *>(Bt + cn * 16 * Q + 4 * q);      // a block = 4 lane groups x 4 Q channels
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+#pragma unroll
+            for (int t = 0; t < MT; t++) an[t] = *reinterpret_cast<const float4 *>(lds + abase[t] + (q + 1 < Q ? aoff(c) + 4 * (q + 1) : aoff(cn)));
+            __builtin_amdgcn_sched_barrier(0);                       // keep the requests above the MFMAs (the scheduler sinks them to their uses)
+#pragma unroll
+            for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[t].x, bcur[q].x, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[t].y, bcur[q].y, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[t].z, bcur[q].z, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[t].w, bcur[q].w, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < MT; t++) acur[t] = an[t];
+        }
+#pragma unroll
+        for (int q = 0; q < Q; q++) bcur[q] = bnext[q];
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) k_conv23(const float *__restrict__ y1, int n_img, const float *__restrict__ B2t, const float *__restrict__ bias2,
+                                                   const float *__restrict__ B3t, const float *__restrict__ bias3, float *__restrict__ out, float *__restrict__ y2_out,
+                                                   uint16_t *__restrict__ mask2, uint16_t *__restrict__ mask3) {
     extern __shared__ __attribute__((aligned(16))) float c2_lds[];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r16 = l & 15, kq = l >> 4;
     const int img0 = blockIdx.x * C2_G, nimg = min(C2_G, n_img - img0);
-    // y1 of the group -> LDS (missing images of the last group as zeros); eight 16-byte loads in flight per thread, then their stores
+    // y1 of the group -> LDS (a missing second image as zeros); eight 16-byte loads in flight per thread, then their stores
     for (int b0 = 0; b0 < C2_G * 1800; b0 += 256 * 8) {
         float4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int i = b0 + u * 256 + tid, g = i / 1800, q = i - g * 1800;
+            const int i = b0 + u * 256 + tid;
             v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < C2_G * 1800 && g < nimg) v[u] = *reinterpret_cast<const float4 *>(y1 + ((size_t)(img0 + g) * 225) * 32 + (size_t)q * 4);
+            if (i < nimg * 1800) v[u] = *reinterpret_cast<const float4 *>(y1 + (size_t)img0 * 7200 + (size_t)i * 4);
         }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const int i = b0 + u * 256 + tid, g = i / 1800, q = i - g * 1800, px = q >> 3, c4 = (q & 7) * 4;
-            if (i < C2_G * 1800) {
-                float2 *d = reinterpret_cast<float2 *>(c2_lds + (g * 225 + px) * C2_PS1 + c4);
-                d[0] = make_float2(v[u].x, v[u].y); d[1] = make_float2(v[u].z, v[u].w);
-            }
+            const int i = b0 + u * 256 + tid;
+            if (i < C2_G * 1800) *reinterpret_cast<float4 *>(c2_lds + (i >> 3) * C2_PS1 + (i & 7) * 4) = v[u];
         }
     }
     __syncthreads();
     const int ncol = 16 * w + r16;
-    // ---- GEMM 1
-    f32x4 acc[9];
-    int abase[9];
-#pragma unroll
-    for (int t = 0; t < 9; t++) {
-        const int m = t * 16 + r16, g = m / 36, p = m - g * 36, oy = p / 6, ox = p - oy * 6;
-        abase[t] = (g * 225 + 2 * oy * 15 + 2 * ox) * C2_PS1 + kq;
-        acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    // ---- GEMM 1: rows m = image * 36 + position (72 = 4.5 tiles: the last half tile is computed from a clamped row and dropped)
+    f32x4 acc[5];
     {
-        const float *Bp = B2 + (size_t)kq * 64 + ncol;              // k = 4 j + kq -> Bp[j * 256]
-        float bcur[8], bnext[8];
+        int abase[5];
 #pragma unroll
-        for (int i = 0; i < 8; i++) bcur[i] = Bp[i * 256];
-        float acur[9];
-#pragma unroll
-        for (int t = 0; t < 9; t++) acur[t] = c2_lds[abase[t]];
-        for (int c = 0; c < 16; c++) {                               // (ky, kx) blocks of 8 k-steps (32 channels)
-            const int cn = min(c + 1, 15);
-#pragma unroll
-            for (int i = 0; i < 8; i++) bnext[i] = Bp[(cn * 8 + i) * 256];
-            const int off = ((c >> 2) * 15 + (c & 3)) * C2_PS1;
-            const int offn = ((cn >> 2) * 15 + (cn & 3)) * C2_PS1;
-            // A of k-step i + 1 is read while the nine MFMAs of k-step i issue (9 x 32 cycles cover the LDS latency)
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                float an[9];
-#pragma unroll
-                for (int t = 0; t < 9; t++) an[t] = c2_lds[abase[t] + (i < 7 ? off + 4 * (i + 1) : offn)];
-                __builtin_amdgcn_sched_barrier(0);                   // keep the reads above the MFMAs (the scheduler sinks them to their uses)
-#pragma unroll
-                for (int t = 0; t < 9; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[t], bcur[i], acc[t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < 9; t++) acur[t] = an[t];
-            }
-#pragma unroll
-            for (int i = 0; i < 8; i++) bcur[i] = bnext[i];
+        for (int t = 0; t < 5; t++) {
+            const int m = min(t * 16 + r16, C2_G * 36 - 1), g = m / 36, p = m - g * 36, oy = p / 6, ox = p - oy * 6;
+            abase[t] = (g * 225 + 2 * oy * 15 + 2 * ox) * C2_PS1 + 8 * kq;
+            acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+        conv_gemm<5, 16, 2>(c2_lds, abase, B2t + (size_t)ncol * 512 + 8 * kq, acc, [](int c) { return ((c >> 2) * 15 + (c & 3)) * C2_PS1; });
     }
     __syncthreads();                                                 // every wave is done reading y1
     {   // y2 = relu(acc + bias) into LDS: lane holds rows 4 kq + r of tile t, column ncol
         const float bn = bias2[ncol];
 #pragma unroll
-        for (int t = 0; t < 9; t++) {
+        for (int t = 0; t < 5; t++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int m = t * 16 + 4 * kq + r;                    // = g * 36 + position
                 const float v = fmaxf(acc[t][r] + bn, 0.f);
-                c2_lds[m * C2_PS2 + ncol] = v;
+                if (m < C2_G * 36) c2_lds[m * C2_PS2 + ncol] = v;
                 if (y2_out) {                                         // training: the activation for the weight gradient, and its ReLU mask -- bit c of the 64-bit word
                     const unsigned long long bal = __ballot(v > 0.f);  // (image, position) = channel c is active; this wave's 16 channels are one uint16 of it
                     if (m < nimg * 36) {
@@ -370,41 +379,14 @@ __global__ void __launch_bounds__(256) k_conv23(const float *__restrict__ y1, in
     __syncthreads();
     // ---- GEMM 2: tile g = image g, row r16 = (oy, ox) of the 4 x 4 output
     f32x4 acc3[C2_G];
-    int a3[C2_G];
-#pragma unroll
-    for (int g = 0; g < C2_G; g++) {
-        a3[g] = (g * 36 + (r16 >> 2) * 6 + (r16 & 3)) * C2_PS2 + kq;
-        acc3[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
     {
-        const float *Bp = B3 + (size_t)kq * 64 + ncol;
-        float bcur[16], bnext[16];
+        int a3[C2_G];
 #pragma unroll
-        for (int i = 0; i < 16; i++) bcur[i] = Bp[i * 256];
-        float acur[C2_G];
-#pragma unroll
-        for (int g = 0; g < C2_G; g++) acur[g] = c2_lds[a3[g]];
-        for (int c = 0; c < 9; c++) {                                // (ky, kx) blocks of 16 k-steps (64 channels)
-            const int cn = min(c + 1, 8);
-#pragma unroll
-            for (int i = 0; i < 16; i++) bnext[i] = Bp[(cn * 16 + i) * 256];
-            const int off = ((c / 3) * 6 + (c % 3)) * C2_PS2;
-            const int offn = ((cn / 3) * 6 + (cn % 3)) * C2_PS2;
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                float an[C2_G];
-#pragma unroll
-                for (int g = 0; g < C2_G; g++) an[g] = c2_lds[a3[g] + (i < 15 ? off + 4 * (i + 1) : offn)];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int g = 0; g < C2_G; g++) acc3[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[g], bcur[i], acc3[g], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int g = 0; g < C2_G; g++) acur[g] = an[g];
-            }
-#pragma unroll
-            for (int i = 0; i < 16; i++) bcur[i] = bnext[i];
+        for (int g = 0; g < C2_G; g++) {
+            a3[g] = (g * 36 + (r16 >> 2) * 6 + (r16 & 3)) * C2_PS2 + 16 * kq;
+            acc3[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+        conv_gemm<C2_G, 9, 4>(c2_lds, a3, B3t + (size_t)ncol * 576 + 16 * kq, acc3, [](int c) { return ((c / 3) * 6 + (c % 3)) * C2_PS2; });
     }
     {
         const float bn = bias3[ncol];
@@ -459,7 +441,7 @@ extern "C" int grip_conv23_train(const float *y1_nhwc_dev, int n, const float *b
             attr_set_mask.fetch_or(bit, std::memory_order_release);
         }
     }
-    hipLaunchKernelGGL(k_conv23, dim3((n + C2_G - 1) / C2_G), dim3(256), lds, (hipStream_t)stream, y1_nhwc_dev, n, b2_mat_dev, bias2_dev, b3_mat_dev, bias3_dev, out_nhwc_dev, y2_nhwc_dev,
+    hipLaunchKernelGGL(k_conv23, dim3((n + C2_G - 1) / C2_G), dim3(256), lds, (hipStream_t)stream, y1_nhwc_dev, n, b2_mat_dev + 512 * 64, bias2_dev, b3_mat_dev + 576 * 64, bias3_dev, out_nhwc_dev, y2_nhwc_dev,
                        (uint16_t *)mask2_dev, (uint16_t *)mask3_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { char buf[160]; snprintf(buf, sizeof buf, "grip_conv23: %s", hipGetErrorString(e)); return grip_fail(buf); }

@@ -46,7 +46,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define D_T1 (DG * 225 * D_PS1)             // g1 tile; the g3 tile (DG * 16 * D_PS2 floats) lives in its first part until GEMM 1 has its operands
 #define D_T2 (DG * 36 * D_PS2)              // g2 tile; later the four 64 x 64 byte planes of one image (16 KB of its 19.1)
 #define D_LDS_FLOATS (D_T1 + D_T2)
-#define TB_PART (256 * 32 + 32)             // floats of a workgroup's partial sums: dW1 as [(ci, ky, kx)][co], then db1[co]
+#define TB_PART (256 * 32 + 32 + 64 + 64)   // floats of a workgroup's partial sums: dW1 as [(ci, ky, kx)][co], then db1[32], db2[64], db3[64]
 
 // MT row tiles x NB column blocks. The lane's A operand of tile t and k-steps 4 q .. 4 q + 3 is the float4 at TA[arow[t] + 4 q] (row t * 16 + (l & 15), co = 16 (l >> 4) + 4 q ..),
 // read again for every column block (20 b128 reads per 80 MFMAs) rather than held (80 registers); bofs(nb) = float offset of the block's weights from Bp;
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ 
     for (int t = 0; t < 2; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) cw[t][r] = 0.f;
-    float4 bs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 bs4 = make_float4(0.f, 0.f, 0.f, 0.f), bs2 = bs4, bs3 = bs4;      // bias gradients: the thread's four channels of each layer, over its rows
     const int ngroups = (n_img + DG - 1) / DG;
     GroupIn gi;
     if ((int)blockIdx.x < ngroups) group_in_load(gi, tid, blockIdx.x * DG, min(DG, n_img - (int)blockIdx.x * DG), g3, reinterpret_cast<const uint16_t *>(m3),
@@ -173,6 +173,7 @@ __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ 
     for (int u = 0; u < 2; u++) {
         const int i = tl + 256 * u, row = i >> 4, c4 = (i & 15) * 4;
         const float4 v = bit_mask(gi.m3[u], gi.g3[u]);
+        bs3.x += v.x; bs3.y += v.y; bs3.z += v.z; bs3.w += v.w;
         if (g3m_out && (row >> 4) < nimg) *reinterpret_cast<float4 *>(g3m_out + ((size_t)img0 * 16 + row) * 64 + c4) = v;
         *reinterpret_cast<float4 *>(T3 + row * D_PS2 + c4) = v;
     }
@@ -199,6 +200,7 @@ __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ 
             const unsigned bits = reinterpret_cast<const unsigned *>(T2)[row * D_PS2 + 64 + (c4 >> 5)] >> (c4 & 31);
             const float4 v = bit_mask(bits, *reinterpret_cast<float4 *>(T2 + row * D_PS2 + c4));
             *reinterpret_cast<float4 *>(T2 + row * D_PS2 + c4) = v;
+            bs2.x += v.x; bs2.y += v.y; bs2.z += v.z; bs2.w += v.w;
             if (row < nimg * 36) *reinterpret_cast<float4 *>(g2m_out + ((size_t)img0 * 36 + row) * 64 + c4) = v;
         }
     }
@@ -315,13 +317,23 @@ __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ 
             for (int k = 0; k < 32; k++) t += d_lds[((tid >> 2) + 8 * k) * 4 + (tid & 3)];
             P[256 * 32 + tid] = t;
         }
+        // db2, db3: channels 4 (tid & 15) .. + 3, 16 threads per channel group
+        __syncthreads();
+        *reinterpret_cast<float4 *>(d_lds + tid * 4) = bs2; *reinterpret_cast<float4 *>(d_lds + 1024 + tid * 4) = bs3;
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, co = tid & 63;
+            float t = 0.f;
+            for (int k = 0; k < 16; k++) t += d_lds[which * 1024 + ((co >> 2) + 16 * k) * 4 + (co & 3)];
+            P[256 * 32 + 32 + tid] = t;
+        }
     }
 }
 
-// dW1[co][ci][ky][kx] = sum over the workgroups' partials / 255 (the forward multiplies bytes by w / 255), db1[co] = sum: 32 outputs per block,
+// dW1[co][ci][ky][kx] = sum over the workgroups' partials / 255 (the forward multiplies bytes by w / 255), db1 / db2 / db3 = sums: 32 outputs per block,
 // 8 slices of the partials each, added in a fixed order
 __global__ void __launch_bounds__(256) k_wgrad1_reduce(const float *__restrict__ part, int nparts, float *__restrict__ gw, long long so, long long sc, long long sy, long long sx,
-                                                        float *__restrict__ gb) {
+                                                        float *__restrict__ gb, float *__restrict__ gb2, float *__restrict__ gb3) {
     __shared__ float red[8][32];
     const int o = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
     float s = 0.f;
@@ -335,7 +347,9 @@ __global__ void __launch_bounds__(256) k_wgrad1_reduce(const float *__restrict__
         if (o < 256 * 32) {
             const int mm = o >> 5, co = o & 31, ci = mm >> 6, ky = (mm >> 3) & 7, kx = mm & 7;
             gw[co * so + ci * sc + ky * sy + kx * sx] = t * (1.0f / 255.0f);
-        } else gb[o - 256 * 32] = t;
+        } else if (o < 256 * 32 + 32) gb[o - 256 * 32] = t;
+        else if (o < 256 * 32 + 96) { if (gb2) gb2[o - 256 * 32 - 32] = t; }
+        else if (gb3) gb3[o - 256 * 32 - 96] = t;
     }
 }
 
@@ -361,12 +375,12 @@ extern "C" int grip_trunk_backward_parts(int n) { const int groups = (n + DG - 1
 
 extern "C" int grip_trunk_backward(const float *g3_dev, const uint64_t *mask3_dev, const uint64_t *mask2_dev, const uint32_t *mask1_dev, const uint8_t *obs_dev, int channels,
                                    const float *b3_mat_dev, const float *b2_mat_dev, int n, float *g3m_dev, float *g2m_dev, float *g1m_dev, float *partials_dev,
-                                   float *grad_w1_dev, const int64_t *grad_w1_strides, float *grad_b1_dev, void *stream) {
+                                   float *grad_w1_dev, const int64_t *grad_w1_strides, float *grad_b1_dev, float *grad_b2_dev, float *grad_b3_dev, void *stream) {
     if (!g3_dev || !mask3_dev || !mask2_dev || !mask1_dev || !b3_mat_dev || !b2_mat_dev || !g2m_dev || n <= 0)
         return grip_fail("grip_trunk_backward: need g3 [n, 4, 4, 64], the three ReLU masks of the training forward (grip_conv1_u8_train, grip_conv23_train), the two weight "
                          "matrices of grip_conv23_prep and the output g2m");
     if (obs_dev && (channels != 5 || !partials_dev || !grad_w1_dev || !grad_w1_strides || !grad_b1_dev))
-        return grip_fail("grip_trunk_backward: with observations (uint8 [n, 5, 64, 64]) the partial-sum scratch (grip_trunk_backward_parts(n) x 8224 floats) and the "
+        return grip_fail("grip_trunk_backward: with observations (uint8 [n, 5, 64, 64]) the partial-sum scratch (grip_trunk_backward_parts(n) x 8352 floats) and the "
                          "first layer's gradient outputs are needed");
     if (!obs_dev && !g1m_dev) return grip_fail("grip_trunk_backward: nothing to do with the first layer's gradient (neither observations nor g1m)");
     static std::atomic<unsigned long long> mask{0ULL};
@@ -377,6 +391,6 @@ extern "C" int grip_trunk_backward(const float *g3_dev, const uint64_t *mask3_de
                        g1m_dev, obs_dev ? partials_dev : (float *)nullptr);
     if (obs_dev)
         hipLaunchKernelGGL(k_wgrad1_reduce, dim3(TB_PART / 32), dim3(256), 0, (hipStream_t)stream, (const float *)partials_dev, parts, grad_w1_dev, (long long)grad_w1_strides[0],
-                           (long long)grad_w1_strides[1], (long long)grad_w1_strides[2], (long long)grad_w1_strides[3], grad_b1_dev);
+                           (long long)grad_w1_strides[1], (long long)grad_w1_strides[2], (long long)grad_w1_strides[3], grad_b1_dev, grad_b2_dev, grad_b3_dev);
     return launch_check("grip_trunk_backward");
 }

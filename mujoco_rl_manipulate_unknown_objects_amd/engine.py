@@ -166,7 +166,7 @@ def lib():
     L.grip_conv23.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.grip_conv23_train.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.grip_conv1_u8_train.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int64), vp, vp, vp, vp, vp, vp]
-    L.grip_trunk_backward.argtypes = [vp] * 5 + [C.c_int, vp, vp, C.c_int] + [vp] * 5 + [C.POINTER(C.c_int64), vp, vp]
+    L.grip_trunk_backward.argtypes = [vp] * 5 + [C.c_int, vp, vp, C.c_int] + [vp] * 5 + [C.POINTER(C.c_int64), vp, vp, vp, vp]
     L.grip_trunk_backward_parts.argtypes = [C.c_int]
     L.grip_ppo_loss.argtypes = [vp] * 7 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float] + [vp] * 5
     L.grip_batch_render_camera.argtypes = [vp, C.c_int, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp]
@@ -251,12 +251,12 @@ def conv1_u8(obs, weight, bias, with_mask=False):
 
 
 def conv23_prep(w2, w3, b2_mat=None, b3_mat=None):
-    """The weights of AugmentedNatureCNN's second and third convolutions as the B matrices grip_conv23 reads (float32 [512, 64] and
-    [576, 64]); pass the previous pair to rewrite it in place (fixed addresses for a captured rollout tick)."""
+    """The weights of AugmentedNatureCNN's second and third convolutions as the GEMM operands grip_conv23 / grip_trunk_backward read (float32
+    [2 x 512, 64] and [2 x 576, 64]: k-major then channel-major); pass the previous pair to rewrite it in place (fixed addresses for a captured rollout tick)."""
     import torch
     assert w2.is_cuda and w2.dtype == torch.float32 and tuple(w2.shape) == (64, 32, 4, 4) and w3.dtype == torch.float32 and tuple(w3.shape) == (64, 64, 3, 3)
     if b2_mat is None:
-        b2_mat = torch.empty((512, 64), dtype=torch.float32, device=w2.device); b3_mat = torch.empty((576, 64), dtype=torch.float32, device=w2.device)
+        b2_mat = torch.empty((1024, 64), dtype=torch.float32, device=w2.device); b3_mat = torch.empty((1152, 64), dtype=torch.float32, device=w2.device)
     s2 = (C.c_int64 * 4)(*w2.stride()); s3 = (C.c_int64 * 4)(*w3.stride())
     stream = C.c_void_p(torch.cuda.current_stream(w2.device).cuda_stream)
     _chk(lib().grip_conv23_prep(C.c_void_p(w2.data_ptr()), s2, C.c_void_p(w3.data_ptr()), s3, C.c_void_p(b2_mat.data_ptr()), C.c_void_p(b3_mat.data_ptr()), stream))
@@ -269,7 +269,7 @@ def conv23(y1, b2_mat, bias2, b3_mat, bias3, train=False):
     import torch
     n = int(y1.shape[0])
     assert y1.is_cuda and y1.dtype == torch.float32 and tuple(y1.shape[1:]) == (32, 15, 15) and y1.is_contiguous(memory_format=torch.channels_last)
-    assert tuple(b2_mat.shape) == (512, 64) and tuple(b3_mat.shape) == (576, 64) and bias2.is_contiguous() and bias3.is_contiguous()
+    assert tuple(b2_mat.shape) == (1024, 64) and tuple(b3_mat.shape) == (1152, 64) and bias2.is_contiguous() and bias3.is_contiguous()
     out = torch.empty((n, 64, 4, 4), dtype=torch.float32, device=y1.device, memory_format=torch.channels_last)
     stream = C.c_void_p(torch.cuda.current_stream(y1.device).cuda_stream)
     # train (the update's forward): also y2 (channels-last [n, 64, 6, 6]) and the two layers' ReLU masks, int64 [n, 36] / [n, 16], bit c = channel c is active
@@ -292,13 +292,14 @@ def trunk_backward(g3, mask3, mask2, mask1, obs, b3_mat, b2_mat, w1=None, want_g
     g3 = d loss / d y3 (channels-last float32 [n, 64, 4, 4]), the ReLU masks of the training forward (conv23(train=True): mask3 int64 [n, 16], mask2
     int64 [n, 36]; conv1_u8(with_mask=True): mask1 int32 [n, 225]), the weight matrices of conv23_prep, the uint8 observations [n, 5, 64, 64] (None:
     no first-layer weight gradient) and the first layer's weight (for the gradient's shape and strides) -> (g3 * mask3, d loss / d conv2's
-    pre-activation, d loss / d w1, d loss / d b1, d loss / d conv1's pre-activation or None), the data gradients channels-last."""
+    pre-activation, d loss / d w1, (d loss / d b1, d loss / d b2, d loss / d b3), d loss / d conv1's pre-activation or None), the data gradients
+    channels-last."""
     import torch
     n = int(g3.shape[0])
     assert _nhwc(g3, 64, 4)
     for m, shape, dt in ((mask3, (n, 16), torch.int64), (mask2, (n, 36), torch.int64), (mask1, (n, 225), torch.int32)):
         assert m.is_cuda and m.dtype == dt and tuple(m.shape) == shape and m.is_contiguous()
-    assert tuple(b2_mat.shape) == (512, 64) and tuple(b3_mat.shape) == (576, 64) and b2_mat.is_contiguous() and b3_mat.is_contiguous()
+    assert tuple(b2_mat.shape) == (1024, 64) and tuple(b3_mat.shape) == (1152, 64) and b2_mat.is_contiguous() and b3_mat.is_contiguous()
     g3m = torch.empty_like(g3)
     g2m = torch.empty((n, 64, 6, 6), dtype=torch.float32, device=g3.device, memory_format=torch.channels_last)
     g1m = torch.empty((n, 32, 15, 15), dtype=torch.float32, device=g3.device, memory_format=torch.channels_last) if want_g1m or obs is None else None
@@ -308,12 +309,12 @@ def trunk_backward(g3, mask3, mask2, mask1, obs, b3_mat, b2_mat, w1=None, want_g
     if obs is not None:
         assert obs.is_cuda and obs.dtype == torch.uint8 and obs.is_contiguous() and tuple(obs.shape) == (n, 5, 64, 64)
         assert w1 is not None and tuple(w1.shape) == (32, 4, 8, 8) and w1.dtype == torch.float32
-        gw = torch.empty_like(w1); gb = torch.empty(32, dtype=torch.float32, device=g3.device)
-        part = torch.empty((int(lib().grip_trunk_backward_parts(n)), 8224), dtype=torch.float32, device=g3.device)
+        gw = torch.empty_like(w1); gb = tuple(torch.empty(k, dtype=torch.float32, device=g3.device) for k in (32, 64, 64))
+        part = torch.empty((int(lib().grip_trunk_backward_parts(n)), 8352), dtype=torch.float32, device=g3.device)
         strides = (C.c_int64 * 4)(*gw.stride())
     stream = C.c_void_p(torch.cuda.current_stream(g3.device).cuda_stream)
     _chk(lib().grip_trunk_backward(vp(g3), vp(mask3), vp(mask2), vp(mask1), vp(obs), 5, vp(b3_mat), vp(b2_mat), n, vp(g3m), vp(g2m), vp(g1m), vp(part), vp(gw), strides,
-                                   vp(gb), stream))
+                                   *([vp(t) for t in gb] if gb else [None] * 3), stream))
     return g3m, g2m, gw, gb, g1m
 
 

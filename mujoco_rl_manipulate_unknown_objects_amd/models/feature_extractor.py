@@ -42,8 +42,8 @@ class _CnnTrunk(th.autograd.Function):
     csrc/grip_train.hip; fp32 products and sums on the matrix cores -- the tensor library's fp32 arithmetic up to summation order,
     tests/test_gpu_train_kernels.py). Forward: grip_conv1_u8 and grip_conv23 as in the rollouts, additionally writing y2 and the three ReLU masks
     as bits. Backward: one launch (grip_trunk_backward) for both data gradients, the three ReLU masks and the first layer's weight and bias
-    gradient straight from the observation bytes; the other two layers' weight gradients stay with the tensor library (they are not what
-    the time goes into). Per 4096-sample minibatch on MI355X: forward 376 us (tensor library 513), backward of these layers ~0.5 ms (~1.0 ms)."""
+    gradient straight from the observation bytes and all three bias gradients; the other two layers' weight gradients stay with the tensor
+    library (at 65 % of the fp32 MFMA rate they are not where the time goes). Per 4096-sample minibatch on MI355X: forward 376 us (tensor library 513), backward of these layers ~0.5 ms (~1.0 ms)."""
 
     @staticmethod
     def forward(ctx, obs, w1, b1, w2, b2, w3, b3):
@@ -59,10 +59,10 @@ class _CnnTrunk(th.autograd.Function):
     def backward(ctx, g3, _gother):
         from ..engine import trunk_backward
         obs, w1, w2, w3, y1, y2, m1, m2, m3, b2m, b3m = ctx.saved_tensors
-        g3m, g2m, gw1, gb1, _ = trunk_backward(g3.contiguous(memory_format=th.channels_last), m3, m2, m1, obs, b3m, b2m, w1)
+        g3m, g2m, gw1, (gb1, gb2, gb3), _ = trunk_backward(g3.contiguous(memory_format=th.channels_last), m3, m2, m1, obs, b3m, b2m, w1)
         cb = th.ops.aten.convolution_backward
-        _, gw3, gb3 = cb(g3m, y2, w3, [64], [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, True])
-        _, gw2, gb2 = cb(g2m, y1, w2, [64], [2, 2], [0, 0], [1, 1], False, [0, 0], 1, [False, True, True])
+        gw3 = cb(g3m, y2, w3, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        gw2 = cb(g2m, y1, w2, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         return None, gw1, gb1, gw2, gb2, gw3, gb3
 
 
