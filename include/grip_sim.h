@@ -232,6 +232,16 @@ int grip_trunk_backward(const float *g3_dev, const uint64_t *mask3_dev, const ui
                         const float *b3_mat_dev, const float *b2_mat_dev, int n, float *g3m_dev, float *g2m_dev, float *g1m_dev, float *partials_dev,
                         float *grad_w1_dev, const int64_t *grad_w1_strides, float *grad_b1_dev, float *grad_b2_dev, float *grad_b3_dev, void *stream);
 
+/* Gradient clipping + Adam for a list of float32 tensors in two launches: what torch.nn.utils.clip_grad_norm_(parameters, max_norm) followed by
+ * torch.optim.Adam.step() (no weight decay, no amsgrad) do in stable_baselines3's PPO.train for the reference's train_agent.py:33-47. Host arrays of
+ * n_tensors (<= 48) device addresses: parameters, gradients (scaled in place by min(1, max_norm / (||g|| + 1e-6))), exp_avg, exp_avg_sq, and the step
+ * counters (one float32 each, advanced by one); numel[t] elements each, all five of a tensor laid out alike. partials_dev: scratch of
+ * grip_clip_adam_chunks(n_tensors, numel) floats; norm_out_dev: the gradient norm before clipping (may be NULL). The addresses travel in the kernel
+ * arguments: the call can be captured in a graph. */
+int grip_clip_adam_chunks(int n_tensors, const int64_t *numel);
+int grip_clip_adam(int n_tensors, const int64_t *numel, float *const *params_dev, float *const *grads_dev, float *const *exp_avg_dev, float *const *exp_avg_sq_dev,
+                   float *const *steps_dev, float lr, float beta1, float beta2, float eps, float max_norm, float *partials_dev, float *norm_out_dev, void *stream);
+
 /* PPO's clipped-surrogate loss of one minibatch and its gradients in one launch (the update stable_baselines3's PPO.train runs for the
  * reference's train_agent.py:33-47: advantages normalised per minibatch, clip_range, no value clipping, diagonal Gaussian with a
  * state-independent log_std): mean_dev / actions_dev float32 [n, action_dim], log_std_dev [action_dim], values / old_log_prob /

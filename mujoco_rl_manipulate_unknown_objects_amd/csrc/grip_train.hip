@@ -187,6 +187,9 @@ __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ 
 #pragma unroll
         for (int t = 0; t < DG; t++) arow[t] = (t * 16 + r16) * D_PS2 + 16 * kq;
         const int tb = kq * 6 * D_PS2 + 16 * w + r16;                      // the lane holds rows 4 kq + r: (oy, ox) = (kq, r)
+#ifdef EXP_NOGEMM1
+        if (n_img < 0)
+#endif
         scatter_gemm<DG, 9>(T3, arow, B3g + (size_t)(16 * w + r16) * 64 + 16 * kq, T2,
                             [](int c) { return c * 4096; },                  // column n = c * 64 + 16 w + r16
                             [&](int c, int t, int r) { return tb + (t * 36 + (c / 3) * 6 + r + (c % 3)) * D_PS2; }, [](int) { return true; });
@@ -226,6 +229,9 @@ __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ 
         }
         const bool pad_ok = kq < 2;                     // tile 4: rows 64 + 4 kq + r exist for kq < 2 only
         // column block nt: tap (ky, kx) = (py + 2 (nt >> 2), px + 2 ((nt >> 1) & 1)), channel half nt & 1; n = (ky * 4 + kx) * 32 + 16 (nt & 1) + r16
+#ifdef EXP_NOGEMM2
+        if (n_img < 0)
+#endif
         scatter_gemm<5, 8>(T2, arow, B2g + (size_t)((py * 4 + px) * 32 + r16) * 64 + 16 * kq, T1,
                            [](int nt) { return (((nt >> 2) * 8 + 2 * ((nt >> 1) & 1)) * 32 + 16 * (nt & 1)) * 64; },
                            [&](int nt, int t, int r) { return base[t][r] + ((nt >> 2) * 30 + 2 * ((nt >> 1) & 1)) * D_PS1 + 16 * (nt & 1); },
@@ -331,19 +337,19 @@ __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ 
 }
 
 // dW1[co][ci][ky][kx] = sum over the workgroups' partials / 255 (the forward multiplies bytes by w / 255), db1 / db2 / db3 = sums: 32 outputs per block,
-// 8 slices of the partials each, added in a fixed order
-__global__ void __launch_bounds__(256) k_wgrad1_reduce(const float *__restrict__ part, int nparts, float *__restrict__ gw, long long so, long long sc, long long sy, long long sx,
-                                                        float *__restrict__ gb, float *__restrict__ gb2, float *__restrict__ gb3) {
-    __shared__ float red[8][32];
-    const int o = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
+// 32 slices of the partials each, added in a fixed order
+__global__ void __launch_bounds__(1024) k_wgrad1_reduce(const float *__restrict__ part, int nparts, float *__restrict__ gw, long long so, long long sc, long long sy, long long sx,
+                                                         float *__restrict__ gb, float *__restrict__ gb2, float *__restrict__ gb3) {
+    __shared__ float red[32][32];
+    const int o = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;         // 32 slices of the partials per output (17 MB to read: parallelism, not arithmetic)
     float s = 0.f;
-    for (int p = sl; p < nparts; p += 8) s += part[(size_t)p * TB_PART + o];
+    for (int p = sl; p < nparts; p += 32) s += part[(size_t)p * TB_PART + o];
     red[sl][threadIdx.x & 31] = s;
     __syncthreads();
     if (sl == 0) {
         float t = red[0][threadIdx.x];
 #pragma unroll
-        for (int i = 1; i < 8; i++) t += red[i][threadIdx.x];
+        for (int i = 1; i < 32; i++) t += red[i][threadIdx.x];
         if (o < 256 * 32) {
             const int mm = o >> 5, co = o & 31, ci = mm >> 6, ky = (mm >> 3) & 7, kx = mm & 7;
             gw[co * so + ci * sc + ky * sy + kx * sx] = t * (1.0f / 255.0f);
@@ -390,7 +396,95 @@ extern "C" int grip_trunk_backward(const float *g3_dev, const uint64_t *mask3_de
     hipLaunchKernelGGL(k_trunk_bwd, dim3(parts), dim3(256), lds, (hipStream_t)stream, g3_dev, mask3_dev, mask2_dev, mask1_dev, obs_dev, channels, b3_mat_dev, b2_mat_dev, n, g3m_dev, g2m_dev,
                        g1m_dev, obs_dev ? partials_dev : (float *)nullptr);
     if (obs_dev)
-        hipLaunchKernelGGL(k_wgrad1_reduce, dim3(TB_PART / 32), dim3(256), 0, (hipStream_t)stream, (const float *)partials_dev, parts, grad_w1_dev, (long long)grad_w1_strides[0],
+        hipLaunchKernelGGL(k_wgrad1_reduce, dim3(TB_PART / 32), dim3(1024), 0, (hipStream_t)stream, (const float *)partials_dev, parts, grad_w1_dev, (long long)grad_w1_strides[0],
                            (long long)grad_w1_strides[1], (long long)grad_w1_strides[2], (long long)grad_w1_strides[3], grad_b1_dev, grad_b2_dev, grad_b3_dev);
     return launch_check("grip_trunk_backward");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Gradient clipping + Adam for the whole parameter list in two launches (stable_baselines3 PPO.train: clip_grad_norm_(max_grad_norm) then Adam.step(), as
+// the reference's train_agent.py:33-47 configures them; torch.optim.Adam without weight decay / amsgrad). As tensor-library calls the pair is ~20 launches,
+// ~105 us per optimiser step of 1.4 M parameters in 21 tensors (multi-tensor norm, its clean-up, six scalar kernels, the in-place scaling, the step counters,
+// the fused Adam); the arithmetic moves 45 MB. The tensors' addresses ride in the kernel arguments (nothing to keep in device memory, capturable in a graph).
+//   k_gradnorm   per 4096-element chunk: sum of g^2 -> partial[chunk]; the first chunk of every tensor advances that tensor's step counter
+//   k_clip_adam  every block adds the partials in the same fixed order -> total norm, c = min(1, max_norm / (norm + 1e-6)); g *= c (written back, as the
+//                reference leaves it), m = b1 m + (1 - b1) g, v = b2 v + (1 - b2) g^2, p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+#define CA_MAXT 48
+#define CA_CHUNK 4096
+struct ClipAdamArgs {
+    float *p[CA_MAXT], *g[CA_MAXT], *m[CA_MAXT], *v[CA_MAXT], *step[CA_MAXT];
+    int chunk0[CA_MAXT + 1];                    // first chunk of tensor t (prefix sums of ceil(numel / CA_CHUNK))
+    int numel[CA_MAXT];
+    int n;
+};
+
+__device__ __forceinline__ int ca_find(const ClipAdamArgs &a, int chunk) { int t = 0; while (t + 1 < a.n && a.chunk0[t + 1] <= chunk) t++; return t; }
+
+__global__ void __launch_bounds__(256) k_gradnorm(const ClipAdamArgs a, float *__restrict__ partial) {
+    __shared__ float red[4];
+    const int t = ca_find(a, blockIdx.x), c = blockIdx.x - a.chunk0[t], base = c * CA_CHUNK, n = a.numel[t];
+    const float *g = a.g[t];
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < CA_CHUNK / 256; u++) { const int i = base + u * 256 + threadIdx.x; if (i < n) { const float x = g[i]; s += x * x; } }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (c == 0) a.step[t][0] += 1.0f;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_clip_adam(const ClipAdamArgs a, const float *__restrict__ partial, int nchunks, float lr, float b1, float b2, float eps, float max_norm,
+                                                   float *__restrict__ norm_out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nchunks; i += 256) s += partial[i];                  // the same order in every block: every block gets the same bits
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    const float coef = fminf(max_norm / (norm + 1e-6f), 1.0f);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = norm;
+    const int t = ca_find(a, blockIdx.x), base = (blockIdx.x - a.chunk0[t]) * CA_CHUNK, n = a.numel[t];
+    const float step = a.step[t][0];                                                   // already advanced by k_gradnorm
+    const float bc1 = 1.0f - powf(b1, step), bc2s = sqrtf(1.0f - powf(b2, step)), step_size = lr / bc1;
+    float *p = a.p[t], *g = a.g[t], *m = a.m[t], *v = a.v[t];
+#pragma unroll
+    for (int u = 0; u < CA_CHUNK / 256; u++) {
+        const int i = base + u * 256 + threadIdx.x;
+        if (i < n) {
+            const float gi = g[i] * coef;
+            const float mi = b1 * m[i] + (1.0f - b1) * gi, vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+            g[i] = gi; m[i] = mi; v[i] = vi;
+            p[i] -= step_size * mi / (sqrtf(vi) / bc2s + eps);
+        }
+    }
+}
+
+extern "C" int grip_clip_adam_chunks(int n_tensors, const int64_t *numel) {
+    long long c = 0;
+    for (int t = 0; t < n_tensors; t++) c += (numel[t] + CA_CHUNK - 1) / CA_CHUNK;
+    return (int)c;
+}
+
+extern "C" int grip_clip_adam(int n_tensors, const int64_t *numel, float *const *params_dev, float *const *grads_dev, float *const *exp_avg_dev, float *const *exp_avg_sq_dev,
+                              float *const *steps_dev, float lr, float beta1, float beta2, float eps, float max_norm, float *partials_dev, float *norm_out_dev, void *stream) {
+    if (n_tensors <= 0 || n_tensors > CA_MAXT || !numel || !params_dev || !grads_dev || !exp_avg_dev || !exp_avg_sq_dev || !steps_dev || !partials_dev)
+        return grip_fail("grip_clip_adam: 1..48 tensors, their element counts, five arrays of device addresses and the partial-sum scratch are needed");
+    ClipAdamArgs a;
+    a.n = n_tensors; a.chunk0[0] = 0;
+    for (int t = 0; t < n_tensors; t++) {
+        if (numel[t] <= 0 || numel[t] > 0x7fffffff || !params_dev[t] || !grads_dev[t] || !exp_avg_dev[t] || !exp_avg_sq_dev[t] || !steps_dev[t])
+            return grip_fail("grip_clip_adam: an empty tensor or a missing address");
+        a.p[t] = params_dev[t]; a.g[t] = grads_dev[t]; a.m[t] = exp_avg_dev[t]; a.v[t] = exp_avg_sq_dev[t]; a.step[t] = steps_dev[t];
+        a.numel[t] = (int)numel[t]; a.chunk0[t + 1] = a.chunk0[t] + (int)((numel[t] + CA_CHUNK - 1) / CA_CHUNK);
+    }
+    const int nchunks = a.chunk0[n_tensors];
+    hipLaunchKernelGGL(k_gradnorm, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a, partials_dev);
+    hipLaunchKernelGGL(k_clip_adam, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a, (const float *)partials_dev, nchunks, lr, beta1, beta2, eps, max_norm, norm_out_dev);
+    return launch_check("grip_clip_adam");
 }

@@ -107,7 +107,7 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward", "grip_obs_preprocess",
            "grip_batch_set_state_storage", "grip_batchset_create", "grip_batchset_destroy", "grip_batchset_refresh", "grip_batchset_num_envs",
            "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list", "grip_conv1_u8", "grip_conv1_u8_rows", "grip_batch_render_camera", "grip_ppo_loss", "grip_conv23_prep", "grip_conv23",
-           "grip_trunk_backward", "grip_trunk_backward_parts", "grip_conv1_u8_train", "grip_conv23_train"]
+           "grip_trunk_backward", "grip_trunk_backward_parts", "grip_conv1_u8_train", "grip_conv23_train", "grip_clip_adam", "grip_clip_adam_chunks"]
 
 
 def lib():
@@ -168,6 +168,8 @@ def lib():
     L.grip_conv1_u8_train.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int64), vp, vp, vp, vp, vp, vp]
     L.grip_trunk_backward.argtypes = [vp] * 5 + [C.c_int, vp, vp, C.c_int] + [vp] * 5 + [C.POINTER(C.c_int64), vp, vp, vp, vp]
     L.grip_trunk_backward_parts.argtypes = [C.c_int]
+    L.grip_clip_adam_chunks.argtypes = [C.c_int, C.POINTER(C.c_int64)]
+    L.grip_clip_adam.argtypes = [C.c_int, C.POINTER(C.c_int64)] + [C.POINTER(vp)] * 5 + [C.c_float] * 5 + [vp, vp, vp]
     L.grip_ppo_loss.argtypes = [vp] * 7 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float] + [vp] * 5
     L.grip_batch_render_camera.argtypes = [vp, C.c_int, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp]
     L.grip_rollout_tick.argtypes = [vp, vp]
@@ -316,6 +318,50 @@ def trunk_backward(g3, mask3, mask2, mask1, obs, b3_mat, b2_mat, w1=None, want_g
     _chk(lib().grip_trunk_backward(vp(g3), vp(mask3), vp(mask2), vp(mask1), vp(obs), 5, vp(b3_mat), vp(b2_mat), n, vp(g3m), vp(g2m), vp(g1m), vp(part), vp(gw), strides,
                                    *([vp(t) for t in gb] if gb else [None] * 3), stream))
     return g3m, g2m, gw, gb, g1m
+
+
+class ClipAdam:
+    """clip_grad_norm_(parameters, max_norm) followed by optimizer.step() of a torch.optim.Adam, in two launches (grip_clip_adam, csrc/grip_train.hip):
+    works on the optimiser's own state tensors (step, exp_avg, exp_avg_sq: its state_dict stays what torch would have written) and hyper-parameters.
+    step() returns False -- nothing done -- when the optimiser or its tensors are not of the kind the kernel handles (the caller then runs the
+    tensor library's pair)."""
+
+    def __init__(self, optimizer, max_norm):
+        self.opt, self.max_norm, self._partials = optimizer, float(max_norm), None
+
+    def step(self):
+        import torch
+        if type(self.opt) is not torch.optim.Adam or len(self.opt.param_groups) != 1:
+            return False
+        g = self.opt.param_groups[0]
+        ps = [p for p in g["params"] if p.grad is not None]
+        if (not ps or len(ps) > 48 or g.get("weight_decay", 0) != 0 or g.get("amsgrad") or g.get("maximize") or g.get("differentiable")
+                or not isinstance(g["lr"], float) or not (g.get("capturable") or g.get("fused"))):
+            return False
+        for p in ps:
+            dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+            if not (p.is_cuda and p.dtype == torch.float32 and dense and p.grad.dtype == torch.float32 and p.grad.stride() == p.stride() and not p.grad.is_sparse):
+                return False
+        for p in ps:                                    # state as torch.optim.Adam._init_group creates it for capturable / fused optimisers
+            st = self.opt.state[p]
+            if len(st) == 0:
+                st["step"] = torch.zeros((), dtype=torch.float32, device=p.device)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if not (st["step"].is_cuda and st["step"].dtype == torch.float32 and st["exp_avg"].stride() == p.stride() and st["exp_avg_sq"].stride() == p.stride()):
+                return False
+        n = len(ps)
+        numel = (C.c_int64 * n)(*[p.numel() for p in ps])
+        arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        nchunks = int(lib().grip_clip_adam_chunks(n, numel))
+        if self._partials is None or self._partials.numel() < nchunks or self._partials.device != ps[0].device:
+            self._partials = torch.empty(nchunks, dtype=torch.float32, device=ps[0].device)
+        b1, b2 = g["betas"]
+        stream = C.c_void_p(torch.cuda.current_stream(ps[0].device).cuda_stream)
+        _chk(lib().grip_clip_adam(n, numel, arr(ps), arr([p.grad for p in ps]), arr([self.opt.state[p]["exp_avg"] for p in ps]),
+                                  arr([self.opt.state[p]["exp_avg_sq"] for p in ps]), arr([self.opt.state[p]["step"] for p in ps]), float(g["lr"]), float(b1), float(b2),
+                                  float(g["eps"]), self.max_norm, C.c_void_p(self._partials.data_ptr()), None, stream))
+        return True
 
 
 def ppo_loss(mean, log_std, values, actions, old_log_prob, advantages, returns, clip_range, ent_coef, vf_coef):

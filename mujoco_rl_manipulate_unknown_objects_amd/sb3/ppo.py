@@ -307,7 +307,16 @@ class PPO:
         loss.backward()
         return pl.detach(), vl.detach(), loss.detach()
 
+    fused_clip_adam = True           # clipping + Adam in two launches (engine.ClipAdam) where the optimiser is a plain torch Adam on float32 CUDA tensors
+
     def _apply(self):
+        if self.fused_clip_adam and self.device.type == "cuda":
+            ca = getattr(self, "_clip_adam", None)
+            if ca is None or ca.opt is not self.optimizer or ca.max_norm != float(self.max_grad_norm):
+                from ..engine import ClipAdam
+                ca = self._clip_adam = ClipAdam(self.optimizer, self.max_grad_norm)
+            if all(p.grad is not None for p in self.policy.parameters()) and ca.step():
+                return
         th.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
         self.optimizer.step()
 
