@@ -209,18 +209,20 @@ int grip_conv23(const float *y1_nhwc_dev, int n, const float *b2_mat_dev, const 
                 float *out_nhwc_dev, void *stream);
 
 /* Update-side forward of the same layers: the kernels above with the extra outputs the backward pass wants. grip_conv1_u8_train also writes the
- * first layer's ReLU mask, mask_dev uint32 [n, 225]: bit c of word (image, position) = channel c is active (NULL: plain grip_conv1_u8_rows).
+ * first layer's ReLU mask, mask_dev uint32 [n, 225]: bit c of word (image, position) = channel c is active (NULL: none), and can take its n images
+ * from rows rows_dev[0 .. n - 1] (int64, device) of obs_dev -- a minibatch read where it lies in the rollout storage (NULL: consecutive rows from row0).
  * grip_conv23_train also writes y2_nhwc_dev float32 [n, 6, 6, 64] (the second layer's output, operand of the third layer's weight gradient) and
  * the two layers' masks, mask2_dev uint64 [n, 36] and mask3_dev uint64 [n, 16], bit c = channel c (all three NULL: plain grip_conv23). */
-int grip_conv1_u8_train(const uint8_t *obs_dev, const int64_t *row0_dev, int n, int channels, const float *weight_dev, const int64_t *weight_strides,
-                        const float *bias_dev, float *scratch_dev, float *out_nhwc_dev, float *other_dev, uint32_t *mask_dev, void *stream);
+int grip_conv1_u8_train(const uint8_t *obs_dev, const int64_t *row0_dev, const int64_t *rows_dev, int n, int channels, const float *weight_dev,
+                        const int64_t *weight_strides, const float *bias_dev, float *scratch_dev, float *out_nhwc_dev, float *other_dev, uint32_t *mask_dev, void *stream);
 int grip_conv23_train(const float *y1_nhwc_dev, int n, const float *b2_mat_dev, const float *bias2_dev, const float *b3_mat_dev, const float *bias3_dev,
                       float *out_nhwc_dev, float *y2_nhwc_dev, uint64_t *mask2_dev, uint64_t *mask3_dev, void *stream);
 
 /* Update-side backward of the three convolutions (csrc/grip_train.hip): what the tensor library's convolution_backward, threshold_backward and
  * bias-gradient sums compute for the reference's fp32 training path (stable_baselines3 PPO.train / SAC.train on models/feature_extractor.py:14-22),
  * in one launch plus a small reduction. g3_dev float32 [n, 4, 4, 64] = d loss / d y3 (NHWC); the three ReLU masks of the training forward; obs_dev
- * uint8 [n, channels = 5, 64, 64] (NULL: no first-layer weight gradient); the weight matrices of grip_conv23_prep. Outputs: g3m_dev = g3 masked (may
+ * uint8 [n, channels = 5, 64, 64] (NULL: no first-layer weight gradient), or with obs_rows_dev (int64 [n], device) the rows of a larger store the
+ * images are; the weight matrices of grip_conv23_prep. Outputs: g3m_dev = g3 masked (may
  * be NULL) and g2m_dev [n, 6, 6, 64] = d loss / d (second layer's pre-activation) -- the operands of those layers' weight gradients; g1m_dev
  * [n, 15, 15, 32] = d loss / d (first layer's pre-activation) (may be NULL when obs_dev is given: the tile is consumed on chip); grad_w1_dev =
  * d loss / d w1 as float32 [32, 4, 8, 8] with element strides grad_w1_strides[4] (w.r.t. the weight that multiplies obs / 255), grad_b1_dev [32].
@@ -228,7 +230,8 @@ int grip_conv23_train(const float *y1_nhwc_dev, int n, const float *b2_mat_dev, 
  * partials_dev: scratch of grip_trunk_backward_parts(n) x 8352 floats. fp32 products and sums on the matrix cores; sums in a fixed order (no
  * atomics): bit-identical from run to run. */
 int grip_trunk_backward_parts(int n);
-int grip_trunk_backward(const float *g3_dev, const uint64_t *mask3_dev, const uint64_t *mask2_dev, const uint32_t *mask1_dev, const uint8_t *obs_dev, int channels,
+int grip_trunk_backward(const float *g3_dev, const uint64_t *mask3_dev, const uint64_t *mask2_dev, const uint32_t *mask1_dev, const uint8_t *obs_dev,
+                        const int64_t *obs_rows_dev, int channels,
                         const float *b3_mat_dev, const float *b2_mat_dev, int n, float *g3m_dev, float *g2m_dev, float *g1m_dev, float *partials_dev,
                         float *grad_w1_dev, const int64_t *grad_w1_strides, float *grad_b1_dev, float *grad_b2_dev, float *grad_b3_dev, void *stream);
 

@@ -40,8 +40,9 @@ __global__ void __launch_bounds__(256) k_conv1_prep(const float *__restrict__ w,
     Bg[i] = w[n * so + ci * sc + ky * sy + kx * sx] * (1.0f / 255.0f);
 }
 
-// row0 != NULL: image b is row row0[0] + b of obs (the trainer's record rows of this tick: the observation kernel renders straight into them)
-__global__ void __launch_bounds__(256, 3) k_conv1_u8(const uint8_t *__restrict__ obs, const long long *__restrict__ row0, int n_img, int channels, const float *__restrict__ Bg,
+// row0 != NULL: image b is row row0[0] + b of obs (the trainer's record rows of this tick: the observation kernel renders straight into them);
+// rows != NULL: image b is row rows[b] (a minibatch of the update, read where it lies instead of gathered first)
+__global__ void __launch_bounds__(256, 3) k_conv1_u8(const uint8_t *__restrict__ obs, const long long *__restrict__ row0, const long long *__restrict__ rows, int n_img, int channels, const float *__restrict__ Bg,
                                                   const float *__restrict__ bias, float *__restrict__ out, float *__restrict__ other, uint32_t *__restrict__ mask) {
     __shared__ __attribute__((aligned(16))) uint8_t img[C1_IN * C1_HW * C1_HW];
     __shared__ __attribute__((aligned(16))) float B[C1_KDIM * C1_OUT];
@@ -55,7 +56,7 @@ __global__ void __launch_bounds__(256, 3) k_conv1_u8(const uint8_t *__restrict__
   // workgroup of a CU stages its next image the other keeps the matrix cores busy (prefetching the next image through
   // registers was slower: the compiler parks it in LDS before the MFMA loop, exposing the load)
   for (int b = blockIdx.x; b < n_img; b += gridDim.x) {
-    const uint8_t *o = obs + ((size_t)(row0 ? row0[0] : 0LL) + (size_t)b) * channels * C1_HW * C1_HW;
+    const uint8_t *o = obs + (size_t)(rows ? rows[b] : (row0 ? row0[0] : 0LL) + b) * channels * C1_HW * C1_HW;
     __syncthreads();                                            // everybody is done with the previous image
     {   const uint4 *src = reinterpret_cast<const uint4 *>(o); uint4 *dst = reinterpret_cast<uint4 *>(img);
         for (int i = tid; i < C1_IN * C1_HW * C1_HW / 16; i += 256) dst[i] = src[i]; }
@@ -126,18 +127,18 @@ __global__ void __launch_bounds__(256, 3) k_conv1_u8(const uint8_t *__restrict__
   }
 }
 
-extern "C" int grip_conv1_u8_train(const uint8_t *obs_dev, const int64_t *row0_dev, int n, int channels, const float *weight_dev, const int64_t *weight_strides,
-                                   const float *bias_dev, float *scratch_dev, float *out_nhwc_dev, float *other_dev, uint32_t *mask_dev, void *stream);
+extern "C" int grip_conv1_u8_train(const uint8_t *obs_dev, const int64_t *row0_dev, const int64_t *rows_dev, int n, int channels, const float *weight_dev,
+                                   const int64_t *weight_strides, const float *bias_dev, float *scratch_dev, float *out_nhwc_dev, float *other_dev, uint32_t *mask_dev, void *stream);
 extern "C" int grip_conv1_u8_rows(const uint8_t *obs_dev, const int64_t *row0_dev, int n, int channels, const float *weight_dev, const int64_t *weight_strides,
                                   const float *bias_dev, float *scratch_dev, float *out_nhwc_dev, float *other_dev, void *stream) {
-    return grip_conv1_u8_train(obs_dev, row0_dev, n, channels, weight_dev, weight_strides, bias_dev, scratch_dev, out_nhwc_dev, other_dev, nullptr, stream);
+    return grip_conv1_u8_train(obs_dev, row0_dev, nullptr, n, channels, weight_dev, weight_strides, bias_dev, scratch_dev, out_nhwc_dev, other_dev, nullptr, stream);
 }
 extern "C" int grip_conv1_u8(const uint8_t *obs_dev, int n, int channels, const float *weight_dev, const int64_t *weight_strides, const float *bias_dev,
                              float *scratch_dev, float *out_nhwc_dev, float *other_dev, void *stream) {
     return grip_conv1_u8_rows(obs_dev, nullptr, n, channels, weight_dev, weight_strides, bias_dev, scratch_dev, out_nhwc_dev, other_dev, stream);
 }
-extern "C" int grip_conv1_u8_train(const uint8_t *obs_dev, const int64_t *row0_dev, int n, int channels, const float *weight_dev, const int64_t *weight_strides,
-                                   const float *bias_dev, float *scratch_dev, float *out_nhwc_dev, float *other_dev, uint32_t *mask_dev, void *stream) {
+extern "C" int grip_conv1_u8_train(const uint8_t *obs_dev, const int64_t *row0_dev, const int64_t *rows_dev, int n, int channels, const float *weight_dev,
+                                   const int64_t *weight_strides, const float *bias_dev, float *scratch_dev, float *out_nhwc_dev, float *other_dev, uint32_t *mask_dev, void *stream) {
     if (!obs_dev || !weight_dev || !weight_strides || !bias_dev || !scratch_dev || !out_nhwc_dev || !other_dev || n <= 0 || channels != C1_IN + 1)
         return grip_fail("grip_conv1_u8: need uint8 [n, 5, 64, 64] observations, Conv2d(4, 32, 8, 4) weights and bias, a 32 KB scratch and the two outputs");
     hipLaunchKernelGGL(k_conv1_prep, dim3(C1_KDIM * C1_OUT / 256), dim3(256), 0, (hipStream_t)stream, weight_dev, (long long)weight_strides[0], (long long)weight_strides[1],
@@ -146,7 +147,7 @@ extern "C" int grip_conv1_u8_train(const uint8_t *obs_dev, const int64_t *row0_d
     // i + 512 under round-robin placement) share the remainder evenly -- sizing the grid for equal counts per WORKGROUP (683 x 6 for 4096 images) left a
     // third of the CUs with two workgroups and the rest with three, 12 % off the balanced time
     const int grid = n < 768 ? n : 768;
-    hipLaunchKernelGGL(k_conv1_u8, dim3(grid), dim3(256), 0, (hipStream_t)stream, obs_dev, (const long long *)row0_dev, n, channels, (const float *)scratch_dev, bias_dev, out_nhwc_dev, other_dev, mask_dev);
+    hipLaunchKernelGGL(k_conv1_u8, dim3(grid), dim3(256), 0, (hipStream_t)stream, obs_dev, (const long long *)row0_dev, (const long long *)rows_dev, n, channels, (const float *)scratch_dev, bias_dev, out_nhwc_dev, other_dev, mask_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { char buf[160]; snprintf(buf, sizeof buf, "grip_conv1_u8: %s", hipGetErrorString(e)); return grip_fail(buf); }
     return 0;

@@ -144,7 +144,7 @@ __device__ __forceinline__ void group_in_load(GroupIn &gi, int tl, int img0, int
 }
 
 __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ g3, const uint64_t *__restrict__ m3, const uint64_t *__restrict__ m2, const uint32_t *__restrict__ m1,
-                                                      const uint8_t *__restrict__ obs, int channels, const float *__restrict__ B3, const float *__restrict__ B2, int n_img,
+                                                      const uint8_t *__restrict__ obs, const long long *__restrict__ obs_rows, int channels, const float *__restrict__ B3, const float *__restrict__ B2, int n_img,
                                                       float *__restrict__ g3m_out, float *__restrict__ g2m_out, float *__restrict__ g1m_out, float *__restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float d_lds[];
     float *T1 = d_lds, *T2 = d_lds + D_T1, *T3 = d_lds;
@@ -187,9 +187,6 @@ __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ 
 #pragma unroll
         for (int t = 0; t < DG; t++) arow[t] = (t * 16 + r16) * D_PS2 + 16 * kq;
         const int tb = kq * 6 * D_PS2 + 16 * w + r16;                      // the lane holds rows 4 kq + r: (oy, ox) = (kq, r)
-#ifdef EXP_NOGEMM1
-        if (n_img < 0)
-#endif
         scatter_gemm<DG, 9>(T3, arow, B3g + (size_t)(16 * w + r16) * 64 + 16 * kq, T2,
                             [](int c) { return c * 4096; },                  // column n = c * 64 + 16 w + r16
                             [&](int c, int t, int r) { return tb + (t * 36 + (c / 3) * 6 + r + (c % 3)) * D_PS2; }, [](int) { return true; });
@@ -229,9 +226,6 @@ __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ 
         }
         const bool pad_ok = kq < 2;                     // tile 4: rows 64 + 4 kq + r exist for kq < 2 only
         // column block nt: tap (ky, kx) = (py + 2 (nt >> 2), px + 2 ((nt >> 1) & 1)), channel half nt & 1; n = (ky * 4 + kx) * 32 + 16 (nt & 1) + r16
-#ifdef EXP_NOGEMM2
-        if (n_img < 0)
-#endif
         scatter_gemm<5, 8>(T2, arow, B2g + (size_t)((py * 4 + px) * 32 + r16) * 64 + 16 * kq, T1,
                            [](int nt) { return (((nt >> 2) * 8 + 2 * ((nt >> 1) & 1)) * 32 + 16 * (nt & 1)) * 64; },
                            [&](int nt, int t, int r) { return base[t][r] + ((nt >> 2) * 30 + 2 * ((nt >> 1) & 1)) * D_PS1 + 16 * (nt & 1); },
@@ -241,7 +235,7 @@ __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ 
     // ---- g1m = g1 * mask1, in place (and to memory when asked for), while the first image's byte planes are on their way (to registers, then U = T2's space)
     uint4 pa = make_uint4(0, 0, 0, 0), pb = pa, pc = pa, pd = pa;            // (scalars: as an array the four land in scratch memory)
     if (obs) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(obs + (size_t)img0 * channels * 4096) + tl;
+        const uint4 *src = reinterpret_cast<const uint4 *>(obs + (size_t)(obs_rows ? obs_rows[img0] : img0) * channels * 4096) + tl;
         pa = src[0]; pb = src[256]; pc = src[512]; pd = src[768];
     }
 #pragma unroll 2
@@ -265,9 +259,6 @@ __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ 
     auto wgrad_image = [&](int g) {
         const uint8_t *ap = U + w * 4096 + (m32 >> 3) * 64 + (m32 & 7) + half * 8 * 256;      // + oy * 256 + 4 ox; second tile (ky + 4): + 256
         const float *bp = T1 + (g * 225 + half * 8 * 15) * D_PS1 + m32;
-#ifdef EXP_NOWGRAD
-        if (n_img < 0)
-#endif
 #pragma unroll 1
         for (int ro = 0; ro < 7; ro++) {
 #pragma unroll
@@ -291,7 +282,7 @@ __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ 
         __syncthreads();
         // requests that fly during the K loop (it issues none of its own): the second image's planes, or the next group's gradient tile and masks
         if (nimg > 1) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(obs + (size_t)(img0 + 1) * channels * 4096) + tl;
+            const uint4 *src = reinterpret_cast<const uint4 *>(obs + (size_t)(obs_rows ? obs_rows[img0 + 1] : img0 + 1) * channels * 4096) + tl;
             pa = src[0]; pb = src[256]; pc = src[512]; pd = src[768];
         } else next_group();
         wgrad_image(0);
@@ -379,7 +370,8 @@ static int launch_check(const char *who) {
 
 extern "C" int grip_trunk_backward_parts(int n) { const int groups = (n + DG - 1) / DG; return groups < 512 ? groups : 512; }
 
-extern "C" int grip_trunk_backward(const float *g3_dev, const uint64_t *mask3_dev, const uint64_t *mask2_dev, const uint32_t *mask1_dev, const uint8_t *obs_dev, int channels,
+extern "C" int grip_trunk_backward(const float *g3_dev, const uint64_t *mask3_dev, const uint64_t *mask2_dev, const uint32_t *mask1_dev, const uint8_t *obs_dev,
+                                   const int64_t *obs_rows_dev, int channels,
                                    const float *b3_mat_dev, const float *b2_mat_dev, int n, float *g3m_dev, float *g2m_dev, float *g1m_dev, float *partials_dev,
                                    float *grad_w1_dev, const int64_t *grad_w1_strides, float *grad_b1_dev, float *grad_b2_dev, float *grad_b3_dev, void *stream) {
     if (!g3_dev || !mask3_dev || !mask2_dev || !mask1_dev || !b3_mat_dev || !b2_mat_dev || !g2m_dev || n <= 0)
@@ -393,7 +385,7 @@ extern "C" int grip_trunk_backward(const float *g3_dev, const uint64_t *mask3_de
     const size_t lds = (size_t)D_LDS_FLOATS * sizeof(float);
     if (set_dyn_lds((const void *)k_trunk_bwd, lds, mask, "grip_trunk_backward")) return -1;
     const int parts = grip_trunk_backward_parts(n);
-    hipLaunchKernelGGL(k_trunk_bwd, dim3(parts), dim3(256), lds, (hipStream_t)stream, g3_dev, mask3_dev, mask2_dev, mask1_dev, obs_dev, channels, b3_mat_dev, b2_mat_dev, n, g3m_dev, g2m_dev,
+    hipLaunchKernelGGL(k_trunk_bwd, dim3(parts), dim3(256), lds, (hipStream_t)stream, g3_dev, mask3_dev, mask2_dev, mask1_dev, obs_dev, (const long long *)obs_rows_dev, channels, b3_mat_dev, b2_mat_dev, n, g3m_dev, g2m_dev,
                        g1m_dev, obs_dev ? partials_dev : (float *)nullptr);
     if (obs_dev)
         hipLaunchKernelGGL(k_wgrad1_reduce, dim3(TB_PART / 32), dim3(1024), 0, (hipStream_t)stream, (const float *)partials_dev, parts, grad_w1_dev, (long long)grad_w1_strides[0],

@@ -165,8 +165,8 @@ def lib():
     L.grip_conv23_prep.argtypes = [vp, C.POINTER(C.c_int64), vp, C.POINTER(C.c_int64), vp, vp, vp]
     L.grip_conv23.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.grip_conv23_train.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-    L.grip_conv1_u8_train.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int64), vp, vp, vp, vp, vp, vp]
-    L.grip_trunk_backward.argtypes = [vp] * 5 + [C.c_int, vp, vp, C.c_int] + [vp] * 5 + [C.POINTER(C.c_int64), vp, vp, vp, vp]
+    L.grip_conv1_u8_train.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int64), vp, vp, vp, vp, vp, vp]
+    L.grip_trunk_backward.argtypes = [vp] * 6 + [C.c_int, vp, vp, C.c_int] + [vp] * 5 + [C.POINTER(C.c_int64), vp, vp, vp, vp]
     L.grip_trunk_backward_parts.argtypes = [C.c_int]
     L.grip_clip_adam_chunks.argtypes = [C.c_int, C.POINTER(C.c_int64)]
     L.grip_clip_adam.argtypes = [C.c_int, C.POINTER(C.c_int64)] + [C.POINTER(vp)] * 5 + [C.c_float] * 5 + [vp, vp, vp]
@@ -228,17 +228,37 @@ class RecordRows:
         return self.records[r:r + self.n]
 
 
+class IndexedRows:
+    """Rows `index` (int64 [n], device) of a uint8 observation store [R, 5, 64, 64]: a minibatch of the update handed to the policy where it lies in the
+    rollout storage, instead of a gathered copy (84 MB moved per 4096-sample minibatch). Quacks like the tensor of those rows where the policy looks."""
+
+    def __init__(self, records, index):
+        import torch
+        assert records.is_cuda and records.dtype == torch.uint8 and records.is_contiguous() and index.dtype == torch.int64 and index.is_cuda and index.dim() == 1
+        self.records, self.index, self.n = records, index.contiguous(), int(index.numel())
+        self.dtype, self.is_cuda, self.device = torch.uint8, True, records.device
+        self.shape = (self.n,) + tuple(records.shape[1:])
+        self.ndim = records.ndim
+
+    def contiguous(self):
+        return self
+
+    def materialize(self):
+        return self.records[self.index]
+
+
 def conv1_u8(obs, weight, bias, with_mask=False):
     """First layer of AugmentedNatureCNN for rollouts (grip_conv1_u8, csrc/grip_policy.hip): uint8 CUDA observations
     [n, 5, 64, 64] -> (relu(conv2d(obs[:, :4] / 255, weight, bias, stride 4)) as a channels-last float32 [n, 32, 15, 15]
     tensor, the two sensor-pad scalars / 255 as [n, 2]) in one launch on the matrix cores (f32 MFMA). No autograd."""
     import torch
     rows = obs if isinstance(obs, RecordRows) else None
-    if rows is not None:
-        obs = rows.records
+    idx = obs if isinstance(obs, IndexedRows) else None
+    if rows is not None or idx is not None:
+        obs = (rows or idx).records
     assert obs.is_cuda and obs.dtype == torch.uint8 and obs.is_contiguous() and tuple(obs.shape[1:]) == (5, 64, 64)
     assert weight.dtype == torch.float32 and tuple(weight.shape) == (32, 4, 8, 8) and bias.dtype == torch.float32 and bias.is_contiguous()
-    n = int(obs.shape[0]) if rows is None else rows.n
+    n = rows.n if rows is not None else idx.n if idx is not None else int(obs.shape[0])
     out = torch.empty((n, 32, 15, 15), dtype=torch.float32, device=obs.device, memory_format=torch.channels_last)
     other = torch.empty((n, 2), dtype=torch.float32, device=obs.device)
     scratch = torch.empty(8192, dtype=torch.float32, device=obs.device)
@@ -246,7 +266,8 @@ def conv1_u8(obs, weight, bias, with_mask=False):
     stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
     # with_mask (the update's forward): also the layer's ReLU mask, int32 [n, 225], bit c of word (image, position) = channel c is active
     mask = torch.empty((n, 225), dtype=torch.int32, device=obs.device) if with_mask else None
-    _chk(lib().grip_conv1_u8_train(C.c_void_p(obs.data_ptr()), None if rows is None else C.c_void_p(rows.row0.data_ptr()), n, 5, C.c_void_p(weight.data_ptr()), strides,
+    _chk(lib().grip_conv1_u8_train(C.c_void_p(obs.data_ptr()), None if rows is None else C.c_void_p(rows.row0.data_ptr()),
+                                   None if idx is None else C.c_void_p(idx.index.data_ptr()), n, 5, C.c_void_p(weight.data_ptr()), strides,
                                    C.c_void_p(bias.data_ptr()), C.c_void_p(scratch.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(other.data_ptr()),
                                    None if mask is None else C.c_void_p(mask.data_ptr()), stream))
     return (out, other, mask) if with_mask else (out, other)
@@ -308,14 +329,18 @@ def trunk_backward(g3, mask3, mask2, mask1, obs, b3_mat, b2_mat, w1=None, want_g
     gw = gb = part = None
     vp = lambda t: None if t is None else C.c_void_p(t.data_ptr())
     strides = None
+    obs_rows = None
+    if isinstance(obs, IndexedRows):
+        assert obs.n == n
+        obs_rows, obs = obs.index, obs.records
     if obs is not None:
-        assert obs.is_cuda and obs.dtype == torch.uint8 and obs.is_contiguous() and tuple(obs.shape) == (n, 5, 64, 64)
+        assert obs.is_cuda and obs.dtype == torch.uint8 and obs.is_contiguous() and tuple(obs.shape[1:]) == (5, 64, 64) and (obs_rows is not None or obs.shape[0] == n)
         assert w1 is not None and tuple(w1.shape) == (32, 4, 8, 8) and w1.dtype == torch.float32
         gw = torch.empty_like(w1); gb = tuple(torch.empty(k, dtype=torch.float32, device=g3.device) for k in (32, 64, 64))
         part = torch.empty((int(lib().grip_trunk_backward_parts(n)), 8352), dtype=torch.float32, device=g3.device)
         strides = (C.c_int64 * 4)(*gw.stride())
     stream = C.c_void_p(torch.cuda.current_stream(g3.device).cuda_stream)
-    _chk(lib().grip_trunk_backward(vp(g3), vp(mask3), vp(mask2), vp(mask1), vp(obs), 5, vp(b3_mat), vp(b2_mat), n, vp(g3m), vp(g2m), vp(g1m), vp(part), vp(gw), strides,
+    _chk(lib().grip_trunk_backward(vp(g3), vp(mask3), vp(mask2), vp(mask1), vp(obs), vp(obs_rows), 5, vp(b3_mat), vp(b2_mat), n, vp(g3m), vp(g2m), vp(g1m), vp(part), vp(gw), strides,
                                    *([vp(t) for t in gb] if gb else [None] * 3), stream))
     return g3m, g2m, gw, gb, g1m
 

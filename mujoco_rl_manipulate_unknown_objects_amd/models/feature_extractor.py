@@ -46,30 +46,33 @@ class _CnnTrunk(th.autograd.Function):
     library (at 65 % of the fp32 MFMA rate they are not where the time goes). Per 4096-sample minibatch on MI355X: forward 376 us (tensor library 513), backward of these layers ~0.5 ms (~1.0 ms)."""
 
     @staticmethod
-    def forward(ctx, obs, w1, b1, w2, b2, w3, b3):
-        from ..engine import conv1_u8, conv23_prep, conv23
-        y1, other, m1 = conv1_u8(obs, w1, b1, with_mask=True)
+    def forward(ctx, obs, index, w1, b1, w2, b2, w3, b3):
+        from ..engine import conv1_u8, conv23_prep, conv23, IndexedRows
+        ctx.indexed = index is not None                  # obs = the whole observation store, index = the minibatch's rows of it
+        y1, other, m1 = conv1_u8(IndexedRows(obs, index) if ctx.indexed else obs, w1, b1, with_mask=True)
         b2m, b3m = conv23_prep(w2, w3)
         y3, y2, m2, m3 = conv23(y1, b2m, b2, b3m, b3, train=True)
-        ctx.save_for_backward(obs, w1, w2, w3, y1, y2, m1, m2, m3, b2m, b3m)
+        ctx.save_for_backward(obs, index if ctx.indexed else obs.new_empty(0), w1, w2, w3, y1, y2, m1, m2, m3, b2m, b3m)
         ctx.mark_non_differentiable(other)
         return y3, other
 
     @staticmethod
     def backward(ctx, g3, _gother):
-        from ..engine import trunk_backward
-        obs, w1, w2, w3, y1, y2, m1, m2, m3, b2m, b3m = ctx.saved_tensors
-        g3m, g2m, gw1, (gb1, gb2, gb3), _ = trunk_backward(g3.contiguous(memory_format=th.channels_last), m3, m2, m1, obs, b3m, b2m, w1)
+        from ..engine import trunk_backward, IndexedRows
+        obs, index, w1, w2, w3, y1, y2, m1, m2, m3, b2m, b3m = ctx.saved_tensors
+        g3m, g2m, gw1, (gb1, gb2, gb3), _ = trunk_backward(g3.contiguous(memory_format=th.channels_last), m3, m2, m1, IndexedRows(obs, index) if ctx.indexed else obs,
+                                                           b3m, b2m, w1)
         cb = th.ops.aten.convolution_backward
         gw3 = cb(g3m, y2, w3, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         gw2 = cb(g2m, y1, w2, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
-        return None, gw1, gb1, gw2, gb2, gw3, gb3
+        return None, None, gw1, gb1, gw2, gb2, gw3, gb3
 
 
 class AugmentedNatureCNN(BaseFeaturesExtractor):
     accepts_raw_uint8 = True        # forward() normalises raw uint8 CUDA observations itself (one fused kernel)
     fused_first_layer_training = True   # the update's first layer through grip_conv1_u8 too (_Conv1U8); False: the tensor library's convolution
     fused_trunk_training = True         # the update's three convolutions hand-written in both directions (_CnnTrunk); False: the above
+    accepts_indexed_rows = True         # forward() takes engine.IndexedRows (a minibatch as row numbers of the rollout storage) where the fused trunk applies
 
     def __init__(self, observation_space, features_dim: int = 514):
         super().__init__(observation_space, features_dim)
@@ -128,7 +131,13 @@ class AugmentedNatureCNN(BaseFeaturesExtractor):
     def forward(self, observations, num_direct_features: int = 2) -> th.Tensor:
         obs = observations["observation"]
         c0 = self.cnn[0]
-        if (obs.dtype == th.uint8 and obs.is_cuda and not th.is_grad_enabled() and num_direct_features == 2 and tuple(obs.shape[1:]) == (5, 64, 64)
+        index = None
+        if hasattr(obs, "index") and hasattr(obs, "records"):          # engine.IndexedRows
+            if self.fused_trunk_training and th.is_grad_enabled() and not th.is_autocast_enabled() and num_direct_features == 2:
+                obs, index = obs.records, obs.index
+            else:
+                obs = obs.materialize()
+        if (index is None and obs.dtype == th.uint8 and obs.is_cuda and not th.is_grad_enabled() and num_direct_features == 2 and tuple(obs.shape[1:]) == (5, 64, 64)
                 and tuple(c0.weight.shape) == (32, 4, 8, 8) and c0.stride == (4, 4) and c0.padding == (0, 0) and c0.weight.dtype == th.float32):
             # rollouts (no autograd): normalisation, first convolution, bias and ReLU in one f32-MFMA launch (csrc/grip_policy.hip)
             from ..engine import conv1_u8
@@ -141,13 +150,15 @@ class AugmentedNatureCNN(BaseFeaturesExtractor):
                 and tuple(obs.shape[1:]) == (5, 64, 64) and tuple(c0.weight.shape) == (32, 4, 8, 8) and c0.stride == (4, 4) and c0.padding == (0, 0)
                 and c0.weight.dtype == th.float32 and not th.is_autocast_enabled() and tuple(c2.weight.shape) == (64, 32, 4, 4) and c2.stride == (2, 2)
                 and c2.padding == (0, 0) and tuple(c3m.weight.shape) == (64, 64, 3, 3) and c3m.stride == (1, 1) and c3m.padding == (0, 0)):
-            y3, other = _CnnTrunk.apply(obs.contiguous(), c0.weight, c0.bias, c2.weight, c2.bias, c3m.weight, c3m.bias)
+            y3, other = _CnnTrunk.apply(obs.contiguous(), index, c0.weight, c0.bias, c2.weight, c2.bias, c3m.weight, c3m.bias)
             # the linear layer on the NHWC tensor as it lies in memory, its weight's columns re-ordered to match (2 MB moved instead of the
             # activations' 17 MB in each direction; the gradient comes back already channels-last)
             lw = self.linear[0].weight
             w_nhwc = lw.view(lw.shape[0], 64, 4, 4).permute(0, 2, 3, 1).reshape(lw.shape[0], -1)
             x = th.relu(th.nn.functional.linear(y3.permute(0, 2, 3, 1).reshape(y3.shape[0], -1), w_nhwc, self.linear[0].bias))
             return th.cat((x, other.to(x.dtype)), dim=1)
+        if index is not None:                          # the fused trunk did not apply after all (another architecture): the gathered rows, below
+            obs = obs[index]
         if (self.fused_first_layer_training and obs.dtype == th.uint8 and obs.is_cuda and th.is_grad_enabled() and num_direct_features == 2
                 and tuple(obs.shape[1:]) == (5, 64, 64) and tuple(c0.weight.shape) == (32, 4, 8, 8) and c0.stride == (4, 4) and c0.padding == (0, 0)
                 and c0.weight.dtype == th.float32 and not th.is_autocast_enabled()):

@@ -122,8 +122,10 @@ class ActorCriticPolicy(nn.Module):
         """(mean, log_std, values): the Gaussian head left un-sampled, for callers that sample and score in a fused kernel."""
         if self._rollout_cache is not None and not th.is_grad_enabled():
             return self._forward_parts_merged(obs)
-        if hasattr(obs["observation"], "materialize"):
-            obs = {"observation": obs["observation"].materialize()}
+        o = obs["observation"]
+        if hasattr(o, "materialize") and not (hasattr(o, "index") and th.is_grad_enabled() and getattr(self.features_extractor, "accepts_indexed_rows", False)
+                                              and getattr(self, "_fused_preprocess", False) and self.vf_features_extractor is None):
+            obs = {"observation": o.materialize()}
         lp, lv = self._latents(obs)
         return self.action_net(lp).float(), self.log_std.float(), self.value_net(lv).float().squeeze(-1)
 

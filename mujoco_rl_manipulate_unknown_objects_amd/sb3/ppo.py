@@ -287,8 +287,13 @@ class PPO:
         """Forward + PPO loss + backward of one minibatch `idx` (record / sample ids into the rollout storage `src`)."""
         obs, actions, old_logp, adv_all, ret_all = src
         if self.fused_loss and obs.is_cuda and hasattr(self.policy, "forward_parts"):
+            if self.indexed_minibatches and obs.dtype == th.uint8 and obs.dim() == 4 and obs.is_contiguous() and idx.dtype == th.int64:
+                from ..engine import IndexedRows              # the minibatch as row numbers: the first layer and its weight gradient read the rows where they lie
+                ob = IndexedRows(obs, idx)
+            else:
+                ob = obs[idx]
             with self._ac():
-                mean, log_std, values = self.policy.forward_parts({"observation": obs[idx]})
+                mean, log_std, values = self.policy.forward_parts({"observation": ob})
             loss, pl, vl = _FusedPPOLoss.apply(mean, log_std, values, actions[idx], old_logp[idx], adv_all[idx], ret_all[idx],
                                                self.clip_range, self.ent_coef, self.vf_coef)
             loss.backward()
@@ -307,6 +312,7 @@ class PPO:
         loss.backward()
         return pl.detach(), vl.detach(), loss.detach()
 
+    indexed_minibatches = True       # minibatch observations handed to the policy as engine.IndexedRows (no gathered copy) on the fused-loss path
     fused_clip_adam = True           # clipping + Adam in two launches (engine.ClipAdam) where the optimiser is a plain torch Adam on float32 CUDA tensors
 
     def _apply(self):

@@ -72,6 +72,15 @@ def test_trunk_backward_matches_autograd(n):
     assert th.equal(a[1], g2m) and th.equal(a[4], g1m) and a[2] is None
     b = trunk_backward(R["g3"], m3r, m2r, m1r, R["obs"], b3m, b2m, R["w1"].detach())
     assert th.equal(b[2], gw) and all(th.equal(x, y) for x, y in zip(b[3], gb)) and b[4] is None
+    # the minibatch as rows of a larger store (engine.IndexedRows): the same bits as on the gathered copy, forward and backward
+    from mujoco_rl_manipulate_unknown_objects_amd.engine import IndexedRows
+    store = th.randint(0, 256, (2 * n + 3, 5, 64, 64), device="cuda", dtype=th.uint8)
+    index = th.randperm(2 * n + 3, device="cuda")[:n]
+    store[index] = R["obs"]
+    y1i, otheri, m1i = conv1_u8(IndexedRows(store, index), R["w1"].detach(), R["b1"].detach(), with_mask=True)
+    assert th.equal(y1i, y1) and th.equal(otheri, other) and th.equal(m1i, m1)
+    c = trunk_backward(R["g3"], m3r, m2r, m1r, IndexedRows(store, index), b3m, b2m, R["w1"].detach())
+    assert th.equal(c[2], gw) and all(th.equal(x, y) for x, y in zip(c[3], gb))
 
 
 def test_extractor_trains_the_same_through_the_fused_trunk():
