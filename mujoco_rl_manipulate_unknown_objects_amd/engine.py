@@ -107,7 +107,7 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward", "grip_obs_preprocess",
            "grip_batch_set_state_storage", "grip_batchset_create", "grip_batchset_destroy", "grip_batchset_refresh", "grip_batchset_num_envs",
            "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list", "grip_conv1_u8", "grip_conv1_u8_rows", "grip_batch_render_camera", "grip_ppo_loss", "grip_conv23_prep", "grip_conv23",
-           "grip_trunk_backward", "grip_trunk_backward_parts", "grip_conv1_u8_train", "grip_conv23_train", "grip_clip_adam", "grip_clip_adam_chunks"]
+           "grip_trunk_backward", "grip_trunk_backward_parts", "grip_conv1_u8_train", "grip_conv23_train", "grip_clip_adam", "grip_clip_adam_chunks", "grip_tanh_backward_colsum"]
 
 
 def lib():
@@ -169,6 +169,7 @@ def lib():
     L.grip_trunk_backward.argtypes = [vp] * 6 + [C.c_int, vp, vp, C.c_int] + [vp] * 5 + [C.POINTER(C.c_int64), vp, vp, vp, vp]
     L.grip_trunk_backward_parts.argtypes = [C.c_int]
     L.grip_clip_adam_chunks.argtypes = [C.c_int, C.POINTER(C.c_int64)]
+    L.grip_tanh_backward_colsum.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp]
     L.grip_clip_adam.argtypes = [C.c_int, C.POINTER(C.c_int64)] + [C.POINTER(vp)] * 5 + [C.c_float] * 5 + [vp, vp, vp]
     L.grip_ppo_loss.argtypes = [vp] * 7 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float] + [vp] * 5
     L.grip_batch_render_camera.argtypes = [vp, C.c_int, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp]
@@ -343,6 +344,28 @@ def trunk_backward(g3, mask3, mask2, mask1, obs, b3_mat, b2_mat, w1=None, want_g
     _chk(lib().grip_trunk_backward(vp(g3), vp(mask3), vp(mask2), vp(mask1), vp(obs), vp(obs_rows), 5, vp(b3_mat), vp(b2_mat), n, vp(g3m), vp(g2m), vp(g1m), vp(part), vp(gw), strides,
                                    *([vp(t) for t in gb] if gb else [None] * 3), stream))
     return g3m, g2m, gw, gb, g1m
+
+
+def tanh_backward_colsum(g, h, batch_major_to_rows=False):
+    """gz = g * (1 - h^2) and its column sums (the tanh layer's bias gradient) in one pass (grip_tanh_backward_colsum, csrc/grip_train.hip).
+    g float32 [B, n, C] contiguous (B = 1 for a 2-D g). batch_major_to_rows=False: h is [B, n, C] like g, gz comes back in that layout. True: h is the
+    row-major [n, B * C] activation whose column blocks are the batch entries, and gz comes back row-major [n, B * C]. Returns (gz, grad_bias [B * C])."""
+    import torch
+    g3 = g if g.dim() == 3 else g.unsqueeze(0)
+    B, n, Cc = (int(x) for x in g3.shape)
+    assert g3.is_cuda and g3.dtype == torch.float32 and g3.is_contiguous() and h.dtype == torch.float32 and h.is_contiguous()
+    if batch_major_to_rows:
+        assert tuple(h.shape) == (n, B * Cc)
+        gz = torch.empty_like(h); row_stride, bstride = B * Cc, Cc
+    else:
+        assert h.numel() == g3.numel()
+        gz = torch.empty_like(g); row_stride, bstride = Cc, n * Cc
+    gb = torch.empty(B * Cc, dtype=torch.float32, device=g.device)
+    sc = torch.empty(((n + 15) // 16) * B * Cc, dtype=torch.float32, device=g.device)
+    stream = C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)
+    _chk(lib().grip_tanh_backward_colsum(C.c_void_p(g3.data_ptr()), C.c_void_p(h.data_ptr()), C.c_void_p(gz.data_ptr()), B, n, Cc, row_stride, bstride,
+                                         C.c_void_p(sc.data_ptr()), C.c_void_p(gb.data_ptr()), stream))
+    return gz, gb
 
 
 class ClipAdam:

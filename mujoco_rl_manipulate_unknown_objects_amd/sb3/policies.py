@@ -22,6 +22,47 @@ def _mlp(in_dim, arch):
     return nn.Sequential(*layers), d
 
 
+class _MergedHeads(th.autograd.Function):
+    """features [n, F] -> (mean [n, A], values [n]) through the policy | value MLPs (two tanh layers each, same shapes) and the action / value heads, as
+    ONE chain with a hand-written backward: first layers = one GEMM with the weights concatenated, second layers and the two heads = batch-of-two
+    GEMMs (the heads zero-padded to 8 outputs), and in the backward the tanh derivative, the bias gradient and the change of layout between the
+    batch-of-two and the concatenated form are one pass per layer (engine.tanh_backward_colsum). The tensor library's fp32 GEMMs, the same sums as the
+    separate modules up to their order (tests/test_gpu_train_kernels.py); about 0.1 ms less per 4096-row minibatch than autograd over the merged forward."""
+
+    @staticmethod
+    def forward(ctx, f, w0p, b0p, w0v, b0v, w1p, b1p, w1v, b1v, wa, ba, wv, bv):
+        n, A, H = f.shape[0], wa.shape[0], w1p.shape[0]
+        W0 = th.cat((w0p, w0v)); h1 = th.tanh_(th.addmm(th.cat((b0p, b0v)), f, W0.t()))                    # [n, 2 H0]
+        H0 = w0p.shape[0]
+        W1 = th.stack((w1p, w1v))                                                                              # [2, H, H0]
+        h2 = th.tanh_(th.baddbmm(th.stack((b1p, b1v)).unsqueeze(1), h1.view(n, 2, H0).transpose(0, 1), W1.transpose(1, 2)))      # [2, n, H]
+        Wo = f.new_zeros((2, 8, H)); Wo[0, :A] = wa; Wo[1, 0] = wv[0]
+        bo = f.new_zeros((2, 1, 8)); bo[0, 0, :A] = ba; bo[1, 0, 0] = bv[0]
+        o = th.baddbmm(bo, h2, Wo.transpose(1, 2))                                                             # [2, n, 8]
+        ctx.save_for_backward(f, h1, h2, W0, W1, Wo)
+        ctx.A = A
+        return o[0, :, :A], o[1, :, 0]
+
+    @staticmethod
+    def backward(ctx, g_mean, g_values):
+        from ..engine import tanh_backward_colsum
+        f, h1, h2, W0, W1, Wo = ctx.saved_tensors
+        n, A, H0 = f.shape[0], ctx.A, W0.shape[0] // 2
+        go = f.new_zeros((2, n, 8))
+        if g_mean is not None:
+            go[0, :, :A] = g_mean
+        if g_values is not None:
+            go[1, :, 0] = g_values
+        gWo = th.bmm(go.transpose(1, 2), h2); gbo = go.sum(1)                                                  # [2, 8, H], [2, 8]
+        gz2, gb1 = tanh_backward_colsum(th.bmm(go, Wo), h2)                                                    # [2, n, H], [2 H]
+        h1b = h1.view(n, 2, H0).transpose(0, 1)
+        gW1 = th.bmm(gz2.transpose(1, 2), h1b)                                                                 # [2, H, H0]
+        gz1, gb0 = tanh_backward_colsum(th.bmm(gz2, W1), h1, batch_major_to_rows=True)                         # [n, 2 H0] row-major, [2 H0]
+        gW0 = th.mm(gz1.t(), f); gf = th.mm(gz1, W0)
+        H = W1.shape[1]
+        return (gf, gW0[:H0], gb0[:H0], gW0[H0:], gb0[H0:], gW1[0], gb1[:H], gW1[1], gb1[H:], gWo[0, :A], gbo[0, :A], gWo[1, :1], gbo[1, :1])
+
+
 class ActorCriticPolicy(nn.Module):
     def __init__(self, observation_space, action_space, features_extractor_class=None,
                  features_extractor_kwargs=None, share_features_extractor=True, net_arch=(256, 256),
@@ -74,6 +115,7 @@ class ActorCriticPolicy(nn.Module):
     # concatenated, deeper layers = a batch-of-two GEMM; backward likewise (one weight-gradient GEMM, one input-gradient GEMM and one bias sum per
     # layer instead of two). The same fp32 sums as the separate modules; [4096 x 256] x [256 x 256] GEMMs alone fill a quarter of the chip.
     merged_heads_training = True
+    fused_heads_training = True      # ... and with the hand-written backward of _MergedHeads where the MLPs are two tanh layers each (the default net_arch)
 
     def _merged_ok(self):
         ok = getattr(self, "_merged_ok_cache", None)
@@ -86,10 +128,25 @@ class ActorCriticPolicy(nn.Module):
             ok = self._merged_ok_cache
         return ok
 
-    def _latents(self, obs):
+    def _mean_values(self, obs):
+        """(mean [n, A], values [n]) of the Gaussian policy and the value function"""
         p = self._prep(obs)
         f = self.features_extractor(p)
         m = self._merged_ok() if (self.merged_heads_training and th.is_grad_enabled() and f.is_cuda) else False
+        if m and self.fused_heads_training and len(m[0]) == 2 and self.action_net.weight.shape[0] <= 8 and f.dtype == th.float32 and not th.is_autocast_enabled():
+            pl, vl = m
+            mean, values = _MergedHeads.apply(f, pl[0].weight, pl[0].bias, vl[0].weight, vl[0].bias, pl[1].weight, pl[1].bias, vl[1].weight, vl[1].bias,
+                                              self.action_net.weight, self.action_net.bias, self.value_net.weight, self.value_net.bias)
+            return mean, values
+        lp, lv = self._latents_from(f, p, m)
+        return self.action_net(lp).float(), self.value_net(lv).float().squeeze(-1)
+
+    def _latents(self, obs):
+        p = self._prep(obs)
+        f = self.features_extractor(p)
+        return self._latents_from(f, p, self._merged_ok() if (self.merged_heads_training and th.is_grad_enabled() and f.is_cuda) else False)
+
+    def _latents_from(self, f, p, m):
         if m:
             pl, vl = m
             h = th.tanh(th.addmm(th.cat((pl[0].bias, vl[0].bias)), f, th.cat((pl[0].weight, vl[0].weight)).t()))      # [n, 2 o]
@@ -107,8 +164,7 @@ class ActorCriticPolicy(nn.Module):
         return (-((actions - mean) ** 2) / (2 * var) - log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
 
     def forward(self, obs, deterministic=False):
-        lp, lv = self._latents(obs)
-        mean = self.action_net(lp).float(); values = self.value_net(lv).float().squeeze(-1)
+        mean, values = self._mean_values(obs)
         log_std = self.log_std.float()
         actions = mean if deterministic else mean + th.randn_like(mean) * th.exp(log_std)
         return actions, values, self._log_prob(mean, log_std, actions)
@@ -126,8 +182,8 @@ class ActorCriticPolicy(nn.Module):
         if hasattr(o, "materialize") and not (hasattr(o, "index") and th.is_grad_enabled() and getattr(self.features_extractor, "accepts_indexed_rows", False)
                                               and getattr(self, "_fused_preprocess", False) and self.vf_features_extractor is None):
             obs = {"observation": o.materialize()}
-        lp, lv = self._latents(obs)
-        return self.action_net(lp).float(), self.log_std.float(), self.value_net(lv).float().squeeze(-1)
+        mean, values = self._mean_values(obs)
+        return mean, self.log_std.float(), values
 
     # ---- rollout-side forward with merged heads (no autograd): the policy and value MLPs have the same shape, so their first layers
     # are one GEMM on the shared features, the deeper ones block-diagonal, the action and value heads one [A + 1]-row GEMM; the
@@ -188,16 +244,15 @@ class ActorCriticPolicy(nn.Module):
         if h is None:                                               # not the observation layout the extractor's fast path handles
             if hasattr(obs["observation"], "materialize"):
                 obs = {"observation": obs["observation"].materialize()}
-            lp, lv = self._latents(obs)
-            return self.action_net(lp).float(), self.log_std.float(), self.value_net(lv).float().squeeze(-1)
+            mean, values = self._mean_values(obs)
+            return mean, self.log_std.float(), values
         for W, b in zip(c["W"], c["b"]):
             h = th.tanh_(th.addmm(b, h, W.t()))
         o = th.addmm(c["bh"], h, c["Wh"].t())
         return o[:, :self.action_dim], self.log_std.float(), o[:, self.action_dim]
 
     def evaluate_actions(self, obs, actions):
-        lp, lv = self._latents(obs)
-        mean = self.action_net(lp).float(); values = self.value_net(lv).float().squeeze(-1)
+        mean, values = self._mean_values(obs)
         log_std = self.log_std.float()
         entropy = (0.5 + 0.5 * math.log(2 * math.pi) + log_std).sum(-1).expand(mean.shape[0])
         return values, self._log_prob(mean, log_std, actions), entropy

@@ -134,17 +134,25 @@ def test_merged_heads_training_gradients_match_the_separate_modules():
     obs = {"observation": th.randint(0, 256, (300, 5, 64, 64), dtype=th.uint8, device="cuda")}
     Gm, Gv = th.randn(300, pol.action_dim, device="cuda"), th.randn(300, device="cuda")
     out, grads = {}, {}
-    for merged in (True, False):
-        pol.merged_heads_training = merged
+    for name, merged, fused in (("hand-written backward", True, True), ("autograd over the merged forward", True, False), ("separate modules", False, False)):
+        pol.merged_heads_training = merged; pol.fused_heads_training = fused
         pol.zero_grad(set_to_none=True)
         mean, log_std, values = pol.forward_parts(obs)
         ((mean * Gm).sum() + (values * Gv).sum()).backward()
-        out[merged] = (mean.detach(), values.detach()); grads[merged] = {k: p.grad.clone() for k, p in pol.named_parameters() if p.grad is not None}
-    _close(out[True][0], out[False][0], 2e-5); _close(out[True][1], out[False][1], 2e-5)
-    assert grads[True].keys() == grads[False].keys()
-    for k in grads[False]:
-        err = (grads[True][k] - grads[False][k]).abs().max().item()
-        assert err <= 2e-4 * max(grads[False][k].abs().max().item(), 1e-6), (k, err, grads[False][k].abs().max().item())
+        out[name] = (mean.detach(), values.detach()); grads[name] = {k: p.grad.clone() for k, p in pol.named_parameters() if p.grad is not None}
+    ref = "separate modules"
+    for name in out:
+        _close(out[name][0], out[ref][0], 2e-5); _close(out[name][1], out[ref][1], 2e-5)
+        assert grads[name].keys() == grads[ref].keys()
+        for k in grads[ref]:
+            err = (grads[name][k] - grads[ref][k]).abs().max().item()
+            assert err <= 2e-4 * max(grads[ref][k].abs().max().item(), 1e-6), (name, k, err, grads[ref][k].abs().max().item())
+    # the value function alone (predict_values / a loss without the policy term): the unused output's gradient is None
+    pol.merged_heads_training = pol.fused_heads_training = True
+    pol.zero_grad(set_to_none=True)
+    _, _, values = pol.forward_parts(obs)
+    (values * Gv).sum().backward()
+    assert pol.value_net.weight.grad is not None and th.isfinite(pol.value_net.weight.grad).all()
 
 
 def test_clip_adam_matches_the_tensor_library():
