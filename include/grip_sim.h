@@ -248,9 +248,13 @@ int grip_clip_adam(int n_tensors, const int64_t *numel, float *const *params_dev
 /* Backward of a tanh layer of the policy | value MLPs with its bias gradient, one pass: gz = g * (1 - h^2), grad_bias[b * cols + c] = sum over rows of gz.
  * g_dev float32 [batch, n, cols] (contiguous); h_dev (the layer's output) and gz_dev are addressed b * h_batch_stride + row * row_stride + c -- with
  * h_batch_stride = cols and row_stride = batch * cols the result is laid out row-major [n, batch * cols] (a transposition of the batch-major gradient
- * folded into the pass), with batch = 1 it is the plain case. scratch_dev: ceil(n / 16) * batch * cols floats. Sums in a fixed order. What torch's tanh_backward + sum(0) compute in stable_baselines3's PPO.train. */
+ * folded into the pass), with batch = 1 it is the plain case. scratch_dev: ceil(n / 32) * batch * cols floats. Sums in a fixed order. What torch's tanh_backward + sum(0) compute in stable_baselines3's PPO.train. */
 int grip_tanh_backward_colsum(const float *g_dev, const float *h_dev, float *gz_dev, int batch, int n, int cols, int row_stride, int64_t h_batch_stride,
                               float *scratch_dev, float *grad_bias_dev, void *stream);
+/* The ReLU counterpart for the extractor's linear layer (models/feature_extractor.py:22): gz = g * (h > 0) and its column sums; g_dev's rows are
+ * g_row_stride >= cols floats apart (the leading columns of a wider gradient), h_dev / gz_dev float32 [n, cols]; scratch_dev: ceil(n / 32) * cols floats. */
+int grip_relu_backward_colsum(const float *g_dev, int g_row_stride, const float *h_dev, float *gz_dev, int n, int cols, float *scratch_dev, float *grad_bias_dev,
+                              void *stream);
 
 /* PPO's clipped-surrogate loss of one minibatch and its gradients in one launch (the update stable_baselines3's PPO.train runs for the
  * reference's train_agent.py:33-47: advantages normalised per minibatch, clip_range, no value clipping, diagonal Gaussian with a

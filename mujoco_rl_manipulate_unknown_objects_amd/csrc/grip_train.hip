@@ -487,9 +487,10 @@ extern "C" int grip_clip_adam(int n_tensors, const int64_t *numel, float *const 
 // in one pass over g and h instead of a tanh_backward pass plus a column reduction (13 + 16 .. 26 us per layer and 4096 rows as tensor-library calls).
 // g is [B][n][C] (the batch-of-two GEMM's output layout); h and gz are addressed as [row][b * C + c] with hs floats per row: hs = B * C stores the result
 // row-major [n][B * C] (what the first layer's concatenated GEMMs want, a transposition folded into the pass), B = 1 is the plain case.
-// 16 rows per workgroup; a second small launch adds the partial column sums in a fixed order (bit-identical from run to run).
-#define TB_ROWS 16
-__global__ void __launch_bounds__(256) k_tanh_bwd_colsum(const float *__restrict__ g, const float *__restrict__ h, float *__restrict__ gz, int B, int n, int C, int hs,
+// 32 rows per workgroup; a second small launch adds the partial column sums in a fixed order (bit-identical from run to run).
+#define TB_ROWS 32
+template <bool RELU>
+__global__ void __launch_bounds__(256) k_tanh_bwd_colsum(const float *__restrict__ g, int g_row_stride, const float *__restrict__ h, float *__restrict__ gz, int B, int n, int C, int hs,
                                                          long long h_bstride, float *__restrict__ partial) {
     const int BC = B * C, r0 = blockIdx.x * TB_ROWS;
     for (int col = threadIdx.x; col < BC; col += 256) {
@@ -498,30 +499,47 @@ __global__ void __launch_bounds__(256) k_tanh_bwd_colsum(const float *__restrict
 #pragma unroll 4
         for (int r = r0; r < min(r0 + TB_ROWS, n); r++) {
             const size_t hi = (size_t)b * h_bstride + (size_t)r * hs + c;
-            const float hv = h[hi], v = g[((size_t)b * n + r) * C + c] * (1.0f - hv * hv);
+            const float hv = h[hi], gv = g[((size_t)b * n + r) * g_row_stride + c], v = RELU ? (hv > 0.f ? gv : 0.f) : gv * (1.0f - hv * hv);
             gz[hi] = v; s += v;
         }
         partial[(size_t)blockIdx.x * BC + col] = s;
     }
 }
 
-__global__ void __launch_bounds__(256) k_colsum_reduce(const float *__restrict__ partial, int blocks, int BC, float *__restrict__ gb) {
-    __shared__ float red[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;          // 64 columns per workgroup, the partials in four slices, added in a fixed order
+__global__ void __launch_bounds__(1024) k_colsum_reduce(const float *__restrict__ partial, int blocks, int BC, float *__restrict__ gb) {
+    __shared__ float red[16][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;          // 64 columns per workgroup, the partials in 16 slices, added in a fixed order
     float s = 0.f;
-    if (col < BC) for (int k = sl; k < blocks; k += 4) s += partial[(size_t)k * BC + col];
+    if (col < BC) for (int k = sl; k < blocks; k += 16) s += partial[(size_t)k * BC + col];
     red[sl][threadIdx.x & 63] = s;
     __syncthreads();
-    if (sl == 0 && col < BC) gb[col] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (sl == 0 && col < BC) {
+        float t = red[0][threadIdx.x];
+#pragma unroll
+        for (int i = 1; i < 16; i++) t += red[i][threadIdx.x];
+        gb[col] = t;
+    }
 }
 
 extern "C" int grip_tanh_backward_colsum(const float *g_dev, const float *h_dev, float *gz_dev, int batch, int n, int cols, int row_stride, int64_t h_batch_stride,
                                          float *scratch_dev, float *grad_bias_dev, void *stream) {
     if (!g_dev || !h_dev || !gz_dev || !scratch_dev || !grad_bias_dev || batch < 1 || n < 1 || cols < 1 || row_stride < cols)
         return grip_fail("grip_tanh_backward_colsum: need g [batch, n, cols], h / gz addressed [b * h_batch_stride + row * row_stride + c], the scratch "
-                         "(ceil(n / 16) * batch * cols floats) and the bias-gradient output [batch * cols]");
+                         "(ceil(n / 32) * batch * cols floats) and the bias-gradient output [batch * cols]");
     const int blocks = (n + TB_ROWS - 1) / TB_ROWS, BC = batch * cols;
-    hipLaunchKernelGGL(k_tanh_bwd_colsum, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g_dev, h_dev, gz_dev, batch, n, cols, row_stride, (long long)h_batch_stride, scratch_dev);
-    hipLaunchKernelGGL(k_colsum_reduce, dim3((BC + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float *)scratch_dev, blocks, BC, grad_bias_dev);
+    hipLaunchKernelGGL(k_tanh_bwd_colsum<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g_dev, cols, h_dev, gz_dev, batch, n, cols, row_stride, (long long)h_batch_stride, scratch_dev);
+    hipLaunchKernelGGL(k_colsum_reduce, dim3((BC + 63) / 64), dim3(1024), 0, (hipStream_t)stream, (const float *)scratch_dev, blocks, BC, grad_bias_dev);
     return launch_check("grip_tanh_backward_colsum");
+}
+
+// The ReLU counterpart for the extractor's linear layer (models/feature_extractor.py:22): gz = g * (h > 0), grad_bias = column sums; g's rows may be
+// g_row_stride floats apart (the first `cols` columns of the gradient of a wider concatenation), h and gz are [n, cols] contiguous.
+extern "C" int grip_relu_backward_colsum(const float *g_dev, int g_row_stride, const float *h_dev, float *gz_dev, int n, int cols, float *scratch_dev, float *grad_bias_dev,
+                                         void *stream) {
+    if (!g_dev || !h_dev || !gz_dev || !scratch_dev || !grad_bias_dev || n < 1 || cols < 1 || g_row_stride < cols)
+        return grip_fail("grip_relu_backward_colsum: need g (rows g_row_stride >= cols apart), h / gz [n, cols], the scratch (ceil(n / 32) * cols floats) and the bias-gradient output");
+    const int blocks = (n + TB_ROWS - 1) / TB_ROWS;
+    hipLaunchKernelGGL(k_tanh_bwd_colsum<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g_dev, g_row_stride, h_dev, gz_dev, 1, n, cols, cols, 0LL, scratch_dev);
+    hipLaunchKernelGGL(k_colsum_reduce, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, (const float *)scratch_dev, blocks, cols, grad_bias_dev);
+    return launch_check("grip_relu_backward_colsum");
 }

@@ -107,7 +107,7 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward", "grip_obs_preprocess",
            "grip_batch_set_state_storage", "grip_batchset_create", "grip_batchset_destroy", "grip_batchset_refresh", "grip_batchset_num_envs",
            "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list", "grip_conv1_u8", "grip_conv1_u8_rows", "grip_batch_render_camera", "grip_ppo_loss", "grip_conv23_prep", "grip_conv23",
-           "grip_trunk_backward", "grip_trunk_backward_parts", "grip_conv1_u8_train", "grip_conv23_train", "grip_clip_adam", "grip_clip_adam_chunks", "grip_tanh_backward_colsum"]
+           "grip_trunk_backward", "grip_trunk_backward_parts", "grip_conv1_u8_train", "grip_conv23_train", "grip_clip_adam", "grip_clip_adam_chunks", "grip_tanh_backward_colsum", "grip_relu_backward_colsum"]
 
 
 def lib():
@@ -169,6 +169,7 @@ def lib():
     L.grip_trunk_backward.argtypes = [vp] * 6 + [C.c_int, vp, vp, C.c_int] + [vp] * 5 + [C.POINTER(C.c_int64), vp, vp, vp, vp]
     L.grip_trunk_backward_parts.argtypes = [C.c_int]
     L.grip_clip_adam_chunks.argtypes = [C.c_int, C.POINTER(C.c_int64)]
+    L.grip_relu_backward_colsum.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     L.grip_tanh_backward_colsum.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp]
     L.grip_clip_adam.argtypes = [C.c_int, C.POINTER(C.c_int64)] + [C.POINTER(vp)] * 5 + [C.c_float] * 5 + [vp, vp, vp]
     L.grip_ppo_loss.argtypes = [vp] * 7 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float] + [vp] * 5
@@ -361,10 +362,24 @@ def tanh_backward_colsum(g, h, batch_major_to_rows=False):
         assert h.numel() == g3.numel()
         gz = torch.empty_like(g); row_stride, bstride = Cc, n * Cc
     gb = torch.empty(B * Cc, dtype=torch.float32, device=g.device)
-    sc = torch.empty(((n + 15) // 16) * B * Cc, dtype=torch.float32, device=g.device)
+    sc = torch.empty(((n + 31) // 32) * B * Cc, dtype=torch.float32, device=g.device)
     stream = C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)
     _chk(lib().grip_tanh_backward_colsum(C.c_void_p(g3.data_ptr()), C.c_void_p(h.data_ptr()), C.c_void_p(gz.data_ptr()), B, n, Cc, row_stride, bstride,
                                          C.c_void_p(sc.data_ptr()), C.c_void_p(gb.data_ptr()), stream))
+    return gz, gb
+
+
+def relu_backward_colsum(g, h):
+    """gz = g * (h > 0) and its column sums (the ReLU layer's bias gradient) in one pass (grip_relu_backward_colsum): g float32 [n, C], rows possibly strided
+    (a column slice of a wider gradient), h float32 [n, C] contiguous. Returns (gz [n, C], grad_bias [C])."""
+    import torch
+    n, Cc = (int(x) for x in h.shape)
+    assert g.is_cuda and g.dtype == torch.float32 and tuple(g.shape) == (n, Cc) and g.stride(1) == 1 and g.stride(0) >= Cc and h.dtype == torch.float32 and h.is_contiguous()
+    gz = torch.empty_like(h); gb = torch.empty(Cc, dtype=torch.float32, device=g.device)
+    sc = torch.empty(((n + 31) // 32) * Cc, dtype=torch.float32, device=g.device)
+    stream = C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)
+    _chk(lib().grip_relu_backward_colsum(C.c_void_p(g.data_ptr()), int(g.stride(0)), C.c_void_p(h.data_ptr()), C.c_void_p(gz.data_ptr()), n, Cc, C.c_void_p(sc.data_ptr()),
+                                         C.c_void_p(gb.data_ptr()), stream))
     return gz, gb
 
 

@@ -68,6 +68,24 @@ class _CnnTrunk(th.autograd.Function):
         return None, None, gw1, gb1, gw2, gb2, gw3, gb3
 
 
+class _LinearReluCat(th.autograd.Function):
+    """cat(relu(x @ W^T + b), other) with the ReLU derivative and the bias gradient as one pass over the leading columns of the incoming gradient
+    (engine.relu_backward_colsum) instead of a slice copy, a threshold_backward and a column reduction; `other` gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, other):
+        h = th.relu_(th.addmm(b, x, W.t()))
+        ctx.save_for_backward(x, W, h)
+        return th.cat((h, other.to(h.dtype)), dim=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        from ..engine import relu_backward_colsum
+        x, W, h = ctx.saved_tensors
+        gz, gb = relu_backward_colsum(g[:, :h.shape[1]], h)
+        return th.mm(gz, W), th.mm(gz.t(), x), gb, None
+
+
 class AugmentedNatureCNN(BaseFeaturesExtractor):
     accepts_raw_uint8 = True        # forward() normalises raw uint8 CUDA observations itself (one fused kernel)
     fused_first_layer_training = True   # the update's first layer through grip_conv1_u8 too (_Conv1U8); False: the tensor library's convolution
@@ -155,8 +173,7 @@ class AugmentedNatureCNN(BaseFeaturesExtractor):
             # activations' 17 MB in each direction; the gradient comes back already channels-last)
             lw = self.linear[0].weight
             w_nhwc = lw.view(lw.shape[0], 64, 4, 4).permute(0, 2, 3, 1).reshape(lw.shape[0], -1)
-            x = th.relu(th.nn.functional.linear(y3.permute(0, 2, 3, 1).reshape(y3.shape[0], -1), w_nhwc, self.linear[0].bias))
-            return th.cat((x, other.to(x.dtype)), dim=1)
+            return _LinearReluCat.apply(y3.permute(0, 2, 3, 1).reshape(y3.shape[0], -1), w_nhwc, self.linear[0].bias, other)
         if index is not None:                          # the fused trunk did not apply after all (another architecture): the gathered rows, below
             obs = obs[index]
         if (self.fused_first_layer_training and obs.dtype == th.uint8 and obs.is_cuda and th.is_grad_enabled() and num_direct_features == 2
