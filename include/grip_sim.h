@@ -185,11 +185,12 @@ int grip_intrinsic_reward(const uint8_t *old_obs_dev, const int64_t *old_rows_de
 int grip_obs_preprocess(const uint8_t *obs_dev, int n, int channels, float *img_nhwc_dev, float *other_dev, void *stream);
 
 /* Rollout-side first layer of AugmentedNatureCNN (models/feature_extractor.py:14-22,41-49) in one launch on the matrix cores
- * (v_mfma_f32_32x32x2_f32: fp32 products and sums): obs_dev uint8 [n, 5, 64, 64] -> out_nhwc_dev float32 [n, 15, 15, 32] =
+ * (fp32 products and sums, computed exactly on v_mfma_f32_32x32x16_bf16: a pixel 0..255 is a bf16, an fp32 weight is the sum of three bf16 terms, and a byte
+ * times a bf16 is exact in the fp32 accumulator): obs_dev uint8 [n, 5, 64, 64] -> out_nhwc_dev float32 [n, 15, 15, 32] =
  * relu(conv2d(obs[:, :4] / 255, weight, bias, stride 4)) (i.e. a channels-last [n, 32, 15, 15] tensor) and other_dev float32
  * [n, 2] = obs[:, 4, 0, :2] / 255. weight_dev float32 [32, 4, 8, 8] with element strides weight_strides[4] (any layout),
- * bias_dev float32 [32], scratch_dev 8192 floats (the weights as the GEMM's B matrix, rewritten by every call).
- * Inference only; the update runs the same layer through the tensor library with autograd. */
+ * bias_dev float32 [32], scratch_dev 12 288 floats (the weights / 255 as three bf16 terms, the GEMM's B operand, rewritten by every call).
+ * No autograd (the update's variant with the ReLU mask: grip_conv1_u8_train; its backward: grip_trunk_backward). */
 int grip_conv1_u8(const uint8_t *obs_dev, int n, int channels, const float *weight_dev, const int64_t *weight_strides, const float *bias_dev,
                   float *scratch_dev, float *out_nhwc_dev, float *other_dev, void *stream);
 /* The same on rows row0_dev[0] .. row0_dev[0] + n - 1 of obs_dev (row0_dev: int64 [1] in device memory, NULL = 0): the time-sliced trainer renders

@@ -1,17 +1,22 @@
-// grip_policy.hip -- first layer of the rollout-side policy forward on the matrix cores.
+// grip_policy.hip -- the policy's convolutions on the matrix cores, the PPO minibatch loss.
 //
 // AugmentedNatureCNN (reference models/feature_extractor.py:14-22) starts with Conv2d(4, 32, kernel 8, stride 4) + ReLU on the
 // image channels of the uint8 observation / 255 (SB3 preprocessing), and reads two scalars from the sensor-pad channel
-// (:41-49). During rollouts that layer is 40 % of the policy's GPU time as separate launches (uint8 -> float NHWC pass, MIOpen
-// implicit GEMM at 37 TFLOP/s, bias, ReLU). k_conv1_u8 does all of it in one launch as an implicit GEMM on
-// v_mfma_f32_32x32x2_f32 (exact f32 products, f32 accumulation: the same arithmetic as the fp32 training path up to the
-// summation order): M = 225 output positions of one image, N = 32 output channels, K = 4 x 8 x 8 = 256.
+// (:41-49). As tensor-library calls that layer is a uint8 -> float NHWC pass, an implicit GEMM at 37 TFLOP/s, bias, ReLU.
+// k_conv1_u8 does all of it in one launch as an implicit GEMM: M = 225 output positions of one image, N = 32 output channels,
+// K = 4 x 8 x 8 = 256 -- in fp32 arithmetic (exact products, fp32 sums: the training path's arithmetic up to the order of summation)
+// at the bf16 matrix rate, because of what the operands ARE: a pixel is an integer 0..255, exactly a bf16; an fp32 weight is
+// exactly the sum of three bf16 numbers (8 + 8 + 8 mantissa bits; w / 255 is split once per call). A byte times a bf16 has 16 significant
+// bits: every product is exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16, and three of those instructions (one per weight
+// term, 32 cycles each for 16 k) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each): 5.3 x less matrix-pipe time, and the operand
+// fragments are 16-byte LDS reads instead of a dword + a conversion per instruction. The fp32-MFMA version ran at 0.65 of the fp32 peak
+// (167 us per 4096 images); this one is bound by the 200 MB it moves.
 //
-// A workgroup (4 waves) per image at a time. LDS: the image's four 64 x 64 uint8 planes (16 KB) and the
-// weights as B[k][n] f32, already divided by 255 (32 KB). Wave w owns the 32-position tiles w and w + 4 (two independent accumulators; positions
-// 225..255 of the last tile are padding). Per (ci, ky) a lane reads the 8 bytes of its position's kernel row once
-// (one ds_read_b32 of its k-half's word, 4-byte aligned because the stride is 4) and converts its four bytes with
-// v_cvt_f32_ubyte0..3; lanes 0-31 / 32-63 read 128-byte rows of B.
+// A workgroup (4 waves) per image at a time, two workgroups per CU. LDS: the image's four planes as bf16 (32 KB, converted while staging:
+// v_cvt_f32_ubyte + the upper halves packed) and the three weight terms as Bt[term][n][k] bf16 (48 KB, 16-byte chunks XOR-swizzled by the row: conflict-free
+// reads without padding -- 80 KB in all, exactly two workgroups per CU).
+// Wave w owns the 32-position tiles w and w + 4 (positions 225..255 of the last tile are padding). k = (ci, ky, kx): an instruction's 16 k are the
+// kernel rows ky, ky + 1 (lanes 0-31 / 32-63) x 8 kx = 8 consecutive pixels, one ds_read2_b64 (8-byte aligned: the stride is 4 pixels).
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <stdint.h>
@@ -19,6 +24,7 @@
 
 int grip_fail(const char *msg);                     // grip_sim.hip
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define C1_IN 4
 #define C1_OUT 32
@@ -28,88 +34,98 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define C1_OHW 15
 #define C1_POS (C1_OHW * C1_OHW)          // 225
 #define C1_KDIM (C1_IN * C1_K * C1_K)     // 256
+#define C1_BROW 256                        // bf16 per row of Bt; the 16-byte chunk c of row n sits at chunk c ^ (n & 7): conflict-free 16-byte reads without padding
+#define C1_BT_HALVES (3 * C1_OUT * C1_BROW)
 
 __device__ __forceinline__ float ubyte_f32(unsigned v, int i) { return (float)((v >> (8 * i)) & 0xffu); }      // v_cvt_f32_ubyte{i}
+__device__ __forceinline__ unsigned bf16_rne_bits(float x) { const unsigned u = __float_as_uint(x); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; }
+__device__ __forceinline__ unsigned pack_hi16(float lo, float hi) { return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u); }   // {hi[31:16], lo[31:16]}
 
-// B[k][n] = w[n][ci][ky][kx] / 255, k = (ci * 8 + ky) * 8 + kx: once per call into a 32 KB scratch (the per-image workgroups
-// then stage it with coalesced 16-byte loads instead of 8192 strided ones each)
-__global__ void __launch_bounds__(256) k_conv1_prep(const float *__restrict__ w, long long so, long long sc, long long sy, long long sx, float *__restrict__ Bg) {
+// Bt[term][n][k] (bf16, rows of C1_BROW) = the three bf16 terms of w[n][ci][ky][kx] / 255, k = (ci * 8 + ky) * 8 + kx: once per call into a 48 KB scratch
+__global__ void __launch_bounds__(256) k_conv1_prep(const float *__restrict__ w, long long so, long long sc, long long sy, long long sx, uint16_t *__restrict__ Bt) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= C1_KDIM * C1_OUT) return;
-    const int n = i & (C1_OUT - 1), k = i >> 5, kx = k & 7, ky = (k >> 3) & 7, ci = k >> 6;
-    Bg[i] = w[n * so + ci * sc + ky * sy + kx * sx] * (1.0f / 255.0f);
+    const int k = i & (C1_KDIM - 1), n = i >> 8, kx = k & 7, ky = (k >> 3) & 7, ci = k >> 6;
+    float r = w[n * so + ci * sc + ky * sy + kx * sx] * (1.0f / 255.0f);
+#pragma unroll
+    for (int t = 0; t < 3; t++) {                                 // r - (its nearest bf16) is exact in fp32: after three terms at most the 25th bit is left
+        const unsigned h = bf16_rne_bits(r);
+        Bt[(t * C1_OUT + n) * C1_BROW + 8 * ((k >> 3) ^ (n & 7)) + (k & 7)] = (uint16_t)h;
+        r -= __uint_as_float(h << 16);
+    }
 }
 
 // row0 != NULL: image b is row row0[0] + b of obs (the trainer's record rows of this tick: the observation kernel renders straight into them);
 // rows != NULL: image b is row rows[b] (a minibatch of the update, read where it lies instead of gathered first)
-__global__ void __launch_bounds__(256, 3) k_conv1_u8(const uint8_t *__restrict__ obs, const long long *__restrict__ row0, const long long *__restrict__ rows, int n_img, int channels, const float *__restrict__ Bg,
-                                                  const float *__restrict__ bias, float *__restrict__ out, float *__restrict__ other, uint32_t *__restrict__ mask) {
-    __shared__ __attribute__((aligned(16))) uint8_t img[C1_IN * C1_HW * C1_HW];
-    __shared__ __attribute__((aligned(16))) float B[C1_KDIM * C1_OUT];
+__global__ void __launch_bounds__(256, 2) k_conv1_u8(const uint8_t *__restrict__ obs, const long long *__restrict__ row0, const long long *__restrict__ rows, int n_img, int channels,
+                                                     const uint16_t *__restrict__ Btg, const float *__restrict__ bias, float *__restrict__ out, float *__restrict__ other,
+                                                     uint32_t *__restrict__ mask) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t c1_lds[];
+    uint16_t *img = c1_lds, *Bt = c1_lds + C1_IN * C1_HW * C1_HW;                             // the planes as bf16 (32 KB), the weight terms (48 KB)
     const int tid = threadIdx.x;
-    {   const uint4 *src = reinterpret_cast<const uint4 *>(Bg); uint4 *dst = reinterpret_cast<uint4 *>(B);
-        for (int i = tid; i < C1_KDIM * C1_OUT / 4; i += 256) dst[i] = src[i]; }
+    {   const uint4 *src = reinterpret_cast<const uint4 *>(Btg); uint4 *dst = reinterpret_cast<uint4 *>(Bt);
+        for (int i = tid; i < C1_BT_HALVES / 8; i += 256) dst[i] = src[i]; }
     const int wave = tid >> 6, l = tid & 63, m = l & 31, half = l >> 5;
     const float bn = bias[m];
-  // a workgroup walks images blockIdx.x, + gridDim.x, ...: the launcher sizes the grid so that every workgroup gets the same
-  // number (the weights are staged once per workgroup, and no partly filled last round of workgroups is left); while one
-  // workgroup of a CU stages its next image the other keeps the matrix cores busy (prefetching the next image through
-  // registers was slower: the compiler parks it in LDS before the MFMA loop, exposing the load)
-  for (int b = blockIdx.x; b < n_img; b += gridDim.x) {
-    const uint8_t *o = obs + (size_t)(rows ? rows[b] : (row0 ? row0[0] : 0LL) + b) * channels * C1_HW * C1_HW;
-    __syncthreads();                                            // everybody is done with the previous image
-    {   const uint4 *src = reinterpret_cast<const uint4 *>(o); uint4 *dst = reinterpret_cast<uint4 *>(img);
-        for (int i = tid; i < C1_IN * C1_HW * C1_HW / 16; i += 256) dst[i] = src[i]; }
-    if (tid < 2) other[(size_t)b * 2 + tid] = (float)o[(size_t)(channels - 1) * C1_HW * C1_HW + tid] * (1.0f / 255.0f);
-    __syncthreads();
     int base[2];
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         const int p = min((wave + 4 * t) * 32 + m, C1_POS - 1);
-        base[t] = (p / C1_OHW) * C1_S * C1_HW + (p % C1_OHW) * C1_S;          // byte offset of the position's window in a plane
+        base[t] = ((p / C1_OHW) * C1_S + half) * C1_HW + (p % C1_OHW) * C1_S;                 // pixel index of the lane's first k of a plane's first block
+    }
+  // a workgroup walks images blockIdx.x, + gridDim.x, ...; the NEXT image's bytes (and its two sensor-pad bytes) are requested before this image's MFMA loop,
+  // which issues no global loads of its own: the latency of the 16 KB rides under the loop and the epilogue's stores
+  auto image = [&](int b) { return obs + (size_t)(rows ? rows[b] : (row0 ? row0[0] : 0LL) + b) * channels * C1_HW * C1_HW; };
+  uint4 px[4];
+  unsigned pad = 0;
+  if ((int)blockIdx.x < n_img) {
+    const uint8_t *o = image(blockIdx.x);
+#pragma unroll
+    for (int u = 0; u < 4; u++) px[u] = reinterpret_cast<const uint4 *>(o)[tid + 256 * u];
+    if (tid < 2) pad = o[(size_t)(channels - 1) * C1_HW * C1_HW + tid];
+  }
+  for (int b = blockIdx.x; b < n_img; b += gridDim.x) {
+    __syncthreads();                                            // everybody is done with the previous image
+#pragma unroll
+    for (int u = 0; u < 4; u++) {                               // 16 pixels -> 16 bf16 = two 16-byte stores
+        const unsigned wv[4] = {px[u].x, px[u].y, px[u].z, px[u].w};
+        unsigned h[8];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { h[2 * q] = pack_hi16(ubyte_f32(wv[q], 0), ubyte_f32(wv[q], 1)); h[2 * q + 1] = pack_hi16(ubyte_f32(wv[q], 2), ubyte_f32(wv[q], 3)); }
+        uint4 *d = reinterpret_cast<uint4 *>(img) + 2 * (tid + 256 * u);
+        d[0] = make_uint4(h[0], h[1], h[2], h[3]); d[1] = make_uint4(h[4], h[5], h[6], h[7]);
+    }
+    if (tid < 2) other[(size_t)b * 2 + tid] = (float)pad * (1.0f / 255.0f);
+    __syncthreads();
+    if (b + (int)gridDim.x < n_img) {
+        const uint8_t *o = image(b + gridDim.x);
+#pragma unroll
+        for (int u = 0; u < 4; u++) px[u] = reinterpret_cast<const uint4 *>(o)[tid + 256 * u];
+        if (tid < 2) pad = o[(size_t)(channels - 1) * C1_HW * C1_HW + tid];
     }
     f32x16 acc[2];
 #pragma unroll
     for (int t = 0; t < 2; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
-    const unsigned *img32 = reinterpret_cast<const unsigned *>(img);
-    // the instruction's two k values are kx = j (lanes 0-31) and kx = j + 4 (lanes 32-63): a lane needs ONE word of its position's kernel row, and the byte it
-    // converts is a compile-time index (v_cvt_f32_ubyte{j}: one VALU instruction per MFMA -- VALU instructions are not free next to MFMAs, they take issue
-    // cycles of the same SIMD: tools/hiptests/t_mfma_peak.hip). The operands of row r + 1 are requested before the eight MFMAs of row r (left to itself the
-    // scheduler reads each B pair right before its use, and every second MFMA waits a full LDS latency).
-    unsigned aw[2];
-    float bw[4];
-    const float *Bh = B + 4 * half * C1_OUT + m;
+    const uint16_t *Bl = Bt + m * C1_BROW;                      // + term * 32 * C1_BROW + 8 * ((2 kb + half) ^ (m & 7))
+#pragma unroll 4
+    for (int kb = 0; kb < 16; kb++) {                           // 16 k: plane kb >> 2, kernel rows 2 (kb & 3) + half
+        const int poff = (kb >> 2) * C1_HW * C1_HW + 2 * (kb & 3) * C1_HW;
+        bf16x8 af[2], bf[3];
 #pragma unroll
-    for (int t = 0; t < 2; t++) aw[t] = img32[(base[t] >> 2) + half];
+        for (int t = 0; t < 2; t++) {
+            const uint2 *ap = reinterpret_cast<const uint2 *>(img + poff + base[t]);         // 8 pixels = 16 bytes, 8-byte aligned
+            const uint2 a0 = ap[0], a1 = ap[1];
+            const uint4 av = make_uint4(a0.x, a0.y, a1.x, a1.y);
+            af[t] = *reinterpret_cast<const bf16x8 *>(&av);
+        }
 #pragma unroll
-    for (int j = 0; j < 4; j++) bw[j] = Bh[j * C1_OUT];
-#pragma unroll 2
-    for (int row = 0; row < C1_IN * C1_K; row++) {                // (ci, ky)
-        const int rn = min(row + 1, C1_IN * C1_K - 1), ci = rn >> 3, ky = rn & 7;
-        unsigned an[2];
-        float bnx[4];
+        for (int term = 0; term < 3; term++) bf[term] = *reinterpret_cast<const bf16x8 *>(Bl + term * C1_OUT * C1_BROW + 8 * ((2 * kb + half) ^ (m & 7)));
 #pragma unroll
-        for (int t = 0; t < 2; t++) an[t] = img32[((ci * C1_HW * C1_HW + ky * C1_HW + base[t]) >> 2) + half];
+        for (int term = 0; term < 3; term++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) bnx[j] = Bh[(rn * 8 + j) * C1_OUT];
-        __builtin_amdgcn_sched_barrier(0);
-        float av[2][4];                                                 // conversions first, then the eight MFMAs back to back (167 us against 175 interleaved, 4096 images)
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int t = 0; t < 2; t++) av[t][j] = ubyte_f32(aw[t], j);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; j++)                                     // k = row * 8 + j + 4 half
-#pragma unroll
-            for (int t = 0; t < 2; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][j], bw[j], acc[t], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 2; t++) aw[t] = an[t];
-#pragma unroll
-        for (int j = 0; j < 4; j++) bw[j] = bnx[j];
+            for (int t = 0; t < 2; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[t], bf[term], acc[t], 0, 0, 0);
     }
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -140,14 +156,25 @@ extern "C" int grip_conv1_u8(const uint8_t *obs_dev, int n, int channels, const 
 extern "C" int grip_conv1_u8_train(const uint8_t *obs_dev, const int64_t *row0_dev, const int64_t *rows_dev, int n, int channels, const float *weight_dev,
                                    const int64_t *weight_strides, const float *bias_dev, float *scratch_dev, float *out_nhwc_dev, float *other_dev, uint32_t *mask_dev, void *stream) {
     if (!obs_dev || !weight_dev || !weight_strides || !bias_dev || !scratch_dev || !out_nhwc_dev || !other_dev || n <= 0 || channels != C1_IN + 1)
-        return grip_fail("grip_conv1_u8: need uint8 [n, 5, 64, 64] observations, Conv2d(4, 32, 8, 4) weights and bias, a 32 KB scratch and the two outputs");
+        return grip_fail("grip_conv1_u8: need uint8 [n, 5, 64, 64] observations, Conv2d(4, 32, 8, 4) weights and bias, a 12 288-float scratch and the two outputs");
     hipLaunchKernelGGL(k_conv1_prep, dim3(C1_KDIM * C1_OUT / 256), dim3(256), 0, (hipStream_t)stream, weight_dev, (long long)weight_strides[0], (long long)weight_strides[1],
-                       (long long)weight_strides[2], (long long)weight_strides[3], scratch_dev);
-    // 48 KB of LDS per workgroup: three per CU, 768 on the chip. Workgroup i takes images i, i + grid, ...: with all 768 launched a CU's three (i, i + 256,
-    // i + 512 under round-robin placement) share the remainder evenly -- sizing the grid for equal counts per WORKGROUP (683 x 6 for 4096 images) left a
-    // third of the CUs with two workgroups and the rest with three, 12 % off the balanced time
-    const int grid = n < 768 ? n : 768;
-    hipLaunchKernelGGL(k_conv1_u8, dim3(grid), dim3(256), 0, (hipStream_t)stream, obs_dev, (const long long *)row0_dev, (const long long *)rows_dev, n, channels, (const float *)scratch_dev, bias_dev, out_nhwc_dev, other_dev, mask_dev);
+                       (long long)weight_strides[2], (long long)weight_strides[3], reinterpret_cast<uint16_t *>(scratch_dev));
+    // 80 KB of LDS per workgroup: exactly two per CU, 512 on the chip. Workgroup i takes images i, i + grid, ...: with all 512 launched a CU's two (i, i + 256 under
+    // round-robin placement) share the remainder evenly -- sizing the grid for equal counts per WORKGROUP left some CUs with one workgroup more than others
+    // (12 % off the balanced time at 4096 images)
+    const size_t lds = (size_t)(C1_IN * C1_HW * C1_HW + C1_BT_HALVES) * sizeof(uint16_t);
+    {   static std::atomic<unsigned long long> attr_set_mask{0ULL};       // the dynamic-LDS opt-in is a per-DEVICE function attribute
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return grip_fail("grip_conv1_u8: no current device");
+        const unsigned long long bit = 1ULL << (dev & 63);
+        if (!(attr_set_mask.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute((const void *)k_conv1_u8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return grip_fail("grip_conv1_u8: cannot reserve LDS");
+            attr_set_mask.fetch_or(bit, std::memory_order_release);
+        }
+    }
+    const int grid = n < 512 ? n : 512;
+    hipLaunchKernelGGL(k_conv1_u8, dim3(grid), dim3(256), lds, (hipStream_t)stream, obs_dev, (const long long *)row0_dev, (const long long *)rows_dev, n, channels,
+                       (const uint16_t *)scratch_dev, bias_dev, out_nhwc_dev, other_dev, mask_dev);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { char buf[160]; snprintf(buf, sizeof buf, "grip_conv1_u8: %s", hipGetErrorString(e)); return grip_fail(buf); }
     return 0;

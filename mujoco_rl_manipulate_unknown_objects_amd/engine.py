@@ -263,7 +263,7 @@ def conv1_u8(obs, weight, bias, with_mask=False):
     n = rows.n if rows is not None else idx.n if idx is not None else int(obs.shape[0])
     out = torch.empty((n, 32, 15, 15), dtype=torch.float32, device=obs.device, memory_format=torch.channels_last)
     other = torch.empty((n, 2), dtype=torch.float32, device=obs.device)
-    scratch = torch.empty(8192, dtype=torch.float32, device=obs.device)
+    scratch = torch.empty(12288, dtype=torch.float32, device=obs.device)
     strides = (C.c_int64 * 4)(*weight.stride())
     stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
     # with_mask (the update's forward): also the layer's ReLU mask, int32 [n, 225], bit c of word (image, position) = channel c is active
