@@ -14,7 +14,7 @@ from ..sb3.torch_layers import BaseFeaturesExtractor
 
 class _Conv1U8(th.autograd.Function):
     """First layer of the extractor for TRAINING on raw uint8 CUDA observations: forward = grip_conv1_u8 (normalisation, Conv2d(4, 32, 8, 4),
-    bias and ReLU as one f32-MFMA launch, the kernel the rollouts use: 167 us per 4096 samples against 64 + 256 + 30 us for the uint8 ->
+    bias and ReLU as one launch, the kernel the rollouts use: 78 us per 4096 samples against 64 + 256 + 30 us for the uint8 ->
     float pass, the tensor library's implicit GEMM and the ReLU); backward = ReLU mask, then the library's weight-gradient kernel on the
     float image, which is recomputed from the bytes (64 us) instead of being kept from the forward (268 MB per 4096-sample minibatch).
     The input needs no gradient. Same arithmetic as the reference path up to summation order (tests/test_gpu_env_api.py)."""
@@ -43,7 +43,7 @@ class _CnnTrunk(th.autograd.Function):
     tests/test_gpu_train_kernels.py). Forward: grip_conv1_u8 and grip_conv23 as in the rollouts, additionally writing y2 and the three ReLU masks
     as bits. Backward: one launch (grip_trunk_backward) for both data gradients, the three ReLU masks and the first layer's weight and bias
     gradient straight from the observation bytes and all three bias gradients; the other two layers' weight gradients stay with the tensor
-    library (at 65 % of the fp32 MFMA rate they are not where the time goes). Per 4096-sample minibatch on MI355X: forward 293 us (tensor library 507), backward of these layers ~0.44 ms (~1.0 ms)."""
+    library (at 65 % of the fp32 MFMA rate they are not where the time goes). Per 4096-sample minibatch on MI355X: forward 198 us (tensor library 497), backward of these layers ~0.44 ms (~1.0 ms)."""
 
     @staticmethod
     def forward(ctx, obs, index, w1, b1, w2, b2, w3, b3):
