@@ -252,7 +252,8 @@ class IndexedRows:
 def conv1_u8(obs, weight, bias, with_mask=False):
     """First layer of AugmentedNatureCNN for rollouts (grip_conv1_u8, csrc/grip_policy.hip): uint8 CUDA observations
     [n, 5, 64, 64] -> (relu(conv2d(obs[:, :4] / 255, weight, bias, stride 4)) as a channels-last float32 [n, 32, 15, 15]
-    tensor, the two sensor-pad scalars / 255 as [n, 2]) in one launch on the matrix cores (f32 MFMA). No autograd."""
+    tensor, the two sensor-pad scalars / 255 as [n, 2]) in one launch on the matrix cores (fp32 arithmetic, computed exactly on the bf16 pipe:
+    csrc/grip_policy.hip). No autograd."""
     import torch
     rows = obs if isinstance(obs, RecordRows) else None
     idx = obs if isinstance(obs, IndexedRows) else None

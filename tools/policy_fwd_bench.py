@@ -34,7 +34,7 @@ ref = timeit("current forward_parts", lambda: pol.forward_parts({"observation": 
 
 from mujoco_rl_manipulate_unknown_objects_amd.engine import conv1_u8
 c0 = pol.features_extractor.cnn[0]
-timeit("conv1_u8 alone (prep + f32 MFMA)", lambda: conv1_u8(obs, c0.weight, c0.bias))
+timeit("conv1_u8 alone (prep + kernel)    ", lambda: conv1_u8(obs, c0.weight, c0.bias))
 fe = pol.features_extractor
 convs = [fe.cnn[0], fe.cnn[2], fe.cnn[4]]
 from mujoco_rl_manipulate_unknown_objects_amd.engine import obs_preprocess
