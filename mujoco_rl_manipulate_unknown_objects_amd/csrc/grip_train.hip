@@ -1,17 +1,20 @@
-// grip_train.hip -- backward pass of AugmentedNatureCNN's three convolutions (reference models/feature_extractor.py:14-22) for the PPO / SAC
-// update, on the matrix cores in exact fp32 (v_mfma_f32_16x16x4_f32 / v_mfma_f32_32x32x2_f32: fp32 products, fp32 sums -- the arithmetic of
-// the tensor library's fp32 path up to the order of summation).
+// grip_train.hip -- the update side of the policy (PPO / SAC minibatches; reference models/feature_extractor.py:14-22 trained by stable_baselines3 as
+// train_agent.py:33-47 configures it), hand-written where the time went, in fp32 arithmetic throughout (v_mfma_f32_16x16x4_f32 / v_mfma_f32_32x32x2_f32:
+// fp32 products, fp32 sums -- the tensor library's fp32 path up to the order of summation; tests/test_gpu_train_kernels.py).
 //
-// As tensor-library calls the backward of the trunk is, per 4096-sample minibatch on MI355X: data gradients 109 + 306 us (the stride-2 4 x 4
+// As tensor-library calls the backward of the three convolutions is, per 4096-sample minibatch on MI355X: data gradients 109 + 306 us (the stride-2 4 x 4
 // layer at 32 TFLOP/s), weight gradients 55 + 93 + 211 us, three ReLU-mask passes (16 + 16 + 49 us), three bias-gradient reductions
 // (14 + 18 + 39 us), a uint8 -> float image pass for the first layer's weight gradient (67 us) and ~40 us of zero-fills: ~1.0 ms of the
 // update's 2.0 ms. Here:
-//   k_conv23_dgrad     g3 (gradient at the third layer's ReLU output) -> masked g3, masked g2, masked g1 in ONE launch: both data gradients as
-//                      scatter GEMMs whose column blocks are summed into an LDS tile, g2 never leaving LDS between the layers, the three ReLU
-//                      masks folded into the loads / stores.
-//   k_conv1_wgrad_u8   first layer's weight + bias gradient straight from the uint8 observation (no float image).
-//   k_conv2_wgrad, k_conv3_wgrad   weight + bias gradients of the other two layers.
-//   k_wgrad_reduce     the workgroups' partial sums -> the gradient tensors (deterministic: fixed order, no atomics).
+//   k_trunk_bwd          g3 (gradient at the third layer's ReLU output) -> masked g3, masked g2 (the operands of the library's two remaining weight
+//                        gradients), the first layer's weight gradient straight from the observation bytes and all three bias gradients, in ONE launch:
+//                        both data gradients as scatter GEMMs whose column blocks are summed into an LDS tile, g2 and g1 never leaving LDS, the ReLU
+//                        masks (bits written by the forward kernels) folded into the passes. 283 us.
+//   k_wgrad1_reduce      the workgroups' partial sums -> the gradient tensors (fixed order, no atomics).
+//   k_gradnorm, k_clip_adam   clip_grad_norm_ + Adam.step() on the optimiser's own state tensors, two launches.
+//   k_tanh_bwd_colsum, k_colsum_reduce   activation derivative + bias gradient of a dense layer in one pass (tanh: the policy | value MLPs; ReLU: the
+//                        extractor's linear layer).
+// The forward kernels the update shares with the rollouts (k_conv1_u8, k_conv23, with the training outputs) are in grip_policy.hip.
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <stdint.h>
@@ -120,8 +123,6 @@ __device__ __forceinline__ void scatter_gemm(const float *TA, const int (&arow)[
         }
     }
 }
-
-__device__ __forceinline__ float4 relu_mask(float4 y, float4 v) { return make_float4(y.x > 0.f ? v.x : 0.f, y.y > 0.f ? v.y : 0.f, y.z > 0.f ? v.z : 0.f, y.w > 0.f ? v.w : 0.f); }
 
 __device__ __forceinline__ float4 bit_mask(unsigned bits, float4 v) { return make_float4(bits & 1u ? v.x : 0.f, bits & 2u ? v.y : 0.f, bits & 4u ? v.z : 0.f, bits & 8u ? v.w : 0.f); }
 
