@@ -1662,6 +1662,24 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
     }
 #ifdef HAVE_DBG_HIST
     if (live) { const int z1 = zone_of(c.jar); DBG_HIST((c.g1 != 0 ? 77 : 84) + z1, 1); if (z1 != zone0) DBG_HIST(c.g1 != 0 ? 80 : 87, 1); }
+    {   // would the cone zones of the PREVIOUS step's solution (same contact pattern) have predicted this solution's? (an active-set start: DESIGN.md section 9)
+        const int z1 = live ? zone_of(c.jar) : 3, base = cx.lane - cx.sub;
+        const unsigned mB = (unsigned)(__ballot(live && z1 == 2) >> base) & 0xffffu, mT = (unsigned)(__ballot(live && z1 == 0) >> base) & 0xffffu;
+        const unsigned mM = (unsigned)(__ballot(live && z1 == 1) >> base) & 0xffffu, mH = (unsigned)(__ballot(live && c.g1 != 0) >> base) & 0xffffu;
+        const unsigned mS = (unsigned)(__ballot(live && z1 != zone0) >> base) & 0xffffu;
+        if (cx.sub == 0 && ncon > 0) {
+            const int curZ = (int)(mB | (mT << 16)), curI = (int)(0x40000000u | ((unsigned)ncon << 16) | mH);
+            DBG_HIST(89, 1);                                            // solves with contacts
+            DBG_HIST(93, mS == 0 ? 1 : 0);                              // ... whose start zones were already the final ones
+            DBG_HIST(94, mM == 0 ? 1 : 0);                              // ... without a middle-zone contact at the end
+            if (MI(cx, 14) == curI) {
+                DBG_HIST(90, 1);                                        // ... with the previous step's contact pattern (count, which are hull contacts)
+                if (MI(cx, 13) == curZ && mM == 0) DBG_HIST(91, 1);     //     ... all in the zones the previous solution had them in, none in the middle zone
+                if (MI(cx, 13) == curZ && mM == 0 && mS != 0) DBG_HIST(92, 1);   //     ... and the start classification was wrong (what the guess would have saved)
+            }
+            MI(cx, 13) = curZ; MI(cx, 14) = curI;
+        }
+    }
 #endif
     // the optimum and its constraint force stay distributed: lane i holds component i (the integrator exchanges them through LDS)
     STAMP(st, 18);

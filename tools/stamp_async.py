@@ -53,3 +53,7 @@ for nm, o in (("hull", 74), ("floor", 81)):
     print(f"{nm} contacts per solve {a / ns:.2f}: zone at start (top, middle, bottom)", " ".join(f"{100 * hist[o + z] / a:.1f}%" for z in range(3)),
           "| at the end", " ".join(f"{100 * hist[o + 3 + z] / a:.1f}%" for z in range(3)), f"| zone changed {100 * hist[o + 6] / a:.1f}%")
 print(f"env-steps with a gripper-object contact (H couples the two blocks): {100 * hist[22] / steps:.1f}%; wave trips with at least one such env: {100 * hist[88] / max(1, hist[23]):.1f}%")
+if hist[89]:
+    n = hist[89]
+    print(f"solves with contacts: start zones already final {100 * hist[93] / n:.1f}%; no middle-zone contact at the end {100 * hist[94] / n:.1f}%; same contact pattern as the previous step "
+          f"{100 * hist[90] / n:.1f}%; previous solution's zones = this solution's (and no middle zone) {100 * hist[91] / n:.1f}%; of those the start classification was wrong {100 * hist[92] / n:.1f}%")
