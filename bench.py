@@ -288,6 +288,8 @@ def main():
         model.finish_updates()
     sync()
     batch.kernel_time(reset=True)
+    if hasattr(batch, "device_time"):
+        batch.device_time(reset=True)
     sub_before = None
     # count sub-steps of the timed region on device without host syncs: accumulate n_substeps after each step
     sub_acc = torch.zeros((), dtype=torch.int64, device=env.device)
@@ -321,7 +323,14 @@ def main():
         lo, hi = cs.clone(), cs.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         replicas_identical = bool(torch.equal(lo, hi))
-    k_ms, k_n = batch.kernel_time(reset=True)
+    ev_ms, ev_n = batch.kernel_time(reset=True)          # host events: the eager launches only (a replayed graph's launches cannot be bracketed)
+    k_ms, k_n = ev_ms, ev_n
+    if ar is not None and hasattr(batch, "device_time"):
+        # every launch of the timed region, replayed graphs' included: start / end stamps the kernel takes with the device's wall clock
+        # (grip_batch_device_time, include/grip_sim.h) on the stream it runs on
+        d_ms, d_n = batch.device_time(reset=True)
+        if d_n > 0:
+            k_ms, k_n = d_ms, int(d_n)
     ar_ms, ar_n = (model.allreduce_ms() if (world > 1 and hasattr(model, "allreduce_ms")) else (None, 0))
 
     if rank == 0:
@@ -366,6 +375,9 @@ def main():
             "allreduce_ms_per_optimizer_step": ar_ms, "allreduce_steps_timed": ar_n, "env_steps_counted": total_env_steps, "env_steps_nominal": a.envs * world * a.steps, "short_rollouts": short_rollouts,
             "roofline": {"bound": "hbm", "kernel": "k_macro_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms_avg": k_ms, "launches": k_n,
+                         "launch_timing": ("device wall-clock stamps of every launch of the timed region (first workgroup's start to the last wave's end, 100 MHz), "
+                                           "graph replays included" if k_n != ev_n or k_ms != ev_ms else "HIP events around the launch on its stream"),
+                         "launch_ms_avg_events": ev_ms, "launches_events": ev_n,
                          "algorithmic_bytes_per_launch": macro_bytes, "overhead_bytes_per_launch": overhead_bytes,
                          "bytes_definition": "SURVEY.md 8(d): physics state in + out (348 B f32 per env and launch) + action / outputs of the macro steps that end in the launch; "
                                              "overhead = suspended macro-step context + narrow-phase pair memory of the time-sliced schedule (not counted in achieved)",
@@ -377,13 +389,14 @@ def main():
             # passes of THIS command at THIS configuration (profiles/r03_pmc_summary.json: separate passes, gfx950 FETCH_SIZE
             # correction) and are attached only when the run is that configuration; otherwise traffic stays null.
             try:
-                pmj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")))
+                pmc_file = next(f for f in ("r04_pmc_summary.json", "r03_pmc_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                pmj = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
                 same_cfg = (pmj.get("config") == {"object": a.object, "envs": a.envs, "state_dtype": a.state_dtype, "mixed": bool(a.mixed)})
                 pm = pmj["kernels"]["k_macro_step"]
                 if same_cfg and not a.lockstep:
                     rf = out["roofline"]
                     rf["traffic"] = pm["hbm_bytes_per_launch_fetch_doubled"]
-                    rf["traffic_source"] = ("profiles/r03_pmc_summary.json, same command and configuration: (2 x FETCH_SIZE + WRITE_SIZE) per launch; raw "
+                    rf["traffic_source"] = (f"profiles/{pmc_file}, same command and configuration: (2 x FETCH_SIZE + WRITE_SIZE) per launch; raw "
                                             f"{pm['hbm_bytes_per_launch_raw']:.0f} B")
                     # the bound that really binds this kernel: VALU issue. lane-operations per physics.step() of one env from the PMC
                     # pass (SQ_INSTS_VALU x 64 lanes / env-substeps of the launch) x the LIVE physics.step() rate of this run
@@ -393,7 +406,12 @@ def main():
                     rf["valu"] = {"achieved": lane_ops, "peak": VALU_PEAK_LANE_OPS, "unit": "fp32 lane-ops/s", "frac": lane_ops / VALU_PEAK_LANE_OPS,
                                   "lane_ops_per_launch": pm["SQ_INSTS_VALU"] * 64.0, "lane_ops_per_env_substep": pm.get("valu_lane_ops_per_env_substep"),
                                   "valu_active_frac": pm["active_inst_valu_frac"], "wait_frac": pm["wait_any_frac"],
-                                  "source": "profiles/r03_pmc_summary.json (SQ_INSTS_VALU per launch of the same command) / live launch duration"}
+                                  # how much of an issued wave instruction's 64 lanes can do anything: two envs x 16 lanes own a wave; lanes 32..63
+                                  # are enabled clones of lanes 0..31 that take a second data set where one instruction stream can serve two (support
+                                  # searches of a pair's two hulls, the cooperative vertex scan, two of a contact's four constraint rows) and
+                                  # repeat the lower half's arithmetic everywhere else
+                                  "enabled_lane_frac": 1.0, "distinct_lane_frac_outside_shared_phases": 0.5,
+                                  "source": f"profiles/{pmc_file} (SQ_INSTS_VALU per launch of the same command) / live launch duration"}
             except Exception:
                 pass
         if not a.no_cpu_baseline and world == 1:

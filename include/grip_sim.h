@@ -322,6 +322,12 @@ int grip_batch_set_state_storage(GripBatch *b, int half, void *stream);
 /* timing of the macro-step kernel on its own stream: average ms per launch since the last call with reset != 0 */
 int grip_batch_kernel_time(GripBatch *b, int reset, float *ms_avg, int *launches);
 
+/* The same figure from the device's own clock, for EVERY time-slice launch since the last call with reset != 0 -- also the launches a
+ * replayed hipGraph makes, which host-side events cannot bracket: the first workgroup of a grip_batch_advance launch stamps its start, every
+ * wave its end (wall clock, 100 MHz), and the compaction that follows the launch on its stream adds end - start to a device counter.
+ * (Measurement only; the reference has no counterpart: bench.py's `roofline` is quoted on it.) Synchronises `stream`. */
+int grip_batch_device_time(GripBatch *b, int reset, double *ms_avg, long long *launches, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

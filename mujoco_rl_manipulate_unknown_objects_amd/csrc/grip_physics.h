@@ -45,8 +45,16 @@ DEVI int wg_env_slot(bool &active) {
 #define EF_FRAMES 0                     // 6 geom frames x 12 (pos3, R9)
 #define EF_STAGE 72                     // G_MAXC staged contacts x ST_STRIDE
 #define ST_STRIDE 11                    // pos3, n3, dist, meta, fs, ft, tran
-#define EF_M (EF_STAGE + G_MAXC * ST_STRIDE)   // 13 x 13 mass matrix, row-major
-#define EF_U ((EF_M + 169 + 3) & ~3)     // per-contact Hessian vectors (16-byte aligned): G_MAXC x 6 slots x U_STRIDE (13 entries + weight)
+// The mass matrix is block diagonal for good (gripper 7 x 7, object 6 x 6): row r is kept as the eight words of ITS block's row
+// ([g0..g6 | 0] for r < 7, [o0..o5 | 0 0] for the others) -- two 16-byte reads per dof lane, no zero blocks in LDS.
+#define EF_M ((EF_STAGE + G_MAXC * ST_STRIDE + 3) & ~3)
+#define M_STRIDE 8
+// packed Cholesky factor (28 words, 1 / L_jj on the diagonal) of the gripper block of M + h D -- mj_Euler's implicit joint damping --
+// factorised by the env's lanes 8..15 in the SAME instruction stream in which lanes 0..7 factorise M for qacc_smooth (forward_dense),
+// parked here for integrate()
+#define EF_LD (EF_M + 13 * M_STRIDE)
+#define EF_U (EF_LD + 28)                // per-contact Hessian vectors (16-byte aligned): G_MAXC x 6 slots x U_STRIDE (13 entries + weight)
+static_assert(EF_U % 4 == 0, "Hessian-vector slots are read with 16-byte loads");
 #define U_STRIDE 16                    // a slot is four ds_read_b128: [ g0 .. g6 | w ][ o0 .. o5 | 0 | w ] -- the seven gripper columns, the six object
                                        // columns, the slot's weight at the end of both halves (a dof lane reads only its block's half when no
                                        // contact couples gripper and object, i.e. when H is block diagonal)
@@ -173,6 +181,18 @@ DEVI void gather13(float xi, float (&v)[13]) {
 DEVI void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 // 16-bit group of a 64-bit ballot that belongs to this lane's environment
 DEVI unsigned group_bits(unsigned long long b, int lane) { return (unsigned)(b >> (lane & 48)) & 0xFFFFu; }
+#if EPW == 2
+// Lanes 32..63 of a two-env wave are bit-identical clones of lanes 0..31: the same env, the same values, the same LDS traffic, no global
+// writes. Where ONE instruction stream can serve two data sets (the support searches of a pair's two hulls, the two halves of a
+// cooperative vertex scan, the two halves of a slot loop) the clones take the second set, and v_permlane32_swap hands each half's result
+// to the other one: `lo` = what lanes 0..31 hold, `hi` = what lanes 32..63 hold, both in all 64 lanes afterwards -- the halves are clones
+// again. (The instruction swaps rows 2, 3 of its first operand with rows 0, 1 of its second; with the same value in both, the first
+// comes back as the lower half twice and the second as the upper half twice. tools/hiptests/t_swap.hip checks that on the device.)
+DEVI void halves_u(unsigned x, unsigned &lo, unsigned &hi) { auto r_ = __builtin_amdgcn_permlane32_swap(x, x, false, false); lo = r_[0]; hi = r_[1]; }
+DEVI void halves_f(float x, float &lo, float &hi) { unsigned a_, b_; halves_u(__float_as_uint(x), a_, b_); lo = __uint_as_float(a_); hi = __uint_as_float(b_); }
+DEVI void halves_i(int x, int &lo, int &hi) { unsigned a_, b_; halves_u((unsigned)x, a_, b_); lo = (int)a_; hi = (int)b_; }
+#define UPPER_HALF(cx) ((cx).lane >= 32)
+#endif
 
 struct Kin {
     V3 pe; M3 Re; V3 a4;
@@ -726,10 +746,16 @@ DEVI void coop_support2(const Tables &T, int baseA, int nA, V3 dA, int baseB, in
     float av = -3.0e38f, bv = -3.0e38f; int ai = 0x7fffffff, bi = 0x7fffffff;
     const float4 *vA = reinterpret_cast<const float4 *>(T.v) + baseA, *vB = reinterpret_cast<const float4 *>(T.v) + baseB;
     const int nmax = max(nA, nB);
-    for (int i = sub; i < nmax; i += 2 * KL) {
+#if EPW == 2
+    // the env's clone lanes 32..63 scan too: 32 lanes per env, vertices s, s + 32, ... (s = 0..31), the two halves' winners meet at the end
+    const int first = sub + ((int)(threadIdx.x & 32) >> 1), stride = 2 * KL;
+#else
+    const int first = sub, stride = KL;
+#endif
+    for (int i = first; i < nmax; i += 2 * stride) {
         int ja[2], jb[2]; float4 a[2], b[2];
 #pragma unroll
-        for (int q = 0; q < 2; q++) { ja[q] = min(i + q * KL, nA - 1); jb[q] = min(i + q * KL, nB - 1); }
+        for (int q = 0; q < 2; q++) { ja[q] = min(i + q * stride, nA - 1); jb[q] = min(i + q * stride, nB - 1); }
 #pragma unroll
         for (int q = 0; q < 2; q++) { a[q] = vA[ja[q]]; b[q] = vB[jb[q]]; }
 #pragma unroll
@@ -746,6 +772,12 @@ DEVI void coop_support2(const Tables &T, int baseA, int nA, V3 dA, int baseB, in
         bool ta = oa > av || (oa == av && oia < ai); av = ta ? oa : av; ai = ta ? oia : ai; bool tb = ob > bv || (ob == bv && oib < bi); bv = tb ? ob : bv; bi = tb ? oib : bi; }
     COOP_STEP2(8) COOP_STEP2(4) COOP_STEP2(2) COOP_STEP2(1)
 #undef COOP_STEP2
+#if EPW == 2
+    {   float al, ah, bl, bh; int ail, aih, bil, bih;
+        halves_f(av, al, ah); halves_i(ai, ail, aih); halves_f(bv, bl, bh); halves_i(bi, bil, bih);
+        ai = (ah > al || (ah == al && aih < ail)) ? aih : ail;
+        bi = (bh > bl || (bh == bl && bih < bil)) ? bih : bil; }
+#endif
     ia = ai; ib = bi;
 }
 
@@ -977,9 +1009,23 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, PairMemo &memo,
             STAMP(st, 21);
             if (!coop && mine) {
                 const bool rem = phase == 6;
+#if EPW == 2
+                // the two hulls of a pair side by side: lanes 0..31 climb hull 2, their clones 32..63 hull 1 -- one hill-climb loop per trip
+                // instead of two (floor items have one hull: the clones repeat it)
+                const bool h1 = UPPER_HALF(cx) && !plane;
+                const V3 dq2 = multv(R2, plane ? dir : -dir), dq1 = multv(R1, dir);
+                V3 vo; unsigned adjo;
+                const int vio = support_vertex(T, h1 ? g1 - 1 : g2 - 1, h1 ? base1 : base2, h1 ? dq1 : dq2, vo, rem ? (h1 ? memo.h1 : memo.h2) : -1, adjo);
+                STAMP(st, 22);
+                unsigned a_lo, a_hi; halves_u(adjo, a_lo, a_hi); adj2 = a_lo;
+                int i_hi; halves_i(vio, vi2, i_hi);
+                V3 v_hi; halves_f(vo.x, vl.x, v_hi.x); halves_f(vo.y, vl.y, v_hi.y); halves_f(vo.z, vl.z, v_hi.z);
+                if (!plane) { vi1 = i_hi; vl1 = v_hi; }
+#else
                 vi2 = support_vertex(T, g2 - 1, base2, multv(R2, plane ? dir : -dir), vl, rem ? memo.h2 : -1, adj2);
                 STAMP(st, 22);
                 if (!plane) vi1 = support_vertex(T, g1 - 1, base1, multv(R1, dir), vl1, rem ? memo.h1 : -1);
+#endif
             }
             STAMP(st, 23);
             if (mine) {
@@ -1193,9 +1239,14 @@ struct LaneCon { float lsgn, lD, laref; float jar_s[4], jar_w[4]; float Md_w, qs
 
 // this lane's row of the env's mass matrix (zero in lanes 13..15)
 DEVI void load_mrow(const Ctx &cx, float (&mrow)[13]) {
-    const float *M = cx.envl + EF_M + min(cx.sub, 12) * 13;
+    const float4 *M4 = reinterpret_cast<const float4 *>(cx.envl + EF_M + min(cx.sub, 12) * M_STRIDE);
+    const float4 a = M4[0], b = M4[1];
+    const float e[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+    const bool g = cx.sub < 7, o = cx.sub >= 7 && cx.sub < 13;
 #pragma unroll
-    for (int j = 0; j < 13; j++) mrow[j] = cx.sub < 13 ? M[j] : 0.f;
+    for (int j = 0; j < 7; j++) mrow[j] = g ? e[j] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; j++) mrow[7 + j] = o ? e[j] : 0.f;
 }
 DEVI float row_dot(const float (&row)[13], const float (&v)[13]) {
     float s = 0.f;
@@ -1281,6 +1332,38 @@ DEVI void make_constraints(const DevModel &m, const Ctx &cx, Contact &c, int nco
             j[5] = sL * dot(k.ak[0], cross(rL, e)); j[6] = sR * dot(k.ak[1], cross(rR, e));
             j[7] = sO * e.x; j[8] = sO * e.y; j[9] = sO * e.z; j[10] = sO * al.x; j[11] = sO * al.y; j[12] = sO * al.z;
         };
+#if EPW == 2
+        // The four rows in two passes of ONE instruction stream: lanes 0..31 build the normal row and the first tangent, their clones 32..63 the
+        // second tangent and the torsion row (the same expressions per row as the one-row-at-a-time form below; the angular row takes e itself
+        // where a linear row takes the lever arm's cross product, and has no translational part). Each half stores its rows to the contact's
+        // slots; the start residuals change hands with v_permlane32_swap.
+        {   const bool up = UPPER_HALF(cx);
+            auto any_row = [&](float (&j)[13], V3 e, bool ang) {
+                const V3 xE = cross(rE, e), xO = cross(rO, e), xL = cross(rL, e), xR = cross(rR, e);
+                const V3 cg = ang ? e : xE, al = multv(k.Ro, ang ? e : xO), bl = ang ? e : xL, br = ang ? e : xR;
+                j[0] = ang ? 0.f : sG * e.x; j[1] = ang ? 0.f : sG * e.y; j[2] = ang ? 0.f : sG * e.z; j[3] = sG * cg.x; j[4] = sG * dot(k.a4, cg);
+                j[5] = sL * dot(k.ak[0], bl); j[6] = sR * dot(k.ak[1], br);
+                j[7] = ang ? 0.f : sO * e.x; j[8] = ang ? 0.f : sO * e.y; j[9] = ang ? 0.f : sO * e.z; j[10] = sO * al.x; j[11] = sO * al.y; j[12] = sO * al.z;
+            };
+            auto finish2 = [&](int r, const float (&j)[13], float kterm, float &vs_out, float &vw_out) {
+                float v = 0.f;
+#pragma unroll
+                for (int i = 0; i < 13; i++) v = fmaf(j[i], qvel[i], v);
+                const float aref = -m.b_con * v - kterm;
+                float vs = -aref, vw = 0.f;
+#pragma unroll
+                for (int i = 0; i < 13; i++) { vs = fmaf(j[i], qs[i], vs); vw = fmaf(j[i], dw[i], vw); }
+                vs_out = vs; vw_out = vs + vw;
+                U[4 * r] = make_float4(j[0], j[1], j[2], j[3]); U[4 * r + 1] = make_float4(j[4], j[5], j[6], 0.f);
+                U[4 * r + 2] = make_float4(j[7], j[8], j[9], j[10]); U[4 * r + 3] = make_float4(j[11], j[12], 0.f, 0.f);
+            };
+            float sA, wA, sB, wB;
+            {   float j[13]; any_row(j, up ? t2 : c.n, false); finish2(up ? 2 : 0, j, up ? 0.f : m.k_con * imp * (c.dist - m.margin), sA, wA); }
+            {   float j[13]; any_row(j, up ? c.n : t1, up); finish2(up ? 3 : 1, j, 0.f, sB, wB); }
+            halves_f(sA, lc.jar_s[0], lc.jar_s[2]); halves_f(wA, lc.jar_w[0], lc.jar_w[2]);
+            halves_f(sB, lc.jar_s[1], lc.jar_s[3]); halves_f(wB, lc.jar_w[1], lc.jar_w[3]);
+        }
+#else
         {   float j[13]; linear_row(j, c.n); finish_row(0, j, m.k_con * imp * (c.dist - m.margin)); }
         {   float j[13]; linear_row(j, t1); finish_row(1, j, 0.f); }
         {   float j[13]; linear_row(j, t2); finish_row(2, j, 0.f); }
@@ -1289,6 +1372,7 @@ DEVI void make_constraints(const DevModel &m, const Ctx &cx, Contact &c, int nco
             j[0] = j[1] = j[2] = 0.f; j[3] = sG * c.n.x; j[4] = sG * dot(k.a4, c.n); j[5] = sL * dot(k.ak[0], c.n); j[6] = sR * dot(k.ak[1], c.n);
             j[7] = j[8] = j[9] = 0.f; j[10] = sO * al.x; j[11] = sO * al.y; j[12] = sO * al.z;
             finish_row(3, j, 0.f); }
+#endif
     }
 }
 
@@ -1329,12 +1413,15 @@ DEVI float price_constraints(const DevModel &m, const Ctx &cx, float lsgn, float
 // The contact's six weighted Hessian vectors  J^T s'' J = sum_r w_r J_r J_r^T + ka ua ua^T - kb ub ub^T  go to the env's
 // LDS slots (rows J_r themselves are already there: written once per step by make_constraints), from where every lane
 // assembles its own row of H (assemble_rows). The rows are re-read from the lane's own slots, four columns at a time.
-DEVI void hessian_vectors(const Ctx &cx, bool live, const Cone &cn) {
+// `rank1`: somebody who is still iterating in this wave needs the two rank-one slots (a contact in the middle zone of its cone, or a coupled
+// env whose full rows read every slot); in the top and bottom zones ka = kb = 0 and the slots' vectors are never read (assemble_rows_block).
+DEVI void hessian_vectors(const Ctx &cx, bool live, const Cone &cn, bool rank1) {
     if (!live) return;
     float *Uf = cx.envl + EF_U + local_sub(cx) * 6 * U_STRIDE;
     float4 *U = reinterpret_cast<float4 *>(Uf);
 #pragma unroll
     for (int r = 0; r < 4; r++) { Uf[r * U_STRIDE + 7] = cn.w[r]; Uf[r * U_STRIDE + 15] = cn.w[r]; }
+    if (!rank1) return;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const float4 j0 = U[q], j1 = U[4 + q], j2 = U[8 + q], j3 = U[12 + q];
@@ -1395,18 +1482,24 @@ DEVI void assemble_rows(const Ctx &cx, int ncon, float hdiag, float (&row)[13]) 
 // the lane's own block -- gripper dofs 0..6 for lanes 0..6, object dofs 7..12 (+ a zero) for the others -- from the matching half of
 // every slot: two 16-byte reads and seven multiply-adds per slot instead of four and thirteen. A slot of the other block has an exact
 // zero in this lane's column, so it adds nothing, as in the full row.
-DEVI void assemble_rows_block(const Ctx &cx, int ncon, const float (&mrow7)[7], float hdiag, float (&row)[7]) {
+// `midmask` (wave-uniform): bit k = contact k of an env of this wave that is still iterating sits in the middle zone of its cone. Only
+// then do the contact's two rank-one slots carry a weight; everywhere else ka = kb = 0 and the slots would add exact zeros (most contacts
+// most of the time: 85 % of the floor contacts and 81 % of the hull contacts end in the bottom zone) -- they are not read.
+DEVI void assemble_rows_block(const Ctx &cx, int ncon, const float (&mrow7)[7], float hdiag, unsigned midmask, float (&row)[7]) {
 #pragma unroll
     for (int j = 0; j < 7; j++) row[j] = mrow7[j];
     const int lsub = local_sub(cx), isub = UPOS(min(lsub, 12)), half = lsub < 7 ? 0 : 2;
     const float *U = cx.envl + EF_U;
-#pragma unroll 4
-    for (int s = 0; s < 6 * ncon; s++) {
+    auto slot = [&](int s) {
         const float4 *u4 = reinterpret_cast<const float4 *>(U + s * U_STRIDE) + half;
         const float4 a = u4[0], b = u4[1];
         const float wi = b.w * U[s * U_STRIDE + isub];
         row[0] = fmaf(wi, a.x, row[0]); row[1] = fmaf(wi, a.y, row[1]); row[2] = fmaf(wi, a.z, row[2]); row[3] = fmaf(wi, a.w, row[3]);
         row[4] = fmaf(wi, b.x, row[4]); row[5] = fmaf(wi, b.y, row[5]); row[6] = fmaf(wi, b.z, row[6]);
+    };
+    for (int k = 0; k < ncon; k++) {
+        slot(6 * k); slot(6 * k + 1); slot(6 * k + 2); slot(6 * k + 3);
+        if ((midmask >> k) & 1u) { slot(6 * k + 4); slot(6 * k + 5); }
     }
     const int own = cx.sub < 7 ? cx.sub : cx.sub - 7;
 #pragma unroll
@@ -1489,9 +1582,11 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
     // this lane's row of the (always block-diagonal) mass matrix, the seven entries of its own block
     float mrow[7];
     {   const int lsub = local_sub(cx);
-        const float *M = cx.envl + EF_M + min(lsub, 12) * 13 + (lsub < 7 ? 0 : 7);
+        const float4 *M4 = reinterpret_cast<const float4 *>(cx.envl + EF_M + min(lsub, 12) * M_STRIDE);
+        const float4 a = M4[0], b = M4[1];                  // (the padding words of a row are zero)
+        const float e[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z};
 #pragma unroll
-        for (int j = 0; j < 7; j++) mrow[j] = (cx.sub < 13 && (j < 6 || cx.sub < 7)) ? M[min(j, cx.sub < 7 ? 6 : 5)] : 0.f;
+        for (int j = 0; j < 7; j++) mrow[j] = cx.sub < 13 ? e[j] : 0.f;
     }
     STAMP(st, 14);
     // ---- both starts priced at once (their residuals jar = J x - aref and M (x - a_s) come from make_constraints)
@@ -1538,12 +1633,16 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
             // ---- one Newton iteration from the priced point (xi, Mdi, jtfi, cn, hdiag, cost)
             const float gi = Mdi - jtfi;                                    // gradient component of this lane
             STAMP(st, 15);
-            hessian_vectors(cx, live, cn);
-            wave_sync();                                    // the contact lanes' Hessian vectors are in LDS
-            STAMP(st, 16);
             // H couples the gripper's and the object's dofs only through a gripper-object contact: unless an env of the wave that is still
             // iterating has one, every lane assembles and factorises its own diagonal block only
             const bool full = __any(lc.coupled);
+            // which contact positions hold a middle-zone contact in an env that is still iterating (wave-uniform, scalar registers)
+            unsigned midmask;
+            {   const unsigned long long mb = __ballot(live && cn.ka != 0.f);
+                midmask = (unsigned)((mb | (mb >> 16) | (mb >> 32) | (mb >> 48)) & 0xffffull); }
+            hessian_vectors(cx, live, cn, full || midmask != 0u);
+            wave_sync();                                    // the contact lanes' Hessian vectors are in LDS
+            STAMP(st, 16);
             float x[7];                                     // the Newton direction's components in this lane's block
             if (full) {
                 float row[13];
@@ -1562,7 +1661,7 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
                 for (int j = 0; j < 7; j++) x[j] = cx.sub < 7 ? p[j] : (j < 6 ? p[7 + j] : 0.f);
             } else {
                 float row[7];
-                assemble_rows_block(cx, ncon, mrow, hdiag, row);
+                assemble_rows_block(cx, ncon, mrow, hdiag, midmask, row);
                 STAMP(st, 8);
                 if (dbgH && iters == 0 && cx.sub < 13) {
 #pragma unroll
@@ -1724,30 +1823,37 @@ DEVI void forward_dense(const DevModel &m, const Ctx &cx, const Kin &k, const fl
     for (int i = 0; i < 13; i++) opaque(qfs[i]);         // (keeps the scheduler from pulling the mass matrix up into the bias block)
     float Mg[28], Mo[21];
     mass_matrix(m, k, Mg, Mo);
-    if (cx.sub == 0) {                  // one lane publishes the env's mass matrix, every lane then owns a row of it (the off-diagonal
-        float *M = S + EF_M;            // blocks are zero for good: env_lds_init)
+    if (cx.sub == 0) {                  // one lane publishes the env's mass matrix, every dof lane then owns a (block) row of it
+        float4 *M4 = reinterpret_cast<float4 *>(S + EF_M);
 #pragma unroll
-        for (int i = 0; i < 7; i++)
+        for (int i = 0; i < 7; i++) {
+            M4[2 * i] = make_float4(Mg[pidx(i, 0)], Mg[pidx(i, 1)], Mg[pidx(i, 2)], Mg[pidx(i, 3)]);
+            M4[2 * i + 1] = make_float4(Mg[pidx(i, 4)], Mg[pidx(i, 5)], Mg[pidx(i, 6)], 0.f);
+        }
 #pragma unroll
-            for (int j = 0; j < 7; j++) M[i * 13 + j] = Mg[pidx(i, j)];
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-#pragma unroll
-            for (int j = 0; j < 6; j++) M[(7 + i) * 13 + 7 + j] = Mo[pidx(i, j)];
+        for (int i = 0; i < 6; i++) {
+            M4[2 * (7 + i)] = make_float4(Mo[pidx(i, 0)], Mo[pidx(i, 1)], Mo[pidx(i, 2)], Mo[pidx(i, 3)]);
+            M4[2 * (7 + i) + 1] = make_float4(Mo[pidx(i, 4)], Mo[pidx(i, 5)], 0.f, 0.f);
+        }
     }
-    // qacc_smooth = M^-1 qfrc_smooth: block-diagonal (gripper 7x7, object 6x6), cheap enough to do redundantly in registers
+    // qacc_smooth = M^-1 qfrc_smooth: block-diagonal (gripper 7x7, object 6x6), cheap enough to do redundantly in registers. Redundancy put to
+    // use: the env's lanes 8..15 add mj_Euler's implicit damping h D to the gripper block's diagonal before the factorisation, so the one
+    // instruction stream yields the factor of M (lanes 0..7: qacc_smooth) AND of M + h D (lanes 8..15), which integrate() would otherwise
+    // build and factorise on its own. (x + 0 = x: lanes 0..7 factorise exactly M; a <freejoint/> object block has no damping.)
+    {   const bool damped = cx.sub >= 8;
+#pragma unroll
+        for (int i = 0; i < 7; i++) Mg[pidx(i, i)] += damped ? m.timestep * m.damping[i] : 0.f; }
     float qs[13];
 #pragma unroll
     for (int i = 0; i < 13; i++) qs[i] = qfs[i];
     block_solve(Mg, Mo, qs);
     if (cx.sub == 0) { lds_st<13>(S + ES_QFS, qfs); lds_st<13>(S + ES_QS, qs); }
+    if (cx.sub == 8) lds_st<28>(S + EF_LD, Mg);
     wave_sync();
     STAMP(st, 2);
 }
-// once per kernel: the parts of the env's LDS region that no step rewrites (the mass matrix' off-diagonal blocks)
+// once per kernel: the parts of the env's LDS region that no step rewrites
 DEVI void env_lds_init(const Ctx &cx) {
-    float *M = cx.envl + EF_M;
-    for (int i = cx.sub; i < 169; i += KL) M[i] = 0.f;
     MI(cx, cx.sub) = 0;                                   // the macro step's integer words, fault bits included
     wave_sync();
 }
@@ -1791,31 +1897,17 @@ DEVI void integrate(const DevModel &m, const Ctx &cx, float qacci, float jtfi, f
     wave_sync();
     float acc[13], qacc[13];
     lds_ld<13>(S + ES_ACC, acc); lds_ld<13>(S + ES_WARM, qacc);
-    {   float Ag[28];
-        const float *M = S + EF_M;
+    {   // gripper block: the factor of M + h D parked by forward_dense(). Object block: a <freejoint/> takes no joint defaults, so it has no
+        // damping (the loader refuses a model that has) and M a = qfrc_smooth + J^T f is what qacc already solves: a' = qacc there.
+        float Lg[28]; lds_ld<28>(S + EF_LD, Lg);
+        float xg[7];
 #pragma unroll
-        for (int i = 0; i < 7; i++)
+        for (int i = 0; i < 7; i++) xg[i] = acc[i];
+        chol_solve_packed<7>(Lg, xg);
 #pragma unroll
-            for (int j = 0; j <= i; j++) Ag[pidx(i, j)] = M[i * 13 + j] + (i == j ? h * m.damping[i] : 0.f);
-        const bool obj_damped = (m.damping[7] != 0.f) | (m.damping[8] != 0.f) | (m.damping[9] != 0.f) | (m.damping[10] != 0.f) |
-                                (m.damping[11] != 0.f) | (m.damping[12] != 0.f);
-        if (obj_damped) {                                   // not the case for a <freejoint/> (no defaults apply), kept for generality
-            float Ao[21];
+        for (int i = 0; i < 7; i++) acc[i] = xg[i];
 #pragma unroll
-            for (int i = 0; i < 6; i++)
-#pragma unroll
-                for (int j = 0; j <= i; j++) Ao[pidx(i, j)] = M[(7 + i) * 13 + 7 + j] + (i == j ? h * m.damping[7 + i] : 0.f);
-            block_solve(Ag, Ao, acc);
-        } else {                                            // M a = qfrc_smooth + J^T f is what qacc solves: a' = qacc for the object
-            float xg[7];
-#pragma unroll
-            for (int i = 0; i < 7; i++) xg[i] = acc[i];
-            chol_packed<7>(Ag); chol_solve_packed<7>(Ag, xg);
-#pragma unroll
-            for (int i = 0; i < 7; i++) acc[i] = xg[i];
-#pragma unroll
-            for (int i = 7; i < 13; i++) acc[i] = qacc[i];
-        }
+        for (int i = 7; i < 13; i++) acc[i] = qacc[i];
     }
     float qvel[13], qpos[14];
     lds_ld<13>(S + ES_QVEL, qvel); lds_ld<14>(S + ES_QPOS, qpos);

@@ -176,6 +176,9 @@ extern "C" int grip_model_load(const char *blob_path, GripModel **out) {
         for (int k = 0; k < 9; k++) if (std::fabs(Re[k] - I3[k]) > 1e-12) { delete gm; return fail("ee body quat must be identity"); }
         for (int k = 0; k < 3; k++) m.ee_pos0[k] = (float)bpos[3 + k]; }
     for (int i = 0; i < 13; i++) { m.armature[i] = (float)arm[i]; m.damping[i] = (float)damp[i]; }
+    // the object hangs on a <freejoint/>, which takes no joint defaults: no damping there (integrate() relies on it: M a = qfrc_smooth + J^T f
+    // is then what qacc already solves for the object block)
+    for (int i = 7; i < 13; i++) if (damp[i] != 0.0) { delete gm; return fail("the object's free joint must be undamped"); }
     for (int j = 0; j < 7; j++) {
         m.range[j][0] = (float)rng[2*j]; m.range[j][1] = (float)rng[2*j+1]; m.gear[j] = (float)gear[j];
         m.ctrlrange[j][0] = (float)crange[2*j]; m.ctrlrange[j][1] = (float)crange[2*j+1]; m.dof_invweight0[j] = (float)diw[j];
@@ -470,8 +473,12 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
     const Ctx cx = stage_tables(m, lds_dyn);
     STAMPS_DECL
     bool act_; int e = block * EPB + wg_env_slot(act_);
-    const bool valid = act_ && e < st.n;
-    if (e >= st.n) e = st.n - 1;          // (idle rows of a 2-env wave mirror the env of the row 32 lanes below: same reads, no writes)
+    // Lanes 32..63 of a two-env wave are CLONES of lanes 0..31: the same env, the same arithmetic, the same LDS traffic (identical values to
+    // identical addresses), no global writes (`valid` is false there). collide(), make_constraints() and the solver hand them the second
+    // half of work that one instruction stream can do for two data sets (grip_physics.h, halves_*).
+    const bool inb = e < st.n;                          // the env exists (clones included)
+    const bool valid = act_ && inb;                     // ... and this lane may write its results
+    if (e >= st.n) e = st.n - 1;
     if (order) e = order[e];
     const bool writer = valid && cx.sub == 0;
     const bool sliced = slice > 0;
@@ -483,11 +490,11 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
     // What the macro step carries lives in the env's LDS region (ES_MAC floats, ES_MACI integers); registers keep what the loop turns on:
     // phase, the step budget, the "first step" flag.
     Contact con; int ncon = 0;
-    int phase = valid ? PH_MOVE : PH_DONE;
+    int phase = inb ? PH_MOVE : PH_DONE;
     bool first = true;
     size_t arow = (size_t)e;
     if (cx.sub == 0) { MI(cx, MI_EPSTEP) = st.episode_step[e]; MI(cx, MI_STATUS) = st.status[e]; MI(cx, MI_GOPEN) = st.gripper_open[e]; }
-    if (sliced && valid) {
+    if (sliced && inb) {
         if (mc.astate[e] != 0) {                        // waiting: start only when the last compaction gave this env a slot
             int sl = mc.slot[e];
             if (sl >= 0 && mc.gen[e] <= mc.tick[0] - lag) arow = (size_t)sl; else phase = PH_DONE;
@@ -503,7 +510,7 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
 #ifndef GRIP_COLD_PORTAL
     // the portal memory lives as long as the macro step: a resumed env gets it back, so that the result does not depend on where
     // the time slices end (lock-step keeps it in registers for the whole macro step)
-    if (sliced && valid && !first) {
+    if (sliced && inb && !first) {
         const float4 m0 = *MEMO4(mc, e, 0, cx.sub);
         const int w0 = __float_as_int(m0.x);
         sep.has = w0 & 1; sep.h1 = ((w0 >> 2) & 0xfff) - 1; sep.h2 = ((w0 >> 14) & 0xfff) - 1;
@@ -516,15 +523,18 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
 #endif
     // the wall-clock budget runs from the moment the FIRST workgroup of the launch started (k_compact clears the stamp), so
     // that a workgroup that was placed late -- other streams' kernels were using its CU -- does not stretch the launch
+    // (the same stamp times the launch: t0[0] = start of the first workgroup, t0[1] = end of the last wave; k_compact, which follows every
+    // slice launch on its stream, adds the difference to t0[2] and counts the launch in t0[3] -- every launch, a replayed graph's too, where
+    // host-side events cannot be recorded: grip_batch_device_time)
     unsigned long long t0v = 0ULL;
-    if (budget_ticks > 0) {
+    if (sliced) {
         if (cx.lane == 0) {
             unsigned long long now = (unsigned long long)wall_clock64();          // 100 MHz
             unsigned long long old = atomicCAS(mc.t0, 0ULL, now);
             t0v = old ? old : now;
             // more workgroups than the chip holds at once (> 4096 envs): the later rounds start when the first ones are done and
             // get a budget of their own; a workgroup that is merely placed a little late still ends with the launch
-            if (now - t0v > (unsigned long long)(budget_ticks / 2)) t0v = now;
+            if (budget_ticks > 0 && now - t0v > (unsigned long long)(budget_ticks / 2)) t0v = now;
         }
         // wave-uniform: keep it in scalar registers
         t0v = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(t0v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(t0v & 0xffffffffULL));
@@ -533,7 +543,7 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
 
     while (__any(phase != PH_DONE && (budget > 0 || phase == PH_FINAL))) {
 #ifdef GRIP_STAMPS
-        stm.acc[12] += __popcll(__ballot(cx.sub == 0 && phase != PH_DONE && (budget > 0 || phase == PH_FINAL)));   // envs of the wave still working
+        stm.acc[12] += __popcll(__ballot(cx.sub == 0 && cx.lane < EPW * KL && phase != PH_DONE && (budget > 0 || phase == PH_FINAL)));   // envs of the wave still working
         stm.acc[13] += 1;
 #endif
         if (phase != PH_DONE && (budget > 0 || phase == PH_FINAL)) {
@@ -708,6 +718,7 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
     if (cx.lane == 0) for (int i = 0; i < NSTAMP; i++) atomicAdd(&g_stamp_acc[i], stm.acc[i]);      // whole-GPU phase totals (diagnostic build)
 #endif
     int ee = e; asm volatile("" : "+v"(ee));                 // (the suspend addresses are formed here, after the loop)
+    if (sliced && cx.lane == 0) atomicMax(mc.t0 + 1, (unsigned long long)wall_clock64());      // end stamp of the launch (no return value: fire and forget)
     if (sliced) {
         // cost estimate of this env's next physics.step(), in units of roughly half a plain step: Newton iterations of the
         // last solve plus 1.5 per hull-hull contact (MPR refinement); k_compact sorts the work order by it
@@ -865,7 +876,12 @@ DEVI void compact_body(const MacroCtx &mc, int n, int capacity, int *list, int *
         for (int k = 0; k < CP_CLASSES; k++) { before[k] += start; start += cls_total[k]; }
         for (int i = 0; i < chunk; i++) { int e = t * chunk + i; if (e < n) order[before[cls_of(e)]++] = e; }
     }
-    if (t == 0) { mc.tick[0] = mc.tick[0] + 1; mc.t0[0] = 0ULL; }     // every thread read the old tick before the first barrier
+    if (t == 0) {                                       // every thread read the old tick before the first barrier
+        mc.tick[0] = mc.tick[0] + 1;
+        const unsigned long long a = mc.t0[0], z = mc.t0[1];          // the slice launch this compaction follows: 100 MHz stamps
+        if (a != 0ULL && z > a) { mc.t0[2] += z - a; mc.t0[3] += 1ULL; }
+        mc.t0[0] = 0ULL; mc.t0[1] = 0ULL;
+    }
 }
 // one block per group: segment g of the list gets the group's waiting envs (global ids), -1 beyond its count (counts[g]);
 // total != NULL receives the number of rows (the merged list of a set has holes: validity is the sign of an entry)
@@ -933,7 +949,10 @@ __global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_debug_forward
     xp[3] = k.pe.x; xp[4] = k.pe.y; xp[5] = k.pe.z;
     for (int g = 1; g <= 6; g++) { xp[3 * (g + 1)] = gpos[3 * (g - 1)]; xp[3 * (g + 1) + 1] = gpos[3 * (g - 1) + 1]; xp[3 * (g + 1) + 2] = gpos[3 * (g - 1) + 2]; }
     for (int i = 0; i < 13; i++) { qacc_out[(size_t)e * 13 + i] = qacc[i]; qs_out[(size_t)e * 13 + i] = qs[i]; if (!getenv_dbgH) bias_out[(size_t)e * 13 + i] = bias[i]; }
-    if (!getenv_dbgH) for (int i = 0; i < 169; i++) M_out[(size_t)e * 169 + i] = cx.envl[EF_M + i];
+    if (!getenv_dbgH) for (int i = 0; i < 169; i++) {        // the 13 x 13 matrix from the block rows kept in LDS
+        const int r = i / 13, c = i % 13, k = c - (r < 7 ? 0 : 7);
+        M_out[(size_t)e * 169 + i] = (k >= 0 && k < (r < 7 ? 7 : 6)) ? cx.envl[EF_M + r * M_STRIDE + k] : 0.f;
+    }
 }
 
 __global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_target_pose(const DevModel m, DevConfig cfg, StatePtrs st, const float *actions, float *target_out) {
@@ -1070,7 +1089,7 @@ static int batch_build(GripBatch *b, const GripModel *m) {
     HIPCHK(hipMalloc(&b->mc_heavy, N * sizeof(int))); HIPCHK(hipMemset(b->mc_heavy, 0, N * sizeof(int)));
     HIPCHK(hipMalloc(&b->mc_tick, sizeof(int))); HIPCHK(hipMemset(b->mc_tick, 0, sizeof(int)));
     HIPCHK(hipMalloc(&b->mc_gen, N * sizeof(int))); HIPCHK(hipMemset(b->mc_gen, 0, N * sizeof(int)));
-    HIPCHK(hipMalloc(&b->mc_t0, sizeof(unsigned long long))); HIPCHK(hipMemset(b->mc_t0, 0, sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&b->mc_t0, 4 * sizeof(unsigned long long))); HIPCHK(hipMemset(b->mc_t0, 0, 4 * sizeof(unsigned long long)));     // start, end, sum, launches
     HIPCHK(hipMalloc(&b->mc_memo, (size_t)MC_MEMO_WORDS * 16 * N * sizeof(float))); HIPCHK(hipMemset(b->mc_memo, 0, (size_t)MC_MEMO_WORDS * 16 * N * sizeof(float)));
     {   std::vector<int> ident(N); for (size_t i = 0; i < N; i++) ident[i] = (int)i;          // work order: identity until the first compaction
         HIPCHK(hipMemcpy(b->mc_order, ident.data(), N * sizeof(int), hipMemcpyHostToDevice)); }
@@ -1176,6 +1195,19 @@ extern "C" int grip_batch_kernel_time(GripBatch *b, int reset, float *ms_avg, in
     if (ms_avg) *ms_avg = n ? (float)(tot / n) : 0.f;
     if (launches) *launches = n;
     if (reset) b->ev_used = 0;
+    return 0;
+}
+
+extern "C" int grip_batch_device_time(GripBatch *b, int reset, double *ms_avg, long long *launches, void *stream) {
+    if (!b) return fail("grip_batch_device_time: null batch");
+    HIPCHK(hipSetDevice(b->device));
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long acc[2] = {0ULL, 0ULL};
+    HIPCHK(hipMemcpyAsync(acc, b->mc_t0 + 2, sizeof acc, hipMemcpyDeviceToHost, s));
+    if (reset) HIPCHK(hipMemsetAsync(b->mc_t0 + 2, 0, sizeof acc, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (ms_avg) *ms_avg = acc[1] ? (double)acc[0] / (double)acc[1] * 1e-5 : 0.0;       // 100 MHz ticks -> ms
+    if (launches) *launches = (long long)acc[1];
     return 0;
 }
 

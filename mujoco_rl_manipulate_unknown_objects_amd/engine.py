@@ -104,7 +104,7 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_destroy", "grip_batch_set_config", "grip_batch_num_envs", "grip_batch_reset", "grip_batch_step",
            "grip_batch_observe", "grip_batch_get_state", "grip_batch_set_state", "grip_batch_get_flags",
            "grip_batch_set_flags", "grip_batch_substep", "grip_batch_debug_forward", "grip_batch_target_pose",
-           "grip_batch_kernel_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward", "grip_obs_preprocess",
+           "grip_batch_kernel_time", "grip_batch_device_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward", "grip_obs_preprocess",
            "grip_batch_set_state_storage", "grip_batchset_create", "grip_batchset_destroy", "grip_batchset_refresh", "grip_batchset_num_envs",
            "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list", "grip_conv1_u8", "grip_conv1_u8_rows", "grip_batch_render_camera", "grip_ppo_loss", "grip_conv23_prep", "grip_conv23",
            "grip_trunk_backward", "grip_trunk_backward_parts", "grip_conv1_u8_train", "grip_conv23_train", "grip_clip_adam", "grip_clip_adam_chunks", "grip_tanh_backward_colsum", "grip_relu_backward_colsum"]
@@ -147,6 +147,7 @@ def lib():
     L.grip_batch_debug_forward.argtypes = [vp] + [vp] * 7 + [vp]
     L.grip_batch_target_pose.argtypes = [vp, vp, vp, vp]
     L.grip_batch_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.grip_batch_device_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong), vp]
     L.grip_selftest_cholesky.argtypes = [vp, vp, vp, C.c_int, vp]
     L.grip_batch_advance.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     L.grip_batch_observe_list.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]
@@ -225,9 +226,10 @@ class RecordRows:
         return self
 
     def materialize(self):
-        """the rows as an ordinary tensor (a host sync: for fallbacks and tests, never on the captured path)"""
-        r = int(self.row0.item())
-        return self.records[r:r + self.n]
+        """the rows as an ordinary tensor: a gathered copy, without a host sync (the row base stays a device scalar), so that a fallback that
+        needs real tensors -- the module-by-module forward under autocast, say -- still works inside a stream capture"""
+        import torch
+        return self.records.index_select(0, self.row0.reshape(1) + torch.arange(self.n, device=self.records.device))
 
 
 class IndexedRows:
@@ -425,7 +427,17 @@ class ClipAdam:
         _chk(lib().grip_clip_adam(n, numel, arr(ps), arr([p.grad for p in ps]), arr([self.opt.state[p]["exp_avg"] for p in ps]),
                                   arr([self.opt.state[p]["exp_avg_sq"] for p in ps]), arr([self.opt.state[p]["step"] for p in ps]), float(g["lr"]), float(b1), float(b2),
                                   float(g["eps"]), self.max_norm, C.c_void_p(self._partials.data_ptr()), None, stream))
+        self.bump_versions(ps)
         return True
+
+    @staticmethod
+    def bump_versions(params):
+        """The kernel writes the parameters through raw pointers: tell autograd's version counters (host side, legal during a stream capture), so
+        that whoever caches something derived from the parameters -- the policy's merged rollout weights -- sees that they changed. A replayed
+        graph does not come through here: PPO.train() calls this once more after its last replay."""
+        import torch
+        for p in params:
+            torch.autograd.graph.increment_version(p)
 
 
 def ppo_loss(mean, log_std, values, actions, old_log_prob, advantages, returns, clip_range, ent_coef, vf_coef):
@@ -657,6 +669,13 @@ class Batch:
         _chk(lib().grip_batch_kernel_time(self.ptr, int(reset), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def device_time(self, reset=True):
+        """(mean duration in ms, number) of ALL time-slice launches since the last reset, replayed graphs' included, from the device's own
+        clock stamps (grip_batch_device_time); kernel_time() is the host-event figure of the eager launches only."""
+        ms = C.c_double(); n = C.c_longlong()
+        _chk(lib().grip_batch_device_time(self.ptr, int(reset), C.byref(ms), C.byref(n), self._stream()))
+        return ms.value, n.value
+
     def close(self):
         if getattr(self, "ptr", None) and _lib is not None:
             _lib.grip_batch_destroy(self.ptr)
@@ -813,6 +832,10 @@ class MixedBatch:
     def kernel_time(self, reset=True):
         """(mean duration in ms of the set's macro-step launches, number of launches): timed on the first group's event ring."""
         return self.parts[0].kernel_time(reset)
+
+    def device_time(self, reset=True):
+        """the same from the device's clock stamps, every launch (the first group's stamps bracket the set's one launch)"""
+        return self.parts[0].device_time(reset)
 
     def close(self):
         if getattr(self, "ptr", None) and _lib is not None:

@@ -106,6 +106,8 @@ class ActorCriticPolicy(nn.Module):
         if o.dtype == th.uint8:
             if o.is_cuda and self.normalize_images and getattr(self, "_fused_preprocess", False):
                 return {"observation": o}        # AugmentedNatureCNN normalises and lays out raw uint8 in one kernel
+            if hasattr(o, "materialize"):        # rows handed over in place (engine.RecordRows / IndexedRows): the tensor path wants a tensor
+                o = o.materialize()
             o = o.float()
             if self.normalize_images:
                 o = o / 255.0
@@ -172,7 +174,8 @@ class ActorCriticPolicy(nn.Module):
     def accepts_record_rows(self):
         """can forward_parts() take engine.RecordRows (the tick's observations read in place from the trainer's record rows)?"""
         fe = self.features_extractor
-        return self._rollout_cache is not None and getattr(fe, "_wl_nhwc", None) is not None and getattr(self, "_fused_preprocess", False)
+        return (self._rollout_cache is not None and getattr(fe, "_wl_nhwc", None) is not None and getattr(self, "_fused_preprocess", False)
+                and bool(getattr(self, "normalize_images", True)))
 
     def forward_parts(self, obs):
         """(mean, log_std, values): the Gaussian head left un-sampled, for callers that sample and score in a fused kernel."""

@@ -155,7 +155,9 @@ class PPO:
             def policy_parts_fn(obs_rows):
                 with th.no_grad(), self._ac():
                     return self.policy_rollout.forward_parts({"observation": obs_rows})
-            policy_parts_fn.accepts_record_rows = lambda: bool(getattr(self.policy_rollout, "accepts_record_rows", lambda: False)())
+            # (under autocast the extractor's in-place fast path steps aside -- rollout_features() returns None -- and the fallback wants real
+            # tensors: the tick then stages the observation rows as before)
+            policy_parts_fn.accepts_record_rows = lambda: self.autocast_dtype is None and bool(getattr(self.policy_rollout, "accepts_record_rows", lambda: False)())
             parts = policy_parts_fn if hasattr(self.policy, "forward_parts") else None
             self._async = AsyncRollout(eng, policy_fn, policy_parts_fn=parts, target=n_steps * self.n_envs, capacity=min(cap, self.n_envs), slice_len=async_slice,
                                        gamma=gamma, gae_lambda=gae_lambda, action_low=env.action_space.low, action_high=env.action_space.high)
@@ -439,6 +441,12 @@ class PPO:
             for s in range(0, total - bs + 1, bs):
                 pl, vl, loss = self._minibatch_update(src, perm[s:s + bs])
                 stats = {"policy_loss": pl, "value_loss": vl, "loss": loss}
+        # the captured update writes the parameters by graph replay, through raw pointers: autograd's version counters did not see it. Bump them,
+        # so that everything cached from the parameters (the policy's merged rollout weights) knows it is stale -- collect_rollouts() refreshes
+        # explicitly, an evaluation straight after train() relies on this.
+        if self.device.type == "cuda":
+            from ..engine import ClipAdam
+            ClipAdam.bump_versions(list(self.policy.parameters()))
         self.logger = stats
         return stats
 

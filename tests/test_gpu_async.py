@@ -278,3 +278,29 @@ def test_observations_rendered_once_into_the_record_rows():
     rows = model._async.window_rows()
     assert int((model._async.obs[rows][:, :3] != 0).sum()) > 1000   # the records hold the rendered observations
     env.close()
+
+
+def test_async_tick_under_bf16_autocast_keeps_its_graph(engine, torch):
+    """PPO(autocast_dtype=bf16) (bench.py --policy-dtype bf16): the extractor's in-place fast path steps aside under autocast, so the tick must
+    not hand the policy engine.RecordRows (whose fallback used to sync with the host: illegal during the stream capture, the tick graph was
+    dropped with a warning). The gate now covers autocast, the fallback is a sync-free gather, and the captured tick survives."""
+    import warnings
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import BatchedRobotEnv, default_config
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3 import PPO, GpuVecEnv
+    from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
+    env = BatchedRobotEnv(default_config(sim_env="/xmls/sand_ball_env.xml"), n_envs=64, auto_reset=True)
+    model = PPO("MultiInputPolicy", GpuVecEnv(env), n_steps=2, batch_size=64, n_epochs=1, async_slice=32, async_capacity=32, async_budget_us=1000,
+                autocast_dtype=torch.bfloat16,
+                policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]))
+    assert not model._async.policy_parts_fn.accepts_record_rows()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                      # "hipGraph capture of the rollout tick failed" would be a warning
+        for _ in range(2):
+            model.collect_rollouts(); st = model.train()
+    torch.cuda.synchronize()
+    assert np.isfinite(float(st["loss"]))
+    assert model._async._graph is not None                  # the tick is replayed from its graph
+    # the fallback itself: rows without a host sync, equal to the slice
+    rec = torch.randint(0, 256, (50, 5, 64, 64), dtype=torch.uint8, device="cuda"); row = torch.tensor([7], dtype=torch.int64, device="cuda")
+    assert torch.equal(engine.RecordRows(rec, row, 9).materialize(), rec[7:16])
+    env.close()

@@ -418,6 +418,21 @@ def test_merged_heads_rollout_forward_matches_the_module_forward(torch):
         pol.load_state_dict(sd)
         loaded = pol.forward_parts(obs)[0]
     assert (auto - before - 1.0).abs().max() < 1e-5 and (fresh - before - 1.0).abs().max() < 1e-5 and (loaded - before).abs().max() < 1e-5
+    # the hand-written optimiser step writes the parameters through raw pointers: it must bump their version counters, or the merged
+    # weights of the step before would be used (advisor, round 3)
+    from mujoco_rl_manipulate_unknown_objects_amd.engine import ClipAdam
+    opt = torch.optim.Adam(pol.parameters(), lr=1e-2, capturable=True)
+    for q in pol.parameters():
+        q.grad = torch.ones_like(q)
+    with torch.no_grad():
+        pre = pol.forward_parts(obs)[0].clone()
+    assert ClipAdam(opt, 0.5).step()
+    with torch.no_grad():
+        post = pol.forward_parts(obs)[0].clone()             # merged path, refreshed by itself
+        cache, pol._rollout_cache = pol._rollout_cache, None
+        ref_post = pol.forward_parts(obs)[0]                 # module path on the stepped parameters
+        pol._rollout_cache = cache
+    assert (post - pre).abs().max() > 1e-3 and (post - ref_post).abs().max() < 2e-5
     # value-only extractor or unequal MLP shapes: no merged path
     pol2 = ActorCriticPolicy(RGBDSensor(config=cfg).setup_observation_space(), Actuator(config=cfg).setup_action_space(),
                              features_extractor_class=AugmentedNatureCNN, net_arch=dict(pi=[64], vf=[64, 64])).cuda()
