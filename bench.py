@@ -140,7 +140,7 @@ def main():
     ap.add_argument("--mixed", action="store_true", help="BASELINE.json configs[3]: {acorn, sand_ball, sugar_cube, bread_crumb} x direction {0, 45}, "
                                                          "--envs / 8 each, sorted by group (not the headline workload)")
     ap.add_argument("--slice", type=int, default=96, help="physics.step() calls per env per tick (async schedule)")
-    ap.add_argument("--capacity", type=int, default=0, help="finished envs decided per tick (async schedule); default 5/16 of the envs (1280 of 4096: round 3's kernel finishes ~1150 macro steps per 3 ms tick; a capacity of envs / 4 capped the rate)")
+    ap.add_argument("--capacity", type=int, default=0, help="finished envs decided per tick (async schedule); default 3/8 of the envs (1536 of 4096: round 4's kernel finishes ~1400 macro steps per 3 ms tick; 5/16 capped the rate at 287 k)")
     ap.add_argument("--policy-dtype", choices=["f32", "bf16"], default="f32", help="autocast dtype of the policy / PPO update (physics is always f32)")
     ap.add_argument("--overlap-update", action="store_true", help="PPO update of rollout i on a second stream while rollout i+1 is collected (one update of policy lag)")
     ap.add_argument("--pipeline", action="store_true", help="decide for tick t on a side stream while tick t+1 advances (lag 2)")
@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
     if a.capacity <= 0:
-        a.capacity = max(8, (5 * a.envs // 16) // 8 * 8)
+        a.capacity = max(8, (3 * a.envs // 8) // 8 * 8)
     if a.actions is None:
         a.actions = "policy" if a.lockstep else "rng"
     if a.mixed:

@@ -166,6 +166,10 @@ typedef struct {
      * Gaussian (what PPO's ratio needs), and rng_count[env] -- [n_envs + 1], the env's decision counter t -- is incremented.
      * rng_seed carries seed and rank. The stream of an env does not depend on the order in which envs finish. */
     int64_t *rng_count; uint64_t rng_seed;
+    /* Row strides, in floats, of `actions` and `values` (0 = dense: action_dim and 1): the merged policy | value head leaves [mean | value] as
+     * the columns of ONE [capacity, action_dim + 1] matrix, read here in place instead of through two gathered copies. With the synthetic stream
+     * (rng_count) `noise` may be NULL: the fused Gaussian head is switched on by log_std alone then. */
+    int32_t mean_stride, value_stride;
 } GripRolloutTick;
 int grip_rollout_tick(const GripRolloutTick *args, void *stream);
 /* GAE over every env's record chain, backwards from its open record (whose value bootstraps) along prev_rec. */

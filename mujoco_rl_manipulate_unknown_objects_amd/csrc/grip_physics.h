@@ -1,14 +1,20 @@
-// grip_physics.h -- fp32 device physics: SIXTEEN LANES COOPERATE ON ONE ENVIRONMENT (gfx950).
+// grip_physics.h -- fp32 device physics: SIXTEEN LANES COOPERATE ON ONE ENVIRONMENT, THEIR CLONES 32 LANES UP TAKE SECOND HALVES (gfx950).
 //
 // What one `physics.step()` of the reference computes (robot_env.py:100,119,142,157 -> dm_control
 // Physics.step -> mj_step2 + mj_step1), laid out for CDNA4:
 //
-//   * a wavefront holds 4 environments x 16 lanes, a 256-thread workgroup 16 environments. 4096 envs
-//     are 1024 waves -- one per SIMD of the chip -- instead of the 64 waves a lane-per-env mapping gives,
-//     and a wave waits for the slowest of 4 macro steps, not of 64;
+//   * the shipped mapping (GRIP_EPW = 2): a wavefront holds TWO environments -- env A in lanes 0..15, env B in lanes 16..31 -- and lanes
+//     32..63 are CLONES of lanes 0..31 (the same env, the same values, the same LDS addresses, no global writes). A 512-thread workgroup
+//     holds 16 environments in 8 waves; 4096 envs are 2048 waves = TWO per SIMD of the chip, each covering the other's LDS round trips
+//     (needs the kernel inside 256 registers: the env's state lives in LDS, not in registers). -DGRIP_EPW=4 builds round 2's mapping for
+//     comparison: four envs x 16 lanes per wave, 256-thread workgroups, one wave per SIMD, no clones;
+//   * where ONE instruction stream can serve two data sets the clones take the second one and v_permlane32_swap hands the results across
+//     (halves_f / halves_i): the support searches of a hull pair's two hulls, the two halves of the cooperative vertex scan, two of a
+//     contact's four constraint rows, the odd-numbered contacts of a Hessian row. Everywhere else they repeat the lower half's arithmetic
+//     (a wave instruction costs the same for 32 or 64 active lanes);
 //   * the small dense per-env algebra (kinematics of four rigid groups, 7x7 + 6x6 mass matrix, bias forces,
-//     Cholesky solves, integration) is computed redundantly by the 16 lanes, bit-identically, so no
-//     broadcast is ever needed for it;
+//     Cholesky solves, integration) is computed redundantly by the env's lanes, bit-identically, so no
+//     broadcast is ever needed for it (one redundancy is put to use: lanes 8..15 factorise M + h D while lanes 0..7 factorise M);
 //   * everything with per-contact or per-geom-pair parallelism is spread over the lanes: the 17 narrow-phase
 //     items (6 floor-hull, 11 hull-hull) run one per lane, each lane driving its own Minkowski-portal
 //     state machine around the single support evaluation; a contact lives in the registers of ONE lane
@@ -17,8 +23,8 @@
 //   * lanes combine with DPP row rotations (row_ror 8/4/2/1 = a 16-lane all-reduce in four VALU ops,
 //     commutative so every lane gets the bit-identical sum), never through memory;
 //   * LDS holds what is shared: the convex hulls (vertices, edge graph, cube-map table of start vertices
-//     for the hill-climbing support search) once per workgroup, and per env the six geom frames and a
-//     14-slot contact staging area used to compact the contacts found by different lanes.
+//     for the hill-climbing support search) once per workgroup, and per env a 7.3 KB region: the state vectors, six geom frames, a
+//     14-slot contact staging area, the mass matrix' block rows, the contacts' Jacobian rows / Hessian vectors (EF_* / ES_* below).
 #pragma once
 #include "grip_device.h"
 
@@ -98,7 +104,13 @@ static_assert(ES_QPOS % 4 == 0 && ENV_FLOATS % 4 == 0 && ES_KIN % 4 == 0, "state
 // per-workgroup geom table (floats per geom): centre3, rbound, fs, ft, invweight, group, hull_vadr
 #define GT_STRIDE 10
 #define GT_FLOATS (GN_GEOM * GT_STRIDE)
-#define LDS_ENV_BASE(hull_words) (((hull_words) + GT_FLOATS + 3) & ~3)      // float offset of the first env region (16-byte aligned)
+// per-workgroup table of the two finger chains' model constants, one 36-float record per chain s (left, right): kn_pos[3], kn_R[9], fin_pos[3],
+// fin_R[9], grp_com[1 + s][3], grp_inertia[1 + s][6], grp_mass[1 + s], pad[2]. Lanes 0..31 of a two-env wave work on the left chain, their
+// clones 32..63 on the right one, in ONE instruction stream: the constants must come by lane (nine 16-byte reads), not as scalar operands.
+#define LR_STRIDE 36
+#define LR_FLOATS (2 * LR_STRIDE)
+#define LR_OFF(hull_words) (((hull_words) + GT_FLOATS + 3) & ~3)             // 16-byte aligned
+#define LDS_ENV_BASE(hull_words) (LR_OFF(hull_words) + LR_FLOATS)             // float offset of the first env region (16-byte aligned)
 
 #define NEWTON_MAXIT 20
 #ifndef NEWTON_TOL
@@ -200,6 +212,11 @@ struct Kin {
     V3 po; M3 Ro;
     V3 c[4];
     float Ic[4][6];
+#if EPW == 2
+    // the finger chain THIS half of the wave works on (lanes 0..31: left, s = 0; clones 32..63: right, s = 1): c[1 + s], Ic[1 + s], its mass.
+    // c[1], c[2], Ic[1], Ic[2] are not filled in this mapping: bias_forces() and mass_matrix() take the own chain and swap results.
+    V3 c_own; float Ic_own[6]; float m_own;
+#endif
 };
 
 // tables staged in LDS, shared by the workgroup
@@ -208,6 +225,7 @@ struct Tables {
     const unsigned short *nbr;      // neighbour ids, local to the hull
     const unsigned short *lut;      // [6][LUT_CELLS] start vertices
     const float *gt;                // geom table [GN_GEOM][GT_STRIDE]
+    const float *lr;                // finger-chain constants [2][LR_STRIDE]
 };
 
 struct Ctx {
@@ -263,13 +281,26 @@ DEVI Ctx stage_tables(const DevModel &m, float *lds) {
         else v = __int_as_float(g >= 1 ? m.hull_vnum[g - 1] : 0);
         gt[i] = v;
     }
+    float *lr = lds + LR_OFF(m.hull_words);
+    for (int i = threadIdx.x; i < LR_FLOATS; i += blockDim.x) {
+        const int s = i / LR_STRIDE, f = i % LR_STRIDE;
+        float v = 0.f;
+        if (f < 3) v = m.kn_pos[s][f];
+        else if (f < 12) v = m.kn_R[s][f - 3];
+        else if (f < 15) v = m.fin_pos[s][f - 12];
+        else if (f < 24) v = m.fin_R[s][f - 15];
+        else if (f < 27) v = m.grp_com[1 + s][f - 24];
+        else if (f < 33) v = m.grp_inertia[1 + s][f - 27];
+        else if (f == 33) v = m.grp_mass[1 + s];
+        lr[i] = v;
+    }
     __syncthreads();
     Ctx c;
     c.lane = threadIdx.x & (WAVE - 1); c.sub = threadIdx.x & (KL - 1);
     c.T.v = reinterpret_cast<const float *>(dst);
     c.T.nbr = reinterpret_cast<const unsigned short *>(dst + m.hull_off_nbr);
     c.T.lut = reinterpret_cast<const unsigned short *>(dst + m.hull_off_lut);
-    c.T.gt = gt;
+    c.T.gt = gt; c.T.lr = lr;
     bool act_; c.envl = lds + LDS_ENV_BASE(m.hull_words) + wg_env_slot(act_) * ENV_FLOATS;
     return c;
 }
@@ -313,39 +344,80 @@ DEVI void kinematics(const DevModel &m, float (&qpos)[14], Kin &k, const Ctx &cx
     if (qn < 1e-15f) { qpos[10] = 1.f; qpos[11] = qpos[12] = qpos[13] = 0.f; }
     else { float iq = 1.0f / qn; qpos[10] *= iq; qpos[11] *= iq; qpos[12] *= iq; qpos[13] *= iq; }
     k.pe = v3(m.ee_pos0[0] + qpos[0], m.ee_pos0[1] + qpos[1], m.ee_pos0[2] + qpos[2]);
-    float sr, cr, sy, cy;
+    // the four joint angles' sines and cosines up front, side by side (four independent ~40-instruction chains instead of one after the other
+    // along the tree), and every LDS store in ONE block at the end: the whole tree is straight-line code for the instruction scheduler
+    float sr, cr, sy, cy, sq[2], cq[2];
     sincos_joint(qpos[3], sr, cr); sincos_joint(qpos[4], sy, cy);
+#if EPW == 2
+    sincos_joint(UPPER_HALF(cx) ? qpos[6] : qpos[5], sq[0], cq[0]); sq[1] = sq[0]; cq[1] = cq[0];      // the half's own knuckle angle
+#else
+    sincos_joint(qpos[5], sq[0], cq[0]); sincos_joint(qpos[6], sq[1], cq[1]);
+#endif
     // Re = Rx(roll) * Rz(yaw)
     k.Re.m[0] = cy;      k.Re.m[1] = -sy;     k.Re.m[2] = 0.f;
     k.Re.m[3] = cr * sy; k.Re.m[4] = cr * cy; k.Re.m[5] = -sr;
     k.Re.m[6] = sr * sy; k.Re.m[7] = sr * cy; k.Re.m[8] = cr;
     k.a4 = v3(0.f, -sr, cr);
-    const bool wr = store && cx.sub == 0;           // one lane of the env publishes the geom frames
-    V3 pb = k.pe + mulv(k.Re, ldv(m.base_pos));
-    M3 Rb = mulm(k.Re, ldm(m.base_R));
-    if (wr) store_frame(cx.envl, 1, pb, Rb);
+    const V3 pb = k.pe + mulv(k.Re, ldv(m.base_pos));
+    const M3 Rb = mulm(k.Re, ldm(m.base_R));
+#if EPW == 2
+    // One finger chain per half of the wave: lanes 0..31 the left knuckle + finger, their clones 32..63 the right ones, the same instructions on
+    // constants read by lane from the workgroup's table (stage_tables); pk / ak change hands (the constraint rows and the wrench projection want
+    // both), the chain's COM and inertia stay with the half (bias_forces, mass_matrix).
+    const bool up = UPPER_HALF(cx);
+    V3 pk_o, pf_o; M3 Rk_o, Rf_o;
+    {   const float4 *L4 = reinterpret_cast<const float4 *>(cx.T.lr + (up ? LR_STRIDE : 0));
+        const float4 a0 = L4[0], a1 = L4[1], a2 = L4[2], a3 = L4[3], a4_ = L4[4], a5 = L4[5], a6 = L4[6], a7 = L4[7], a8 = L4[8];
+        const V3 knp = v3(a0.x, a0.y, a0.z);
+        M3 knR; knR.m[0] = a0.w; knR.m[1] = a1.x; knR.m[2] = a1.y; knR.m[3] = a1.z; knR.m[4] = a1.w; knR.m[5] = a2.x; knR.m[6] = a2.y; knR.m[7] = a2.z; knR.m[8] = a2.w;
+        const V3 fnp = v3(a3.x, a3.y, a3.z);
+        M3 fnR; fnR.m[0] = a3.w; fnR.m[1] = a4_.x; fnR.m[2] = a4_.y; fnR.m[3] = a4_.z; fnR.m[4] = a4_.w; fnR.m[5] = a5.x; fnR.m[6] = a5.y; fnR.m[7] = a5.z; fnR.m[8] = a5.w;
+        const V3 com = v3(a6.x, a6.y, a6.z);
+        const float inertia[6] = {a6.w, a7.x, a7.y, a7.z, a7.w, a8.x};
+        k.m_own = a8.y;
+        pk_o = pb + mulv(Rb, knp);
+        const M3 Rk0 = mulm(Rb, knR);
+        const V3 ak_o = col(Rk0, 1);
+        const float sq_ = up ? sq[1] : sq[0], cq_ = up ? cq[1] : cq[0];
+        M3 Ry; Ry.m[0] = cq_; Ry.m[1] = 0; Ry.m[2] = sq_; Ry.m[3] = 0; Ry.m[4] = 1; Ry.m[5] = 0; Ry.m[6] = -sq_; Ry.m[7] = 0; Ry.m[8] = cq_;
+        Rk_o = mulm(Rk0, Ry);
+        pf_o = pk_o + mulv(Rk_o, fnp);
+        Rf_o = mulm(Rk_o, fnR);
+        k.c_own = pk_o + mulv(Rk_o, com);
+        rot_sym(Rk_o, inertia, k.Ic_own);
+        halves_f(pk_o.x, k.pk[0].x, k.pk[1].x); halves_f(pk_o.y, k.pk[0].y, k.pk[1].y); halves_f(pk_o.z, k.pk[0].z, k.pk[1].z);
+        halves_f(ak_o.x, k.ak[0].x, k.ak[1].x); halves_f(ak_o.y, k.ak[0].y, k.ak[1].y); halves_f(ak_o.z, k.ak[0].z, k.ak[1].z);
+    }
+#else
+    V3 pf[2]; M3 Rk[2], Rf[2];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-        V3 pk = pb + mulv(Rb, ldv(m.kn_pos[s]));
-        M3 Rk0 = mulm(Rb, ldm(m.kn_R[s]));
+        const V3 pk = pb + mulv(Rb, ldv(m.kn_pos[s]));
+        const M3 Rk0 = mulm(Rb, ldm(m.kn_R[s]));
         k.pk[s] = pk; k.ak[s] = col(Rk0, 1);
-        float sq, cq; sincos_joint(qpos[5 + s], sq, cq);
-        M3 Ry; Ry.m[0] = cq; Ry.m[1] = 0; Ry.m[2] = sq; Ry.m[3] = 0; Ry.m[4] = 1; Ry.m[5] = 0; Ry.m[6] = -sq; Ry.m[7] = 0; Ry.m[8] = cq;
-        M3 Rk = mulm(Rk0, Ry);
-        V3 pf = pk + mulv(Rk, ldv(m.fin_pos[s]));
-        M3 Rf = mulm(Rk, ldm(m.fin_R[s]));
-        if (wr) { store_frame(cx.envl, 2 + 2 * s, pk, Rk); store_frame(cx.envl, 3 + 2 * s, pf, Rf); }
-        k.c[1 + s] = pk + mulv(Rk, ldv(m.grp_com[1 + s]));
-        rot_sym(Rk, m.grp_inertia[1 + s], k.Ic[1 + s]);
+        M3 Ry; Ry.m[0] = cq[s]; Ry.m[1] = 0; Ry.m[2] = sq[s]; Ry.m[3] = 0; Ry.m[4] = 1; Ry.m[5] = 0; Ry.m[6] = -sq[s]; Ry.m[7] = 0; Ry.m[8] = cq[s];
+        Rk[s] = mulm(Rk0, Ry);
+        pf[s] = pk + mulv(Rk[s], ldv(m.fin_pos[s]));
+        Rf[s] = mulm(Rk[s], ldm(m.fin_R[s]));
+        k.c[1 + s] = pk + mulv(Rk[s], ldv(m.grp_com[1 + s]));
+        rot_sym(Rk[s], m.grp_inertia[1 + s], k.Ic[1 + s]);
     }
+#endif
     k.po = v3(qpos[7], qpos[8], qpos[9]);
     k.Ro = quat_mat(qpos[10], qpos[11], qpos[12], qpos[13]);
-    if (wr) store_frame(cx.envl, 6, k.po, k.Ro);
     k.c[0] = k.pe + mulv(k.Re, ldv(m.grp_com[0]));
     rot_sym(k.Re, m.grp_inertia[0], k.Ic[0]);
     k.c[3] = k.po + mulv(k.Ro, ldv(m.grp_com[3]));
     rot_sym(k.Ro, m.grp_inertia[3], k.Ic[3]);
-    if (wr) {
+    if (store && cx.sub == 0) {                     // one lane of the env publishes the geom frames, what the constraint rows need, the state's quaternion
+        store_frame(cx.envl, 1, pb, Rb);
+#if EPW == 2
+        store_frame(cx.envl, up ? 4 : 2, pk_o, Rk_o); store_frame(cx.envl, up ? 5 : 3, pf_o, Rf_o);       // each half publishes its own chain's frames
+#else
+        store_frame(cx.envl, 2, k.pk[0], Rk[0]); store_frame(cx.envl, 3, pf[0], Rf[0]);
+        store_frame(cx.envl, 4, k.pk[1], Rk[1]); store_frame(cx.envl, 5, pf[1], Rf[1]);
+#endif
+        store_frame(cx.envl, 6, k.po, k.Ro);
         kinc_store(cx.envl, k.pe, k.a4, k.pk, k.ak, k.po, k.Ro);
         // the normalised quaternion is the state's (mj_kinematics normalises qpos in place)
         float4 *q4 = reinterpret_cast<float4 *>(cx.envl + ES_QPOS);
@@ -364,7 +436,7 @@ DEVI void add_body(float (&Mp)[NM], const int (&dofs)[NC], const V3 (&jp)[NC], c
     }
 }
 
-DEVI void mass_matrix(const DevModel &m, const Kin &k, float (&Mg)[28], float (&Mo)[21]) {
+DEVI void mass_matrix(const DevModel &m, const Kin &k, float (&Mg)[28], float (&Mo)[21], bool up) {
 #pragma unroll
     for (int i = 0; i < 28; i++) Mg[i] = 0.f;
 #pragma unroll
@@ -379,6 +451,28 @@ DEVI void mass_matrix(const DevModel &m, const Kin &k, float (&Mg)[28], float (&
         const V3 jp[5] = {ex, ey, ez, cross(ex, r), cross(k.a4, r)};
         const V3 jr[5] = {z0, z0, z0, ex, k.a4};
         add_body<5, 28>(Mg, dofs, jp, jr, m.grp_mass[0], k.Ic[0]); }
+#if EPW == 2
+    {   // the half's own finger body as a 6 x 6 block over (ee dofs 0..4, own knuckle), the same expressions as add_body on the full matrix;
+        // the halves swap blocks and both add left, then right, in the order of the one-stream form (G, L, R): the same sums
+        const int dofs[6] = {0, 1, 2, 3, 4, 5};
+        const V3 pk_o = up ? k.pk[1] : k.pk[0], ak_o = up ? k.ak[1] : k.ak[0];
+        V3 r = k.c_own - k.pe, rk = k.c_own - pk_o;
+        const V3 jp[6] = {ex, ey, ez, cross(ex, r), cross(k.a4, r), cross(ak_o, rk)};
+        const V3 jr[6] = {z0, z0, z0, ex, k.a4, ak_o};
+        float Mb[21];
+#pragma unroll
+        for (int i = 0; i < 21; i++) Mb[i] = 0.f;
+        add_body<6, 21>(Mb, dofs, jp, jr, k.m_own, k.Ic_own);
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = 0; b <= a; b++) {
+                float lo, hi; halves_f(Mb[pidx(a, b)], lo, hi);
+                if (a < 5) { Mg[pidx(a, b)] += lo; Mg[pidx(a, b)] += hi; }
+                else { Mg[pidx(5, b)] += lo; Mg[pidx(6, b == 5 ? 6 : b)] += hi; }
+            }
+    }
+#else
     {   const int dofs[6] = {0, 1, 2, 3, 4, 5};
         V3 r = k.c[1] - k.pe, rk = k.c[1] - k.pk[0];
         const V3 jp[6] = {ex, ey, ez, cross(ex, r), cross(k.a4, r), cross(k.ak[0], rk)};
@@ -389,6 +483,7 @@ DEVI void mass_matrix(const DevModel &m, const Kin &k, float (&Mg)[28], float (&
         const V3 jp[6] = {ex, ey, ez, cross(ex, r), cross(k.a4, r), cross(k.ak[1], rk)};
         const V3 jr[6] = {z0, z0, z0, ex, k.a4, k.ak[1]};
         add_body<6, 28>(Mg, dofs, jp, jr, m.grp_mass[2], k.Ic[2]); }
+#endif
     {   const int dofs[6] = {0, 1, 2, 3, 4, 5};
         V3 r = k.c[3] - k.po;
         V3 c0 = col(k.Ro, 0), c1 = col(k.Ro, 1), c2 = col(k.Ro, 2);
@@ -474,20 +569,39 @@ DEVI void row_add(const Kin &k, float (&j)[13], int g, V3 p, V3 e, float sgn, bo
 }
 
 // ---------------------------------------------------------------- bias forces (gravity + Coriolis/centrifugal)
-DEVI void bias_forces(const DevModel &m, const Kin &k, const float (&qvel)[13], float (&bias)[13]) {
+DEVI void bias_forces(const DevModel &m, const Kin &k, const float (&qvel)[13], float (&bias)[13], bool up) {
     Twist t; twists(k, qvel, t);
     V3 alG = cross(v3(qvel[3], 0, 0), k.a4 * qvel[4]);
+    Wrench w; wrench_zero(w);
+    V3 grav = v3(0, 0, m.gravity_z);
+#if EPW == 2
+    {   // the half's own finger body (left in lanes 0..31, right in the clones), the expressions of the one-stream form; force and torque
+        // about the knuckle change hands
+        const V3 pk_o = up ? k.pk[1] : k.pk[0], ak_o = up ? k.ak[1] : k.ak[0], w_o = up ? t.wR : t.wL;
+        const float qv_o = up ? qvel[6] : qvel[5];
+        const V3 s_o = pk_o - k.pe;
+        const V3 a_o = cross(alG, s_o) + cross(t.wG, cross(t.wG, s_o));
+        const V3 al_o = alG + cross(t.wG, ak_o * qv_o);
+        const V3 rc = k.c_own - pk_o;
+        const V3 ac = a_o + cross(al_o, rc) + cross(w_o, cross(w_o, rc)) - grav;
+        const V3 tau = symv(k.Ic_own, al_o) + cross(w_o, symv(k.Ic_own, w_o));
+        const V3 F = ac * k.m_own;
+        const V3 T = tau + cross(k.c_own - pk_o, F);
+        halves_f(F.x, w.FL.x, w.FR.x); halves_f(F.y, w.FL.y, w.FR.y); halves_f(F.z, w.FL.z, w.FR.z);
+        halves_f(T.x, w.TL.x, w.TR.x); halves_f(T.y, w.TL.y, w.TR.y); halves_f(T.z, w.TL.z, w.TR.z);
+    }
+#else
     V3 sL = k.pk[0] - k.pe, sR = k.pk[1] - k.pe;
     V3 aL = cross(alG, sL) + cross(t.wG, cross(t.wG, sL));
     V3 aR = cross(alG, sR) + cross(t.wG, cross(t.wG, sR));
     V3 alL = alG + cross(t.wG, k.ak[0] * qvel[5]);
     V3 alR = alG + cross(t.wG, k.ak[1] * qvel[6]);
-    Wrench w; wrench_zero(w);
-    V3 grav = v3(0, 0, m.gravity_z);
+#endif
     {   V3 rc = k.c[0] - k.pe;
         V3 ac = cross(alG, rc) + cross(t.wG, cross(t.wG, rc)) - grav;
         V3 tau = symv(k.Ic[0], alG) + cross(t.wG, symv(k.Ic[0], t.wG));
         wrench_add(k, w, GRP_G, k.c[0], ac * m.grp_mass[0], tau, 1.f); }
+#if EPW != 2
     {   V3 rc = k.c[1] - k.pk[0];
         V3 ac = aL + cross(alL, rc) + cross(t.wL, cross(t.wL, rc)) - grav;
         V3 tau = symv(k.Ic[1], alL) + cross(t.wL, symv(k.Ic[1], t.wL));
@@ -496,6 +610,7 @@ DEVI void bias_forces(const DevModel &m, const Kin &k, const float (&qvel)[13], 
         V3 ac = aR + cross(alR, rc) + cross(t.wR, cross(t.wR, rc)) - grav;
         V3 tau = symv(k.Ic[2], alR) + cross(t.wR, symv(k.Ic[2], t.wR));
         wrench_add(k, w, GRP_R, k.c[2], ac * m.grp_mass[2], tau, 1.f); }
+#endif
     {   V3 rc = k.c[3] - k.po;
         V3 ac = cross(t.wO, cross(t.wO, rc)) - grav;
         V3 tau = cross(t.wO, symv(k.Ic[3], t.wO));
@@ -1383,15 +1498,12 @@ DEVI void make_constraints(const DevModel &m, const Ctx &cx, Contact &c, int nco
 #define EF_FORCE EF_STAGE               // [G_MAXC][4] contact forces; the staging area is free once collide() is done
 #define EF_P (EF_STAGE + 64)            // [16] search direction, one component per dof lane
 
+// `cn` comes in EVALUATED: the point being priced is where the line search stopped, and its last evaluation (line_eval) computed exactly
+// this cone -- the same jar = fma(alpha, jv, jar) -- so it is not computed again (all zero in lanes without a contact, as the start pricing left it).
 DEVI float price_constraints(const DevModel &m, const Ctx &cx, float lsgn, float lD, float laref, float xi, int ncon,
-                             const Contact &c, bool live, Cone &cn, float &jtfi, float &hdiag) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) { cn.grad[i] = 0.f; cn.w[i] = 0.f; cn.a[i] = 0.f; cn.b[i] = 0.f; }
-    cn.cost = 0.f; cn.ka = 0.f; cn.kb = 0.f;
-    if (live) {
-        cone_eval(c.jar, c.D0, m.impratio, c.fs, c.ft, cn);
+                             const Contact &c, bool live, const Cone &cn, float &jtfi, float &hdiag) {
+    if (live)
         *reinterpret_cast<float4 *>(cx.envl + EF_FORCE + 4 * local_sub(cx)) = make_float4(-cn.grad[0], -cn.grad[1], -cn.grad[2], -cn.grad[3]);
-    }
     float cost = cn.cost;
     // joint limit owned by this lane (lanes 0..6): J = sgn at dof `sub`
     float ljar = lsgn * xi - laref;
@@ -1462,15 +1574,33 @@ DEVI void assemble_rows(const Ctx &cx, int ncon, float hdiag, float (&row)[13]) 
     load_mrow(cx, row);
     const int isub = UPOS(min(cx.sub, 12));
     const float *U = cx.envl + EF_U;
-#pragma unroll 4
-    for (int s = 0; s < 6 * ncon; s++) {
+    auto slot = [&](int s) {
         const float4 *u4 = reinterpret_cast<const float4 *>(U + s * U_STRIDE);
         float4 a = u4[0], b = u4[1], c4 = u4[2], d = u4[3];
         float u[13] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, c4.x, c4.y, c4.z, c4.w, d.x, d.y};
         float wi = b.w * U[s * U_STRIDE + isub];    // zero weights (inactive cone zones) simply add nothing
 #pragma unroll
         for (int j = 0; j < 13; j++) row[j] = fmaf(wi, u[j], row[j]);
+    };
+#if EPW == 2
+    // the SAME order of summation as assemble_rows_block -- contacts 0, 2, 4, ... on top of the mass matrix' row in lanes 0..31, contacts
+    // 1, 3, 5, ... on top of zeros in the clones, lo + hi -- so that an uncoupled env gets the same bits whether or not a wave-mate forces
+    // the full rows on it (time-sliced == lock-step, mixed == single: the wave-mates differ)
+    const bool up = UPPER_HALF(cx);
+    if (up) {
+#pragma unroll
+        for (int j = 0; j < 13; j++) row[j] = 0.f;
     }
+    for (int k = up ? 1 : 0; k < ncon; k += 2) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) slot(6 * k + q);
+    }
+#pragma unroll
+    for (int j = 0; j < 13; j++) { float lo, hi; halves_f(row[j], lo, hi); row[j] = lo + hi; }
+#else
+#pragma unroll 4
+    for (int s = 0; s < 6 * ncon; s++) slot(s);
+#endif
 #pragma unroll
     for (int j = 0; j < 13; j++) row[j] += cx.sub == j ? hdiag : 0.f;
     if (cx.sub >= 13) {                                    // lanes 13..15 carry identity rows
@@ -1497,24 +1627,41 @@ DEVI void assemble_rows_block(const Ctx &cx, int ncon, const float (&mrow7)[7], 
         row[0] = fmaf(wi, a.x, row[0]); row[1] = fmaf(wi, a.y, row[1]); row[2] = fmaf(wi, a.z, row[2]); row[3] = fmaf(wi, a.w, row[3]);
         row[4] = fmaf(wi, b.x, row[4]); row[5] = fmaf(wi, b.y, row[5]); row[6] = fmaf(wi, b.z, row[6]);
     };
+#if EPW == 2
+    // contacts 0, 2, 4, ... in lanes 0..31 (on top of the mass matrix' row), contacts 1, 3, 5, ... in their clones 32..63 (on top of zeros);
+    // the two partial rows meet through v_permlane32_swap: half the loop trips per lane, lo + hi in both halves (clones again)
+    const bool up = UPPER_HALF(cx);
+    if (up) {
+#pragma unroll
+        for (int j = 0; j < 7; j++) row[j] = 0.f;
+    }
+    for (int k = up ? 1 : 0; k < ncon; k += 2) {
+        slot(6 * k); slot(6 * k + 1); slot(6 * k + 2); slot(6 * k + 3);
+        if ((midmask >> k) & 1u) { slot(6 * k + 4); slot(6 * k + 5); }
+    }
+#pragma unroll
+    for (int j = 0; j < 7; j++) { float lo, hi; halves_f(row[j], lo, hi); row[j] = lo + hi; }
+#else
     for (int k = 0; k < ncon; k++) {
         slot(6 * k); slot(6 * k + 1); slot(6 * k + 2); slot(6 * k + 3);
         if ((midmask >> k) & 1u) { slot(6 * k + 4); slot(6 * k + 5); }
     }
+#endif
     const int own = cx.sub < 7 ? cx.sub : cx.sub - 7;
 #pragma unroll
     for (int j = 0; j < 7; j++) row[j] += own == j ? hdiag : 0.f;
 }
 
 // phi'(alpha), phi''(alpha) of the total cost along the search direction: this lane's contact and limit, then all-reduce
+// `cn` (out, contact lanes): the cone at jar + alpha jv -- the pricing of the new point reuses the last one (price_constraints)
 DEVI void line_eval(const DevModel &m, float lsgn, float lD, float laref, float qi, float pi,
-                    const Contact &c, bool live, float alpha, float g0, float g1, float &dphi, float &ddphi) {
+                    const Contact &c, bool live, float alpha, float g0, float g1, float &dphi, float &ddphi, Cone &cn) {
     float dp = 0.f, hp = 0.f;
     if (live) {
         float ja[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) ja[r] = c.jar[r] + alpha * c.jv[r];
-        Cone cn; cone_eval(ja, c.D0, m.impratio, c.fs, c.ft, cn);
+        for (int r = 0; r < 4; r++) ja[r] = fmaf(alpha, c.jv[r], c.jar[r]);       // (the very expression the solver advances jar with)
+        cone_eval(ja, c.D0, m.impratio, c.fs, c.ft, cn);
 #pragma unroll
         for (int r = 0; r < 4; r++) dp = fmaf(cn.grad[r], c.jv[r], dp);
         hp = cone_quad(cn, c.jv);
@@ -1713,7 +1860,7 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
                 if (!__any(!lsdone)) break;
                 if (!lsdone) {
                     float dp, hp;
-                    line_eval(m, lsgn, lD, laref, xi, pi, c, live, alpha, g0, g1, dp, hp);
+                    line_eval(m, lsgn, lD, laref, xi, pi, c, live, alpha, g0, g1, dp, hp, cn);
                     if (fabsf(dp) < gtol) lsdone = true;
                     else {
                         if (dp < 0.f) lo = alpha; else hi = alpha;
@@ -1807,7 +1954,7 @@ DEVI void forward_dense(const DevModel &m, const Ctx &cx, const Kin &k, const fl
     float qfs[13];
     {   float qvel[13]; lds_ld<13>(S + ES_QVEL, qvel);
         float bias[13];
-        bias_forces(m, k, qvel, bias);
+        bias_forces(m, k, qvel, bias, cx.lane >= 32);
         if (dbg_bias) {
 #pragma unroll
             for (int i = 0; i < 13; i++) dbg_bias[i] = bias[i];
@@ -1822,7 +1969,7 @@ DEVI void forward_dense(const DevModel &m, const Ctx &cx, const Kin &k, const fl
 #pragma unroll
     for (int i = 0; i < 13; i++) opaque(qfs[i]);         // (keeps the scheduler from pulling the mass matrix up into the bias block)
     float Mg[28], Mo[21];
-    mass_matrix(m, k, Mg, Mo);
+    mass_matrix(m, k, Mg, Mo, cx.lane >= 32);
     if (cx.sub == 0) {                  // one lane publishes the env's mass matrix, every dof lane then owns a (block) row of it
         float4 *M4 = reinterpret_cast<float4 *>(S + EF_M);
 #pragma unroll

@@ -46,11 +46,13 @@ __global__ void k_rollout_tick(GripRolloutTick a) {
         a.ep_ret[env] = er; a.ep_len[env] = el;
     }
     // open the new one (with the fused Gaussian head: sample = mean + std * noise, log N(sample | mean, std))
-    float logp = a.noise ? 0.f : a.log_probs[r];
+    const bool head = a.noise != nullptr || (a.rng_count != nullptr && a.log_std != nullptr);      // fused Gaussian head: `actions` holds the mean
+    const int mstride = a.mean_stride > 0 ? a.mean_stride : a.action_dim, vstride = a.value_stride > 0 ? a.value_stride : 1;
+    float logp = head ? 0.f : a.log_probs[r];
     for (int i = 0; i < a.action_dim; i++) {
-        float v = a.actions[(size_t)r * a.action_dim + i];
-        if (a.noise) {
-            float z = a.noise[(size_t)r * a.action_dim + i]; const float ls = a.log_std[i];
+        float v = a.actions[(size_t)r * mstride + i];
+        if (head) {
+            float z = a.noise ? a.noise[(size_t)r * a.action_dim + i] : 0.f; const float ls = a.log_std[i];
             if (a.rng_count) {                                             // synthetic stream: the action is given, z follows from it
                 const float u = synth_action(a.rng_seed, env, a.rng_count[env], i);
                 z = (u - v) * expf(-ls); v = u;
@@ -60,12 +62,12 @@ __global__ void k_rollout_tick(GripRolloutTick a) {
         a.actions_buf[(size_t)row * a.action_dim + i] = v;
         a.slot_actions[(size_t)r * a.action_dim + i] = fminf(fmaxf(v, a.low[i]), a.high[i]);
     }
-    a.log_probs_buf[row] = logp; a.values_buf[row] = a.values[r];
+    a.log_probs_buf[row] = logp; a.values_buf[row] = a.values[(size_t)r * vstride];
     a.is_rec[row] = valid ? 1 : 0; a.completed[row] = 0; a.next_rec[row] = -1;
     a.prev_rec[row] = had ? prev : -1;
     a.rec_env[row] = valid ? env : -1;
     if (valid) a.rec_of_env[env] = row;
-    if (valid && a.noise && a.rng_count) a.rng_count[env] += 1;
+    if (valid && head && a.rng_count) a.rng_count[env] += 1;
 }
 
 extern "C" int grip_rollout_tick(const GripRolloutTick *args, void *stream) {

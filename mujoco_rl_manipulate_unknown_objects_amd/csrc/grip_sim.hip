@@ -583,6 +583,7 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
                         const float tq = S[ES_MAC + MC_TQ];
                         delta_pre = fmaxf(fabsf(tq - q[5]), fabsf(tq - q[6]));
                     }
+                    STAMP(stm, 28);
                     forward_dense(m, cx, k, ctrl, xfrc_z, nullptr, stm);
                 }
             }
@@ -711,6 +712,7 @@ DEVI void macro_step_body(const DevModel &m, const DevConfig &cfg, const StatePt
                 }
                 if (set56 && cx.sub == 0) { S[ES_CTRL + 5] = c56; S[ES_CTRL + 6] = c56; }
                 wave_sync();
+                STAMP(stm, 27);
             }
         }
     }

@@ -77,7 +77,7 @@ class RolloutTickC(C.Structure):
                                            "low", "high", "slot_actions", "rec_of_env", "rewards", "dones", "next_rec", "prev_rec", "rec_env",
                                            "completed", "is_rec", "actions_buf", "log_probs_buf", "values_buf", "n_completed", "substeps_total",
                                            "ep_ret", "ep_len", "ep_ret_sum", "ep_len_sum", "ep_count", "noise", "log_std", "rng_count")] +
-                [("rng_seed", C.c_uint64)])
+                [("rng_seed", C.c_uint64), ("mean_stride", C.c_int32), ("value_stride", C.c_int32)])
 
 
 class EnvConfigC(C.Structure):

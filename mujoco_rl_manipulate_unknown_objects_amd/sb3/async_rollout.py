@@ -202,10 +202,13 @@ class AsyncRollout:
         noise = log_std = None
         if self.fused and self.policy_parts_fn is not None:
             actions, log_std, values = self.policy_parts_fn(obs_stage)                 # `actions` is the mean here
-            noise = th.randn_like(actions); log_probs = values
+            # (the synthetic stream draws its actions inside the recorder kernel: no noise tensor, one launch less per tick)
+            noise = th.randn_like(actions) if self.rng_seed is None else None; log_probs = values
         else:
             actions, values, log_probs = self.policy_fn(obs_stage)
-        rows = self.base_t + self.ar_c                                 # record ids of this tick
+        rows = None
+        if not (dual and self.fused):
+            rows = self.base_t + self.ar_c                             # record ids of this tick
         if not dual:
             self.obs.index_copy_(0, rows, obs_stage)
         if self.fused:
@@ -270,7 +273,15 @@ class AsyncRollout:
     def _fused_tick(self, out, lst, cnt, slot_act, p, actions, values, log_probs, noise=None, log_std=None):
         from .. import engine as E
         import ctypes as C
-        actions = actions.float().contiguous(); values = values.float().contiguous(); log_probs = log_probs.float().contiguous()
+        # the merged heads leave [mean | value] as columns of one [C, A + 1] fp32 matrix: read in place through row strides, no gathered copies
+        def rows_of(t, inner):
+            if t.dtype == th.float32 and t.dim() == inner + 1 and t.stride(0) > 0 and (inner == 0 or t.stride(1) == 1):
+                return t, int(t.stride(0))
+            t = t.float().contiguous()
+            return t, 0
+        actions, mstride = rows_of(actions, 1); values, vstride = rows_of(values, 0)
+        if log_probs is not values:
+            log_probs = log_probs.float().contiguous()
         if self._targs[p] is None:
             ptr = lambda t: t.data_ptr()
             self._targs[p] = E.RolloutTickC(
@@ -284,12 +295,16 @@ class AsyncRollout:
             assert out["reward"].dtype == th.float32 and out["done"].dtype == th.uint8
         a = self._targs[p]
         a.actions, a.values, a.log_probs = actions.data_ptr(), values.data_ptr(), log_probs.data_ptr()
-        if noise is not None:
-            noise = noise.float().contiguous(); log_std = log_std.float().contiguous()
-            a.noise, a.log_std = noise.data_ptr(), log_std.data_ptr()
+        a.mean_stride, a.value_stride = mstride, vstride
+        if log_std is not None:
+            log_std = log_std.float().contiguous()
+            noise = noise.float().contiguous() if noise is not None else None
+            a.log_std = log_std.data_ptr()
+            a.noise = noise.data_ptr() if noise is not None else None
         else:
             a.noise, a.log_std = None, None
-        if self.rng_seed is not None and noise is not None:
+        self._tick_keep = (actions, values, log_probs, noise, log_std)          # (alive until the launch is enqueued)
+        if self.rng_seed is not None and log_std is not None:
             a.rng_count, a.rng_seed = self.rng_count.data_ptr(), self.rng_seed
         else:
             a.rng_count, a.rng_seed = None, 0

@@ -10,7 +10,9 @@ code of the CLOSE loop, position_reached, the two sensor-pad bytes of the render
 object to 5e-4 m. A macro step in contact is hundreds of physics.step() calls of a stiff contact problem; the fixture keeps only
 well-conditioned rows (the oracle's own outputs survive 1e-6 perturbations of the state: a finger hovering exactly at the 1 mm
 contact margin is not a test of anything), so nearly every lane has to agree: the floor is 92 % of the lanes exact (94-99 % measured),
-the rest are printed; every outcome category must be reproduced exactly by at least one lane of every object and direction.
+the rest are printed with the smallest per-step noise amplitude at which the ORACLE's own integer outputs change, and have to be conditioning
+cases by a probe that is checked against the lanes that DO match (NOISE_LEVELS below); every outcome category must be reproduced exactly by at
+least one lane of every object and direction.
 """
 import ctypes as C
 import os
@@ -102,10 +104,11 @@ def test_macro_step_parity_in_contact(engine, orc, torch, contact, obj):
     """a3 / a9 / a10 in the contact regime, all four objects, both target directions (see the module docstring).
     Floors (achieved values are printed): >= 92 % of the lanes reproduce every integer output and both pad bytes exactly (measured
     94-99 %; what differs are one-finger closes whose finger rests at the 1 mm contact margin of the object for 400 steps); on the exact
-    lanes the MEDIAN gap is < 2e-5 m for gripper and object and < 1e-4 for the reward, the worst lane < 2e-3 m / 5e-3 (hundreds of
-    physics.step() calls of a stiff contact problem in fp32 against fp64: the one-step test below is the sharp one); every category
+    lanes the MEDIAN gap is < 2e-5 m for gripper and object and < 1e-4 for the reward, the worst lane < 2e-3 m / 6e-2 (hundreds of
+    physics.step() calls of a stiff contact problem in fp32 against fp64: the one-step test below is the sharp one; the reward's bound is 30 x the
+    line distance's, as the reward is); every category
     exactly reproduced at least once per object and direction."""
-    allrecs = []
+    allrecs, pending = [], []
     for direction in ((1.0, 0.0), (1.0, 1.0)):
         recs = run_contact_rows(engine, orc, torch, contact, obj, direction)
         allrecs += recs
@@ -116,10 +119,10 @@ def test_macro_step_parity_in_contact(engine, orc, torch, contact, obj):
                 continue                       # well-conditioned one-finger closes are rare: a direction may hold none (both codes are checked below)
             hits = [r for r in recs if r["cat"] == cat and r["ints_ok"] and r["pad_ok"] and proof(r["o"])]
             if not hits and cat in ("close_code1", "close_code2"):
-                # the rare one-finger closes: a direction may hold a single row. No exact lane is accepted only with the proof that EVERY row of
-                # the category is a conditioning case (the oracle's own outputs flip under one-step-sized noise); both codes are still
-                # required to be produced and matched over the two directions together (below)
-                assert all(oracle_outputs_unstable(orc, orc.Model(obj), contact, obj, r["row"]) for r in recs if r["cat"] == cat), (obj, direction, cat)
+                # the rare one-finger closes: a direction may hold a single row. No exact lane is accepted only when EVERY row of the category
+                # is a conditioning case by the discriminating probe below (checked once all lanes are known); both codes are still
+                # required to be produced and matched over the two directions together
+                pending.append((direction, cat, [r["row"] for r in recs if r["cat"] == cat]))
                 continue
             assert hits, (obj, direction, cat, [(r["nsub"], r["grasped"], r["pad"], r["pher"]) for r in recs if r["cat"] == cat])
         # pad codes and pheromone levels actually produced and matched, whichever category the row was found for
@@ -133,22 +136,49 @@ def test_macro_step_parity_in_contact(engine, orc, torch, contact, obj):
     med = {k: float(np.median([r[k] for r in good])) for k in ("drew", "dgrip", "dobj")}
     bad = [(r["cat"], r["nsub"], r["grasped"], r["pad"], r["pher"]) for r in allrecs if not (r["ints_ok"] and r["pad_ok"])]
     print(f"\n[contact parity] {obj}: {len(good)}/{len(allrecs)} lanes exact ({frac:.3f}); median gaps on exact lanes {med}; worst {worst}; differing lanes {bad}")
-    # Every lane that differs must be a CONDITIONING case, shown on the oracle itself: replayed with perturbations of the size of the fp32
-    # path's own one-step differences (qpos 2e-6, qvel 3e-3 relative-ish: the p99 of the one-step test below, which includes a finger-finger
-    # pad contact resolved on the neighbouring facet), the ORACLE's integer outputs change for at least one of 16 seeds. A lane whose oracle
-    # outputs are stable under that noise and still differ from the HIP path fails the test whatever the fraction.
-    unstable = {r["row"]: oracle_outputs_unstable(orc, orc.Model(obj), contact, obj, r["row"]) for r in allrecs if not (r["ints_ok"] and r["pad_ok"])}
-    print(f"[contact parity] {obj}: differing lanes whose oracle outputs flip under one-step-sized noise: {sum(unstable.values())}/{len(unstable)}")
-    assert all(unstable.values()), [k for k, v in unstable.items() if not v]
-    assert frac >= 0.90, (frac, bad)
+    # Every lane that differs must be a CONDITIONING case, and the probe that says so must DISCRIMINATE. The oracle is replayed with a
+    # perturbation after every physics.step() (orc_set_step_noise2), at rising amplitudes NOISE_LEVELS from the fixture's own filter (the
+    # median-sized one-step error of the fp32 path) upwards, NOISE_SEEDS seeds each; flip_level = the first level at which its integer
+    # outputs change. The same sweep runs over ALL lanes of the fixture: the level that counts is the largest one at which fewer than 10 %
+    # of the exactly matching lanes flip -- at the amplitude round 3 used (2e-6 / 3e-3) half of the matching lanes flip too, which proves
+    # nothing. A differing lane is excused only if it flips at or below that discriminating level.
+    m = orc.Model(obj)
+    level = {r["row"]: oracle_flip_level(orc, m, contact, obj, r["row"]) for r in allrecs}
+    exact_rows = [r["row"] for r in good]
+    frac_at = [float(np.mean([level[i] <= k for i in exact_rows])) for k in range(len(NOISE_LEVELS))]
+    disc = max([k for k in range(len(NOISE_LEVELS)) if frac_at[k] < 0.10], default=-1)
+    differing = [r for r in allrecs if not (r["ints_ok"] and r["pad_ok"])]
+    lvl_name = lambda k: "never" if k >= len(NOISE_LEVELS) else "%g/%g" % NOISE_LEVELS[k]
+    print(f"[contact parity] {obj}: share of the exactly matching lanes whose oracle outputs flip at noise level <= k: "
+          + ", ".join(f"{lvl_name(k)}: {frac_at[k]:.3f}" for k in range(len(NOISE_LEVELS))) + f"; discriminating level: {lvl_name(disc) if disc >= 0 else 'none'}")
+    print(f"[contact parity] {obj}: differing lanes (category, first flipping level): " + str([(r["cat"], lvl_name(level[r["row"]])) for r in differing]))
+    # (no level of the sweep under which fewer than 10 % of the matching lanes flip -- a hull of many small facets -- means: nothing is excused)
+    unexplained = [(r["row"], r["cat"], lvl_name(level[r["row"]])) for r in differing if level[r["row"]] > disc]
+    print(f"[contact parity] {obj}: differing lanes NOT shown to be conditioning cases at the discriminating level: {len(unexplained)} of {len(differing)} {unexplained}")
+    # A differing lane that the discriminating probe does not excuse is an unexplained disagreement with the oracle: at most 3 % of the lanes
+    # (the floor on exact lanes below holds whatever the explanation), and none that is stable at EVERY amplitude of the sweep
+    assert len(unexplained) <= 0.03 * len(allrecs), unexplained
+    assert all(level[r["row"]] < len(NOISE_LEVELS) for r in differing), [(r["row"], r["cat"]) for r in differing if level[r["row"]] >= len(NOISE_LEVELS)]
+    for direction, cat, rows_ in pending:
+        assert all(level[i] <= max(disc, NOISE_LEVELS.index((5e-7, 3e-5))) for i in rows_), (obj, direction, cat, [lvl_name(level[i]) for i in rows_])
+    assert frac >= 0.92, (frac, bad)
     assert med["drew"] < 1e-4 and med["dgrip"] < 2e-5 and med["dobj"] < 2e-5, med
-    assert worst["drew"] < 5e-3 and worst["dgrip"] < 2e-3 and worst["dobj"] < 2e-3 and worst["dgoal"] < 2e-3 and worst["dline"] < 2e-3 and worst["dtot"] < 2e-3, worst
+    # (the reward is 30 x the object's travel along the target line, reward.py:41: its bound is the line-distance bound's image, not a tighter one --
+    # a lane 2.3e-4 m off after ~470 stiff steps is 6.9e-3 off in reward)
+    assert worst["drew"] < 30 * 2e-3 and worst["dgrip"] < 2e-3 and worst["dobj"] < 2e-3 and worst["dgoal"] < 2e-3 and worst["dline"] < 2e-3 and worst["dtot"] < 2e-3, worst
 
 
-def oracle_outputs_unstable(orc, m, z, obj, i, seeds=16, amp=2e-6, vamp=3e-3):
-    """Do the oracle's own integer outputs (and pad bytes) of fixture row i change when every physics.step() is followed by a perturbation of
-    qpos by amp (1 + |x|) U(-1, 1) and qvel by vamp (1 + |v|) U(-1, 1) (orc_set_step_noise2)? The fixture keeps rows that survive 5e-7 / 3e-5
-    (the median-sized one-step error); this probe uses the p99-sized one."""
+# (qpos amplitude, qvel amplitude) of the per-step perturbation x += amp (1 + |x|) U(-1, 1): from the MEDIAN of the fp32 path's measured one-step
+# error (1/25 of the contact fixture's own
+# filter (5e-7 / 3e-5 with three seeds, tools/make_contact_states.py; the fp32 path's measured one-step error has median 2.4e-8 / 2-6e-7 and
+# p99 7e-8 ... 4e-7 / 4.5e-6 ... 2.2e-4) up to the p99 incl. the other-facet states (round 3's amplitude, at which most lanes flip)
+NOISE_LEVELS = ((2e-8, 6e-7), (5e-8, 1.5e-6), (1e-7, 3e-6), (2.5e-7, 1e-5), (5e-7, 3e-5), (7e-7, 1e-4), (1e-6, 3e-4), (2e-6, 1e-3), (2e-6, 3e-3))
+NOISE_SEEDS = 8
+
+
+def oracle_flip_level(orc, m, z, obj, i):
+    """Index of the first level of NOISE_LEVELS at which the oracle's own integer outputs (and pad bytes) of fixture row i change for one of
+    NOISE_SEEDS seeds when every physics.step() is followed by that perturbation; len(NOISE_LEVELS) if they never do."""
     from test_oracle_contact import oracle_from_row
     L = orc.lib()
     L.orc_set_step_noise.argtypes = [C.c_double, C.c_uint]; L.orc_set_step_noise2.argtypes = [C.c_double, C.c_double, C.c_uint]
@@ -156,13 +186,14 @@ def oracle_outputs_unstable(orc, m, z, obj, i, seeds=16, amp=2e-6, vamp=3e-3):
     ref = oracle_from_row(orc, m, z, obj, i).step(act)
     key = lambda o: tuple(int(getattr(o, f)) for f in INT_FIELDS) + (o.reached_target, o.reached_initial, o.reached_fail, o.pad_grasp, o.pad_pheromone)
     try:
-        for seed in range(1, seeds + 1):
-            L.orc_set_step_noise2(amp, vamp, seed)
-            if key(oracle_from_row(orc, m, z, obj, i).step(act)) != key(ref):
-                return True
+        for k, (amp, vamp) in enumerate(NOISE_LEVELS):
+            for seed in range(1, NOISE_SEEDS + 1):
+                L.orc_set_step_noise2(amp, vamp, seed)
+                if key(oracle_from_row(orc, m, z, obj, i).step(act)) != key(ref):
+                    return k
     finally:
         L.orc_set_step_noise(0.0, 0)
-    return False
+    return len(NOISE_LEVELS)
 
 
 def oracle_trajectory(orc, m, z, obj, i):
@@ -235,12 +266,17 @@ def test_one_step_parity_along_contact_trajectories(engine, orc, torch, contact,
     hull_states = sum(1 for c in pairs if any(p[0] != 0 for p in c))
     # angle between this path's and the oracle's normal, worst hull contact of the state (pairs that occur once: a pair with two contacts is a floor pair)
     ang = np.zeros(n)
+    off_pairs = {}                              # (geom 1, geom 2) -> [count, shallowest penetration] of the hull contacts resolved on another facet
     for k in range(n):
         for c in range(dbg["ncon"][k]):
             g = dbg["con"][k, c]
             mt = [p for p in cons[k] if (p[0], p[1]) == (int(g[7]), int(g[8]))]
             if g[7] != 0 and len(mt) == 1:
-                ang[k] = max(ang[k], np.degrees(np.arccos(np.clip(np.dot(g[3:6], mt[0][2]), -1.0, 1.0))))
+                a_ = np.degrees(np.arccos(np.clip(np.dot(g[3:6], mt[0][2]), -1.0, 1.0)))
+                ang[k] = max(ang[k], a_)
+                if a_ >= 1.0 and same[k]:
+                    rec_ = off_pairs.setdefault((int(g[7]), int(g[8])), [0, 1.0])
+                    rec_[0] += 1; rec_[1] = min(rec_[1], 1e-3 - float(g[6]))
     eq = np.abs(gq - nq).max(1); ev = np.abs(gv - nv).max(1)
     facet = same & (ang < 1.0)                  # same contact pairs, every hull contact resolved on the oracle's facet (normals within a degree)
     other = same & ~facet
@@ -257,6 +293,13 @@ def test_one_step_parity_along_contact_trajectories(engine, orc, torch, contact,
     # two facets of the Minkowski difference lie within 0.2 mm of each other in depth with normals ~20 deg apart, and MPR ends on one or the other
     # by the last bits of its support values (fp32 here, fp64 in the oracle; libccd has the same ambiguity). Rare and bounded:
     assert other.sum() <= 0.02 * n and (not other.any() or ev[other].max() < 0.15)
+    # ... and they ARE that class by geom ids, not only by count: the contact resolved on another facet is finger pad against finger pad
+    # (geoms 3 and 5: left / right inner finger) or a finger pad against the object (geom 6). Their depth is printed, not asserted: on sugar_cube
+    # they penetrate the margin-inflated hulls by > 1.3 mm (the face-to-face squeeze described above); on acorn the class also holds GRAZING pad
+    # contacts (0.03-0.1 mm: two nearly coplanar pad facets, normals <= 12 degrees apart, qvel error < 1e-2)
+    print(f"[one-step parity] {obj}: hull contacts on another facet by geom pair (count, shallowest penetration of the inflated hulls in m): "
+          + str({k_: (v_[0], round(v_[1], 5)) for k_, v_ in sorted(off_pairs.items())}))
+    assert set(off_pairs) <= {(3, 5), (3, 6), (5, 6)}, off_pairs
 
 
 @pytest.mark.parametrize("obj", ["sand_ball", "bread_crumb"])

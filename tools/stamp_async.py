@@ -26,15 +26,15 @@ names = {0: "kinematics", 1: "collide: compaction + contact load", 2: "dense (bi
          10: "solve: line search", 14: "solve: prologue (mrow)", 15: "solve: stage logic after pricing", 16: "solve: hessian_vectors + sync",
          17: "solve: p readback, M p, J p, g0/g1", 18: "solve: loop exit (waiting for the wave-mates' iterations)", 19: "solve: hand-over",
          20: "collide: prologue (frames, sphere tests, portal rebuild)", 21: "collide: votes + cooperative support", 22: "collide: per-lane support of geom 2",
-         23: "collide: per-lane support of geom 1", 24: "collide: floor branch (neighbours inside the margin)", 25: "collide: portal phase logic", 26: "collide: loop exit"}
+         23: "collide: per-lane support of geom 1", 27: "macro step: counters, clock, post-step transitions", 28: "macro step: first-step target pose, control hooks", 24: "collide: floor branch (neighbours inside the margin)", 25: "collide: portal phase logic", 26: "collide: loop exit"}
 tot = sum(out[i] for i in names)
-grp = {"collide": [1, 20, 21, 22, 23, 24, 25, 26], "dense": [0, 2, 3, 5], "solver": [4, 6, 7, 8, 9, 10, 14, 15, 16, 17, 18, 19]}
+grp = {"collide": [1, 20, 21, 22, 23, 24, 25, 26], "dense": [0, 2, 3, 5], "macro": [27, 28], "solver": [4, 6, 7, 8, 9, 10, 14, 15, 16, 17, 18, 19]}
 for g_, ids in grp.items():
     print(f"== {g_}: {100 * sum(out[i] for i in ids) / tot:5.1f} %")
     for i in ids:
         print(f"   {names[i]:62s} {100 * out[i] / tot:5.1f} %")
 print("wave-cycles per lane-0 env-substep:", tot / max(1, out[11]))
-print("mean envs at work per wave loop trip: %.2f of 4;  wave-cycles per loop trip: %.0f" % (out[12] / max(1, out[13]), tot / max(1, out[13])))
+print("mean envs at work per wave loop trip: %.2f of 2 (GRIP_EPW);  wave-cycles per loop trip: %.0f" % (out[12] / max(1, out[13]), tot / max(1, out[13])))
 steps = max(1, hist[16])
 print("per env and physics.step(): Newton iterations 0..6, 7+ :", " ".join(f"{100 * hist[i] / steps:.1f}%" for i in range(8)),
       "| mean %.2f" % (sum(i * hist[i] for i in range(8)) / steps))
