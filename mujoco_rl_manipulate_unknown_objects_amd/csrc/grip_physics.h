@@ -1386,11 +1386,14 @@ DEVI void make_constraints(const DevModel &m, const Ctx &cx, Contact &c, int nco
         float lo = qj - r0, hi = r1 - qj;
         float sgn = 0.f, dist = 0.f;
         if (lo < 0.f) { sgn = 1.f; dist = lo; } else if (hi < 0.f) { sgn = -1.f; dist = hi; }
-        float imp = impedance(m.lim_solimp, dist, 0.f);
-        float R = fmaxf(1e-15f, (1.f - imp) * iw / imp);
         const bool own = sub < 7;
-        lc.lsgn = own ? sgn : 0.f; lc.lD = own ? 1.0f / R : 0.f;
-        lc.laref = own ? -m.b_lim * (sgn * vj) - m.k_lim * imp * dist : 0.f;
+        lc.lsgn = own ? sgn : 0.f; lc.lD = 0.f; lc.laref = 0.f;
+        if (__any(own && sgn != 0.f)) {                     // a joint at its limit is rare (0.1 % of the steps): impedance, regularisation and aref only then
+            float imp = impedance(m.lim_solimp, dist, 0.f);     // (lD and laref are read only where lsgn != 0)
+            float R = fmaxf(1e-15f, (1.f - imp) * iw / imp);
+            lc.lD = own ? 1.0f / R : 0.f;
+            lc.laref = own ? -m.b_lim * (sgn * vj) - m.k_lim * imp * dist : 0.f;
+        }
     }
     const bool anylim = group_bits(__ballot(lc.lsgn != 0.f), cx.lane) != 0u;
     lc.constrained = ncon > 0 || anylim;
@@ -1410,8 +1413,15 @@ DEVI void make_constraints(const DevModel &m, const Ctx &cx, Contact &c, int nco
     {   float warm[13]; lds_ld<13>(S + ES_WARM, warm);
 #pragma unroll
         for (int i = 0; i < 13; i++) dw[i] = ((i < 7 && !lc.grip) ? qs[i] : warm[i]) - qs[i];
-        float mrow[13]; load_mrow(cx, mrow);
-        lc.Md_w = row_dot(mrow, dw);
+        // (M dw)_i from the lane's block row: the seven products of its own block, in the order the 13-wide dot product takes them
+        const float4 *M4 = reinterpret_cast<const float4 *>(S + EF_M + min(sub, 12) * M_STRIDE);
+        const float4 a = M4[0], b = M4[1];
+        const bool g = sub < 7;
+        float sacc = 0.f;
+        sacc = fmaf(a.x, g ? dw[0] : dw[7], sacc); sacc = fmaf(a.y, g ? dw[1] : dw[8], sacc); sacc = fmaf(a.z, g ? dw[2] : dw[9], sacc);
+        sacc = fmaf(a.w, g ? dw[3] : dw[10], sacc); sacc = fmaf(b.x, g ? dw[4] : dw[11], sacc); sacc = fmaf(b.y, g ? dw[5] : dw[12], sacc);
+        sacc = fmaf(b.z, g ? dw[6] : 0.f, sacc);
+        lc.Md_w = sub < 13 ? sacc : 0.f;
     }
     if (live) {
         float qvel[13]; lds_ld<13>(S + ES_QVEL, qvel);
