@@ -381,7 +381,7 @@ def main():
                          "algorithmic_bytes_per_launch": macro_bytes, "overhead_bytes_per_launch": overhead_bytes,
                          "bytes_definition": "SURVEY.md 8(d): physics state in + out (348 B f32 per env and launch) + action / outputs of the macro steps that end in the launch; "
                                              "overhead = suspended macro-step context + narrow-phase pair memory of the time-sliced schedule (not counted in achieved)",
-                         "note": "the macro-step kernel is latency / VALU-issue-bound, not HBM-bound (DESIGN.md §4)"},
+                         "note": "the macro-step kernel is VALU-issue-bound (the SIMD's vector ALU is busy ~93 % of the time with two waves on it), not HBM-bound (DESIGN.md §4)"},
         }
         if ar is not None:
             out["ticks"] = ar.total_ticks - ticks0
@@ -411,6 +411,10 @@ def main():
                                   # searches of a pair's two hulls, the cooperative vertex scan, two of a contact's four constraint rows) and
                                   # repeat the lower half's arithmetic everywhere else
                                   "enabled_lane_frac": 1.0, "distinct_lane_frac_outside_shared_phases": 0.5,
+                                  # what really bounds the kernel: VALU instruction ISSUE. SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES is per wave; the two waves
+                                  # of a SIMD share its one vector ALU, so the ALU is busy 2 x that fraction of the time ("Round 4")
+                                  "simd_valu_busy_frac": min(1.0, 2.0 * pm["active_inst_valu_frac"]), "waves_per_simd": 2,
+                                  "valu_instructions_per_env_substep": (pm.get("physics_only_probe") or {}).get("valu_wave_instructions_per_env_substep"),
                                   "source": f"profiles/{pmc_file} (SQ_INSTS_VALU per launch of the same command) / live launch duration"}
             except Exception:
                 pass

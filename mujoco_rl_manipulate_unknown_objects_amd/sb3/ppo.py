@@ -320,9 +320,15 @@ class PPO:
     def _apply(self):
         if self.fused_clip_adam and self.device.type == "cuda":
             ca = getattr(self, "_clip_adam", None)
-            if ca is None or ca.opt is not self.optimizer or ca.max_norm != float(self.max_grad_norm):
+            g0 = self.optimizer.param_groups[0] if self.optimizer.param_groups else {}
+            hyper = (g0.get("lr"), tuple(g0.get("betas", ())), g0.get("eps"))
+            if ca is None or ca.opt is not self.optimizer or ca.max_norm != float(self.max_grad_norm) or getattr(self, "_clip_adam_hyper", hyper) != hyper:
                 from ..engine import ClipAdam
+                # a captured update graph has the old object's scratch address and the optimiser's hyper-parameters baked into its launches: capture again
+                if ca is not None and getattr(self, "_upd", None) is not None:
+                    self._upd = None
                 ca = self._clip_adam = ClipAdam(self.optimizer, self.max_grad_norm)
+            self._clip_adam_hyper = hyper
             if all(p.grad is not None for p in self.policy.parameters()) and ca.step():
                 return
         th.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)

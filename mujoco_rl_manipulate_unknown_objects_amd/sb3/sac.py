@@ -237,6 +237,11 @@ class FlatHerReplayBuffer(FlatReplayBuffer):
         self.cur_slot = th.arange(self.n_envs + 1, dtype=th.int64, device=device) % self.n_slots   # env n_envs: dump
         self.cur_step = th.zeros(self.n_envs + 1, dtype=th.int64, device=device)
         self.alloc = th.full((1,), self.n_envs % self.n_slots, dtype=th.int64, device=device)      # next slot to hand out
+        # Who writes a slot: slots are handed out round-robin, and an episode that outlasts n_slots - n_envs completions of the other envs finds its slot
+        # given to a newcomer. The displaced episode then writes to the dump slot for the rest of its life (its earlier rows are already dead: the
+        # newcomer bumped the slot's generation), so two envs never mix their goals in one trajectory.
+        self.slot_owner = th.full((self.n_slots + 1,), self.n_envs, dtype=th.int64, device=device)
+        self.slot_owner[:min(self.n_envs, self.n_slots)] = th.arange(min(self.n_envs, self.n_slots), device=device)
 
     def add_rows(self, mask, obs, next_obs, action, reward, done, env=None, goals=None):
         """env: env id of every ready-list row (n_envs for masked-out rows); goals = (achieved, desired, next_achieved, next_desired), [rows, 2] each."""
@@ -248,7 +253,7 @@ class FlatHerReplayBuffer(FlatReplayBuffer):
         ag, dg, nag, ndg = goals
         self.achieved.index_copy_(0, pos, ag); self.desired.index_copy_(0, pos, dg); self.next_achieved.index_copy_(0, pos, nag); self.next_desired.index_copy_(0, pos, ndg)
         slot, step = self.cur_slot[e], self.cur_step[e].clamp(max=self.L - 1)
-        slot = th.where(mask, slot, th.full_like(slot, self.n_slots))
+        slot = th.where(mask & (self.slot_owner[slot] == e), slot, th.full_like(slot, self.n_slots))       # masked-out rows and displaced episodes: the dump slot
         self.row_slot.index_copy_(0, pos, slot); self.row_step.index_copy_(0, pos, step); self.row_gen.index_copy_(0, pos, self.slot_gen[slot])
         self.traj_goal[slot, step] = nag                      # the goal achieved AFTER this step: what 'future' hands to earlier steps
         fin = mask & (done > 0)
@@ -259,6 +264,7 @@ class FlatHerReplayBuffer(FlatReplayBuffer):
         new = (self.alloc + th.cumsum(f, 0) - 1) % self.n_slots
         new = th.where(fin, new, th.full_like(new, self.n_slots))
         self.slot_gen.index_add_(0, new, f); self.traj_len.index_fill_(0, new, 0); self.slot_gen[self.n_slots] = 0
+        self.slot_owner.index_copy_(0, new, th.where(fin, e, th.full_like(e, self.n_envs))); self.slot_owner[self.n_slots] = self.n_envs
         self.cur_slot.index_copy_(0, th.where(fin, e, th.full_like(e, self.n_envs)), new); self.cur_slot[self.n_envs] = self.n_slots
         self.alloc += f.sum()
 
