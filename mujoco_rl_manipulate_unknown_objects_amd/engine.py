@@ -147,7 +147,8 @@ def lib():
     L.grip_batch_debug_forward.argtypes = [vp] + [vp] * 7 + [vp]
     L.grip_batch_target_pose.argtypes = [vp, vp, vp, vp]
     L.grip_batch_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int)]
-    L.grip_batch_device_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong), vp]
+    if hasattr(L, "grip_batch_device_time"):             # (absent from comparison builds of earlier rounds' sources: tools/physics_rate.py <variant>)
+        L.grip_batch_device_time.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong), vp]
     L.grip_selftest_cholesky.argtypes = [vp, vp, vp, C.c_int, vp]
     L.grip_batch_advance.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     L.grip_batch_observe_list.argtypes = [vp, vp, vp, C.c_int, vp, vp, vp, vp]

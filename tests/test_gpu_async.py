@@ -1,9 +1,12 @@
 """-m gpu: time-sliced stepping (grip_batch_advance) against lock-step grip_batch_step. Same arithmetic per env, other
 schedule: every per-env output has to be bit-identical."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 FIELDS = ["reward", "done", "achieved_goal", "desired_goal", "status", "episode_step", "gripper_open", "object_grasped",
           "position_reached", "total_distance", "line_distance", "gripper_position", "object_position", "init_obj_pos",
@@ -304,3 +307,43 @@ def test_async_tick_under_bf16_autocast_keeps_its_graph(engine, torch):
     rec = torch.randint(0, 256, (50, 5, 64, 64), dtype=torch.uint8, device="cuda"); row = torch.tensor([7], dtype=torch.int64, device="cuda")
     assert torch.equal(engine.RecordRows(rec, row, 9).materialize(), rec[7:16])
     env.close()
+
+
+def test_every_slice_launch_is_timed_by_the_device_clock(engine, torch):
+    """grip_batch_device_time (round 4): the first workgroup of a grip_batch_advance launch stamps its start, every wave its end, the compaction that
+    follows adds the difference to a device counter -- so launches replayed from a hipGraph are timed too. Eager and replayed launches are both counted,
+    the mean duration is positive and no longer than the wall-clock budget plus one physics.step()."""
+    b = engine.Batch("sand_ball", 256, auto_reset=1)
+    cap = 64
+    lst = torch.full((cap,), -1, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    act = torch.rand(cap, 6, device="cuda") * 2 - 1
+    b.device_time(reset=True)
+    for _ in range(5):
+        b.advance(act, 24, lst, cnt, 500)
+    ms, n = b.device_time(reset=False)
+    assert n == 5 and 0.0 < ms < 0.5 + 0.2
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        b.advance(act, 24, lst, cnt, 500)                   # warm up on the capture stream
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            b.advance(act, 24, lst, cnt, 500)
+        for _ in range(7):
+            g.replay()
+    torch.cuda.synchronize()
+    ms2, n2 = b.device_time(reset=True)
+    assert n2 == 5 + 1 + 7 and 0.0 < ms2 < 0.7                # the captured launch itself does not run; its seven replays do
+    assert b.device_time(reset=False)[1] == 0
+    b.close()
+
+
+def test_permlane32_swap_hands_each_half_of_a_wave_to_the_other(torch):
+    """halves_u / halves_f of csrc/grip_physics.h (v_permlane32_swap with the same register in both operands: the lower half twice, the upper half twice),
+    on which every clone-lane split of the physics kernel rests: tools/hiptests/t_swap.hip, compiled here and run on the device."""
+    import subprocess, tempfile
+    src = os.path.join(ROOT, "tools", "hiptests", "t_swap.hip")
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "t_swap")
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-w", "-o", exe, src], check=True, capture_output=True, timeout=300)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "t_swap: ok" in r.stdout, (r.stdout, r.stderr)

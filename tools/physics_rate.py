@@ -17,12 +17,15 @@ b = engine.Batch(obj, n, auto_reset=1)
 lst = torch.full((cap,), -1, dtype=torch.int32, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
 g = torch.Generator(device="cuda"); g.manual_seed(0)
 total = torch.zeros(1, dtype=torch.int64, device="cuda"); subs = torch.zeros(1, dtype=torch.int64, device="cuda")
+fbits = torch.zeros(3, dtype=torch.int64, device="cuda")      # finished macro steps that reported fault bit 1 (diverged) / 2 (contact overflow) / 4 (Newton iteration limit)
 ar = torch.arange(cap, device="cuda")
 def tick():
     act = torch.rand(cap, 6, device="cuda", generator=g) * 2 - 1
     out = b.advance(act, S, lst, cnt, bud)
     valid = (ar < cnt) & (lst >= 0)
     total.add_(valid.sum()); subs.add_((out["n_substeps"][lst.clamp(min=0).long()] * valid).sum())
+    f = out["fault"][lst.clamp(min=0).long()]
+    fbits.add_(torch.stack([(((f & 1) != 0) & valid).sum(), (((f & 2) != 0) & valid).sum(), (((f & 4) != 0) & valid).sum()]))
 for _ in range(pre): tick()
 torch.cuda.synchronize(); b.kernel_time(True); c0, s0 = int(total.item()), int(subs.item()); T = 400; t0 = time.time()
 for _ in range(T): tick()
@@ -30,4 +33,4 @@ torch.cuda.synchronize(); dt = time.time() - t0; c1, s1 = int(total.item()), int
 kms, kn = b.kernel_time(True)
 print(json.dumps({"lib": var, "object": obj, "slice": S, "budget_us": bud, "env_steps_per_s": (c1 - c0) / dt, "substeps_per_s": (s1 - s0) / dt,
                   "substeps_per_env_step": (s1 - s0) / max(1, c1 - c0), "capacity": cap, "ready_per_tick": (c1 - c0) / T, "ms_per_tick": dt / T * 1e3, "slice_kernel_ms": kms, "fault_max": int(b.out["fault"].max()),
-                  "all_ticks": pre + T, "all_substeps_of_finished_macro_steps": s1, "all_env_steps": c1}))
+                  "macro_steps_with_fault_bits_1_2_4": fbits.tolist(), "all_ticks": pre + T, "all_substeps_of_finished_macro_steps": s1, "all_env_steps": c1}))
