@@ -58,6 +58,13 @@ struct DevModel {
     float geom_rgba[GN_GEOM][4];
     float floor_rgb[6], sky_rgb[6];
     float light_dir[2][3];
+    // materials and lights of MuJoCo's fixed-function lighting (robot xml :29-34, :50-51): per geom specular / shininess / emission of its material;
+    // per light position, directional flag, diffuse / specular / ambient intensity, spot cutoff (cosine) and exponent; the headlight's ambient /
+    // diffuse / specular. (reflectance is 0 for every material a geom of these scenes uses)
+    float geom_material[GN_GEOM][3];
+    float light_pos[2][3]; int light_directional[2];
+    float light_params[2][5];                   // diffuse, specular, ambient, cos(cutoff), exponent
+    float headlight[3];
     int hull_padr[GN_HULL], hull_pnum[GN_HULL];
     float hull_aabb[GN_HULL][6];                // min xyz, max xyz of the hull's vertices in its geom frame (observation kernel: ray cull)
     const float *hull_planes;                   // [nplane][4] n.x <= d, body frame

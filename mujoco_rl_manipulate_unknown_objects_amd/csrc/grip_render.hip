@@ -3,7 +3,7 @@
 // One 1024-thread workgroup per environment, a 2 x 2 pixel tile per thread. Rays from `gripper_camera`
 // (robot xml :60) are clipped against the floor plane and the six convex hulls (Cyrus-Beck over
 // the hull face planes, read with workgroup-uniform indices, after a per-ray bounding-sphere
-// test); flat Lambert shading gives RGB (sensor.py:64-66), the distance along the optical axis
+// test); the materials and lights of the scene (lit_colour) give RGB (sensor.py:64-66), the distance along the optical axis
 // gives depth (sensor.py:69-72), which goes through transform_depth (utils.py:11-19) with its
 // two whole-image reductions done in LDS. The uint8 CHW observation (5 x 64 x 64 = 20 480 B per
 // env, 98 % of the macro step's algorithmic HBM bytes) is written once, coalesced, together with
@@ -93,6 +93,37 @@ __device__ __forceinline__ void frame_role(const DevModel &m, const float *qpos,
 }
 
 __device__ static uint8_t to_u8(float v) { v *= 255.f; v = fminf(fmaxf(v, 0.f), 255.f); return (uint8_t)v; }
+
+// Colour of one surface point under the fixed-function lighting MuJoCo's renderer applies to these scenes (robot xml :29-34 materials, :50-51 lights;
+// [3P-recall], unpinned like the rest of the rendering): material ambient = diffuse = the geom's rgb, specular = (s, s, s), shininess x 128, emission x rgb;
+// a headlight at the camera (ambient 0.1, diffuse 0.4, specular 0.5 by default) + the scene's lights -- a directional one and a spot (cutoff 45 degrees,
+// exponent 10 by default) -- without attenuation or shadows; the sum is clamped per channel by the byte conversion. Flat face normals of the collision
+// hulls (the reference shades its visual meshes). reflectance is 0 for every material a geom uses, so no mirror term.
+__device__ __forceinline__ void lit_colour(const DevModel &m, int geom, float b0, float b1, float b2, V3 P, V3 N, V3 co, float &c0, float &c1, float &c2) {
+    const float spec = m.geom_material[geom][0], shin = 128.f * m.geom_material[geom][1];
+    const V3 V = normalized(co - P);
+    float diff = m.geom_material[geom][2] + m.headlight[0], sp = 0.f;
+    {   const float nv = dot(N, V);                                  // headlight: L = V, so the half vector is V too
+        if (nv > 0.f) { diff += m.headlight[1] * nv; sp += m.headlight[2] * __powf(nv, shin); } }
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        const V3 ld = normalized(ldv(m.light_dir[l]));
+        V3 L = -ld; float spot = 1.f;
+        if (!m.light_directional[l]) {
+            L = normalized(ldv(m.light_pos[l]) - P);
+            const float c = -dot(L, ld);
+            spot = c > m.light_params[l][3] ? __powf(c, m.light_params[l][4]) : 0.f;
+        }
+        diff += m.light_params[l][2];
+        const float nl = dot(N, L);
+        if (nl > 0.f && spot > 0.f) {
+            diff += spot * m.light_params[l][0] * nl;
+            const float nh = fmaxf(dot(N, normalized(L + V)), 0.f);
+            sp += spot * m.light_params[l][1] * __powf(nh, shin);
+        }
+    }
+    c0 = b0 * diff + spec * sp; c1 = b1 * diff + spec * sp; c2 = b2 * diff + spec * sp;
+}
 
 // Per env, every hull plane n.x <= d (body frame) is first rewritten for rays leaving the camera origin in CAMERA
 // coordinates dc = (x, y, -1):  n.(ol + t dl) <= d  with  dl = Rg^T Rc dc, ol = Rg^T (co - pg)  becomes
@@ -344,8 +375,7 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
             best[q] = ok ? tin[q / TW][q % TW] : best[q]; hitent[q] = ok ? ((g << 16) | ent[q]) : hitent[q];
         }
     }
-    // shading (flat Lambert, headlight-free: the scene's first directional light) and the RGB bytes
-    const V3 L = normalized(v3(-m.light_dir[0][0], -m.light_dir[0][1], -m.light_dir[0][2]));
+    // shading (lit_colour: the materials' and lights' fixed-function model) and the RGB bytes
     asm volatile("" : "+v"(frl));
     const V3 co = ldv(frl->cam_o); const M3 Rc = ldm(frl->cam_R);
     float lmin = 3.0e38f;
@@ -361,18 +391,17 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
             c0 = m.sky_rgb[3] + f * (m.sky_rgb[0] - m.sky_rgb[3]); c1 = m.sky_rgb[4] + f * (m.sky_rgb[1] - m.sky_rgb[4]); c2 = m.sky_rgb[5] + f * (m.sky_rgb[2] - m.sky_rgb[5]);
         } else {
             float b0, b1, b2; V3 nrm = v3(0, 0, 1);
+            const V3 Pw = co + dir * best[q];
             if (hit == 0) {
-                float pxw = co.x + best[q] * dir.x, pyw = co.y + best[q] * dir.y;
-                int cx = (int)floorf(pxw * 8.0f), cy = (int)floorf(pyw * 8.0f);
+                int cx = (int)floorf(Pw.x * 8.0f), cy = (int)floorf(Pw.y * 8.0f);
                 int off = ((cx + cy) & 1) ? 3 : 0;
                 b0 = m.floor_rgb[off]; b1 = m.floor_rgb[off + 1]; b2 = m.floor_rgb[off + 2];
             } else {
                 b0 = m.geom_rgba[hit][0]; b1 = m.geom_rgba[hit][1]; b2 = m.geom_rgba[hit][2];
                 const float4 P = spl[gadr[hit] + NBOX + (hitent[q] & 0xffff)];        // the entering plane's normal in camera coordinates
-                nrm = mulv(Rc, v3(P.x, P.y, P.z));
+                nrm = normalized(mulv(Rc, v3(P.x, P.y, P.z)));
             }
-            float shade = 0.4f + 0.6f * fmaxf(dot(nrm, L), 0.f);
-            c0 = b0 * shade; c1 = b1 * shade; c2 = b2 * shade;
+            lit_colour(m, hit, b0, b1, b2, Pw, nrm, co, c0, c1, c2);
         }
         cb[0][q] = to_u8(c0); cb[1][q] = to_u8(c1); cb[2][q] = to_u8(c2);
         lmin = fminf(lmin, best[q]);
@@ -501,21 +530,19 @@ __global__ void __launch_bounds__(256) k_render_camera(const RenderGroup *__rest
     }
     if (depth) depth[px] = best;
     if (!rgb) return;
-    const V3 L = normalized(v3(-m.light_dir[0][0], -m.light_dir[0][1], -m.light_dir[0][2]));
     float c0, c1, c2;
     if (hit < 0) {
         V3 dn = normalized(dir); float f = 0.5f * (dn.z + 1.0f);
         c0 = m.sky_rgb[3] + f * (m.sky_rgb[0] - m.sky_rgb[3]); c1 = m.sky_rgb[4] + f * (m.sky_rgb[1] - m.sky_rgb[4]); c2 = m.sky_rgb[5] + f * (m.sky_rgb[2] - m.sky_rgb[5]);
     } else {
         float b0, b1, b2;
+        const V3 Pw = co + dir * best;
         if (hit == 0) {
-            float pxw = co.x + best * dir.x, pyw = co.y + best * dir.y;
-            int cx = (int)floorf(pxw * 8.0f), cy = (int)floorf(pyw * 8.0f);
+            int cx = (int)floorf(Pw.x * 8.0f), cy = (int)floorf(Pw.y * 8.0f);
             int off = ((cx + cy) & 1) ? 3 : 0;
             b0 = m.floor_rgb[off]; b1 = m.floor_rgb[off + 1]; b2 = m.floor_rgb[off + 2];
         } else { b0 = m.geom_rgba[hit][0]; b1 = m.geom_rgba[hit][1]; b2 = m.geom_rgba[hit][2]; }
-        float shade = 0.4f + 0.6f * fmaxf(dot(nrm, L), 0.f);
-        c0 = b0 * shade; c1 = b1 * shade; c2 = b2 * shade;
+        lit_colour(m, hit, b0, b1, b2, Pw, normalized(nrm), co, c0, c1, c2);
     }
     rgb[3 * px] = to_u8(c0); rgb[3 * px + 1] = to_u8(c1); rgb[3 * px + 2] = to_u8(c2);
 }

@@ -121,8 +121,8 @@ extern "C" int grip_model_load(const char *blob_path, GripModel **out) {
     Blob b;
     if (!b.load(blob_path)) return fail(std::string("cannot read model blob ") + blob_path);
     std::vector<double> opt, margin, solref, solimp, lsolref, lsolimp, bpos, bquat, bmass, bipos, biquat, binert, arm, damp, rng, gear,
-        crange, qpos0, gfric, gcen, grb, grgba, hverts, hplanes, biw, diw, mi, campos, camquat, camfovy, visual, frgb, srgb, ldir;
-    std::vector<int> gbody, hvadr, hvnum, hpadr, hpnum, nadr, nbr, pairs, lut;
+        crange, qpos0, gfric, gcen, grb, grgba, hverts, hplanes, biw, diw, mi, campos, camquat, camfovy, visual, frgb, srgb, ldir, lpos, lpar, gmat, hlight;
+    std::vector<int> gbody, hvadr, hvnum, hpadr, hpnum, nadr, nbr, pairs, lut, ldirl;
     bool ok = b.f64("opt", opt, 5) && b.f64("geom_margin", margin, 1) && b.f64("geom_solref", solref, 2) && b.f64("geom_solimp", solimp, 5) &&
               b.f64("lim_solref", lsolref, 2) && b.f64("lim_solimp", lsolimp, 5) && b.f64("body_pos", bpos, 24) && b.f64("body_quat", bquat, 32) &&
               b.f64("body_mass", bmass, 8) && b.f64("body_ipos", bipos, 24) && b.f64("body_iquat", biquat, 32) && b.f64("body_inertia", binert, 24) &&
@@ -244,6 +244,18 @@ extern "C" int grip_model_load(const char *blob_path, GripModel **out) {
     {   double Rc[9]; hm::qmat(camquat.data(), Rc); for (int k = 0; k < 9; k++) m.cam_R[k] = (float)Rc[k]; }
     m.cam_fovy = (float)camfovy[0]; m.znear = (float)visual[1]; m.zfar = (float)visual[2];
     for (int k = 0; k < 6; k++) { m.floor_rgb[k] = (float)frgb[k]; m.sky_rgb[k] = (float)srgb[k]; m.light_dir[k / 3][k % 3] = (float)ldir[k]; }
+    // materials / lights (round 4): blobs compiled before them lack the arrays
+    if (!(b.f64("geom_material", gmat, 21) && b.f64("light_params", lpar, 10) && b.f64("headlight", hlight, 3) && b.f64("light_pos", lpos, 6) && b.i32("light_directional", ldirl, 2))) {
+        delete gm; return fail(std::string("model blob lacks the material / light arrays: recompile it with model/compiler.py (") + blob_path + ")");
+    }
+    for (int g = 0; g < GN_GEOM; g++) for (int k = 0; k < 3; k++) m.geom_material[g][k] = (float)gmat[3 * g + k];
+    for (int l = 0; l < 2; l++) {
+        for (int k = 0; k < 3; k++) m.light_pos[l][k] = (float)lpos[3 * l + k];
+        m.light_directional[l] = ldirl[l];
+        m.light_params[l][0] = (float)lpar[5 * l]; m.light_params[l][1] = (float)lpar[5 * l + 1]; m.light_params[l][2] = (float)lpar[5 * l + 2];
+        m.light_params[l][3] = (float)cos(lpar[5 * l + 3] * 0.017453292519943295); m.light_params[l][4] = (float)lpar[5 * l + 4];
+    }
+    for (int k = 0; k < 3; k++) m.headlight[k] = (float)hlight[k];
     *out = gm;
     return 0;
 }

@@ -303,10 +303,12 @@ def parse_mjcf(xml_path):
     static_cams = [dict(pos=_floats(c.attrib.get("pos", "0 0 0")), name=cam.attrib["name"], fovy=float(cam.attrib["fovy"]))
                    for c in wb.findall("body") for cam in c.findall("camera") if cam.attrib.get("mode") == "targetbodycom"]
     floor = [dfl.get("geom", g) for g in wb.findall("geom")]
-    lights = [l.attrib for l in wb.findall("light")]
+    lights = [dfl.get("light", l) for l in wb.findall("light")]        # with the <default><light .../> class (diffuse "1 1 1" here)
     acts = [dfl.get("motor", a) for a in root.find("actuator").findall("motor")]
     znear = float(root.find("visual").find("map").attrib["znear"])
-    return dict(opt=opt, bodies=bodies, floor=floor, acts=acts, meshes=meshes,
+    hl = root.find("visual").find("headlight")
+    headlight = dict(hl.attrib) if hl is not None else {}
+    return dict(headlight=headlight, opt=opt, bodies=bodies, floor=floor, acts=acts, meshes=meshes,
                 mats=mats, texs=texs, lights=lights, znear=znear, static_cams=static_cams,
                 name=root.attrib.get("model", ""))
 
@@ -419,9 +421,11 @@ def compile_model(xml_path, mesh_dir, standin_acorn=False):
     geom_body = np.zeros(NG, dtype=np.int32)
     geom_fric = np.zeros((NG, 3)); geom_center = np.zeros((NG, 3)); geom_rbound = np.zeros(NG)
     geom_rgba = np.ones((NG, 4)); geom_condim = np.zeros(NG, dtype=np.int32)
+    geom_material = np.tile(np.array([0.5, 0.5, 0.0]), (NG, 1))        # specular, shininess, emission
     fl = x["floor"][0]
     assert fl["type"] == "plane"
     geom_fric[0] = _floats(fl.get("friction", "1 0.005 0.0001")); geom_condim[0] = int(fl["condim"])
+    geom_material[0] = material_of(x, fl)
     gm = fl  # margin / solref / solimp are identical for every geom (one default class)
     mdl["geom_margin"] = np.array([float(gm["margin"])])
     mdl["geom_solref"] = _floats(gm["solref"]); mdl["geom_solimp"] = _floats(gm["solimp"])
@@ -464,6 +468,7 @@ def compile_model(xml_path, mesh_dir, standin_acorn=False):
             geom_rgba[gi] = _floats(g["rgba"])
         elif "material" in g:
             geom_rgba[gi] = _floats(x["mats"][g["material"]]["rgba"])
+        geom_material[gi] = material_of(x, g)
         hv.append(verts); hvnum.append(len(verts)); hvadr.append(hvadr[-1] + len(verts))
         hn_adr.append(nadr[1:] + sum(len(a) for a in hn))
         hn.append(nbr)
@@ -526,8 +531,25 @@ def compile_model(xml_path, mesh_dir, standin_acorn=False):
     ld = np.array([_floats(l["dir"]) for l in x["lights"]]); lp = np.array([_floats(l["pos"]) for l in x["lights"]])
     mdl["light_dir"], mdl["light_pos"] = ld, lp
     mdl["light_directional"] = np.array([1 if l["directional"] == "true" else 0 for l in x["lights"]], dtype=np.int32)
+    # materials and light colours of the fixed-function lighting MuJoCo's renderer applies (robot xml :29-34, :50-51; n4). Per geom: specular,
+    # shininess, emission of its <material> (MuJoCo's defaults 0.5 / 0.5 / 0 where the geom names none; reflectance is 0 for every material a geom
+    # of these scenes uses). Per light: the mean of its diffuse / specular / ambient colour (the scenes' lights are white), spot cutoff in degrees,
+    # spot exponent -- MuJoCo's defaults 0.7 / 0.3 / 0 / 45 / 10 under the xml's <default><light diffuse="1 1 1"/>. The headlight: MuJoCo's
+    # defaults ambient 0.1, diffuse 0.4, specular 0.5 unless <visual><headlight/> says otherwise. [3P-recall]
+    mdl["geom_material"] = geom_material
+    col = lambda l, k, d: float(np.mean(_floats(l[k]))) if k in l else d
+    mdl["light_params"] = np.array([[col(l, "diffuse", 0.7), col(l, "specular", 0.3), col(l, "ambient", 0.0), float(l.get("cutoff", 45.0)), float(l.get("exponent", 10.0))]
+                                    for l in x["lights"]])
+    h = x["headlight"]
+    mdl["headlight"] = np.array([col(h, "ambient", 0.1), col(h, "diffuse", 0.4), col(h, "specular", 0.5)]) * (0.0 if h.get("active", "1") == "0" else 1.0)
     mdl["flags"] = np.array([standin], dtype=np.int32)
     return mdl
+
+
+def material_of(x, g):
+    """(specular, shininess, emission) of a geom: its <material>'s attributes, MuJoCo's material defaults 0.5 / 0.5 / 0 otherwise [3P-recall]."""
+    mt = x["mats"].get(g.get("material", ""), {})
+    return np.array([float(mt.get("specular", 0.5)), float(mt.get("shininess", 0.5)), float(mt.get("emission", 0.0))])
 
 
 OBJECTS = ["acorn", "sand_ball", "sugar_cube", "bread_crumb"]

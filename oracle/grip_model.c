@@ -100,6 +100,9 @@ OrcModel *orc_model_load(const char *path) {
     bad |= get_f64(buf, len, "light_dir", &m->light_dir[0][0], 6);
     bad |= get_f64(buf, len, "light_pos", &m->light_pos[0][0], 6);
     bad |= get_i32(buf, len, "light_directional", m->light_directional, 2);
+    bad |= get_f64(buf, len, "geom_material", &m->geom_material[0][0], NG * 3);
+    bad |= get_f64(buf, len, "light_params", &m->light_params[0][0], 10);
+    bad |= get_f64(buf, len, "headlight", m->headlight, 3);
     if (!bad) {
         m->nvert = (int)(entry_count(buf, len, "hull_verts") / 3);
         m->nplane = (int)(entry_count(buf, len, "hull_planes") / 4);

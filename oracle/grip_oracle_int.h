@@ -34,6 +34,9 @@ struct OrcModel {
     double body_invweight0[NB][2], dof_invweight0[NV], meaninertia;
     double cam_pos[3], cam_quat[4], cam_fovy, visual[3], floor_rgb[6], sky_rgb[6];
     double light_dir[2][3], light_pos[2][3]; int light_directional[2];
+    /* materials and light colours of MuJoCo's fixed-function lighting (robot xml :29-34, :50-51): per geom specular, shininess, emission; per light
+     * diffuse, specular, ambient, spot cutoff (degrees), spot exponent; the headlight's ambient, diffuse, specular */
+    double geom_material[NG][3], light_params[2][5], headlight[3];
 };
 
 /* ---- tiny vector helpers ---- */

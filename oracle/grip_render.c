@@ -10,7 +10,7 @@
  * is not attainable and this renderer is UNPINNED. It is a ray caster over the same
  * scene: `gripper_camera` (robot xml :60, fovy 135 deg, on body ee), the floor plane with the
  * 2x2-checker `grid` material (:30-31,54), the six convex hulls with their rgba, the skybox
- * gradient (:29), one directional light (:50), flat Lambert shading. Depth is the distance along
+ * gradient (:29), the materials (:32-34) and both lights (:50-51) under the fixed-function lighting model (lit_colour), flat face normals. Depth is the distance along
  * the optical axis in metres, as dm_control's depth render returns it.
  */
 #include "grip_oracle_int.h"
@@ -51,12 +51,41 @@ static int ray_hull(const OrcModel *m, const OrcData *d, int g, const double o[3
     return 1;
 }
 
+/* MuJoCo's fixed-function lighting of one surface point [3P-recall; unpinned like the rest of the rendering] (robot xml :29-34 materials, :50-51 lights):
+ * material ambient = diffuse = the geom's rgb, specular (s, s, s), shininess x 128, emission x rgb; a headlight at the camera + the scene's lights
+ * (a directional one and a spot with cutoff and exponent), no attenuation, no shadows; clamped per channel by the byte conversion. */
+static void lit_colour(const OrcModel *m, int geom, const double *base, const double *P, const double *N, const double *co, double *col) {
+    const double spec = m->geom_material[geom][0], shin = 128.0 * m->geom_material[geom][1];
+    double V[3] = {co[0] - P[0], co[1] - P[1], co[2] - P[2]}; normalize3(V);
+    double diff = m->geom_material[geom][2] + m->headlight[0], sp = 0.0;
+    double nv = dot3(N, V);
+    if (nv > 0) { diff += m->headlight[1] * nv; sp += m->headlight[2] * pow(nv, shin); }
+    for (int l = 0; l < 2; l++) {
+        double ld[3] = {m->light_dir[l][0], m->light_dir[l][1], m->light_dir[l][2]}; normalize3(ld);
+        double L[3] = {-ld[0], -ld[1], -ld[2]}, spot = 1.0;
+        if (!m->light_directional[l]) {
+            for (int k = 0; k < 3; k++) L[k] = m->light_pos[l][k] - P[k];
+            normalize3(L);
+            double c = -dot3(L, ld);
+            spot = c > cos(m->light_params[l][3] * 0.017453292519943295) ? pow(c, m->light_params[l][4]) : 0.0;
+        }
+        diff += m->light_params[l][2];
+        double nl = dot3(N, L);
+        if (nl > 0 && spot > 0) {
+            diff += spot * m->light_params[l][0] * nl;
+            double H[3] = {L[0] + V[0], L[1] + V[1], L[2] + V[2]}; normalize3(H);
+            double nh = dot3(N, H); if (nh < 0) nh = 0;
+            sp += spot * m->light_params[l][1] * pow(nh, shin);
+        }
+    }
+    for (int k = 0; k < 3; k++) col[k] = base[k] * diff + spec * sp;
+}
+
 static unsigned char to_u8(double v) { v = v * 255.0; if (v < 0) v = 0; if (v > 255) v = 255; return (unsigned char)v; }
 
 void orc_render(const OrcModel *m, const OrcData *d, int width, int height, unsigned char *rgb, float *depth) {
     Cam cam; camera_pose(m, d, &cam);
     const double znear = m->visual[1], zfar = m->visual[2];
-    double L[3] = {-m->light_dir[0][0], -m->light_dir[0][1], -m->light_dir[0][2]}; normalize3(L);
     for (int i = 0; i < height; i++) for (int j = 0; j < width; j++) {
         double x = (2.0 * (j + 0.5) / width - 1.0) * cam.tanh * ((double)width / height);
         double y = (1.0 - 2.0 * (i + 0.5) / height) * cam.tanh;
@@ -76,16 +105,14 @@ void orc_render(const OrcModel *m, const OrcData *d, int width, int height, unsi
             double f = 0.5 * (dn[2] + 1.0);
             for (int k = 0; k < 3; k++) col[k] = m->sky_rgb[3 + k] + f * (m->sky_rgb[k] - m->sky_rgb[3 + k]);
         } else {
-            double base[3];
+            double base[3], P[3] = {cam.o[0] + best * dir[0], cam.o[1] + best * dir[1], cam.o[2] + best * dir[2]};
             if (hit == 0) {
-                double px = cam.o[0] + best * dir[0], py = cam.o[1] + best * dir[1];
-                int cx = (int)floor(px * 8.0), cy = (int)floor(py * 8.0);     /* texrepeat 4, 2x2 checker per repeat */
+                int cx = (int)floor(P[0] * 8.0), cy = (int)floor(P[1] * 8.0);     /* texrepeat 4, 2x2 checker per repeat */
                 const double *c = ((cx + cy) & 1) ? m->floor_rgb + 3 : m->floor_rgb;
                 copy3(base, c);
             } else copy3(base, m->geom_rgba[hit]);
-            double lam = dot3(nrm, L); if (lam < 0) lam = 0;
-            double shade = 0.4 + 0.6 * lam;
-            for (int k = 0; k < 3; k++) col[k] = base[k] * shade;
+            normalize3(nrm);
+            lit_colour(m, hit, base, P, nrm, cam.o, col);
         }
         int px = i * width + j;
         rgb[3 * px] = to_u8(col[0]); rgb[3 * px + 1] = to_u8(col[1]); rgb[3 * px + 2] = to_u8(col[2]);
