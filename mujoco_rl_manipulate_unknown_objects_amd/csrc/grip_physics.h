@@ -108,7 +108,7 @@ static_assert(ES_QPOS % 4 == 0 && ENV_FLOATS % 4 == 0 && ES_KIN % 4 == 0, "state
 // fin_R[9], grp_com[1 + s][3], grp_inertia[1 + s][6], grp_mass[1 + s], pad[2]. Lanes 0..31 of a two-env wave work on the left chain, their
 // clones 32..63 on the right one, in ONE instruction stream: the constants must come by lane (nine 16-byte reads), not as scalar operands.
 #define LR_STRIDE 36
-#define LR_FLOATS (2 * LR_STRIDE)
+#define LR_FLOATS (4 * LR_STRIDE)       // records 2 (ee + base group) and 3 (object) carry only grp_com, grp_inertia, grp_mass (the same word positions): lanes 0..31 / clones
 #define LR_OFF(hull_words) (((hull_words) + GT_FLOATS + 3) & ~3)             // 16-byte aligned
 #define LDS_ENV_BASE(hull_words) (LR_OFF(hull_words) + LR_FLOATS)             // float offset of the first env region (16-byte aligned)
 
@@ -216,6 +216,8 @@ struct Kin {
     // the finger chain THIS half of the wave works on (lanes 0..31: left, s = 0; clones 32..63: right, s = 1): c[1 + s], Ic[1 + s], its mass.
     // c[1], c[2], Ic[1], Ic[2] are not filled in this mapping: bias_forces() and mass_matrix() take the own chain and swap results.
     V3 c_own; float Ic_own[6]; float m_own;
+    // ... and the big body of the half: the ee + base group (lanes 0..31) or the object (clones): c[0] / c[3], Ic[0] / Ic[3], its mass (c[0], c[3], Ic[0], Ic[3] are not filled)
+    V3 c_go; float Ic_go[6]; float m_go;
 #endif
 };
 
@@ -283,15 +285,18 @@ DEVI Ctx stage_tables(const DevModel &m, float *lds) {
     }
     float *lr = lds + LR_OFF(m.hull_words);
     for (int i = threadIdx.x; i < LR_FLOATS; i += blockDim.x) {
-        const int s = i / LR_STRIDE, f = i % LR_STRIDE;
+        const int s = i / LR_STRIDE, f = i % LR_STRIDE, grp = s < 2 ? 1 + s : (s == 2 ? 0 : 3);
         float v = 0.f;
-        if (f < 3) v = m.kn_pos[s][f];
-        else if (f < 12) v = m.kn_R[s][f - 3];
-        else if (f < 15) v = m.fin_pos[s][f - 12];
-        else if (f < 24) v = m.fin_R[s][f - 15];
-        else if (f < 27) v = m.grp_com[1 + s][f - 24];
-        else if (f < 33) v = m.grp_inertia[1 + s][f - 27];
-        else if (f == 33) v = m.grp_mass[1 + s];
+        if (f < 24) {
+            if (s >= 2) v = 0.f;
+            else if (f < 3) v = m.kn_pos[s][f];
+            else if (f < 12) v = m.kn_R[s][f - 3];
+            else if (f < 15) v = m.fin_pos[s][f - 12];
+            else v = m.fin_R[s][f - 15];
+        }
+        else if (f < 27) v = m.grp_com[grp][f - 24];
+        else if (f < 33) v = m.grp_inertia[grp][f - 27];
+        else if (f == 33) v = m.grp_mass[grp];
         lr[i] = v;
     }
     __syncthreads();
@@ -405,10 +410,25 @@ DEVI void kinematics(const DevModel &m, float (&qpos)[14], Kin &k, const Ctx &cx
 #endif
     k.po = v3(qpos[7], qpos[8], qpos[9]);
     k.Ro = quat_mat(qpos[10], qpos[11], qpos[12], qpos[13]);
+#if EPW == 2
+    {   // the ee + base group in lanes 0..31, the object in the clones: one COM and one rotated inertia per half, constants by lane from the table
+        const float4 *G4 = reinterpret_cast<const float4 *>(cx.T.lr + (up ? 3 : 2) * LR_STRIDE + 24);
+        const float4 g0 = G4[0], g1 = G4[1], g2 = G4[2];
+        const float inertia[6] = {g0.w, g1.x, g1.y, g1.z, g1.w, g2.x};
+        M3 Rs;
+#pragma unroll
+        for (int i = 0; i < 9; i++) Rs.m[i] = up ? k.Ro.m[i] : k.Re.m[i];
+        const V3 ps = up ? k.po : k.pe;
+        k.m_go = g2.y;
+        k.c_go = ps + mulv(Rs, v3(g0.x, g0.y, g0.z));
+        rot_sym(Rs, inertia, k.Ic_go);
+    }
+#else
     k.c[0] = k.pe + mulv(k.Re, ldv(m.grp_com[0]));
     rot_sym(k.Re, m.grp_inertia[0], k.Ic[0]);
     k.c[3] = k.po + mulv(k.Ro, ldv(m.grp_com[3]));
     rot_sym(k.Ro, m.grp_inertia[3], k.Ic[3]);
+#endif
     if (store && cx.sub == 0) {                     // one lane of the env publishes the geom frames, what the constraint rows need, the state's quaternion
         store_frame(cx.envl, 1, pb, Rb);
 #if EPW == 2
@@ -446,11 +466,35 @@ DEVI void mass_matrix(const DevModel &m, const Kin &k, float (&Mg)[28], float (&
 #pragma unroll
     for (int i = 0; i < 6; i++) Mo[pidx(i, i)] = m.armature[7 + i];
     const V3 ex = v3(1, 0, 0), ey = v3(0, 1, 0), ez = v3(0, 0, 1), z0 = v3(0, 0, 0);
+#if EPW == 2
+    {   // the half's big body as a 6 x 6 block: the ee + base group over (ee dofs 0..4, a zero sixth axis) in lanes 0..31, the object over its six dofs in the
+        // clones; the halves swap blocks, the gripper's matrix takes the lower half's (first, as in the one-stream form: G, L, R), the object's the upper half's
+        const int dofs[6] = {0, 1, 2, 3, 4, 5};
+        const V3 ref = up ? k.po : k.pe;
+        const V3 a3 = up ? col(k.Ro, 0) : ex, a4v = up ? col(k.Ro, 1) : k.a4, a5 = up ? col(k.Ro, 2) : z0;
+        const V3 r = k.c_go - ref;
+        const V3 jp[6] = {ex, ey, ez, cross(a3, r), cross(a4v, r), cross(a5, r)};
+        const V3 jr[6] = {z0, z0, z0, a3, a4v, a5};
+        float Mb2[21];
+#pragma unroll
+        for (int i = 0; i < 21; i++) Mb2[i] = 0.f;
+        add_body<6, 21>(Mb2, dofs, jp, jr, k.m_go, k.Ic_go);
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = 0; b <= a; b++) {
+                float lo, hi; halves_f(Mb2[pidx(a, b)], lo, hi);
+                if (a < 5) Mg[pidx(a, b)] += lo;
+                Mo[pidx(a, b)] += hi;
+            }
+    }
+#else
     {   const int dofs[5] = {0, 1, 2, 3, 4};
         V3 r = k.c[0] - k.pe;
         const V3 jp[5] = {ex, ey, ez, cross(ex, r), cross(k.a4, r)};
         const V3 jr[5] = {z0, z0, z0, ex, k.a4};
         add_body<5, 28>(Mg, dofs, jp, jr, m.grp_mass[0], k.Ic[0]); }
+#endif
 #if EPW == 2
     {   // the half's own finger body as a 6 x 6 block over (ee dofs 0..4, own knuckle), the same expressions as add_body on the full matrix;
         // the halves swap blocks and both add left, then right, in the order of the one-stream form (G, L, R): the same sums
@@ -484,12 +528,14 @@ DEVI void mass_matrix(const DevModel &m, const Kin &k, float (&Mg)[28], float (&
         const V3 jr[6] = {z0, z0, z0, ex, k.a4, k.ak[1]};
         add_body<6, 28>(Mg, dofs, jp, jr, m.grp_mass[2], k.Ic[2]); }
 #endif
+#if EPW != 2
     {   const int dofs[6] = {0, 1, 2, 3, 4, 5};
         V3 r = k.c[3] - k.po;
         V3 c0 = col(k.Ro, 0), c1 = col(k.Ro, 1), c2 = col(k.Ro, 2);
         const V3 jp[6] = {ex, ey, ez, cross(c0, r), cross(c1, r), cross(c2, r)};
         const V3 jr[6] = {z0, z0, z0, c0, c1, c2};
         add_body<6, 21>(Mo, dofs, jp, jr, m.grp_mass[3], k.Ic[3]); }
+#endif
 }
 
 // y = M x with the block-diagonal mass matrix
@@ -597,10 +643,23 @@ DEVI void bias_forces(const DevModel &m, const Kin &k, const float (&qvel)[13], 
     V3 alL = alG + cross(t.wG, k.ak[0] * qvel[5]);
     V3 alR = alG + cross(t.wG, k.ak[1] * qvel[6]);
 #endif
+#if EPW == 2
+    {   // the half's big body (ee + base group | object): the one-stream expressions with the object's zero angular acceleration written out
+        const V3 ref = up ? k.po : k.pe, w_ = up ? t.wO : t.wG, al_ = up ? v3(0, 0, 0) : alG;
+        const V3 rc = k.c_go - ref;
+        const V3 ac = cross(al_, rc) + cross(w_, cross(w_, rc)) - grav;
+        const V3 tau = symv(k.Ic_go, al_) + cross(w_, symv(k.Ic_go, w_));
+        const V3 F = ac * k.m_go;
+        const V3 T = tau + cross(k.c_go - ref, F);
+        halves_f(F.x, w.FG.x, w.FO.x); halves_f(F.y, w.FG.y, w.FO.y); halves_f(F.z, w.FG.z, w.FO.z);
+        halves_f(T.x, w.TG.x, w.TO.x); halves_f(T.y, w.TG.y, w.TO.y); halves_f(T.z, w.TG.z, w.TO.z);
+    }
+#else
     {   V3 rc = k.c[0] - k.pe;
         V3 ac = cross(alG, rc) + cross(t.wG, cross(t.wG, rc)) - grav;
         V3 tau = symv(k.Ic[0], alG) + cross(t.wG, symv(k.Ic[0], t.wG));
         wrench_add(k, w, GRP_G, k.c[0], ac * m.grp_mass[0], tau, 1.f); }
+#endif
 #if EPW != 2
     {   V3 rc = k.c[1] - k.pk[0];
         V3 ac = aL + cross(alL, rc) + cross(t.wL, cross(t.wL, rc)) - grav;
@@ -611,10 +670,12 @@ DEVI void bias_forces(const DevModel &m, const Kin &k, const float (&qvel)[13], 
         V3 tau = symv(k.Ic[2], alR) + cross(t.wR, symv(k.Ic[2], t.wR));
         wrench_add(k, w, GRP_R, k.c[2], ac * m.grp_mass[2], tau, 1.f); }
 #endif
+#if EPW != 2
     {   V3 rc = k.c[3] - k.po;
         V3 ac = cross(t.wO, cross(t.wO, rc)) - grav;
         V3 tau = cross(t.wO, symv(k.Ic[3], t.wO));
         wrench_add(k, w, GRP_O, k.c[3], ac * m.grp_mass[3], tau, 1.f); }
+#endif
     wrench_project(k, w, bias);
 }
 
@@ -764,19 +825,19 @@ DEVI void gathered_solve_block(const Ctx &cx, const float (&row)[7], float gi, f
     float4 *H4 = reinterpret_cast<float4 *>(cx.envl + EF_H);
     const int lsub = local_sub(cx);
     if (lsub < 13) { H4[2 * lsub] = make_float4(row[0], row[1], row[2], row[3]); H4[2 * lsub + 1] = make_float4(row[4], row[5], row[6], -gi); }
+    // row 13 does not exist: the object block's seventh row is the identity, with a zero right-hand side -- written once per solve by lane 13, so that the
+    // object lanes read rows 7..13 like the gripper lanes read rows 0..6 (no per-entry selects; an object row's seventh word is zero already)
+    if (lsub == 13) { H4[26] = make_float4(0.f, 0.f, 0.f, 0.f); H4[27] = make_float4(0.f, 0.f, 1.f, 0.f); }
     wave_sync();
-    const bool grip = lsub < 7;
-    const int base = grip ? 0 : 7;
+    const int base = lsub < 7 ? 0 : 7;
     float A[28];
 #pragma unroll
     for (int i = 0; i < 7; i++) {
-        const int r = (i < 6 || grip) ? base + i : base;            // row 13 does not exist: the object block's seventh row is the identity
-        const float4 a = H4[2 * r], b = H4[2 * r + 1];
+        const float4 a = H4[2 * (base + i)], b = H4[2 * (base + i) + 1];
         const float e[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z};
-        const bool pad = i == 6 && !grip;
 #pragma unroll
-        for (int j = 0; j <= i; j++) A[pidx(i, j)] = pad ? (j == 6 ? 1.f : 0.f) : e[j];
-        x[i] = pad ? 0.f : b.w;
+        for (int j = 0; j <= i; j++) A[pidx(i, j)] = e[j];
+        x[i] = b.w;
     }
     wave_sync();                                        // the area is rewritten by the next pricing: reads first (one wave, in order)
     chol_packed<7>(A);
@@ -812,9 +873,9 @@ DEVI int support_vertex(const Tables &T, int h, int base, V3 dl, V3 &vout, int h
     float bx = v0.x, by = v0.y, bz = v0.z;
     float bv = fmaf(bx, dl.x, fmaf(by, dl.y, bz * dl.z));
     // the vertex's own 4th word holds its adjacency range: moving to a neighbour needs no trip through the CSR offset table
-    unsigned aw = __float_as_uint(v0.w), caw = aw;
+    unsigned aw = __float_as_uint(v0.w);
     int e = (int)(aw & 0xffffu), eend = e + (int)(aw >> 16);
-    int cand = cur; float cv = bv, cx = bx, cy = by, cz = bz;
+    int cand = cur; float cv = bv;
 #ifdef GRIP_STAMPS
     const unsigned long long act_ = __ballot(1);
     const bool first_ = (__ffsll((long long)act_) - 1) == (int)(threadIdx.x & 63);
@@ -825,20 +886,22 @@ DEVI int support_vertex(const Tables &T, int h, int base, V3 dl, V3 &vout, int h
 #ifdef GRIP_STAMPS
         if ((__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) DBG_COUNT(14, 1);
 #endif
-        int j[SUP_NB]; float x[SUP_NB], y[SUP_NB], z[SUP_NB]; unsigned w[SUP_NB];
+        int j[SUP_NB]; float x[SUP_NB], y[SUP_NB], z[SUP_NB];
 #pragma unroll
         for (int q = 0; q < SUP_NB; q++) j[q] = T.nbr[min(e + q, eend - 1)];
 #pragma unroll
-        for (int q = 0; q < SUP_NB; q++) { const float4 vq = vb[j[q]]; x[q] = vq.x; y[q] = vq.y; z[q] = vq.z; w[q] = __float_as_uint(vq.w); }
+        for (int q = 0; q < SUP_NB; q++) { const float4 vq = vb[j[q]]; x[q] = vq.x; y[q] = vq.y; z[q] = vq.z; }
 #pragma unroll
-        for (int q = 0; q < SUP_NB; q++) {
-            float s = fmaf(x[q], dl.x, fmaf(y[q], dl.y, z[q] * dl.z));
-            if (s > cv) { cv = s; cand = j[q]; cx = x[q]; cy = y[q]; cz = z[q]; caw = w[q]; }
+        for (int q = 0; q < SUP_NB; q++) {                 // (only the value and the index of the best neighbour are tracked -- two selects per neighbour, not six:
+            float s = fmaf(x[q], dl.x, fmaf(y[q], dl.y, z[q] * dl.z));      // the winner's record is read once more when the climb moves there)
+            if (s > cv) { cv = s; cand = j[q]; }
         }
         e += SUP_NB;
         if (e >= eend) {                                   // this vertex's neighbours are all seen
             if (cand == cur) break;
-            cur = cand; bx = cx; by = cy; bz = cz; aw = caw;
+            cur = cand;
+            const float4 vn = vb[cur];
+            bx = vn.x; by = vn.y; bz = vn.z; aw = __float_as_uint(vn.w);
             e = (int)(aw & 0xffffu); eend = e + (int)(aw >> 16);
             DBG_COUNT(6, 1);
         }
@@ -875,11 +938,13 @@ DEVI void coop_support2(const Tables &T, int baseA, int nA, V3 dA, int baseB, in
         for (int q = 0; q < 2; q++) { a[q] = vA[ja[q]]; b[q] = vB[jb[q]]; }
 #pragma unroll
         for (int q = 0; q < 2; q++) {
+            // (a lane's indices ascend, so the strict comparison alone keeps the lowest index among equal values; the index breaks ties only
+            // where lanes meet, below)
             const float sa = fmaf(a[q].x, dA.x, fmaf(a[q].y, dA.y, a[q].z * dA.z));
-            const bool ta = sa > av || (sa == av && ja[q] < ai);
+            const bool ta = sa > av;
             av = ta ? sa : av; ai = ta ? ja[q] : ai;
             const float sb = fmaf(b[q].x, dB.x, fmaf(b[q].y, dB.y, b[q].z * dB.z));
-            const bool tb = sb > bv || (sb == bv && jb[q] < bi);
+            const bool tb = sb > bv;
             bv = tb ? sb : bv; bi = tb ? jb[q] : bi;
         }
     }
@@ -1510,17 +1575,20 @@ DEVI void make_constraints(const DevModel &m, const Ctx &cx, Contact &c, int nco
 
 // `cn` comes in EVALUATED: the point being priced is where the line search stopped, and its last evaluation (line_eval) computed exactly
 // this cone -- the same jar = fma(alpha, jv, jar) -- so it is not computed again (all zero in lanes without a contact, as the start pricing left it).
+// `wlim` (wave-uniform): a joint of one of the wave's envs is at its limit (0.1 % of the steps); otherwise every limit term below is an exact zero and is skipped.
 DEVI float price_constraints(const DevModel &m, const Ctx &cx, float lsgn, float lD, float laref, float xi, int ncon,
-                             const Contact &c, bool live, const Cone &cn, float &jtfi, float &hdiag) {
+                             const Contact &c, bool live, const Cone &cn, float &jtfi, float &hdiag, bool wlim) {
     if (live)
         *reinterpret_cast<float4 *>(cx.envl + EF_FORCE + 4 * local_sub(cx)) = make_float4(-cn.grad[0], -cn.grad[1], -cn.grad[2], -cn.grad[3]);
-    float cost = cn.cost;
-    // joint limit owned by this lane (lanes 0..6): J = sgn at dof `sub`
-    float ljar = lsgn * xi - laref;
-    bool lact = lsgn != 0.f && ljar < 0.f;
-    float jt = lact ? -lD * ljar * lsgn : 0.f;
-    cost += lact ? 0.5f * lD * ljar * ljar : 0.f;
-    hdiag = lact ? lD : 0.f;
+    float cost = cn.cost, jt = 0.f;
+    hdiag = 0.f;
+    if (wlim) {                         // joint limit owned by this lane (lanes 0..6): J = sgn at dof `sub`
+        float ljar = lsgn * xi - laref;
+        bool lact = lsgn != 0.f && ljar < 0.f;
+        jt = lact ? -lD * ljar * lsgn : 0.f;
+        cost += lact ? 0.5f * lD * ljar * ljar : 0.f;
+        hdiag = lact ? lD : 0.f;
+    }
     wave_sync();
     const int isub = UPOS(min(local_sub(cx), 12));
     for (int k = 0; k < ncon; k++) {
@@ -1611,8 +1679,10 @@ DEVI void assemble_rows(const Ctx &cx, int ncon, float hdiag, float (&row)[13]) 
 #pragma unroll 4
     for (int s = 0; s < 6 * ncon; s++) slot(s);
 #endif
+    if (__any(hdiag != 0.f)) {
 #pragma unroll
-    for (int j = 0; j < 13; j++) row[j] += cx.sub == j ? hdiag : 0.f;
+        for (int j = 0; j < 13; j++) row[j] += cx.sub == j ? hdiag : 0.f;
+    }
     if (cx.sub >= 13) {                                    // lanes 13..15 carry identity rows
 #pragma unroll
         for (int j = 0; j < 13; j++) row[j] = 0.f;
@@ -1657,15 +1727,17 @@ DEVI void assemble_rows_block(const Ctx &cx, int ncon, const float (&mrow7)[7], 
         if ((midmask >> k) & 1u) { slot(6 * k + 4); slot(6 * k + 5); }
     }
 #endif
-    const int own = cx.sub < 7 ? cx.sub : cx.sub - 7;
+    if (__any(hdiag != 0.f)) {                          // an active joint limit's term on the diagonal (rare)
+        const int own = cx.sub < 7 ? cx.sub : cx.sub - 7;
 #pragma unroll
-    for (int j = 0; j < 7; j++) row[j] += own == j ? hdiag : 0.f;
+        for (int j = 0; j < 7; j++) row[j] += own == j ? hdiag : 0.f;
+    }
 }
 
 // phi'(alpha), phi''(alpha) of the total cost along the search direction: this lane's contact and limit, then all-reduce
 // `cn` (out, contact lanes): the cone at jar + alpha jv -- the pricing of the new point reuses the last one (price_constraints)
 DEVI void line_eval(const DevModel &m, float lsgn, float lD, float laref, float qi, float pi,
-                    const Contact &c, bool live, float alpha, float g0, float g1, float &dphi, float &ddphi, Cone &cn) {
+                    const Contact &c, bool live, float alpha, float g0, float g1, float &dphi, float &ddphi, Cone &cn, bool wlim) {
     float dp = 0.f, hp = 0.f;
     if (live) {
         float ja[4];
@@ -1676,7 +1748,8 @@ DEVI void line_eval(const DevModel &m, float lsgn, float lD, float laref, float 
         for (int r = 0; r < 4; r++) dp = fmaf(cn.grad[r], c.jv[r], dp);
         hp = cone_quad(cn, c.jv);
     }
-    {   float jv = lsgn * pi;
+    if (wlim) {
+        float jv = lsgn * pi;
         float xx = lsgn * qi - laref + alpha * jv;
         bool act = lsgn != 0.f && xx < 0.f;
         dp += act ? lD * xx * jv : 0.f; hp += act ? lD * jv * jv : 0.f; }
@@ -1689,7 +1762,7 @@ DEVI void line_eval(const DevModel &m, float lsgn, float lD, float laref, float 
 static_assert(EF_FORCE2 + 4 * G_MAXC <= EF_M, "second force set must fit the staging area");
 DEVI void price_two_starts(const DevModel &m, const Ctx &cx, float lsgn, float lD, float laref, float xs, float xw, int ncon, const Contact &c, bool live,
                            const float (&jar_s)[4], const float (&jar_w)[4], Cone &cn_s, Cone &cn_w, float &lc_s, float &lc_w,
-                           float &jt_s, float &jt_w, float &hd_s, float &hd_w) {
+                           float &jt_s, float &jt_w, float &hd_s, float &hd_w, bool wlim) {
 #pragma unroll
     for (int i = 0; i < 4; i++) { cn_s.grad[i] = cn_s.w[i] = cn_s.a[i] = cn_s.b[i] = 0.f; cn_w.grad[i] = cn_w.w[i] = cn_w.a[i] = cn_w.b[i] = 0.f; }
     cn_s.cost = cn_s.ka = cn_s.kb = 0.f; cn_w.cost = cn_w.ka = cn_w.kb = 0.f;
@@ -1700,10 +1773,13 @@ DEVI void price_two_starts(const DevModel &m, const Ctx &cx, float lsgn, float l
         *reinterpret_cast<float4 *>(cx.envl + EF_FORCE2 + 4 * local_sub(cx)) = make_float4(-cn_w.grad[0], -cn_w.grad[1], -cn_w.grad[2], -cn_w.grad[3]);
     }
     lc_s = cn_s.cost; lc_w = cn_w.cost;
-    {   float lj = lsgn * xs - laref; bool la = lsgn != 0.f && lj < 0.f;
-        jt_s = la ? -lD * lj * lsgn : 0.f; lc_s += la ? 0.5f * lD * lj * lj : 0.f; hd_s = la ? lD : 0.f; }
-    {   float lj = lsgn * xw - laref; bool la = lsgn != 0.f && lj < 0.f;
-        jt_w = la ? -lD * lj * lsgn : 0.f; lc_w += la ? 0.5f * lD * lj * lj : 0.f; hd_w = la ? lD : 0.f; }
+    jt_s = jt_w = 0.f; hd_s = hd_w = 0.f;
+    if (wlim) {
+        {   float lj = lsgn * xs - laref; bool la = lsgn != 0.f && lj < 0.f;
+            jt_s = la ? -lD * lj * lsgn : 0.f; lc_s += la ? 0.5f * lD * lj * lj : 0.f; hd_s = la ? lD : 0.f; }
+        {   float lj = lsgn * xw - laref; bool la = lsgn != 0.f && lj < 0.f;
+            jt_w = la ? -lD * lj * lsgn : 0.f; lc_w += la ? 0.5f * lD * lj * lj : 0.f; hd_w = la ? lD : 0.f; }
+    }
     wave_sync();
     const int isub = UPOS(min(local_sub(cx), 12));
     for (int k = 0; k < ncon; k++) {
@@ -1734,6 +1810,7 @@ DEVI void cone_sel(Cone &d, bool take, const Cone &s) {
 DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Contact &c, bool live, int ncon,
                        float &xi_out, float &jtfi_out, int &iters, Stamps &st, float *dbgH = nullptr) {
     const float lsgn = lc.lsgn, lD = lc.lD, laref = lc.laref, qsi = lc.qsi, warmi = lc.warmi, Md_w = lc.Md_w;
+    const bool wlim = __any(lsgn != 0.f);               // wave-uniform: somebody's joint is at its limit (rare): every limit term is guarded by it
     const float scale = 1.0f / (m.meaninertia * 13.f);
     const float tol = fmaxf(m.tolerance, NEWTON_TOL);       // fp32 noise floor of the scaled gradient is ~1e-6
     // this lane's row of the (always block-diagonal) mass matrix, the seven entries of its own block
@@ -1752,7 +1829,7 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
     bool take_w_dbg = false; float g2w_dbg = 0.f, g2s_dbg = 0.f;
 #endif
     {   Cone cn_w; float lc_s, lc_w, jt_s, jt_w, hd_s, hd_w;
-        price_two_starts(m, cx, lsgn, lD, laref, qsi, warmi, ncon, c, live, lc.jar_s, lc.jar_w, cn, cn_w, lc_s, lc_w, jt_s, jt_w, hd_s, hd_w);
+        price_two_starts(m, cx, lsgn, lD, laref, qsi, warmi, ncon, c, live, lc.jar_s, lc.jar_w, cn, cn_w, lc_s, lc_w, jt_s, jt_w, hd_s, hd_w, wlim);
         const float cost_s = sum16(lc_s);                                   // M (x - a_s) = 0 at x = a_s
         const float cost_w = sum16(0.5f * Md_w * (warmi - qsi) + lc_w);
         // converged when the scaled gradient is below the model's tolerance -- or below what fp32 can resolve: g = M(x - a_s) - J^T f
@@ -1857,7 +1934,8 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
                     for (int r = 0; r < 4; r++) dp = fmaf(cn.grad[r], c.jv[r], dp);
                     hp = cone_quad(cn, c.jv);
                 }
-                {   float jv = lsgn * pi, xx = lsgn * xi - laref;
+                if (wlim) {
+                    float jv = lsgn * pi, xx = lsgn * xi - laref;
                     bool act = lsgn != 0.f && xx < 0.f;
                     dp += act ? lD * xx * jv : 0.f; hp += act ? lD * jv * jv : 0.f; }
                 dp = sum16(dp) + g0; hp = sum16(hp) + g1;
@@ -1870,7 +1948,7 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
                 if (!__any(!lsdone)) break;
                 if (!lsdone) {
                     float dp, hp;
-                    line_eval(m, lsgn, lD, laref, xi, pi, c, live, alpha, g0, g1, dp, hp, cn);
+                    line_eval(m, lsgn, lD, laref, xi, pi, c, live, alpha, g0, g1, dp, hp, cn, wlim);
                     if (fabsf(dp) < gtol) lsdone = true;
                     else {
                         if (dp < 0.f) lo = alpha; else hi = alpha;
@@ -1892,7 +1970,7 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
                 iters++;
                 // ---- price the new point; stop on the gradient, on a stalled cost, or at the iteration limit
                 STAMP(st, 4);
-                const float lcst = price_constraints(m, cx, lsgn, lD, laref, xi, ncon, c, live, cn, jtfi, hdiag);
+                const float lcst = price_constraints(m, cx, lsgn, lD, laref, xi, ncon, c, live, cn, jtfi, hdiag, wlim);
                 const float gn = Mdi - jtfi;
                 const float g2 = sum16(gn * gn), t2 = sum16(Mdi * Mdi + jtfi * jtfi);
                 bool stop = scale * sqrtf(g2) < tol || g2 < NEWTON_GRAD_NOISE * NEWTON_GRAD_NOISE * t2;
@@ -2086,12 +2164,14 @@ DEVI void integrate(const DevModel &m, const Ctx &cx, float qacci, float jtfi, f
         float inv = rsqrtf(rw * rw + rx * rx + ry * ry + rz * rz);
         qpos[10] = rw * inv; qpos[11] = rx * inv; qpos[12] = ry * inv; qpos[13] = rz * inv;
     }
-    bool bad = false;
+    // diverged? One sum of magnitudes instead of 27 compares: it is NaN or huge as soon as any component is (a runaway state grows by orders of
+    // magnitude per step, so "some component beyond 1e6" and "the sum beyond 1e6" fire on the same step)
+    float mag = 0.f;
 #pragma unroll
-    for (int i = 0; i < 14; i++) bad |= !(fabsf(qpos[i]) < 1e6f);
+    for (int i = 0; i < 14; i++) mag += fabsf(qpos[i]);
 #pragma unroll
-    for (int i = 0; i < 13; i++) bad |= !(fabsf(qvel[i]) < 1e6f);
-    if (bad) env_fault_or(cx, 1);
+    for (int i = 0; i < 13; i++) mag += fabsf(qvel[i]);
+    if (!(mag < 1e6f)) env_fault_or(cx, 1);
     if (cx.sub == 0) { lds_st<14>(S + ES_QPOS, qpos); lds_st<13>(S + ES_QVEL, qvel); }
 #pragma unroll
     for (int i = 0; i < 7; i++) qnew[i] = qpos[i];
