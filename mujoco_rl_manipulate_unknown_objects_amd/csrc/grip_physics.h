@@ -825,19 +825,21 @@ DEVI void gathered_solve_block(const Ctx &cx, const float (&row)[7], float gi, f
     float4 *H4 = reinterpret_cast<float4 *>(cx.envl + EF_H);
     const int lsub = local_sub(cx);
     if (lsub < 13) { H4[2 * lsub] = make_float4(row[0], row[1], row[2], row[3]); H4[2 * lsub + 1] = make_float4(row[4], row[5], row[6], -gi); }
-    // row 13 does not exist: the object block's seventh row is the identity, with a zero right-hand side -- written once per solve by lane 13, so that the
-    // object lanes read rows 7..13 like the gripper lanes read rows 0..6 (no per-entry selects; an object row's seventh word is zero already)
-    if (lsub == 13) { H4[26] = make_float4(0.f, 0.f, 0.f, 0.f); H4[27] = make_float4(0.f, 0.f, 1.f, 0.f); }
     wave_sync();
-    const int base = lsub < 7 ? 0 : 7;
+    const bool grip = lsub < 7;
+    const int base = grip ? 0 : 7;
     float A[28];
 #pragma unroll
     for (int i = 0; i < 7; i++) {
-        const float4 a = H4[2 * (base + i)], b = H4[2 * (base + i) + 1];
+        // row 13 does not exist: the object block's seventh row is the identity, selected per entry (reading it from an LDS row that lane 13 writes once per
+        // solve instead was measured: -0.5 %, the extra store and its wait cost more than the ~30 selects)
+        const int r = (i < 6 || grip) ? base + i : base;
+        const float4 a = H4[2 * r], b = H4[2 * r + 1];
         const float e[7] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z};
+        const bool pad = i == 6 && !grip;
 #pragma unroll
-        for (int j = 0; j <= i; j++) A[pidx(i, j)] = e[j];
-        x[i] = b.w;
+        for (int j = 0; j <= i; j++) A[pidx(i, j)] = pad ? (j == 6 ? 1.f : 0.f) : e[j];
+        x[i] = pad ? 0.f : b.w;
     }
     wave_sync();                                        // the area is rewritten by the next pricing: reads first (one wave, in order)
     chol_packed<7>(A);
