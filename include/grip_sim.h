@@ -261,6 +261,10 @@ int grip_tanh_backward_colsum(const float *g_dev, const float *h_dev, float *gz_
 int grip_relu_backward_colsum(const float *g_dev, int g_row_stride, const float *h_dev, float *gz_dev, int n, int cols, float *scratch_dev, float *grad_bias_dev,
                               void *stream);
 
+/* z = tanh(z + bias) in place: z_dev float32 [batch, n, cols] contiguous, bias_dev [batch, cols], cols a multiple of 4 (a tanh layer of the policy | value MLPs,
+ * models as stable_baselines3's MlpExtractor builds them for the reference's net_arch, after a batched GEMM that has no bias epilogue). */
+int grip_bias_tanh(float *z_dev, const float *bias_dev, int batch, int n, int cols, void *stream);
+
 /* PPO's clipped-surrogate loss of one minibatch and its gradients in one launch (the update stable_baselines3's PPO.train runs for the
  * reference's train_agent.py:33-47: advantages normalised per minibatch, clip_range, no value clipping, diagonal Gaussian with a
  * state-independent log_std): mean_dev / actions_dev float32 [n, action_dim], log_std_dev [action_dim], values / old_log_prob /
@@ -269,6 +273,15 @@ int grip_relu_backward_colsum(const float *g_dev, int g_row_stride, const float 
 int grip_ppo_loss(const float *mean_dev, const float *log_std_dev, const float *values_dev, const float *actions_dev, const float *old_log_prob_dev,
                   const float *advantages_dev, const float *returns_dev, int n, int action_dim, float clip_range, float ent_coef, float vf_coef,
                   float *out_dev, float *grad_mean_dev, float *grad_values_dev, float *grad_log_std_dev, void *stream);
+/* The same loss for the update's explicit launch sequence (sb3/fused_update.py), two launches: (1) the minibatch's rows rows_dev[0..n) (int64) of the rollout's
+ * sample arrays actions_dev [R, action_dim], old_log_prob_dev / advantages_dev / returns_dev [R] are gathered into samples_dev (n * (action_dim + 3) floats:
+ * actions | old_log_prob | advantages | returns); (2) the loss reads mean and value in the layout of the merged heads' last batch-of-two GEMM --
+ * heads_out_dev float32 [2, n, 8] WITHOUT the heads' biases, head_bias_dev [2, 8] beside it: [0, i, :action_dim] + bias[0] = mean_i, [1, i, 0] + bias[1][0] =
+ * value_i -- and writes grad_heads_out_dev [2, n, 8] in that layout (padding = 0),
+ * grad_head_bias_dev [2, 8] = its column sums (the action / value heads' bias gradients) and grad_log_std_dev [action_dim]; out_dev as above. */
+int grip_ppo_loss_heads(const float *heads_out_dev, const float *head_bias_dev, const float *log_std_dev, const float *actions_dev, const float *old_log_prob_dev, const float *advantages_dev,
+                        const float *returns_dev, const int64_t *rows_dev, int n, int action_dim, float clip_range, float ent_coef, float vf_coef, float *samples_dev,
+                        float *out_dev, float *grad_heads_out_dev, float *grad_head_bias_dev, float *grad_log_std_dev, void *stream);
 
 /* ---- batch sets: several batches -- other object models, other target directions -- stepped by ONE launch per phase
  * (BASELINE.json configs[3]: {acorn, sand_ball, sugar_cube, bread_crumb} x direction {0, 45} in one process). Env ids are

@@ -68,6 +68,9 @@ struct DevModel {
     int hull_padr[GN_HULL], hull_pnum[GN_HULL];
     float hull_aabb[GN_HULL][6];                // min xyz, max xyz of the hull's vertices in its geom frame (observation kernel: ray cull)
     const float *hull_planes;                   // [nplane][4] n.x <= d, body frame
+    // face polygons (observation kernel's rasteriser): plane j's corners are hull_loops[hull_ladr[j] .. hull_ladr[j + 1]) -- vertex ids local to the plane's
+    // hull, counter-clockwise seen from outside; an empty range = the plane is a duplicate of an earlier one of the same face
+    const int *hull_ladr, *hull_loops;
 };
 
 struct DevConfig {

@@ -121,8 +121,9 @@ static_assert(ES_QPOS % 4 == 0 && ENV_FLOATS % 4 == 0 && ES_KIN % 4 == 0, "state
 #define LS_MAXIT 16
 #endif
 #ifndef LS_GTOL
-#define LS_GTOL 1e-4f
-#endif
+#define LS_GTOL 1e-4f          // relative slope at which the exact line search stops. 1e-3 (MuJoCo's own ls_tolerance is 1e-2) measures +1 % with the same number of
+#endif                       // exactly matching fixture lanes (372 of 379), but the solutions get ~75 x more sensitive to their inputs: the warm- against cold-portal
+                             // builds end 2.6e-4 m apart after 25 steps instead of 3.5e-6 (tests/test_gpu_parity.py) -- measured in round 4, not taken; 1e-2: +2.5 %, three lanes lost
 #define MPR_TOL_F 1e-6f
 #define MPR_MAXIT 50
 #define LUT_RES 8
@@ -854,10 +855,10 @@ DEVI void make_tangents(V3 n, V3 &t1, V3 &t2) {
 }
 
 // Support vertex of the hull starting at vertex offset `base` (cube-map table `h`) for the LOCAL direction dl:
-// start at the table entry and hill-climb the edge graph to the best neighbour until none improves. Four
-// neighbour tests per iteration so that their dependent index -> vertex LDS hops overlap.
+// start at the table entry and hill-climb the edge graph to the best neighbour until none improves. Six
+// neighbour tests per iteration so that their dependent index -> vertex LDS hops overlap (2: -1.5 %, 4: -0.5 % against 6, same box).
 #ifndef SUP_NB
-#define SUP_NB 4                // neighbours tested per pass of the hill climb
+#define SUP_NB 6                // neighbours tested per pass of the hill climb
 #endif
 // `adj` (out): the support vertex's adjacency range as packed in its 4th word (CSR offset | degree << 16).
 DEVI int support_vertex(const Tables &T, int h, int base, V3 dl, V3 &vout, int hint, unsigned &adj) {

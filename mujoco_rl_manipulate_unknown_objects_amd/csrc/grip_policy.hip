@@ -207,11 +207,18 @@ __device__ __forceinline__ float pl_block_sum(float v, float *red) {
     return s;
 }
 
+// HEADS (the update's explicit path, sb3/fused_update.py): mean / values are read from, and their gradients written in, the layout of the merged heads' last
+// batch-of-two GEMM -- o [2, n, 8]: o[0, i, :A] = mean_i, o[1, i, 0] = value_i, go likewise with the padding written as zeros -- and g_head_bias [2, 8] receives go's
+// column sums (the action / value heads' bias gradients), so that nothing elementwise is left between the loss and the backward GEMMs.
+template <bool HEADS>
 __global__ void __launch_bounds__(PL_THREADS) k_ppo_loss(const float *__restrict__ mean, const float *__restrict__ log_std, const float *__restrict__ values,
                                                         const float *__restrict__ actions, const float *__restrict__ old_logp, const float *__restrict__ adv,
                                                         const float *__restrict__ ret, int n, int A, float clip, float ent_coef, float vf_coef,
-                                                        float *__restrict__ out, float *__restrict__ g_mean, float *__restrict__ g_values, float *__restrict__ g_log_std) {
+                                                        float *__restrict__ out, float *__restrict__ g_mean, float *__restrict__ g_values, float *__restrict__ g_log_std,
+                                                        const float *__restrict__ head_bias, float *__restrict__ g_head_bias) {
+    const int MS = HEADS ? PL_MAXA : A, VS = HEADS ? PL_MAXA : 1;             // row strides of mean / g_mean and of values / g_values
     __shared__ float red[PL_THREADS / 64];
+    __shared__ float redm[PL_THREADS / 64][2 * PL_MAXA + 4];                  // the end's sums, all at once: one barrier instead of one pair per sum
     const int tid = threadIdx.x;
     float s = 0.f;
     for (int i = tid; i < n; i += PL_THREADS) s += adv[i];
@@ -220,15 +227,20 @@ __global__ void __launch_bounds__(PL_THREADS) k_ppo_loss(const float *__restrict
     for (int i = tid; i < n; i += PL_THREADS) { const float d = adv[i] - am; s += d * d; }
     const float asd = sqrtf(pl_block_sum(s, red) / (float)(n - 1));
     const float ainv = 1.0f / (asd + 1e-8f), invn = 1.0f / (float)n;
-    float ls[PL_MAXA], isig[PL_MAXA], gls[PL_MAXA], lsum = 0.f;
+    float ls[PL_MAXA], isig[PL_MAXA], gls[PL_MAXA], gms[PL_MAXA], hb[PL_MAXA], lsum = 0.f;
 #pragma unroll
-    for (int k = 0; k < PL_MAXA; k++) { ls[k] = k < A ? log_std[k] : 0.f; isig[k] = expf(-ls[k]); gls[k] = 0.f; lsum += k < A ? ls[k] : 0.f; }
-    float sobj = 0.f, sv = 0.f;
+    for (int k = 0; k < PL_MAXA; k++) {
+        ls[k] = k < A ? log_std[k] : 0.f; isig[k] = expf(-ls[k]); gls[k] = 0.f; gms[k] = 0.f; lsum += k < A ? ls[k] : 0.f;
+        hb[k] = (HEADS && k < A) ? head_bias[k] : 0.f;                        // HEADS: the heads' GEMM ran without its bias
+    }
+    const float hbv = HEADS ? head_bias[PL_MAXA] : 0.f;
+    float sobj = 0.f, sv = 0.f, gvs = 0.f;
     for (int i = tid; i < n; i += PL_THREADS) {
         float z[PL_MAXA], lp = 0.f;
 #pragma unroll
         for (int k = 0; k < PL_MAXA; k++) {
-            z[k] = k < A ? (actions[(size_t)i * A + k] - mean[(size_t)i * A + k]) * isig[k] : 0.f;
+            const float mu = k < A ? (HEADS ? mean[(size_t)i * MS + k] + hb[k] : mean[(size_t)i * MS + k]) : 0.f;
+            z[k] = k < A ? (actions[(size_t)i * A + k] - mu) * isig[k] : 0.f;
             lp += k < A ? -0.5f * z[k] * z[k] - ls[k] - 0.9189385332046727f : 0.f;
         }
         const float lr_raw = lp - old_logp[i];
@@ -242,24 +254,66 @@ __global__ void __launch_bounds__(PL_THREADS) k_ppo_loss(const float *__restrict
         const float w1 = s1 < s2 ? 1.f : (s1 == s2 ? 0.5f : 0.f), w2 = (s2 < s1 ? 1.f : (s1 == s2 ? 0.5f : 0.f)) * (inside ? 1.f : 0.f);
         const float pass = (lr_raw >= -20.f && lr_raw <= 20.f) ? 1.f : 0.f;
         const float coef = -invn * Ai * (w1 + w2) * ratio * pass;                  // dloss / dlogp_i
+        if (HEADS) {                                                               // the padded rows leave as two 16-byte stores each
+            float gm[PL_MAXA];
 #pragma unroll
-        for (int k = 0; k < PL_MAXA; k++) if (k < A) {
-            g_mean[(size_t)i * A + k] = coef * z[k] * isig[k];
-            gls[k] += coef * (z[k] * z[k] - 1.f);
+            for (int k = 0; k < PL_MAXA; k++) {
+                gm[k] = k < A ? coef * z[k] * isig[k] : 0.f;
+                gms[k] += gm[k];
+                gls[k] += k < A ? coef * (z[k] * z[k] - 1.f) : 0.f;
+            }
+            float4 *gp = reinterpret_cast<float4 *>(g_mean + (size_t)i * PL_MAXA);
+            gp[0] = make_float4(gm[0], gm[1], gm[2], gm[3]); gp[1] = make_float4(gm[4], gm[5], gm[6], gm[7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < PL_MAXA; k++) if (k < A) {
+                g_mean[(size_t)i * A + k] = coef * z[k] * isig[k];
+                gls[k] += coef * (z[k] * z[k] - 1.f);
+            }
         }
-        const float dv = values[i] - ret[i];
+        const float dv = (HEADS ? values[(size_t)i * VS] + hbv : values[i]) - ret[i];
         sv += dv * dv;
-        g_values[i] = vf_coef * 2.f * dv * invn;
+        const float gv = vf_coef * 2.f * dv * invn;
+        if (HEADS) {
+            float4 *gp = reinterpret_cast<float4 *>(g_values + (size_t)i * PL_MAXA);
+            gp[0] = make_float4(gv, 0.f, 0.f, 0.f); gp[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            gvs += gv;
+        } else g_values[i] = gv;
     }
-    const float pl = -pl_block_sum(sobj, red) * invn, vl = pl_block_sum(sv, red) * invn;
+    // every sum of the end in one pass: wave sums by shuffles, one barrier, then thread k adds the 16 wave sums of value k in wave order (the order
+    // pl_block_sum adds them in: the results are the bits the one-sum-at-a-time version produced)
+    auto wsum = [](float v) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+        return v;
+    };
+    const int w = tid >> 6;
+    const bool lead = (tid & 63) == 0;
+    { const float v = wsum(sobj); if (lead) redm[w][0] = v; }
+    { const float v = wsum(sv); if (lead) redm[w][1] = v; }
+    { const float v = wsum(gvs); if (lead) redm[w][2] = v; }
 #pragma unroll
     for (int k = 0; k < PL_MAXA; k++) {
-        if (k < A) {                                                                // A is uniform: every thread takes the same reductions
-            const float g = pl_block_sum(gls[k], red);
-            if (tid == 0) g_log_std[k] = g - ent_coef;
-        }
+        { const float v = wsum(gls[k]); if (lead) redm[w][4 + k] = v; }
+        if (HEADS) { const float v = wsum(gms[k]); if (lead) redm[w][4 + PL_MAXA + k] = v; }
     }
+    __syncthreads();
+    float tot = 0.f;
+    if (tid < 2 * PL_MAXA + 4) {
+#pragma unroll
+        for (int i = 0; i < PL_THREADS / 64; i++) tot += redm[i][tid];
+    }
+    if (tid >= 4 && tid < 4 + A) g_log_std[tid - 4] = tot - ent_coef;
+    if (HEADS) {
+        if (tid >= 4 + PL_MAXA && tid < 4 + 2 * PL_MAXA) { const int k = tid - 4 - PL_MAXA; g_head_bias[k] = k < A ? tot : 0.f; if (k > 0) g_head_bias[PL_MAXA + k] = 0.f; }
+        if (tid == 2) g_head_bias[PL_MAXA] = tot;
+    }
+    __syncthreads();
     if (tid == 0) {
+        float so = 0.f, sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < PL_THREADS / 64; i++) { so += redm[i][0]; sq += redm[i][1]; }
+        const float pl = -so * invn, vl = sq * invn;
         const float el = -((float)A * (0.5f + 0.9189385332046727f) + lsum);
         out[0] = pl + ent_coef * el + vf_coef * vl; out[1] = pl; out[2] = vl;
     }
@@ -271,10 +325,39 @@ extern "C" int grip_ppo_loss(const float *mean_dev, const float *log_std_dev, co
     if (!mean_dev || !log_std_dev || !values_dev || !actions_dev || !old_log_prob_dev || !advantages_dev || !returns_dev || !out_dev || !grad_mean_dev ||
         !grad_values_dev || !grad_log_std_dev || n < 2 || action_dim < 1 || action_dim > PL_MAXA)
         return grip_fail("grip_ppo_loss: need n >= 2 rows, 1..8 action dimensions and every array");
-    hipLaunchKernelGGL(k_ppo_loss, dim3(1), dim3(PL_THREADS), 0, (hipStream_t)stream, mean_dev, log_std_dev, values_dev, actions_dev, old_log_prob_dev, advantages_dev,
-                       returns_dev, n, action_dim, clip_range, ent_coef, vf_coef, out_dev, grad_mean_dev, grad_values_dev, grad_log_std_dev);
+    hipLaunchKernelGGL(k_ppo_loss<false>, dim3(1), dim3(PL_THREADS), 0, (hipStream_t)stream, mean_dev, log_std_dev, values_dev, actions_dev, old_log_prob_dev, advantages_dev,
+                       returns_dev, n, action_dim, clip_range, ent_coef, vf_coef, out_dev, grad_mean_dev, grad_values_dev, grad_log_std_dev, (const float *)nullptr, (float *)nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { char buf[160]; snprintf(buf, sizeof buf, "grip_ppo_loss: %s", hipGetErrorString(e)); return grip_fail(buf); }
+    return 0;
+}
+
+// rows idx[0..n) of the rollout's sample arrays into one packed block: samples = actions [n, A] | old_log_prob [n] | advantages [n] | returns [n]  (one launch for
+// the four gathers of a minibatch)
+__global__ void __launch_bounds__(256) k_gather_samples(const float *__restrict__ actions, const float *__restrict__ logp, const float *__restrict__ adv,
+                                                       const float *__restrict__ ret, const int64_t *__restrict__ idx, int n, int A, float *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = idx[i];
+    for (int k = 0; k < A; k++) out[(size_t)i * A + k] = actions[r * A + k];
+    out[(size_t)n * A + i] = logp[r]; out[(size_t)n * (A + 1) + i] = adv[r]; out[(size_t)n * (A + 2) + i] = ret[r];
+}
+
+extern "C" int grip_ppo_loss_heads(const float *heads_out_dev, const float *head_bias_dev, const float *log_std_dev, const float *actions_dev, const float *old_log_prob_dev,
+                                   const float *advantages_dev, const float *returns_dev, const int64_t *rows_dev, int n, int action_dim, float clip_range,
+                                   float ent_coef, float vf_coef, float *samples_dev, float *out_dev, float *grad_heads_out_dev, float *grad_head_bias_dev,
+                                   float *grad_log_std_dev, void *stream) {
+    if (!heads_out_dev || !head_bias_dev || !log_std_dev || !actions_dev || !old_log_prob_dev || !advantages_dev || !returns_dev || !rows_dev || !samples_dev || !out_dev ||
+        !grad_heads_out_dev || !grad_head_bias_dev || !grad_log_std_dev || n < 2 || action_dim < 1 || action_dim > PL_MAXA)
+        return grip_fail("grip_ppo_loss_heads: need n >= 2 rows, 1..8 action dimensions and every array");
+    const int A = action_dim;
+    hipLaunchKernelGGL(k_gather_samples, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, actions_dev, old_log_prob_dev, advantages_dev, returns_dev, rows_dev, n, A,
+                       samples_dev);
+    float *sa = samples_dev, *sl = samples_dev + (size_t)n * A, *sd = sl + n, *sr = sd + n;
+    hipLaunchKernelGGL(k_ppo_loss<true>, dim3(1), dim3(PL_THREADS), 0, (hipStream_t)stream, heads_out_dev, log_std_dev, heads_out_dev + (size_t)n * PL_MAXA, sa, sl, sd, sr, n, A,
+                       clip_range, ent_coef, vf_coef, out_dev, grad_heads_out_dev, grad_heads_out_dev + (size_t)n * PL_MAXA, grad_log_std_dev, head_bias_dev, grad_head_bias_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { char buf[160]; snprintf(buf, sizeof buf, "grip_ppo_loss_heads: %s", hipGetErrorString(e)); return grip_fail(buf); }
     return 0;
 }
 

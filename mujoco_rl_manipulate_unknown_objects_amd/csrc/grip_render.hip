@@ -453,6 +453,316 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same observation by RASTERISING the hulls' faces instead of clipping every ray against every plane (round 4, second half). The ray caster above
+// spends 85 % of its time in the two plane loops -- a ray that passes a hull's bounding box is tested against all of the hull's planes, twice -- although a
+// convex hull shows every pixel exactly one camera-facing face. Here the loop is turned round: the model carries every face's corner loop (DevModel::hull_loops,
+// model/compiler.py build_hull), the hull vertices are taken to camera coordinates once per env, and every camera-facing face (B < 0 in t (A.dc) <= B) tests
+// only the pixels of its own screen bounding box:
+//   a ray t dc hits the face  <=>  dc . (v_i x v_{i+1}) <= 0 for every edge of the loop (counter-clockwise seen from outside; the edge planes pass through the
+//   camera, so nothing is projected and vertices behind the camera need no clipping), and then t = B / (A.dc) -- the quotient the ray caster forms for its
+//   entering plane, from the same A and B: the depth of a pixel is bit-identical wherever the same face wins.
+// An edge's normal is always formed from its two vertices in the order of their indices and negated for the face that runs it backwards: the two faces of an
+// edge see exactly opposite values, so a ray through an edge is claimed by both or by either, never by none (no holes), and the z-buffer -- 64-bit LDS words
+// (depth bits | geom | plane) under an atomic minimum -- makes the outcome independent of the order of arrival: the image is reproducible bit for bit.
+// Work distribution: one thread per face sets it up (plane, loop, screen box); faces of at most RS_SMALL box pixels and four corners (the bulk: the hulls are
+// tessellated meshes) are rasterised by that thread; the others leave a record (plane, edge normals) and one work item per 8 x 8 pixel tile their box touches,
+// which the waves then take in turn, a lane per pixel. Tables that overflow fall back to the setting-up thread walking the box itself (correct, slow, not seen).
+// Differences from the ray caster: only pixels whose ray passes within rounding of a face's edge (tools/render_ab.py counts them).
+#define RS_SMALL 16
+#define RS_FACES 384
+#define RS_ITEMS 3072
+#define RS_EDGES 1024
+#define RS_DYN_BYTES(nverts) ((size_t)(((nverts) * 3 + 3) / 4 * 4) * 4 + (size_t)RS_FACES * 32 + (size_t)RS_EDGES * 12 + (size_t)RS_ITEMS * 2)
+struct __align__(16) RsFace { float4 P; int ebase, k, id, pad; };
+
+__device__ __forceinline__ void rs_claim(unsigned long long *zb, int pix, float t, int id) {
+    atomicMin(zb + pix, ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)id);
+}
+
+__device__ __forceinline__ void observe_body_raster(const DevModel &m, const DevConfig &cfg, const float *qpos, const int *pad_grasp, const int *pad_pher,
+                                                    int n, int e, uint8_t *obs, uint8_t *obs2, const long long *row2, int nverts_max) {
+    __shared__ Frames fr;
+    __shared__ float gmx[GN_GEOM][12];          // plane / vertex transform of a hull: Rg^T Rc (row-major), Rg^T (co - pg)
+    __shared__ int gadr[GN_GEOM + 1], gvadr[GN_GEOM + 1], gnum[GN_GEOM];      // visible hulls: prefix sums of their planes / vertices; planes (0 = not visible)
+    __shared__ int nfaces, nedges, nitems;
+    // the z-buffer (32 KB) while the faces are drawn; afterwards the composed observation (20 KB) and the two reductions' scratch
+    __shared__ __align__(16) unsigned char pool[8 * RPIX];
+    extern __shared__ float4 rs_dyn[];
+    unsigned long long *zb = reinterpret_cast<unsigned long long *>(pool);
+    uint8_t *img = pool; float *red = reinterpret_cast<float *>(pool + 5 * RPIX); int *redi = reinterpret_cast<int *>(pool + 6 * RPIX);
+    float *cv = reinterpret_cast<float *>(rs_dyn);                                       // camera-space vertices of the visible hulls, xyz
+    RsFace *frec = reinterpret_cast<RsFace *>(cv + (nverts_max * 3 + 3) / 4 * 4);
+    float *en = reinterpret_cast<float *>(frec + RS_FACES);                               // edge normals of the recorded faces
+    unsigned short *items = reinterpret_cast<unsigned short *>(en + 3 * RS_EDGES);        // record << 6 | tile
+    const int tid = threadIdx.x;
+    if (tid < 7) frame_role(m, qpos, n, e, cfg.state_half, tid, fr);
+    if (tid == 0) { nfaces = 0; nedges = 0; nitems = 0; }
+    for (int i = tid; i < RPIX; i += RTHREADS) zb[i] = ~0ull;
+    for (int i = tid; i < RS_ITEMS; i += RTHREADS) items[i] = 0xffffu;
+    __syncthreads();
+    if (tid >= 1 && tid < GN_GEOM) {                                    // thread g: is hull g in front of the camera? its transform (as in the ray caster)
+        const int g = tid;
+        V3 co = ldv(fr.cam_o); M3 Rc = ldm(fr.cam_R);
+        V3 p = ldv(fr.p[g - 1]); M3 R = ldm(fr.R[g - 1]);
+        V3 c = multv(Rc, p + mulv(R, ldv(m.geom_center[g])) - co);
+        float r = m.geom_rbound[g];
+        gnum[g] = c.z - r < 0.f ? m.hull_pnum[g - 1] : 0;
+        M3 Mx = mulm(M3{{R.m[0], R.m[3], R.m[6], R.m[1], R.m[4], R.m[7], R.m[2], R.m[5], R.m[8]}}, Rc);
+        V3 ol = multv(R, co - p);
+#pragma unroll
+        for (int i = 0; i < 9; i++) gmx[g][i] = Mx.m[i];
+        gmx[g][9] = ol.x; gmx[g][10] = ol.y; gmx[g][11] = ol.z;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int a = 0, v = 0;
+        for (int g = 1; g < GN_GEOM; g++) { gadr[g] = a; gvadr[g] = v; if (gnum[g]) { a += gnum[g]; v += m.hull_vnum[g - 1]; } }
+        gadr[GN_GEOM] = a; gvadr[GN_GEOM] = v;
+    }
+    __syncthreads();
+    const float tanh_ = tanf(0.5f * m.cam_fovy * 0.017453292519943295f);
+    auto ray_x = [&](int px) { return (2.0f * (px + 0.5f) / RW - 1.0f) * tanh_; };       // the ray caster's expressions: the same floats
+    auto ray_y = [&](int py) { return (1.0f - 2.0f * (py + 0.5f) / RH) * tanh_; };
+    auto hull_of = [&](const int *adr, int i) { int g = 1; for (int h = 2; h < GN_GEOM; h++) g = (gnum[h] && i >= adr[h]) ? h : g; if (!gnum[g]) { for (int h = 1; h < GN_GEOM; h++) if (gnum[h]) { g = h; break; } } return g; };
+    // ---- vertices of the visible hulls -> camera coordinates: Mx^T (v - ol)
+    {
+        const int nv = gvadr[GN_GEOM];
+        const float4 *vb = reinterpret_cast<const float4 *>(m.hull_blob);
+        for (int i = tid; i < nv; i += RTHREADS) {
+            const int g = hull_of(gvadr, i);
+            const float4 v = vb[m.hull_vadr[g - 1] + (i - gvadr[g])];
+            const M3 Mx = ldm(gmx[g]);
+            const V3 c = multv(Mx, v3(v.x - gmx[g][9], v.y - gmx[g][10], v.z - gmx[g][11]));
+            cv[3 * i] = c.x; cv[3 * i + 1] = c.y; cv[3 * i + 2] = c.z;
+        }
+    }
+    __syncthreads();
+    // ---- one thread per face: set-up, and the small ones drawn on the spot
+    {
+        const int np = gadr[GN_GEOM];
+        for (int i = tid; i < np; i += RTHREADS) {
+            const int g = hull_of(gadr, i), j = i - gadr[g], jg = m.hull_padr[g - 1] + j;
+            const int l0 = m.hull_ladr[jg], K = m.hull_ladr[jg + 1] - l0;
+            if (K < 3) continue;                                        // a duplicate of an earlier plane of the same face
+            const float *pl = m.hull_planes + 4 * jg;
+            const V3 nn = v3(pl[0], pl[1], pl[2]);
+            const M3 Mx = ldm(gmx[g]);
+            const V3 A = multv(Mx, nn);
+            const float B = pl[3] - dot(nn, v3(gmx[g][9], gmx[g][10], gmx[g][11]));
+            if (!(B < 0.f)) continue;                                   // the camera is not outside this plane: no ray enters through it
+            const float *cvg = cv + 3 * gvadr[g];
+            const int *lp = m.hull_loops + l0;
+            // screen box of the loop; a corner at or behind the camera plane makes it the whole screen (the edge tests need no projection)
+            int id4[4]; V3 v4[4];
+            float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f, zmax = -3.0e38f, zmin = 3.0e38f;
+            auto take = [&](V3 v) {
+                const float iz = rcp(-v.z), px = v.x * iz, py = v.y * iz;
+                xmin = fminf(xmin, px); xmax = fmaxf(xmax, px); ymin = fminf(ymin, py); ymax = fmaxf(ymax, py); zmax = fmaxf(zmax, v.z); zmin = fminf(zmin, v.z);
+            };
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                id4[k] = lp[k < K ? k : 0];
+                v4[k] = v3(cvg[3 * id4[k]], cvg[3 * id4[k] + 1], cvg[3 * id4[k] + 2]);
+                take(v4[k]);
+            }
+            for (int k = 4; k < K; k++) { const int id = lp[k]; take(v3(cvg[3 * id], cvg[3 * id + 1], cvg[3 * id + 2])); }
+            if (zmin >= 0.f) continue;                                  // wholly behind the camera plane
+            int x0 = 0, x1 = RW - 1, y0 = 0, y1 = RH - 1;
+            const bool behind = zmax > -1e-4f;
+            if (!behind) {
+                // pixel px's ray is ((2 (px + 0.5) / RW - 1) tanh): px + 0.5 = (x / tanh + 1) RW / 2
+                const float sx = 0.5f * RW / tanh_, sy = 0.5f * RH / tanh_;
+                const float fx0 = xmin * sx + 0.5f * RW - 0.5f, fx1 = xmax * sx + 0.5f * RW - 0.5f;
+                const float fy0 = 0.5f * RH - ymax * sy - 0.5f, fy1 = 0.5f * RH - ymin * sy - 0.5f;
+                if (fx1 < -0.01f || fy1 < -0.01f || fx0 > RW - 0.99f || fy0 > RH - 0.99f) continue;       // off screen
+                x0 = max(0, (int)ceilf(fx0 - 0.01f)); x1 = min(RW - 1, (int)floorf(fx1 + 0.01f));
+                y0 = max(0, (int)ceilf(fy0 - 0.01f)); y1 = min(RH - 1, (int)floorf(fy1 + 0.01f));
+                if (x0 > x1 || y0 > y1) continue;                       // between pixel centres
+            }
+            const int idw = (g << 16) | j;
+            const int area = (x1 - x0 + 1) * (y1 - y0 + 1);
+            // the edge (a, b) of the loop: normal of the plane through the camera, formed in index order
+            auto edge = [&](int ia, V3 a, int ib, V3 b) { const bool sw = ia > ib; const V3 c = cross(sw ? b : a, sw ? a : b); return sw ? -c : c; };
+            if (K <= 4 && area <= RS_SMALL) {
+                V3 ne[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int kn = (k + 1 < K) ? k + 1 : 0;
+                    ne[k] = k < K ? edge(id4[k], v4[k], id4[kn], v4[kn]) : v3(0.f, 0.f, 0.f);
+                }
+                int px = x0, py = y0;
+                for (int q = 0; q < area; q++) {
+                    const float x = ray_x(px), y = ray_y(py);
+                    bool in = true;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) in &= !(fmaf(ne[k].x, x, fmaf(ne[k].y, y, -ne[k].z)) > 0.f);
+                    const float den = fmaf(A.y, y, fmaf(A.x, x, -A.z));
+                    const float t = B * rcp(den);
+                    if (in && den < 0.f && t > 0.f && t > m.znear) rs_claim(zb, py * RW + px, t, idw);
+                    if (++px > x1) { px = x0; ++py; }
+                }
+                continue;
+            }
+            // a larger face: a record, its edge normals, one item per tile of its box
+            const int tx0 = x0 >> 3, tx1 = x1 >> 3, ty0 = y0 >> 3, ty1 = y1 >> 3, ntile = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+            int fi = atomicAdd(&nfaces, 1), eb = -1, ib = -1;
+            if (fi < RS_FACES) { eb = atomicAdd(&nedges, K); if (eb + K <= RS_EDGES) { ib = atomicAdd(&nitems, ntile); if (ib + ntile > RS_ITEMS) ib = -1; } }
+            if (ib >= 0) {
+                RsFace f; f.P = make_float4(A.x, A.y, A.z, B); f.ebase = eb; f.k = K; f.id = idw; f.pad = 0;
+                frec[fi] = f;
+                int ia = lp[0]; V3 a = v3(cvg[3 * ia], cvg[3 * ia + 1], cvg[3 * ia + 2]);
+                const int i0 = ia; const V3 a0 = a;
+                for (int k = 0; k < K; k++) {
+                    const int ib2 = k + 1 < K ? lp[k + 1] : i0;
+                    const V3 b = k + 1 < K ? v3(cvg[3 * ib2], cvg[3 * ib2 + 1], cvg[3 * ib2 + 2]) : a0;
+                    const V3 c = edge(ia, a, ib2, b);
+                    en[3 * (eb + k)] = c.x; en[3 * (eb + k) + 1] = c.y; en[3 * (eb + k) + 2] = c.z;
+                    ia = ib2; a = b;
+                }
+                int w = ib;
+                for (int ty = ty0; ty <= ty1; ty++) for (int tx = tx0; tx <= tx1; tx++) items[w++] = (unsigned short)((fi << 6) | (ty * 8 + tx));
+                continue;
+            }
+            // tables full: this thread walks the box itself
+            for (int py = y0; py <= y1; py++) for (int px = x0; px <= x1; px++) {
+                const float x = ray_x(px), y = ray_y(py);
+                bool in = true;
+                int ia = lp[0]; V3 a = v3(cvg[3 * ia], cvg[3 * ia + 1], cvg[3 * ia + 2]);
+                const int i0 = ia; const V3 a0 = a;
+                for (int k = 0; k < K; k++) {
+                    const int ib2 = k + 1 < K ? lp[k + 1] : i0;
+                    const V3 b = k + 1 < K ? v3(cvg[3 * ib2], cvg[3 * ib2 + 1], cvg[3 * ib2 + 2]) : a0;
+                    const V3 c = edge(ia, a, ib2, b);
+                    in &= !(fmaf(c.x, x, fmaf(c.y, y, -c.z)) > 0.f);
+                    ia = ib2; a = b;
+                }
+                const float den = fmaf(A.y, y, fmaf(A.x, x, -A.z));
+                const float t = B * rcp(den);
+                if (in && den < 0.f && t > 0.f && t > m.znear) rs_claim(zb, py * RW + px, t, idw);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the recorded faces, tile by tile: a wave per item, a lane per pixel
+    {
+        const int ni = min(nitems, RS_ITEMS), wv = tid >> 6, ln = tid & 63;
+        for (int it = wv; it < ni; it += RTHREADS / 64) {
+            const unsigned item = items[it];
+            if (item == 0xffffu) continue;                              // (the hole a refused allocation leaves)
+            const RsFace f = frec[item >> 6];
+            const int tile = item & 63, px = (tile & 7) * 8 + (ln & 7), py = (tile >> 3) * 8 + (ln >> 3);
+            const float x = ray_x(px), y = ray_y(py);
+            bool in = true;
+            const float *ep = en + 3 * f.ebase;
+            for (int k = 0; k < f.k; k++) in &= !(fmaf(ep[3 * k], x, fmaf(ep[3 * k + 1], y, -ep[3 * k + 2])) > 0.f);
+            const float den = fmaf(f.P.y, y, fmaf(f.P.x, x, -f.P.z));
+            const float t = f.P.w * rcp(den);
+            if (in && den < 0.f && t > 0.f && t > m.znear) rs_claim(zb, py * RW + px, t, f.id);
+        }
+    }
+    __syncthreads();
+    // ---- resolve: the thread's 2 x 2 tile against the floor, as the ray caster orders its hits
+    const Frames *frl = &fr;
+    asm volatile("" : "+v"(frl));
+    const int nch = cfg.full_observation ? 5 : 4;
+    uint8_t *o = obs ? obs + (size_t)blockIdx.x * nch * RPIX : nullptr;
+    uint8_t *o2 = obs2 ? obs2 + (size_t)(row2[0] + blockIdx.x) * nch * RPIX : nullptr;
+    constexpr int WPR = RW / (8 * TW);
+    const int w = tid >> 6, l = tid & 63;
+    const int tx = (l & 7) + 8 * (w % WPR), ty = (l >> 3) + 8 * (w / WPR);
+    float xs[TW], ys[TW];
+#pragma unroll
+    for (int a = 0; a < TW; a++) { xs[a] = ray_x(TW * tx + a); ys[a] = ray_y(TW * ty + a); }
+    float best[TPX]; int hitent[TPX];
+#pragma unroll
+    for (int q = 0; q < TPX; q++) {
+        float x = xs[q % TW], y = ys[q / TW];
+        float dz = frl->cam_R[6] * x + frl->cam_R[7] * y - frl->cam_R[8];
+        best[q] = m.zfar; hitent[q] = -1;
+        if (dz < 0.f) { float t = -frl->cam_o[2] / dz; if (t > m.znear && t < best[q]) { best[q] = t; hitent[q] = 0; } }
+        const unsigned long long z = zb[(TW * ty + q / TW) * RW + TW * tx + q % TW];
+        const float th = __uint_as_float((unsigned)(z >> 32));
+        if (z != ~0ull && th < best[q]) { best[q] = th; hitent[q] = (int)(unsigned)z; }
+    }
+    __syncthreads();                                                    // the z-buffer's space becomes the image and the reductions' scratch
+    // shading (lit_colour) and the RGB bytes
+    asm volatile("" : "+v"(frl));
+    const V3 co = ldv(frl->cam_o); const M3 Rc = ldm(frl->cam_R);
+    float lmin = 3.0e38f;
+    unsigned cb[3][TPX];
+#pragma unroll
+    for (int q = 0; q < TPX; q++) {
+        const float x = xs[q % TW], y = ys[q / TW];
+        const V3 dir = mulv(Rc, v3(x, y, -1.f));
+        const int hit = hitent[q] < 0 ? -1 : (hitent[q] >> 16);
+        float c0, c1, c2;
+        if (hit < 0) {
+            V3 dn = normalized(dir); float f = 0.5f * (dn.z + 1.0f);
+            c0 = m.sky_rgb[3] + f * (m.sky_rgb[0] - m.sky_rgb[3]); c1 = m.sky_rgb[4] + f * (m.sky_rgb[1] - m.sky_rgb[4]); c2 = m.sky_rgb[5] + f * (m.sky_rgb[2] - m.sky_rgb[5]);
+        } else {
+            float b0, b1, b2; V3 nrm = v3(0, 0, 1);
+            const V3 Pw = co + dir * best[q];
+            if (hit == 0) {
+                int cx = (int)floorf(Pw.x * 8.0f), cy = (int)floorf(Pw.y * 8.0f);
+                int off = ((cx + cy) & 1) ? 3 : 0;
+                b0 = m.floor_rgb[off]; b1 = m.floor_rgb[off + 1]; b2 = m.floor_rgb[off + 2];
+            } else {
+                b0 = m.geom_rgba[hit][0]; b1 = m.geom_rgba[hit][1]; b2 = m.geom_rgba[hit][2];
+                const float *pl = m.hull_planes + 4 * (m.hull_padr[hit - 1] + (hitent[q] & 0xffff));     // the winning face's normal in camera coordinates, as the set-up formed it
+                const V3 A = multv(ldm(gmx[hit]), v3(pl[0], pl[1], pl[2]));
+                nrm = normalized(mulv(Rc, A));
+            }
+            lit_colour(m, hit, b0, b1, b2, Pw, nrm, co, c0, c1, c2);
+        }
+        cb[0][q] = to_u8(c0); cb[1][q] = to_u8(c1); cb[2][q] = to_u8(c2);
+        lmin = fminf(lmin, best[q]);
+    }
+    auto put2 = [&](int ch, int r, unsigned lo, unsigned hi) {
+        const int px = (TW * ty + r) * RW + TW * tx;
+        *reinterpret_cast<uint16_t *>(img + ch * RPIX + px) = (uint16_t)(lo | (hi << 8));
+    };
+#pragma unroll
+    for (int r = 0; r < TW; r++) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) put2(ch, r, cb[ch][2 * r], cb[ch][2 * r + 1]);
+        put2(nch - 1, r, 0u, 0u);
+    }
+    // transform_depth (utils.py:11-19), as above
+    red[tid] = lmin; __syncthreads();
+    for (int s = RTHREADS / 2; s > 0; s >>= 1) { if (tid < s) red[tid] = fminf(red[tid], red[tid + s]); __syncthreads(); }
+    float dmin = red[0]; __syncthreads();
+    float lsum = 0.f; int lcnt = 0;
+#pragma unroll
+    for (int q = 0; q < TPX; q++) { float d = best[q] - dmin; if (d <= 1.0f) { lsum += d; lcnt++; } }
+    red[tid] = lsum; redi[tid] = lcnt; __syncthreads();
+    for (int s = RTHREADS / 2; s > 0; s >>= 1) { if (tid < s) { red[tid] += red[tid + s]; redi[tid] += redi[tid + s]; } __syncthreads(); }
+    float scale = 2.0f * (red[0] / (float)redi[0]);
+    if (cfg.full_observation) {
+        unsigned db[TPX];
+#pragma unroll
+        for (int q = 0; q < TPX; q++) {
+            float v = (best[q] - dmin) / scale; v = fminf(fmaxf(v, 0.f), 1.f);
+            float p = 255.0f * v;
+            db[q] = (p != p) ? 0u : (unsigned)(uint8_t)p;
+        }
+#pragma unroll
+        for (int r = 0; r < TW; r++) put2(3, r, db[2 * r], db[2 * r + 1]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int pg_ = GPTR(const int, pad_grasp)[e], pp_ = GPTR(const int, pad_pher)[e];
+        img[(nch - 1) * RPIX] = (uint8_t)pg_; img[(nch - 1) * RPIX + 1] = (uint8_t)pp_;
+    }
+    __syncthreads();
+    const uint4 *src = reinterpret_cast<const uint4 *>(img);
+    for (int i = tid; i < nch * RPIX / 16; i += RTHREADS) {
+        const uint4 v = src[i];
+        if (o) reinterpret_cast<uint4 *>(o)[i] = v;
+        if (o2) reinterpret_cast<uint4 *>(o2)[i] = v;
+    }
+}
+
 // One kernel for a batch and for a set of batches: per-batch arguments in device memory behind a const __restrict__ pointer
 // (workgroup-uniform index -> scalar loads). list != NULL: row b shows env list[b] (global id over the set; a negative entry is a
 // hole, rows >= *count -- when count is given -- are skipped too: their rows are left alone); list == NULL: row b = env b.

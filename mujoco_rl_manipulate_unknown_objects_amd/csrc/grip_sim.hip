@@ -71,6 +71,7 @@ struct GripModel {
     DevModel host;                       // pointer members are filled per device at batch creation
     std::vector<unsigned> hull_blob;     // vertices | nadr | nbr | lut (see DevModel)
     std::vector<float> planes;           // [nplane][4]
+    std::vector<int> loops;              // face polygons: CSR offsets [nplane + 1] | corner vertex ids (see DevModel)
     int nvert = 0;
 };
 
@@ -256,6 +257,20 @@ extern "C" int grip_model_load(const char *blob_path, GripModel **out) {
         m.light_params[l][3] = (float)cos(lpar[5 * l + 3] * 0.017453292519943295); m.light_params[l][4] = (float)lpar[5 * l + 4];
     }
     for (int k = 0; k < 3; k++) m.headlight[k] = (float)hlight[k];
+    {   // face polygons (round 4, second half): the observation kernel rasterises the hulls' faces
+        std::vector<int> ladr, lids;
+        const size_t np = gm->planes.size() / 4;
+        if (!(b.i32("hull_ladr", ladr, np + 1) && b.i32("hull_loops", lids))) {
+            delete gm; return fail(std::string("model blob lacks the face polygons (hull_ladr / hull_loops): recompile it with model/compiler.py (") + blob_path + ")");
+        }
+        bool ok = ladr[0] == 0 && (size_t)ladr[np] == lids.size();
+        for (size_t j = 0; ok && j < np; j++) ok = ladr[j + 1] >= ladr[j] && (ladr[j + 1] == ladr[j] || ladr[j + 1] - ladr[j] >= 3);
+        for (int h = 0; ok && h < 6; h++)
+            for (int j = hpadr[h]; ok && (ok = hpadr[h] >= 0 && (size_t)(hpadr[h] + hpnum[h]) <= np) && j < hpadr[h] + hpnum[h]; j++)
+                for (int k = ladr[j]; ok && k < ladr[j + 1]; k++) ok = lids[k] >= 0 && lids[k] < hvnum[h];
+        if (!ok) { delete gm; return fail("hull_ladr / hull_loops are not face polygons over the hulls' vertices"); }
+        gm->loops = ladr; gm->loops.insert(gm->loops.end(), lids.begin(), lids.end());
+    }
     *out = gm;
     return 0;
 }
@@ -273,7 +288,7 @@ struct StepOutDev {     // device copy of GripStepOut (kernel argument)
 
 struct GripBatch {
     int n = 0, device = 0;
-    DevModel hmodel; unsigned *d_hull = nullptr; float *d_planes = nullptr; size_t lds_bytes = 0;
+    DevModel hmodel; unsigned *d_hull = nullptr; float *d_planes = nullptr; int *d_loops = nullptr; size_t lds_bytes = 0;
     DevConfig cfg;
     float *qpos = nullptr, *qvel = nullptr, *ctrl = nullptr, *warm = nullptr;     // SoA [field][N]
     int *episode_step = nullptr, *status = nullptr, *gripper_open = nullptr;
@@ -1091,7 +1106,9 @@ static int batch_build(GripBatch *b, const GripModel *m) {
     b->nplanes = (int)(m->planes.size() / 4);
     HIPCHK(hipMalloc(&b->d_planes, m->planes.size() * sizeof(float)));
     HIPCHK(hipMemcpy(b->d_planes, m->planes.data(), m->planes.size() * sizeof(float), hipMemcpyHostToDevice));
-    DevModel hm_ = m->host; hm_.hull_blob = b->d_hull; hm_.hull_planes = b->d_planes;
+    HIPCHK(hipMalloc(&b->d_loops, m->loops.size() * sizeof(int)));
+    HIPCHK(hipMemcpy(b->d_loops, m->loops.data(), m->loops.size() * sizeof(int), hipMemcpyHostToDevice));
+    DevModel hm_ = m->host; hm_.hull_blob = b->d_hull; hm_.hull_planes = b->d_planes; hm_.hull_ladr = b->d_loops; hm_.hull_loops = b->d_loops + b->nplanes + 1;
     b->hmodel = hm_;
     HIPCHK(hipMalloc(&b->qpos, 14 * N * sizeof(float))); HIPCHK(hipMalloc(&b->qvel, 13 * N * sizeof(float)));
     HIPCHK(hipMalloc(&b->ctrl, 7 * N * sizeof(float))); HIPCHK(hipMalloc(&b->warm, 13 * N * sizeof(float)));
@@ -1124,7 +1141,7 @@ extern "C" void grip_batch_destroy(GripBatch *b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {b->d_hull, b->d_planes, b->qpos, b->qvel, b->ctrl, b->warm, b->episode_step, b->status,
+    void *ptrs[] = {b->d_hull, b->d_planes, b->d_loops, b->qpos, b->qvel, b->ctrl, b->warm, b->episode_step, b->status,
                     b->gripper_open, b->pad_grasp, b->pad_pher, b->reset_info, b->scratch, b->mc_ints, b->mc_flts, b->mc_astate,
                     b->mc_slot, b->mc_order, b->mc_heavy, b->mc_tick, b->mc_gen, b->mc_t0, b->mc_memo, b->d_self, b->d_rself};
     for (void *p : ptrs) if (p) (void)hipFree(p);

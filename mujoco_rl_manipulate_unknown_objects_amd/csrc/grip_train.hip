@@ -17,6 +17,7 @@
 // The forward kernels the update shares with the rollouts (k_conv1_u8, k_conv23, with the training outputs) are in grip_policy.hip.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <algorithm>
 #include <stdint.h>
 #include <cstdio>
 
@@ -543,4 +544,27 @@ extern "C" int grip_relu_backward_colsum(const float *g_dev, int g_row_stride, c
     hipLaunchKernelGGL(k_tanh_bwd_colsum<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g_dev, g_row_stride, h_dev, gz_dev, 1, n, cols, cols, 0LL, scratch_dev);
     hipLaunchKernelGGL(k_colsum_reduce, dim3((cols + 63) / 64), dim3(1024), 0, (hipStream_t)stream, (const float *)scratch_dev, blocks, cols, grad_bias_dev);
     return launch_check("grip_relu_backward_colsum");
+}
+
+// z = tanh(z + bias) in place for a batch of matrices: z [batch, n, cols] contiguous, bias [batch, cols] (cols % 4 == 0). The second layers of the policy | value MLPs
+// are a batch-of-two GEMM, which has no bias epilogue in the library: as tensor-library calls the bias costs a broadcast copy into the GEMM's output before it and the
+// tanh a pass after it; here both are one pass.
+__global__ void __launch_bounds__(256) k_bias_tanh(float *__restrict__ z, const float *__restrict__ bias, int n, int cols, long long total4) {
+    const int c4 = cols >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const long long row = i / c4; const int c = (int)(i - row * c4);
+        const int b = (int)(row / n);
+        const float4 v = reinterpret_cast<const float4 *>(z)[i];
+        const float4 bb = reinterpret_cast<const float4 *>(bias)[(size_t)b * c4 + c];
+        reinterpret_cast<float4 *>(z)[i] = make_float4(tanhf(v.x + bb.x), tanhf(v.y + bb.y), tanhf(v.z + bb.z), tanhf(v.w + bb.w));
+    }
+}
+
+extern "C" int grip_bias_tanh(float *z_dev, const float *bias_dev, int batch, int n, int cols, void *stream) {
+    if (!z_dev || !bias_dev || batch < 1 || n < 1 || cols < 4 || (cols & 3))
+        return grip_fail("grip_bias_tanh: need z [batch, n, cols] and bias [batch, cols] with cols a multiple of 4");
+    const long long total4 = (long long)batch * n * (cols >> 2);
+    const int blocks = (int)std::min<long long>((total4 + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_bias_tanh, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z_dev, bias_dev, n, cols, total4);
+    return launch_check("grip_bias_tanh");
 }

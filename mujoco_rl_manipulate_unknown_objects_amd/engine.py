@@ -107,7 +107,7 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_kernel_time", "grip_batch_device_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward", "grip_obs_preprocess",
            "grip_batch_set_state_storage", "grip_batchset_create", "grip_batchset_destroy", "grip_batchset_refresh", "grip_batchset_num_envs",
            "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list", "grip_conv1_u8", "grip_conv1_u8_rows", "grip_batch_render_camera", "grip_ppo_loss", "grip_conv23_prep", "grip_conv23",
-           "grip_trunk_backward", "grip_trunk_backward_parts", "grip_conv1_u8_train", "grip_conv23_train", "grip_clip_adam", "grip_clip_adam_chunks", "grip_tanh_backward_colsum", "grip_relu_backward_colsum"]
+           "grip_trunk_backward", "grip_trunk_backward_parts", "grip_conv1_u8_train", "grip_conv23_train", "grip_clip_adam", "grip_clip_adam_chunks", "grip_tanh_backward_colsum", "grip_relu_backward_colsum", "grip_ppo_loss_heads", "grip_bias_tanh"]
 
 
 def lib():
@@ -175,6 +175,8 @@ def lib():
     L.grip_tanh_backward_colsum.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp]
     L.grip_clip_adam.argtypes = [C.c_int, C.POINTER(C.c_int64)] + [C.POINTER(vp)] * 5 + [C.c_float] * 5 + [vp, vp, vp]
     L.grip_ppo_loss.argtypes = [vp] * 7 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float] + [vp] * 5
+    L.grip_ppo_loss_heads.argtypes = [vp] * 8 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float] + [vp] * 6
+    L.grip_bias_tanh.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
     L.grip_batch_render_camera.argtypes = [vp, C.c_int, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp]
     L.grip_rollout_tick.argtypes = [vp, vp]
     L.grip_rollout_gae.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
@@ -316,13 +318,13 @@ def _nhwc(t, c, hw):
     return t.is_cuda and t.dtype == torch.float32 and tuple(t.shape[1:]) == (c, hw, hw) and t.is_contiguous(memory_format=torch.channels_last)
 
 
-def trunk_backward(g3, mask3, mask2, mask1, obs, b3_mat, b2_mat, w1=None, want_g1m=False):
+def trunk_backward(g3, mask3, mask2, mask1, obs, b3_mat, b2_mat, w1=None, want_g1m=False, gw_out=None, gb_out=None):
     """Backward of AugmentedNatureCNN's convolutions below the third layer's output, one launch (grip_trunk_backward, csrc/grip_train.hip):
     g3 = d loss / d y3 (channels-last float32 [n, 64, 4, 4]), the ReLU masks of the training forward (conv23(train=True): mask3 int64 [n, 16], mask2
     int64 [n, 36]; conv1_u8(with_mask=True): mask1 int32 [n, 225]), the weight matrices of conv23_prep, the uint8 observations [n, 5, 64, 64] (None:
     no first-layer weight gradient) and the first layer's weight (for the gradient's shape and strides) -> (g3 * mask3, d loss / d conv2's
     pre-activation, d loss / d w1, (d loss / d b1, d loss / d b2, d loss / d b3), d loss / d conv1's pre-activation or None), the data gradients
-    channels-last."""
+    channels-last. gw_out / gb_out: write d loss / d w1 (strides of w1) and the three bias gradients there instead of into fresh tensors."""
     import torch
     n = int(g3.shape[0])
     assert _nhwc(g3, 64, 4)
@@ -342,7 +344,9 @@ def trunk_backward(g3, mask3, mask2, mask1, obs, b3_mat, b2_mat, w1=None, want_g
     if obs is not None:
         assert obs.is_cuda and obs.dtype == torch.uint8 and obs.is_contiguous() and tuple(obs.shape[1:]) == (5, 64, 64) and (obs_rows is not None or obs.shape[0] == n)
         assert w1 is not None and tuple(w1.shape) == (32, 4, 8, 8) and w1.dtype == torch.float32
-        gw = torch.empty_like(w1); gb = tuple(torch.empty(k, dtype=torch.float32, device=g3.device) for k in (32, 64, 64))
+        gw = torch.empty_like(w1) if gw_out is None else gw_out
+        gb = tuple(torch.empty(k, dtype=torch.float32, device=g3.device) for k in (32, 64, 64)) if gb_out is None else tuple(gb_out)
+        assert gw.stride() == w1.stride() and gw.dtype == torch.float32 and all(t.is_contiguous() and t.numel() == k and t.dtype == torch.float32 for t, k in zip(gb, (32, 64, 64)))
         part = torch.empty((int(lib().grip_trunk_backward_parts(n)), 8352), dtype=torch.float32, device=g3.device)
         strides = (C.c_int64 * 4)(*gw.stride())
     stream = C.c_void_p(torch.cuda.current_stream(g3.device).cuda_stream)
@@ -351,7 +355,7 @@ def trunk_backward(g3, mask3, mask2, mask1, obs, b3_mat, b2_mat, w1=None, want_g
     return g3m, g2m, gw, gb, g1m
 
 
-def tanh_backward_colsum(g, h, batch_major_to_rows=False):
+def tanh_backward_colsum(g, h, batch_major_to_rows=False, gb_out=None):
     """gz = g * (1 - h^2) and its column sums (the tanh layer's bias gradient) in one pass (grip_tanh_backward_colsum, csrc/grip_train.hip).
     g float32 [B, n, C] contiguous (B = 1 for a 2-D g). batch_major_to_rows=False: h is [B, n, C] like g, gz comes back in that layout. True: h is the
     row-major [n, B * C] activation whose column blocks are the batch entries, and gz comes back row-major [n, B * C]. Returns (gz, grad_bias [B * C])."""
@@ -365,7 +369,8 @@ def tanh_backward_colsum(g, h, batch_major_to_rows=False):
     else:
         assert h.numel() == g3.numel()
         gz = torch.empty_like(g); row_stride, bstride = Cc, n * Cc
-    gb = torch.empty(B * Cc, dtype=torch.float32, device=g.device)
+    gb = torch.empty(B * Cc, dtype=torch.float32, device=g.device) if gb_out is None else gb_out
+    assert gb.is_contiguous() and gb.numel() == B * Cc and gb.dtype == torch.float32
     sc = torch.empty(((n + 31) // 32) * B * Cc, dtype=torch.float32, device=g.device)
     stream = C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)
     _chk(lib().grip_tanh_backward_colsum(C.c_void_p(g3.data_ptr()), C.c_void_p(h.data_ptr()), C.c_void_p(gz.data_ptr()), B, n, Cc, row_stride, bstride,
@@ -373,13 +378,14 @@ def tanh_backward_colsum(g, h, batch_major_to_rows=False):
     return gz, gb
 
 
-def relu_backward_colsum(g, h):
+def relu_backward_colsum(g, h, gb_out=None):
     """gz = g * (h > 0) and its column sums (the ReLU layer's bias gradient) in one pass (grip_relu_backward_colsum): g float32 [n, C], rows possibly strided
     (a column slice of a wider gradient), h float32 [n, C] contiguous. Returns (gz [n, C], grad_bias [C])."""
     import torch
     n, Cc = (int(x) for x in h.shape)
     assert g.is_cuda and g.dtype == torch.float32 and tuple(g.shape) == (n, Cc) and g.stride(1) == 1 and g.stride(0) >= Cc and h.dtype == torch.float32 and h.is_contiguous()
-    gz = torch.empty_like(h); gb = torch.empty(Cc, dtype=torch.float32, device=g.device)
+    gz = torch.empty_like(h); gb = torch.empty(Cc, dtype=torch.float32, device=g.device) if gb_out is None else gb_out
+    assert gb.is_contiguous() and gb.numel() == Cc and gb.dtype == torch.float32
     sc = torch.empty(((n + 31) // 32) * Cc, dtype=torch.float32, device=g.device)
     stream = C.c_void_p(torch.cuda.current_stream(g.device).cuda_stream)
     _chk(lib().grip_relu_backward_colsum(C.c_void_p(g.data_ptr()), int(g.stride(0)), C.c_void_p(h.data_ptr()), C.c_void_p(gz.data_ptr()), n, Cc, C.c_void_p(sc.data_ptr()),
@@ -455,6 +461,37 @@ def ppo_loss(mean, log_std, values, actions, old_log_prob, advantages, returns, 
     _chk(lib().grip_ppo_loss(*[C.c_void_p(t.data_ptr()) for t in ts], n, A, float(clip_range), float(ent_coef), float(vf_coef),
                              C.c_void_p(out.data_ptr()), C.c_void_p(gm.data_ptr()), C.c_void_p(gv.data_ptr()), C.c_void_p(gl.data_ptr()), stream))
     return out, gm, gv, gl
+
+
+def bias_tanh_(z, bias):
+    """z = tanh(z + bias) in place (grip_bias_tanh): z float32 [B, n, C] contiguous, bias [B * C]; returns z"""
+    import torch
+    B, n, Cc = (int(x) for x in z.shape)
+    assert z.is_cuda and z.dtype == torch.float32 and z.is_contiguous() and bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == B * Cc and Cc % 4 == 0
+    _chk(lib().grip_bias_tanh(C.c_void_p(z.data_ptr()), C.c_void_p(bias.data_ptr()), B, n, Cc, C.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)))
+    return z
+
+
+def ppo_loss_heads(heads_out, head_bias, log_std, actions, old_log_prob, advantages, returns, rows, clip_range, ent_coef, vf_coef, grad_head_bias, grad_log_std):
+    """The minibatch loss for the update's explicit launch sequence (grip_ppo_loss_heads, two launches): heads_out float32 [2, n, 8] (the merged heads' last
+    batch-of-two GEMM WITHOUT its bias, head_bias [2, 8] beside it: [0, i, :A] + bias = mean, [1, i, 0] + bias = value), the ROLLOUT's sample arrays (actions [R, A], old_log_prob / advantages / returns [R]) and the
+    minibatch's rows of them (int64 [n]) -> (out[3] = loss / policy loss / value loss, d loss / d heads_out [2, n, 8]); the heads' bias gradients [2, 8] and
+    d loss / d log_std [A] are written into grad_head_bias / grad_log_std."""
+    import torch
+    n, A = int(heads_out.shape[1]), int(log_std.numel())
+    f32 = lambda t, shape: t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and (shape is None or tuple(t.shape) == shape)
+    R = int(actions.shape[0])
+    assert f32(heads_out, (2, n, 8)) and f32(head_bias, None) and head_bias.numel() == 16 and f32(log_std, (A,)) and f32(actions, (R, A)) and all(f32(t, None) and t.numel() == R for t in (old_log_prob, advantages, returns))
+    assert rows.is_cuda and rows.dtype == torch.int64 and rows.is_contiguous() and rows.numel() == n
+    assert f32(grad_head_bias, None) and grad_head_bias.numel() == 16 and f32(grad_log_std, None) and grad_log_std.numel() >= A
+    dev = heads_out.device
+    out = torch.empty(3, dtype=torch.float32, device=dev); go = torch.empty_like(heads_out)
+    samples = torch.empty(n * (A + 3), dtype=torch.float32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _chk(lib().grip_ppo_loss_heads(p(heads_out), p(head_bias), p(log_std), p(actions), p(old_log_prob), p(advantages), p(returns), p(rows), n, A, float(clip_range), float(ent_coef),
+                                   float(vf_coef), p(samples), p(out), p(go), p(grad_head_bias), p(grad_log_std), stream))
+    return out, go
 
 
 class Model:

@@ -182,8 +182,29 @@ def principal_axes(I):
     return w, mat_to_quat(v)
 
 
-def build_hull(points):
-    """Convex hull of a point cloud -> verts, CSR adjacency, face planes."""
+def _convex_loop(pts2):
+    """indices of the boundary points of a planar point set's convex hull, counter-clockwise (monotone chain). Points ON an edge stay in the loop: they are
+    corners of the neighbouring faces, and the rasteriser's edge tests are bit-consistent only between faces that share the SAME edge segments."""
+    order = np.lexsort((pts2[:, 1], pts2[:, 0]))
+    scale = max(1e-30, np.abs(pts2 - pts2.mean(0)).max()) ** 2
+
+    def half(seq):
+        out = []
+        for i in seq:
+            while len(out) >= 2:
+                a, b = pts2[out[-2]], pts2[out[-1]]
+                if (b[0] - a[0]) * (pts2[i][1] - a[1]) - (b[1] - a[1]) * (pts2[i][0] - a[0]) < -1e-9 * scale:
+                    out.pop()
+                else:
+                    break
+            out.append(int(i))
+        return out
+    lo, up = half(order), half(order[::-1])
+    return lo[:-1] + up[:-1]
+
+
+def build_hull(points, with_loops=False):
+    """Convex hull of a point cloud -> verts, CSR adjacency, face planes (with_loops: and every face's corner loop, counter-clockwise seen from outside)."""
     uniq = np.unique(points, axis=0)
     h = ConvexHull(uniq)
     vid = np.sort(h.vertices)
@@ -204,10 +225,27 @@ def build_hull(points):
     # merged (unique) face planes n.x <= d, outward normals
     eq = h.equations
     key = np.round(eq / np.maximum(1e-12, np.linalg.norm(eq[:, :3], axis=1))[:, None], 7)
-    _, idx = np.unique(key, axis=0, return_index=True)
-    eq = eq[np.sort(idx)]
+    _, idx, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
+    first = np.sort(idx)
+    eq = eq[first]
     planes = np.c_[eq[:, :3], -eq[:, 3]]
-    return verts, nadr, np.array(flat, dtype=np.int32), planes
+    if not with_loops:
+        return verts, nadr, np.array(flat, dtype=np.int32), planes
+    # the corners of every listed face: the vertices of the simplices that lie in its plane, as a convex loop in the plane. "Lie in" means the rounded key of the plane list or
+    # the next rounding bucket (2e-7 on every component of the unit equation), not only "same rounded key": where rounding split one flat face into two listed planes, BOTH get the whole
+    # face's loop (a part of a convex polygon's triangulation need not be convex) -- a ray then finds the face twice, at the same depth.
+    unit = h.equations / np.maximum(1e-12, np.linalg.norm(h.equations[:, :3], axis=1))[:, None]
+    loops = []
+    for j, f in enumerate(first):
+        same = np.abs(unit - unit[f]).max(1) < 2e-7
+        on = np.unique(remap[h.simplices[same].ravel()])
+        n = unit[f, :3]
+        a = np.cross(n, [1.0, 0, 0]) if abs(n[0]) < 0.9 else np.cross(n, [0, 1.0, 0])
+        a /= np.linalg.norm(a); b = np.cross(n, a)                       # a x b = n: counter-clockwise in (a, b) = seen from outside
+        loop = on[_convex_loop(np.c_[verts[on] @ a, verts[on] @ b])]
+        assert len(loop) >= 3
+        loops.append(loop.astype(np.int32))
+    return verts, nadr, np.array(flat, dtype=np.int32), planes, loops
 
 
 LUT_RES = 8
@@ -435,6 +473,7 @@ def compile_model(xml_path, mesh_dir, standin_acorn=False):
     hn_adr, hn = [np.zeros(1, dtype=np.int32)], []
     hp, hpadr, hpnum = [], [0], []
     hlut = []
+    hloops, hladr = [], [0]          # every face's corner loop (local vertex ids, counter-clockwise seen from outside), CSR over all hull planes
     standin = 0
     for gi, bn in enumerate(BODY_NAMES[2:], start=1):
         bi = BODY_NAMES.index(bn)
@@ -459,7 +498,7 @@ def compile_model(xml_path, mesh_dir, standin_acorn=False):
         Ic = Ic * (mass / V)
         diag, iq = principal_axes(Ic)
         body_mass[bi], body_ipos[bi], body_iquat[bi], body_inertia[bi] = mass, com, iq, diag
-        verts, nadr, nbr, planes = build_hull(tris.reshape(-1, 3))
+        verts, nadr, nbr, planes, loops = build_hull(tris.reshape(-1, 3), with_loops=True)
         geom_body[gi] = bi
         geom_fric[gi] = _floats(g.get("friction", "1 0.005 0.0001")); geom_condim[gi] = int(g["condim"])
         geom_center[gi] = com                     # MuJoCo re-centres a mesh geom at its COM [3P-recall]
@@ -474,6 +513,13 @@ def compile_model(xml_path, mesh_dir, standin_acorn=False):
         hn.append(nbr)
         hp.append(planes); hpnum.append(len(planes)); hpadr.append(hpadr[-1] + len(planes))
         hlut.append(support_lut(verts))
+        seen = {}
+        for lp in loops:                          # listed planes that are one geometric face (rounding split it) share a loop: the first keeps it, the others get none
+            k = tuple(sorted(int(v) for v in lp))
+            if k in seen:
+                lp = lp[:0]
+            seen[k] = True
+            hloops.append(lp); hladr.append(hladr[-1] + len(lp))
     # ee keeps its explicit <inertial> (no geoms on it)
     ine = B["ee"]["inertial"]
     body_mass[1] = float(ine["mass"]); body_ipos[1] = _floats(ine["pos"]); body_inertia[1] = _floats(ine["diaginertia"])
@@ -489,6 +535,9 @@ def compile_model(xml_path, mesh_dir, standin_acorn=False):
     mdl["hull_padr"] = np.array(hpadr[:-1], dtype=np.int32); mdl["hull_pnum"] = np.array(hpnum, dtype=np.int32)
     mdl["hull_planes"] = np.vstack(hp)
     mdl["hull_lut"] = np.concatenate(hlut).astype(np.int32)          # [6 hulls][6 * LUT_RES^2]
+    # face polygons for the observation kernel's rasteriser (round 4): plane j's corners are hull_loops[hull_ladr[j] : hull_ladr[j + 1]] (vertex ids local
+    # to the plane's hull; an empty range = a duplicate of an earlier plane of the same face)
+    mdl["hull_ladr"] = np.array(hladr, dtype=np.int32); mdl["hull_loops"] = np.concatenate(hloops).astype(np.int32)
     # --- qpos0
     qpos0 = np.zeros(NQ); qpos0[7:10] = body_pos[7]; qpos0[10:14] = body_quat[7]
     mdl["qpos0"] = qpos0

@@ -230,7 +230,11 @@ class PPO:
     def _bind_flat_grads(self):
         """One flat fp32 bucket IS the gradient storage: every parameter's .grad is a view into it (layout = parameter order), so the
         all-reduce of a minibatch is one collective on memory the backward pass wrote in place -- no concatenation before it, no
-        copy-back after it, and the addresses the captured update graphs hold never change."""
+        copy-back after it, and the addresses the captured update graphs hold never change. (With the explicit update path the bucket is
+        FusedUpdate's gradient buffer, in ITS layout.)"""
+        if getattr(self, "_fused", None) is not None:
+            self._fused.bind()
+            return
         params = list(self.policy.parameters())
         n = sum(p.numel() for p in params)
         if self._flat_grad is None or self._flat_grad.numel() != n:
@@ -288,6 +292,9 @@ class PPO:
     def _loss_backward(self, src, idx):
         """Forward + PPO loss + backward of one minibatch `idx` (record / sample ids into the rollout storage `src`)."""
         obs, actions, old_logp, adv_all, ret_all = src
+        fu = getattr(self, "_fused", None)
+        if fu is not None:
+            return fu.loss_backward(src, idx)
         if self.fused_loss and obs.is_cuda and hasattr(self.policy, "forward_parts"):
             if self.indexed_minibatches and obs.dtype == th.uint8 and obs.dim() == 4 and obs.is_contiguous() and idx.dtype == th.int64:
                 from ..engine import IndexedRows              # the minibatch as row numbers: the first layer and its weight gradient read the rows where they lie
@@ -315,6 +322,39 @@ class PPO:
         return pl.detach(), vl.detach(), loss.detach()
 
     indexed_minibatches = True       # minibatch observations handed to the policy as engine.IndexedRows (no gathered copy) on the fused-loss path
+    explicit_update = True           # forward / loss / backward of a minibatch as an explicit launch sequence over flat parameter and gradient buffers
+                                     # (sb3/fused_update.py) where the policy is the default one; False: autograd over the same kernels
+    _fused = None
+
+    def _select_update_path(self, src, idx):
+        """Decide (once per storage) whether the explicit launch sequence applies; it re-lays the parameters when it is first taken."""
+        fu = self._fused
+        obs, actions, old_logp, adv_all, ret_all = src
+        fits = (self.explicit_update and obs.is_cuda and obs.dtype == th.uint8 and obs.dim() == 4 and obs.is_contiguous() and idx.dtype == th.int64 and idx.dim() == 1
+                and actions.dim() == 2 and all(t.is_cuda and t.dtype == th.float32 and t.is_contiguous() for t in (actions, old_logp, adv_all, ret_all))
+                and all(t.dim() == 1 and t.numel() == actions.shape[0] for t in (old_logp, adv_all, ret_all)) and idx.numel() >= 2)
+        if fu is not None and (not fits or not fu.intact()):
+            self._fused = fu = None                      # somebody moved the parameters (they are laid out again below), or another kind of storage (autograd)
+            self._flat_grad = None
+            for p in self.policy.parameters():
+                p.grad = None
+            self._upd = None
+        if fu is None and fits and not getattr(self, "_fused_declined", False):
+            from .fused_update import FusedUpdate
+            if FusedUpdate.applies(self):
+                self._fused = FusedUpdate(self)
+                self._upd = None
+            else:
+                self._fused_declined = True
+
+    def _fresh_grads(self, to_none):
+        """what a backward pass needs of .grad beforehand"""
+        if self._fused is not None:
+            self._fused.bind()                           # every slot is overwritten: nothing to zero
+        elif self.distributed:
+            self._zero_grads()
+        else:
+            self.optimizer.zero_grad(set_to_none=to_none)
     fused_clip_adam = True           # clipping + Adam in two launches (engine.ClipAdam) where the optimiser is a plain torch Adam on float32 CUDA tensors
 
     def _apply(self):
@@ -346,8 +386,12 @@ class PPO:
         return self._minibatch_update_impl(src, idx)
 
     def _minibatch_update_impl(self, src, idx):
+        self._select_update_path(src, idx)
         if not self.graph_update:
-            self._zero_grads()
+            if self._fused is not None:
+                self._fused.bind()
+            else:
+                self._zero_grads()
             out = self._loss_backward(src, idx)
             if self.distributed:
                 self._allreduce_grads()
@@ -361,10 +405,7 @@ class PPO:
         if u["warm"] < 2:                           # two eager steps on a side stream before capturing (PyTorch's capture recipe)
             cur = th.cuda.current_stream(self.device); side = th.cuda.Stream(self.device); side.wait_stream(cur)
             with th.cuda.stream(side):
-                if self.distributed:
-                    self._zero_grads()
-                else:
-                    self.optimizer.zero_grad(set_to_none=True)
+                self._fresh_grads(to_none=True)
                 out = self._loss_backward(src, u["idx"])
                 if self.distributed:
                     self._allreduce_grads()
@@ -375,17 +416,18 @@ class PPO:
         if u["fwd"] is None:
             th.cuda.synchronize(self.device)
             try:
-                if self.distributed:
-                    self._zero_grads()                          # .grad = views of the flat bucket: the captured backward accumulates in place
-                else:
-                    self.optimizer.zero_grad(set_to_none=True)  # the captured backward allocates .grad from the graph's pool
+                # distributed: .grad = views of the flat bucket, the captured backward accumulates in place; single process: the captured backward
+                # allocates .grad from the graph's pool; explicit path: the gradient buffer's slots are overwritten
+                self._fresh_grads(to_none=True)
                 g1 = th.cuda.CUDAGraph()
                 with th.cuda.graph(g1, capture_error_mode="thread_local"):
                     u["out"] = self._loss_backward(src, u["idx"])
                 g2 = th.cuda.CUDAGraph()
                 with th.cuda.graph(g2, capture_error_mode="thread_local"):
                     self._apply()
-                    if self.distributed:
+                    if self._fused is not None:
+                        pass
+                    elif self.distributed:
                         self._flat_grad.zero_()
                     else:
                         self.optimizer.zero_grad(set_to_none=False)

@@ -1,5 +1,7 @@
 """Wall time of the captured PPO update (32768 records, minibatches of 4096, 2 epochs) on synthetic rollout data, variants side by side:
-    python tools/update_time.py [find] [tune]      find: torch.backends.cudnn.benchmark = True (MIOpen find mode on the first eager steps); tune: TunableOp for the GEMMs"""
+    python tools/update_time.py [find] [tune] [autograd] [nofork]
+find: torch.backends.cudnn.benchmark = True (MIOpen find mode on the first eager steps); tune: TunableOp for the GEMMs; autograd: the autograd graph instead of the
+explicit launch sequence (sb3/fused_update.py); nofork: the explicit sequence with its weight-gradient GEMMs on the main stream"""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
@@ -14,9 +16,14 @@ if "tune" in sys.argv[1:]:           # TunableOp: every GEMM shape is timed over
 env = GpuVecEnv(BatchedRobotEnv(default_config(sim_env="/xmls/acorn_env.xml", time_horizon=50), n_envs=4096, device_index=0, auto_reset=True))
 model = PPO("MultiInputPolicy", env, n_steps=8, batch_size=4096, n_epochs=2, seed=0, async_slice=96, async_capacity=1024, async_budget_us=2000,
             policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]))
+if "autograd" in sys.argv[1:]:
+    model.explicit_update = False
+if "nofork" in sys.argv[1:]:
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3.fused_update import FusedUpdate
+    FusedUpdate.fork_weight_grads = False
 model.collect_rollouts()
 for _ in range(3): model.train()
 torch.cuda.synchronize(); t = time.perf_counter(); n = 10
 for _ in range(n): st = model.train()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t) / n
-print(f"update {'find' if torch.backends.cudnn.benchmark else 'default'}{' + TunableOp' if 'tune' in sys.argv[1:] else ''}: {dt * 1e3:.2f} ms per train() = {dt / 16 * 1e3:.3f} ms per minibatch; loss {float(st['loss']):.6f}")
+print(f"update {'find' if torch.backends.cudnn.benchmark else 'default'}{' + TunableOp' if 'tune' in sys.argv[1:] else ''} {'explicit' if model._fused is not None else 'autograd'}{' nofork' if 'nofork' in sys.argv[1:] else ''}: {dt * 1e3:.2f} ms per train() = {dt / 16 * 1e3:.3f} ms per minibatch; loss {float(st['loss']):.6f}")
