@@ -11,6 +11,7 @@
 // that the step kernel left in pad_grasp / pad_pher.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include "grip_device.h"
 #include <atomic>
 
@@ -469,11 +470,18 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
 // tessellated meshes) are rasterised by that thread; the others leave a record (plane, edge normals) and one work item per 8 x 8 pixel tile their box touches,
 // which the waves then take in turn, a lane per pixel. Tables that overflow fall back to the setting-up thread walking the box itself (correct, slow, not seen).
 // Differences from the ray caster: only pixels whose ray passes within rounding of a face's edge (tools/render_ab.py counts them).
+#ifndef RS_SMALL
 #define RS_SMALL 16
-#define RS_FACES 384
-#define RS_ITEMS 3072
-#define RS_EDGES 1024
-#define RS_DYN_BYTES(nverts) ((size_t)(((nverts) * 3 + 3) / 4 * 4) * 4 + (size_t)RS_FACES * 32 + (size_t)RS_EDGES * 12 + (size_t)RS_ITEMS * 2)
+#endif
+#ifndef RS_WAVES
+#define RS_WAVES 8          // waves per SIMD the rasteriser is compiled for (64 registers; 2 workgroups per CU fit the LDS)
+#endif
+#ifndef RS_FACES
+#define RS_FACES 256         // face records (measured per env: mean 78-93, max 188 on bread_crumb)
+#define RS_ITEMS 2048        // (face, tile) items (mean 354-386, max 910)
+#define RS_EDGES 1024        // edge normals of the recorded faces (mean 269-311, max 614)
+#endif
+#define RS_DYN_BYTES(nverts) ((size_t)(((nverts) * 3 + 3) / 4 * 4) * 4 + (size_t)RS_FACES * 32 + (size_t)RS_EDGES * 16 + (size_t)RS_ITEMS * 2)
 struct __align__(16) RsFace { float4 P; int ebase, k, id, pad; };
 
 __device__ __forceinline__ void rs_claim(unsigned long long *zb, int pix, float t, int id) {
@@ -493,8 +501,8 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
     uint8_t *img = pool; float *red = reinterpret_cast<float *>(pool + 5 * RPIX); int *redi = reinterpret_cast<int *>(pool + 6 * RPIX);
     float *cv = reinterpret_cast<float *>(rs_dyn);                                       // camera-space vertices of the visible hulls, xyz
     RsFace *frec = reinterpret_cast<RsFace *>(cv + (nverts_max * 3 + 3) / 4 * 4);
-    float *en = reinterpret_cast<float *>(frec + RS_FACES);                               // edge normals of the recorded faces
-    unsigned short *items = reinterpret_cast<unsigned short *>(en + 3 * RS_EDGES);        // record << 6 | tile
+    float4 *en = reinterpret_cast<float4 *>(frec + RS_FACES);                             // edge normals of the recorded faces (one 16-byte read per edge and item)
+    unsigned short *items = reinterpret_cast<unsigned short *>(en + RS_EDGES);            // record << 6 | tile
     const int tid = threadIdx.x;
     if (tid < 7) frame_role(m, qpos, n, e, cfg.state_half, tid, fr);
     if (tid == 0) { nfaces = 0; nedges = 0; nitems = 0; }
@@ -507,12 +515,27 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
         V3 p = ldv(fr.p[g - 1]); M3 R = ldm(fr.R[g - 1]);
         V3 c = multv(Rc, p + mulv(R, ldv(m.geom_center[g])) - co);
         float r = m.geom_rbound[g];
-        gnum[g] = c.z - r < 0.f ? m.hull_pnum[g - 1] : 0;
         M3 Mx = mulm(M3{{R.m[0], R.m[3], R.m[6], R.m[1], R.m[4], R.m[7], R.m[2], R.m[5], R.m[8]}}, Rc);
         V3 ol = multv(R, co - p);
 #pragma unroll
         for (int i = 0; i < 9; i++) gmx[g][i] = Mx.m[i];
         gmx[g][9] = ol.x; gmx[g][10] = ol.y; gmx[g][11] = ol.z;
+        // visible = the corners of the hull's vertex box are not all on the far side of one of the view pyramid's planes (near plane, four sides; the sides
+        // pushed out by a hundredth of the box's depth against rounding): a hull that fails this covers no pixel's ray
+        bool vis = c.z - r < 0.f;
+        if (vis) {
+            const float th = tanf(0.5f * m.cam_fovy * 0.017453292519943295f) * 1.0001f;
+            unsigned out = 0x1fu;
+            for (int k = 0; k < 8; k++) {
+                const V3 q = multv(Mx, v3(m.hull_aabb[g - 1][(k & 1) ? 3 : 0] - ol.x, m.hull_aabb[g - 1][(k & 2) ? 4 : 1] - ol.y, m.hull_aabb[g - 1][(k & 4) ? 5 : 2] - ol.z));
+                const float d = -q.z * th + 1e-6f;                                        // half-width of the pyramid at the corner's depth
+                unsigned o_ = 0u;
+                o_ |= q.z > -m.znear ? 1u : 0u; o_ |= q.x > d ? 2u : 0u; o_ |= q.x < -d ? 4u : 0u; o_ |= q.y > d ? 8u : 0u; o_ |= q.y < -d ? 16u : 0u;
+                out &= o_;
+            }
+            vis = out == 0u;
+        }
+        gnum[g] = vis ? m.hull_pnum[g - 1] : 0;
     }
     __syncthreads();
     if (tid == 0) {
@@ -524,7 +547,7 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
     const float tanh_ = tanf(0.5f * m.cam_fovy * 0.017453292519943295f);
     auto ray_x = [&](int px) { return (2.0f * (px + 0.5f) / RW - 1.0f) * tanh_; };       // the ray caster's expressions: the same floats
     auto ray_y = [&](int py) { return (1.0f - 2.0f * (py + 0.5f) / RH) * tanh_; };
-    auto hull_of = [&](const int *adr, int i) { int g = 1; for (int h = 2; h < GN_GEOM; h++) g = (gnum[h] && i >= adr[h]) ? h : g; if (!gnum[g]) { for (int h = 1; h < GN_GEOM; h++) if (gnum[h]) { g = h; break; } } return g; };
+    auto hull_of = [&](const int *adr, int i) { int g = 1; for (int h = 2; h < GN_GEOM; h++) g = (gnum[h] && i >= adr[h]) ? h : g; return g; };   // (the first visible hull starts at 0)
     // ---- vertices of the visible hulls -> camera coordinates: Mx^T (v - ol)
     {
         const int nv = gvadr[GN_GEOM];
@@ -539,7 +562,10 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
     }
     __syncthreads();
     // ---- one thread per face: set-up, and the small ones drawn on the spot
-    {
+#ifndef RS_STOP
+#define RS_STOP 0          // diagnostic builds: 1 = leave after the vertex transform, 2 = after the per-face pass (tools/render_ab.py times the difference)
+#endif
+    if (RS_STOP != 1) {
         const int np = gadr[GN_GEOM];
         for (int i = tid; i < np; i += RTHREADS) {
             const int g = hull_of(gadr, i), j = i - gadr[g], jg = m.hull_padr[g - 1] + j;
@@ -553,31 +579,36 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
             if (!(B < 0.f)) continue;                                   // the camera is not outside this plane: no ray enters through it
             const float *cvg = cv + 3 * gvadr[g];
             const int *lp = m.hull_loops + l0;
-            // screen box of the loop; a corner at or behind the camera plane makes it the whole screen (the edge tests need no projection)
+            // screen box of the part of the loop beyond the near plane z = -znear (nothing nearer is drawn: t > znear): its corners there and the points where
+            // its edges cross the plane. Conservative by a hundredth of a pixel; the edge tests below decide, and they need no projection or clipping.
             int id4[4]; V3 v4[4];
-            float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f, zmax = -3.0e38f, zmin = 3.0e38f;
-            auto take = [&](V3 v) {
-                const float iz = rcp(-v.z), px = v.x * iz, py = v.y * iz;
-                xmin = fminf(xmin, px); xmax = fmaxf(xmax, px); ymin = fminf(ymin, py); ymax = fmaxf(ymax, py); zmax = fmaxf(zmax, v.z); zmin = fminf(zmin, v.z);
+            float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
+            const float zn = -m.znear;
+            auto take = [&](float x, float y, float z) {
+                const float iz = rcp(-z), px = x * iz, py = y * iz;
+                xmin = fminf(xmin, px); xmax = fmaxf(xmax, px); ymin = fminf(ymin, py); ymax = fmaxf(ymax, py);
             };
+            auto corner = [&](V3 prev, V3 cur) {
+                const bool ic = cur.z <= zn, ip = prev.z <= zn;
+                if (ic) take(cur.x, cur.y, cur.z);
+                if (ic != ip) { const float s_ = (zn - prev.z) * rcp(cur.z - prev.z); take(fmaf(s_, cur.x - prev.x, prev.x), fmaf(s_, cur.y - prev.y, prev.y), zn); }
+            };
+            auto vert = [&](int id) { return v3(cvg[3 * id], cvg[3 * id + 1], cvg[3 * id + 2]); };
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                id4[k] = lp[k < K ? k : 0];
-                v4[k] = v3(cvg[3 * id4[k]], cvg[3 * id4[k] + 1], cvg[3 * id4[k] + 2]);
-                take(v4[k]);
-            }
-            for (int k = 4; k < K; k++) { const int id = lp[k]; take(v3(cvg[3 * id], cvg[3 * id + 1], cvg[3 * id + 2])); }
-            if (zmin >= 0.f) continue;                                  // wholly behind the camera plane
-            int x0 = 0, x1 = RW - 1, y0 = 0, y1 = RH - 1;
-            const bool behind = zmax > -1e-4f;
-            if (!behind) {
-                // pixel px's ray is ((2 (px + 0.5) / RW - 1) tanh): px + 0.5 = (x / tanh + 1) RW / 2
+            for (int k = 0; k < 4; k++) { id4[k] = lp[k < K ? k : 0]; v4[k] = vert(id4[k]); }
+            V3 prev = K == 3 ? v4[2] : (K == 4 ? v4[3] : vert(lp[K - 1]));
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (k < K) { corner(prev, v4[k]); prev = v4[k]; }
+            for (int k = 4; k < K; k++) { const V3 c = vert(lp[k]); corner(prev, c); prev = c; }
+            if (!(xmin <= xmax)) continue;                              // nothing of the face lies beyond the near plane
+            int x0, x1, y0, y1;
+            {   // pixel px's ray is ((2 (px + 0.5) / RW - 1) tanh): px + 0.5 = (x / tanh + 1) RW / 2
                 const float sx = 0.5f * RW / tanh_, sy = 0.5f * RH / tanh_;
                 const float fx0 = xmin * sx + 0.5f * RW - 0.5f, fx1 = xmax * sx + 0.5f * RW - 0.5f;
                 const float fy0 = 0.5f * RH - ymax * sy - 0.5f, fy1 = 0.5f * RH - ymin * sy - 0.5f;
                 if (fx1 < -0.01f || fy1 < -0.01f || fx0 > RW - 0.99f || fy0 > RH - 0.99f) continue;       // off screen
-                x0 = max(0, (int)ceilf(fx0 - 0.01f)); x1 = min(RW - 1, (int)floorf(fx1 + 0.01f));
-                y0 = max(0, (int)ceilf(fy0 - 0.01f)); y1 = min(RH - 1, (int)floorf(fy1 + 0.01f));
+                x0 = (int)ceilf(fmaxf(fx0 - 0.01f, 0.f)); x1 = (int)floorf(fminf(fx1 + 0.01f, RW - 1.f));
+                y0 = (int)ceilf(fmaxf(fy0 - 0.01f, 0.f)); y1 = (int)floorf(fminf(fy1 + 0.01f, RH - 1.f));
                 if (x0 > x1 || y0 > y1) continue;                       // between pixel centres
             }
             const int idw = (g << 16) | j;
@@ -617,7 +648,7 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
                     const int ib2 = k + 1 < K ? lp[k + 1] : i0;
                     const V3 b = k + 1 < K ? v3(cvg[3 * ib2], cvg[3 * ib2 + 1], cvg[3 * ib2 + 2]) : a0;
                     const V3 c = edge(ia, a, ib2, b);
-                    en[3 * (eb + k)] = c.x; en[3 * (eb + k) + 1] = c.y; en[3 * (eb + k) + 2] = c.z;
+                    en[eb + k] = make_float4(c.x, c.y, c.z, 0.f);
                     ia = ib2; a = b;
                 }
                 int w = ib;
@@ -645,17 +676,18 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
     }
     __syncthreads();
     // ---- the recorded faces, tile by tile: a wave per item, a lane per pixel
-    {
+    if (RS_STOP != 1 && RS_STOP != 2) {
         const int ni = min(nitems, RS_ITEMS), wv = tid >> 6, ln = tid & 63;
         for (int it = wv; it < ni; it += RTHREADS / 64) {
-            const unsigned item = items[it];
+            const unsigned item = __builtin_amdgcn_readfirstlane((unsigned)items[it]);
             if (item == 0xffffu) continue;                              // (the hole a refused allocation leaves)
-            const RsFace f = frec[item >> 6];
+            RsFace f = frec[item >> 6];
+            f.k = __builtin_amdgcn_readfirstlane(f.k); f.ebase = __builtin_amdgcn_readfirstlane(f.ebase);
             const int tile = item & 63, px = (tile & 7) * 8 + (ln & 7), py = (tile >> 3) * 8 + (ln >> 3);
             const float x = ray_x(px), y = ray_y(py);
             bool in = true;
-            const float *ep = en + 3 * f.ebase;
-            for (int k = 0; k < f.k; k++) in &= !(fmaf(ep[3 * k], x, fmaf(ep[3 * k + 1], y, -ep[3 * k + 2])) > 0.f);
+            const float4 *ep = en + f.ebase;
+            for (int k = 0; k < f.k; k++) { const float4 c = ep[k]; in &= !(fmaf(c.x, x, fmaf(c.y, y, -c.z)) > 0.f); }
             const float den = fmaf(f.P.y, y, fmaf(f.P.x, x, -f.P.z));
             const float t = f.P.w * rcp(den);
             if (in && den < 0.f && t > 0.f && t > m.znear) rs_claim(zb, py * RW + px, t, f.id);
@@ -755,6 +787,10 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
         img[(nch - 1) * RPIX] = (uint8_t)pg_; img[(nch - 1) * RPIX + 1] = (uint8_t)pp_;
     }
     __syncthreads();
+#ifdef RS_DEBUG_COUNTS          // diagnostic build: the row starts with the env's table counts (faces, edges, items, visible planes) instead of pixels
+    if (tid == 0) { int *d = reinterpret_cast<int *>(img); d[0] = nfaces; d[1] = nedges; d[2] = nitems; d[3] = gadr[GN_GEOM]; }
+    __syncthreads();
+#endif
     const uint4 *src = reinterpret_cast<const uint4 *>(img);
     for (int i = tid; i < nch * RPIX / 16; i += RTHREADS) {
         const uint4 v = src[i];
@@ -766,8 +802,8 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
 // One kernel for a batch and for a set of batches: per-batch arguments in device memory behind a const __restrict__ pointer
 // (workgroup-uniform index -> scalar loads). list != NULL: row b shows env list[b] (global id over the set; a negative entry is a
 // hole, rows >= *count -- when count is given -- are skipped too: their rows are left alone); list == NULL: row b = env b.
-__global__ void __launch_bounds__(RTHREADS, 8) k_observe(const RenderGroup *__restrict__ groups, int ngroups, const int *list, const int *count,
-                                                      uint8_t *obs, uint8_t *obs2, const long long *row2) {
+__global__ void __launch_bounds__(RTHREADS, 8) k_observe_rays(const RenderGroup *__restrict__ groups, int ngroups, const int *list, const int *count,
+                                                           uint8_t *obs, uint8_t *obs2, const long long *row2) {
     if (list && count && (int)blockIdx.x >= *count) return;
     const int ge = list ? list[blockIdx.x] : (int)blockIdx.x;
     if (ge < 0) return;
@@ -778,19 +814,44 @@ __global__ void __launch_bounds__(RTHREADS, 8) k_observe(const RenderGroup *__re
     observe_body(rg.m, cfg, rg.qpos, rg.pad_grasp, rg.pad_pher, rg.n, ge - rg.env0, obs, obs2, row2);
 }
 
-extern "C" int grip_render_launch(const RenderGroup *groups_dev, int ngroups, const int *list, const int *count, int nblocks, int nplanes_max,
+__global__ void __launch_bounds__(RTHREADS, RS_WAVES) k_observe(const RenderGroup *__restrict__ groups, int ngroups, const int *list, const int *count,
+                                                      uint8_t *obs, uint8_t *obs2, const long long *row2, int nverts_max) {
+    if (list && count && (int)blockIdx.x >= *count) return;
+    const int ge = list ? list[blockIdx.x] : (int)blockIdx.x;
+    if (ge < 0) return;
+    int g = 0;
+    for (int i = 1; i < ngroups; i++) g = ge >= groups[i].env0 ? i : g;
+    const RenderGroup &rg = groups[g];
+    const DevConfig cfg = rg.cfg;
+    observe_body_raster(rg.m, cfg, rg.qpos, rg.pad_grasp, rg.pad_pher, rg.n, ge - rg.env0, obs, obs2, row2, nverts_max);
+}
+
+// GRIP_OBSERVE_RAYS=1 in the environment (read once): the ray-casting kernel of rounds 1-4 instead of the rasteriser, for tools/render_ab.py's pixel comparison
+static bool observe_by_rays() {
+    static const bool v = [] { const char *e = getenv("GRIP_OBSERVE_RAYS"); return e && e[0] == '1'; }();
+    return v;
+}
+#define RS_MAX_VERTS 4096
+
+extern "C" int grip_render_launch(const RenderGroup *groups_dev, int ngroups, const int *list, const int *count, int nblocks, int nplanes_max, int nverts_max,
                                   uint8_t *obs, uint8_t *obs2, const long long *row2, hipStream_t s) {
-    {   // static (image, reductions, frames: ~29 KB) + dynamic LDS (up to 41 KB of planes) passes 64 KB for the largest hulls: opt in, once per device
+    const bool rays = observe_by_rays();
+    if (!rays && (nverts_max < 1 || nverts_max > RS_MAX_VERTS)) return grip_fail("grip_render_launch: the model's hulls have more vertices than the observation kernel's LDS table holds (RS_MAX_VERTS)");
+    {   // static + dynamic LDS pass 64 KB (ray caster: ~29 KB + up to 41 KB of planes; rasteriser: ~34 KB + vertices, face records, items): opt in, once per device
         static std::atomic<unsigned long long> attr_set_mask{0ULL};
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return -1;
         const unsigned long long bit = 1ULL << (dev & 63);
         if (!(attr_set_mask.load(std::memory_order_acquire) & bit)) {
-            if (hipFuncSetAttribute((const void *)k_observe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((RMAXPL + NBOX * GN_HULL) * sizeof(float4))) != hipSuccess) return -1;
+            if (hipFuncSetAttribute((const void *)k_observe_rays, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((RMAXPL + NBOX * GN_HULL) * sizeof(float4))) != hipSuccess) return -1;
+            if (hipFuncSetAttribute((const void *)k_observe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS_DYN_BYTES(RS_MAX_VERTS)) != hipSuccess) return -1;
             attr_set_mask.fetch_or(bit, std::memory_order_release);
         }
     }
-    hipLaunchKernelGGL(k_observe, dim3(nblocks), dim3(RTHREADS), (size_t)(nplanes_max + NBOX * GN_HULL) * sizeof(float4), s, groups_dev, ngroups, list, count, obs, obs2, row2);
+    if (rays)
+        hipLaunchKernelGGL(k_observe_rays, dim3(nblocks), dim3(RTHREADS), (size_t)(nplanes_max + NBOX * GN_HULL) * sizeof(float4), s, groups_dev, ngroups, list, count, obs, obs2, row2);
+    else
+        hipLaunchKernelGGL(k_observe, dim3(nblocks), dim3(RTHREADS), RS_DYN_BYTES(nverts_max), s, groups_dev, ngroups, list, count, obs, obs2, row2, nverts_max);
     return launch_status("grip_render_launch");
 }
 

@@ -293,7 +293,7 @@ struct GripBatch {
     float *qpos = nullptr, *qvel = nullptr, *ctrl = nullptr, *warm = nullptr;     // SoA [field][N]
     int *episode_step = nullptr, *status = nullptr, *gripper_open = nullptr;
     int *pad_grasp = nullptr, *pad_pher = nullptr;                              // sensor-pad scalars of the current state
-    int nplanes = 0;
+    int nplanes = 0, nverts = 0;
     int *mc_ints = nullptr, *mc_astate = nullptr, *mc_slot = nullptr, *mc_order = nullptr, *mc_heavy = nullptr, *mc_tick = nullptr, *mc_gen = nullptr; unsigned long long *mc_t0 = nullptr; float *mc_flts = nullptr, *mc_memo = nullptr;   // suspended macro steps
     float *reset_info = nullptr;                                                // grasp0, pher0, objx0, objy0 of the reset state
     float *scratch = nullptr; size_t scratch_bytes = 0;
@@ -1035,7 +1035,7 @@ static MacroCtx macro_ctx(GripBatch *b) { MacroCtx c; c.ints = b->mc_ints; c.flt
 static int grid_of(const GripBatch *b) { return (b->n + EPB - 1) / EPB; }
 
 // observation kernel (grip_render.hip)
-extern "C" int grip_render_launch(const RenderGroup *groups_dev, int ngroups, const int *list, const int *count, int nblocks, int nplanes_max,
+extern "C" int grip_render_launch(const RenderGroup *groups_dev, int ngroups, const int *list, const int *count, int nblocks, int nplanes_max, int nverts_max,
                                   uint8_t *obs, uint8_t *obs2, const long long *row2, hipStream_t s);
 
 template <class T> static T *off(T *p, size_t n) { return p ? p + n : nullptr; }
@@ -1103,7 +1103,7 @@ static int batch_build(GripBatch *b, const GripModel *m) {
     static_assert(ENV_FLOATS % 4 == 0 && EF_U % 4 == 0, "Hessian-vector slots must stay 16-byte aligned");
     if (b->lds_bytes > 160 * 1024) return fail("model hull tables do not fit the 160 KiB LDS next to the per-lane contact storage");
     if (m->planes.size() / 4 > RMAXPL) return fail("model has more hull face planes than the observation kernel's LDS table holds (RMAXPL)");
-    b->nplanes = (int)(m->planes.size() / 4);
+    b->nplanes = (int)(m->planes.size() / 4); b->nverts = m->nvert;
     HIPCHK(hipMalloc(&b->d_planes, m->planes.size() * sizeof(float)));
     HIPCHK(hipMemcpy(b->d_planes, m->planes.data(), m->planes.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&b->d_loops, m->loops.size() * sizeof(int)));
@@ -1372,7 +1372,7 @@ extern "C" int grip_batch_target_pose(GripBatch *b, const float *actions_dev, fl
 extern "C" int grip_batch_observe(GripBatch *b, uint8_t *obs_dev, void *stream) {
     if (!b || !obs_dev) return fail("grip_batch_observe: null argument");
     HIPCHK(hipSetDevice(b->device));
-    if (grip_render_launch((const RenderGroup *)b->d_rself, 1, nullptr, nullptr, b->n, b->nplanes, obs_dev, nullptr, nullptr, (hipStream_t)stream)) return -1;
+    if (grip_render_launch((const RenderGroup *)b->d_rself, 1, nullptr, nullptr, b->n, b->nplanes, b->nverts, obs_dev, nullptr, nullptr, (hipStream_t)stream)) return -1;
     return 0;
 }
 extern "C" int grip_render_camera_launch(const RenderGroup *group_dev, int env, const float *cam_dev, float fovy_deg, int w, int h, uint8_t *rgb_dev,
@@ -1388,7 +1388,7 @@ extern "C" int grip_batch_observe_list(GripBatch *b, const int32_t *list_dev, co
                                        uint8_t *records_dev, const int64_t *record_row_dev, void *stream) {
     if (!b || (!obs_dev && !records_dev) || !list_dev || !count_dev || capacity <= 0 || (records_dev && !record_row_dev)) return fail("grip_batch_observe_list: bad argument");
     HIPCHK(hipSetDevice(b->device));
-    if (grip_render_launch((const RenderGroup *)b->d_rself, 1, list_dev, count_dev, capacity, b->nplanes, obs_dev, records_dev, (const long long *)record_row_dev, (hipStream_t)stream)) return -1;
+    if (grip_render_launch((const RenderGroup *)b->d_rself, 1, list_dev, count_dev, capacity, b->nplanes, b->nverts, obs_dev, records_dev, (const long long *)record_row_dev, (hipStream_t)stream)) return -1;
     return 0;
 }
 
@@ -1396,7 +1396,7 @@ extern "C" int grip_batch_observe_list(GripBatch *b, const int32_t *list_dev, co
 // batch sets: several batches (object models / target directions) behind one launch per phase
 // ------------------------------------------------------------------------------------------------
 struct GripBatchSet {
-    std::vector<GripBatch *> b; int device = 0, total_envs = 0, total_wgs = 0, nplanes_max = 0; size_t lds_max = 0;
+    std::vector<GripBatch *> b; int device = 0, total_envs = 0, total_wgs = 0, nplanes_max = 0, nverts_max = 0; size_t lds_max = 0;
     std::vector<int> env0, wg0;
     GripStepOut out; bool has_out = false;
     GroupArgs *d_groups = nullptr; RenderGroup *d_rgroups = nullptr;
@@ -1426,7 +1426,7 @@ extern "C" int grip_batchset_create(GripBatch *const *batches, int n, const Grip
         GripBatch *b = batches[g];
         s->b.push_back(b); s->env0.push_back(s->total_envs); s->wg0.push_back(s->total_wgs);
         s->total_envs += b->n; s->total_wgs += grid_of(b);
-        s->lds_max = std::max(s->lds_max, b->lds_bytes); s->nplanes_max = std::max(s->nplanes_max, b->nplanes);
+        s->lds_max = std::max(s->lds_max, b->lds_bytes); s->nplanes_max = std::max(s->nplanes_max, b->nplanes); s->nverts_max = std::max(s->nverts_max, b->nverts);
     }
     if (out) { s->out = *out; s->has_out = true; }
     if (hipSetDevice(s->device) != hipSuccess || hipMalloc(&s->counts, n * sizeof(int)) != hipSuccess || hipMemset(s->counts, 0, n * sizeof(int)) != hipSuccess ||
@@ -1495,14 +1495,14 @@ extern "C" int grip_batchset_advance(GripBatchSet *s, const float *slot_actions_
 extern "C" int grip_batchset_observe(GripBatchSet *s, uint8_t *obs_dev, void *stream) {
     if (!s || !obs_dev) return fail("grip_batchset_observe: null argument");
     HIPCHK(hipSetDevice(s->device));
-    return grip_render_launch(s->d_rgroups, (int)s->b.size(), nullptr, nullptr, s->total_envs, s->nplanes_max, obs_dev, nullptr, nullptr, (hipStream_t)stream);
+    return grip_render_launch(s->d_rgroups, (int)s->b.size(), nullptr, nullptr, s->total_envs, s->nplanes_max, s->nverts_max, obs_dev, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int grip_batchset_observe_list(GripBatchSet *s, const int32_t *list_dev, int capacity, uint8_t *obs_dev, uint8_t *records_dev,
                                           const int64_t *record_row_dev, void *stream) {
     if (!s || !list_dev || (!obs_dev && !records_dev) || capacity <= 0 || (records_dev && !record_row_dev)) return fail("grip_batchset_observe_list: bad argument");
     HIPCHK(hipSetDevice(s->device));
-    return grip_render_launch(s->d_rgroups, (int)s->b.size(), list_dev, nullptr, capacity, s->nplanes_max, obs_dev, records_dev, (const long long *)record_row_dev, (hipStream_t)stream);
+    return grip_render_launch(s->d_rgroups, (int)s->b.size(), list_dev, nullptr, capacity, s->nplanes_max, s->nverts_max, obs_dev, records_dev, (const long long *)record_row_dev, (hipStream_t)stream);
 }
 
 #ifdef GRIP_STAMPS

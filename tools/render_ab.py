@@ -1,12 +1,14 @@
 """Pixels of the observation kernel, build A against build B, on the same states (4096 envs after random macro steps, all rendered):
-    python tools/render_ab.py <variantA|-> <variantB|-> [object] [macro steps of pre-roll]
+    python tools/render_ab.py <variantA|-|rays> <variantB|-|rays> [object] [macro steps of pre-roll]        (rays: the shipped build with GRIP_OBSERVE_RAYS=1)
 Each build runs in its own process (the library is chosen per process); prints the time per 1024 listed rows and how many bytes differ."""
 import sys, os, subprocess; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import torch
     from mujoco_rl_manipulate_unknown_objects_amd import engine
     var, obj, pre, out = sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
-    if var != "-":
+    if var == "rays":                 # the shipped library's ray-casting kernel (rounds 1-4) instead of its rasteriser
+        os.environ["GRIP_OBSERVE_RAYS"] = "1"
+    elif var != "-":
         engine.LIB_PATH = os.path.join(engine.CSRC, f"libgrip_sim_{var}.so")
     n = 4096
     b = engine.Batch(obj, n, auto_reset=1)
