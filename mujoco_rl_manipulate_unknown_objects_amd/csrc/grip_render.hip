@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include "grip_device.h"
 #include <atomic>
 
@@ -477,19 +478,24 @@ __device__ __forceinline__ void observe_body(const DevModel &m, const DevConfig 
 #define RS_WAVES 8          // waves per SIMD the rasteriser is compiled for (64 registers; 2 workgroups per CU fit the LDS)
 #endif
 #ifndef RS_FACES
-#define RS_FACES 256         // face records (measured per env: mean 78-93, max 188 on bread_crumb)
-#define RS_ITEMS 2048        // (face, tile) items (mean 354-386, max 910)
-#define RS_EDGES 1024        // edge normals of the recorded faces (mean 269-311, max 614)
+#define RS_FACES 255         // face records (measured per env: mean 78-93, max 188 on bread_crumb); an item is record << 8 | quad in 16 bits, 0xffff = none
 #endif
-#define RS_DYN_BYTES(nverts) ((size_t)(((nverts) * 3 + 3) / 4 * 4) * 4 + (size_t)RS_FACES * 32 + (size_t)RS_EDGES * 16 + (size_t)RS_ITEMS * 2)
+#ifndef RS_QUAD
+#define RS_QUAD 1            // work items are (face, 4 x 4 pixel quad), four per wave pass (0: (face, 8 x 8 tile), one per pass -- most faces cover a fraction of a tile)
+#endif
+// edge normals (mean 269-311 per env, max 614 measured) and items (8 x 8 tiles: mean 354-386, max 910) share what is left of 80 KB -- two workgroups per CU --
+// after the static part, the vertices and the face records: the launcher sizes them (rs_caps)
+#define RS_LDS_BUDGET (80 * 1024 - 34 * 1024)
+#define RS_DYN_BYTES(nverts, edges, items) ((size_t)(((nverts) * 3 + 3) / 4 * 4) * 4 + (size_t)RS_FACES * 32 + (size_t)(edges) * 16 + (size_t)(items) * 2)
 struct __align__(16) RsFace { float4 P; int ebase, k, id, pad; };
+static_assert(!RS_QUAD || RS_FACES <= 255, "a quad item holds the face record in 8 bits, and 0xffff must stay free");
 
 __device__ __forceinline__ void rs_claim(unsigned long long *zb, int pix, float t, int id) {
     atomicMin(zb + pix, ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)id);
 }
 
 __device__ __forceinline__ void observe_body_raster(const DevModel &m, const DevConfig &cfg, const float *qpos, const int *pad_grasp, const int *pad_pher,
-                                                    int n, int e, uint8_t *obs, uint8_t *obs2, const long long *row2, int nverts_max) {
+                                                    int n, int e, uint8_t *obs, uint8_t *obs2, const long long *row2, int nverts_max, const int RS_EDGES, const int RS_ITEMS) {
     __shared__ Frames fr;
     __shared__ float gmx[GN_GEOM][12];          // plane / vertex transform of a hull: Rg^T Rc (row-major), Rg^T (co - pg)
     __shared__ int gadr[GN_GEOM + 1], gvadr[GN_GEOM + 1], gnum[GN_GEOM];      // visible hulls: prefix sums of their planes / vertices; planes (0 = not visible)
@@ -502,7 +508,7 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
     float *cv = reinterpret_cast<float *>(rs_dyn);                                       // camera-space vertices of the visible hulls, xyz
     RsFace *frec = reinterpret_cast<RsFace *>(cv + (nverts_max * 3 + 3) / 4 * 4);
     float4 *en = reinterpret_cast<float4 *>(frec + RS_FACES);                             // edge normals of the recorded faces (one 16-byte read per edge and item)
-    unsigned short *items = reinterpret_cast<unsigned short *>(en + RS_EDGES);            // record << 6 | tile
+    unsigned short *items = reinterpret_cast<unsigned short *>(en + RS_EDGES);            // record << 8 | quad (RS_QUAD = 0: record << 6 | tile)
     const int tid = threadIdx.x;
     if (tid < 7) frame_role(m, qpos, n, e, cfg.state_half, tid, fr);
     if (tid == 0) { nfaces = 0; nedges = 0; nitems = 0; }
@@ -635,8 +641,9 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
                 }
                 continue;
             }
-            // a larger face: a record, its edge normals, one item per tile of its box
-            const int tx0 = x0 >> 3, tx1 = x1 >> 3, ty0 = y0 >> 3, ty1 = y1 >> 3, ntile = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+            // a larger face: a record, its edge normals, one item per tile (quad) of its box
+            constexpr int TS = RS_QUAD ? 2 : 3, TB = RS_QUAD ? 8 : 6;              // log2 of the tile's side; bits of a tile number
+            const int tx0 = x0 >> TS, tx1 = x1 >> TS, ty0 = y0 >> TS, ty1 = y1 >> TS, ntile = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
             int fi = atomicAdd(&nfaces, 1), eb = -1, ib = -1;
             if (fi < RS_FACES) { eb = atomicAdd(&nedges, K); if (eb + K <= RS_EDGES) { ib = atomicAdd(&nitems, ntile); if (ib + ntile > RS_ITEMS) ib = -1; } }
             if (ib >= 0) {
@@ -652,7 +659,7 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
                     ia = ib2; a = b;
                 }
                 int w = ib;
-                for (int ty = ty0; ty <= ty1; ty++) for (int tx = tx0; tx <= tx1; tx++) items[w++] = (unsigned short)((fi << 6) | (ty * 8 + tx));
+                for (int ty = ty0; ty <= ty1; ty++) for (int tx = tx0; tx <= tx1; tx++) items[w++] = (unsigned short)((fi << TB) | ((ty << (6 - TS)) + tx));
                 continue;
             }
             // tables full: this thread walks the box itself
@@ -675,9 +682,26 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
         }
     }
     __syncthreads();
-    // ---- the recorded faces, tile by tile: a wave per item, a lane per pixel
+    // ---- the recorded faces, tile by tile: a lane per pixel; a wave takes one 8 x 8 tile or four 4 x 4 quads (of any faces) per pass
     if (RS_STOP != 1 && RS_STOP != 2) {
         const int ni = min(nitems, RS_ITEMS), wv = tid >> 6, ln = tid & 63;
+#if RS_QUAD
+        for (int it0 = 4 * wv; it0 < ni; it0 += 4 * (RTHREADS / 64)) {
+            const int it = it0 + (ln >> 4);
+            const unsigned item = it < ni ? (unsigned)items[it] : 0xffffu;
+            const bool live = item != 0xffffu;                          // (0xffff: past the end, or the hole a refused allocation leaves)
+            const RsFace f = frec[live ? (item >> 8) : 0];
+            const int K = live ? f.k : 0;
+            const int quad = item & 255, px = (quad & 15) * 4 + (ln & 3), py = (quad >> 4) * 4 + ((ln >> 2) & 3);
+            const float x = ray_x(px), y = ray_y(py);
+            bool in = live;
+            const float4 *ep = en + f.ebase;
+            for (int k = 0; __any(k < K); k++) if (k < K) { const float4 c = ep[k]; in &= !(fmaf(c.x, x, fmaf(c.y, y, -c.z)) > 0.f); }
+            const float den = fmaf(f.P.y, y, fmaf(f.P.x, x, -f.P.z));
+            const float t = f.P.w * rcp(den);
+            if (in && den < 0.f && t > 0.f && t > m.znear) rs_claim(zb, py * RW + px, t, f.id);
+        }
+#else
         for (int it = wv; it < ni; it += RTHREADS / 64) {
             const unsigned item = __builtin_amdgcn_readfirstlane((unsigned)items[it]);
             if (item == 0xffffu) continue;                              // (the hole a refused allocation leaves)
@@ -692,6 +716,7 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
             const float t = f.P.w * rcp(den);
             if (in && den < 0.f && t > 0.f && t > m.znear) rs_claim(zb, py * RW + px, t, f.id);
         }
+#endif
     }
     __syncthreads();
     // ---- resolve: the thread's 2 x 2 tile against the floor, as the ray caster orders its hits
@@ -815,7 +840,7 @@ __global__ void __launch_bounds__(RTHREADS, 8) k_observe_rays(const RenderGroup 
 }
 
 __global__ void __launch_bounds__(RTHREADS, RS_WAVES) k_observe(const RenderGroup *__restrict__ groups, int ngroups, const int *list, const int *count,
-                                                      uint8_t *obs, uint8_t *obs2, const long long *row2, int nverts_max) {
+                                                      uint8_t *obs, uint8_t *obs2, const long long *row2, int nverts_max, int edges_cap, int items_cap) {
     if (list && count && (int)blockIdx.x >= *count) return;
     const int ge = list ? list[blockIdx.x] : (int)blockIdx.x;
     if (ge < 0) return;
@@ -823,7 +848,7 @@ __global__ void __launch_bounds__(RTHREADS, RS_WAVES) k_observe(const RenderGrou
     for (int i = 1; i < ngroups; i++) g = ge >= groups[i].env0 ? i : g;
     const RenderGroup &rg = groups[g];
     const DevConfig cfg = rg.cfg;
-    observe_body_raster(rg.m, cfg, rg.qpos, rg.pad_grasp, rg.pad_pher, rg.n, ge - rg.env0, obs, obs2, row2, nverts_max);
+    observe_body_raster(rg.m, cfg, rg.qpos, rg.pad_grasp, rg.pad_pher, rg.n, ge - rg.env0, obs, obs2, row2, nverts_max, edges_cap, items_cap);
 }
 
 // GRIP_OBSERVE_RAYS=1 in the environment (read once): the ray-casting kernel of rounds 1-4 instead of the rasteriser, for tools/render_ab.py's pixel comparison
@@ -844,14 +869,20 @@ extern "C" int grip_render_launch(const RenderGroup *groups_dev, int ngroups, co
         const unsigned long long bit = 1ULL << (dev & 63);
         if (!(attr_set_mask.load(std::memory_order_acquire) & bit)) {
             if (hipFuncSetAttribute((const void *)k_observe_rays, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((RMAXPL + NBOX * GN_HULL) * sizeof(float4))) != hipSuccess) return -1;
-            if (hipFuncSetAttribute((const void *)k_observe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS_DYN_BYTES(RS_MAX_VERTS)) != hipSuccess) return -1;
+            if (hipFuncSetAttribute((const void *)k_observe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RS_DYN_BYTES(RS_MAX_VERTS, 1024, 8192)) != hipSuccess) return -1;
             attr_set_mask.fetch_or(bit, std::memory_order_release);
         }
     }
     if (rays)
         hipLaunchKernelGGL(k_observe_rays, dim3(nblocks), dim3(RTHREADS), (size_t)(nplanes_max + NBOX * GN_HULL) * sizeof(float4), s, groups_dev, ngroups, list, count, obs, obs2, row2);
-    else
-        hipLaunchKernelGGL(k_observe, dim3(nblocks), dim3(RTHREADS), RS_DYN_BYTES(nverts_max), s, groups_dev, ngroups, list, count, obs, obs2, row2, nverts_max);
+    else {
+        // 1024 edge normals where they fit (512 at least), the rest of the budget for items (at least 1024: beyond the budget a workgroup has the CU to itself)
+        const long long left = (long long)RS_LDS_BUDGET - (long long)RS_DYN_BYTES(nverts_max, 0, 0);
+        const int edges_cap = left >= 1024 * 16 + 2048 * 2 ? 1024 : 512;
+        const int items_cap = (int)std::min<long long>(8192, std::max<long long>(1024, (left - edges_cap * 16) / 2)) & ~7;
+        hipLaunchKernelGGL(k_observe, dim3(nblocks), dim3(RTHREADS), RS_DYN_BYTES(nverts_max, edges_cap, items_cap), s, groups_dev, ngroups, list, count, obs, obs2, row2, nverts_max,
+                           edges_cap, items_cap);
+    }
     return launch_status("grip_render_launch");
 }
 
