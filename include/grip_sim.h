@@ -193,8 +193,10 @@ int grip_obs_preprocess(const uint8_t *obs_dev, int n, int channels, float *img_
  * times a bf16 is exact in the fp32 accumulator): obs_dev uint8 [n, 5, 64, 64] -> out_nhwc_dev float32 [n, 15, 15, 32] =
  * relu(conv2d(obs[:, :4] / 255, weight, bias, stride 4)) (i.e. a channels-last [n, 32, 15, 15] tensor) and other_dev float32
  * [n, 2] = obs[:, 4, 0, :2] / 255. weight_dev float32 [32, 4, 8, 8] with element strides weight_strides[4] (any layout),
- * bias_dev float32 [32], scratch_dev 12 288 floats (the weights / 255 as three bf16 terms, the GEMM's B operand, rewritten by every call).
+ * bias_dev float32 [32], scratch_dev 12 288 floats (the weights / 255 as three bf16 terms, the GEMM's B operand, rewritten by every call -- or, with
+ * weight_dev == NULL, taken as grip_conv1_prep left them: the rollouts split the weights once per policy update, not once per tick).
  * No autograd (the update's variant with the ReLU mask: grip_conv1_u8_train; its backward: grip_trunk_backward). */
+int grip_conv1_prep(const float *weight_dev, const int64_t *weight_strides, float *scratch_dev, void *stream);
 int grip_conv1_u8(const uint8_t *obs_dev, int n, int channels, const float *weight_dev, const int64_t *weight_strides, const float *bias_dev,
                   float *scratch_dev, float *out_nhwc_dev, float *other_dev, void *stream);
 /* The same on rows row0_dev[0] .. row0_dev[0] + n - 1 of obs_dev (row0_dev: int64 [1] in device memory, NULL = 0): the time-sliced trainer renders

@@ -155,12 +155,23 @@ extern "C" int grip_conv1_u8(const uint8_t *obs_dev, int n, int channels, const 
                              float *scratch_dev, float *out_nhwc_dev, float *other_dev, void *stream) {
     return grip_conv1_u8_rows(obs_dev, nullptr, n, channels, weight_dev, weight_strides, bias_dev, scratch_dev, out_nhwc_dev, other_dev, stream);
 }
-extern "C" int grip_conv1_u8_train(const uint8_t *obs_dev, const int64_t *row0_dev, const int64_t *rows_dev, int n, int channels, const float *weight_dev,
-                                   const int64_t *weight_strides, const float *bias_dev, float *scratch_dev, float *out_nhwc_dev, float *other_dev, uint32_t *mask_dev, void *stream) {
-    if (!obs_dev || !weight_dev || !weight_strides || !bias_dev || !scratch_dev || !out_nhwc_dev || !other_dev || n <= 0 || channels != C1_IN + 1)
-        return grip_fail("grip_conv1_u8: need uint8 [n, 5, 64, 64] observations, Conv2d(4, 32, 8, 4) weights and bias, a 12 288-float scratch and the two outputs");
+extern "C" int grip_conv1_prep(const float *weight_dev, const int64_t *weight_strides, float *scratch_dev, void *stream) {
+    if (!weight_dev || !weight_strides || !scratch_dev) return grip_fail("grip_conv1_prep: need the Conv2d(4, 32, 8, 4) weight, its element strides and the 12 288-float scratch");
     hipLaunchKernelGGL(k_conv1_prep, dim3(C1_KDIM * C1_OUT / 256), dim3(256), 0, (hipStream_t)stream, weight_dev, (long long)weight_strides[0], (long long)weight_strides[1],
                        (long long)weight_strides[2], (long long)weight_strides[3], reinterpret_cast<uint16_t *>(scratch_dev));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { char buf[160]; snprintf(buf, sizeof buf, "grip_conv1_prep: %s", hipGetErrorString(e)); return grip_fail(buf); }
+    return 0;
+}
+extern "C" int grip_conv1_u8_train(const uint8_t *obs_dev, const int64_t *row0_dev, const int64_t *rows_dev, int n, int channels, const float *weight_dev,
+                                   const int64_t *weight_strides, const float *bias_dev, float *scratch_dev, float *out_nhwc_dev, float *other_dev, uint32_t *mask_dev, void *stream) {
+    if (!obs_dev || (weight_dev && !weight_strides) || !bias_dev || !scratch_dev || !out_nhwc_dev || !other_dev || n <= 0 || channels != C1_IN + 1)
+        return grip_fail("grip_conv1_u8: need uint8 [n, 5, 64, 64] observations, Conv2d(4, 32, 8, 4) weights and bias, a 12 288-float scratch and the two outputs");
+    // weight_dev == NULL: scratch_dev already holds the weight's three bf16 terms (grip_conv1_prep, or an earlier call with the same weights): the rollouts split
+    // the weights once per policy update, not once per tick
+    if (weight_dev)
+        hipLaunchKernelGGL(k_conv1_prep, dim3(C1_KDIM * C1_OUT / 256), dim3(256), 0, (hipStream_t)stream, weight_dev, (long long)weight_strides[0], (long long)weight_strides[1],
+                           (long long)weight_strides[2], (long long)weight_strides[3], reinterpret_cast<uint16_t *>(scratch_dev));
     // 80 KB of LDS per workgroup: exactly two per CU, 512 on the chip. Workgroup i takes images i, i + grid, ...: with all 512 launched a CU's two (i, i + 256 under
     // round-robin placement) share the remainder evenly -- sizing the grid for equal counts per WORKGROUP left some CUs with one workgroup more than others
     // (12 % off the balanced time at 4096 images)

@@ -107,7 +107,7 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_kernel_time", "grip_batch_device_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward", "grip_obs_preprocess",
            "grip_batch_set_state_storage", "grip_batchset_create", "grip_batchset_destroy", "grip_batchset_refresh", "grip_batchset_num_envs",
            "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list", "grip_conv1_u8", "grip_conv1_u8_rows", "grip_batch_render_camera", "grip_ppo_loss", "grip_conv23_prep", "grip_conv23",
-           "grip_trunk_backward", "grip_trunk_backward_parts", "grip_conv1_u8_train", "grip_conv23_train", "grip_clip_adam", "grip_clip_adam_chunks", "grip_tanh_backward_colsum", "grip_relu_backward_colsum", "grip_ppo_loss_heads", "grip_bias_tanh"]
+           "grip_trunk_backward", "grip_trunk_backward_parts", "grip_conv1_u8_train", "grip_conv23_train", "grip_clip_adam", "grip_clip_adam_chunks", "grip_tanh_backward_colsum", "grip_relu_backward_colsum", "grip_ppo_loss_heads", "grip_bias_tanh", "grip_conv1_prep"]
 
 
 def lib():
@@ -177,6 +177,7 @@ def lib():
     L.grip_ppo_loss.argtypes = [vp] * 7 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float] + [vp] * 5
     L.grip_ppo_loss_heads.argtypes = [vp] * 8 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_float] + [vp] * 6
     L.grip_bias_tanh.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+    L.grip_conv1_prep.argtypes = [vp, C.POINTER(C.c_int64), vp, vp]
     L.grip_batch_render_camera.argtypes = [vp, C.c_int, vp, C.c_float, C.c_int, C.c_int, vp, vp, vp]
     L.grip_rollout_tick.argtypes = [vp, vp]
     L.grip_rollout_gae.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]
@@ -254,11 +255,23 @@ class IndexedRows:
         return self.records[self.index]
 
 
-def conv1_u8(obs, weight, bias, with_mask=False):
+def conv1_prep(weight, out=None):
+    """The first layer's weight / 255 as three bf16 terms, the B operand of grip_conv1_u8 (float32 [12288] scratch; `out`: rewrite it in place -- fixed address for
+    a captured rollout tick). conv1_u8(..., prepared=...) then skips the split: once per policy update instead of once per tick."""
+    import torch
+    assert weight.is_cuda and weight.dtype == torch.float32 and tuple(weight.shape) == (32, 4, 8, 8)
+    if out is None:
+        out = torch.empty(12288, dtype=torch.float32, device=weight.device)
+    strides = (C.c_int64 * 4)(*weight.stride())
+    _chk(lib().grip_conv1_prep(C.c_void_p(weight.data_ptr()), strides, C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(weight.device).cuda_stream)))
+    return out
+
+
+def conv1_u8(obs, weight, bias, with_mask=False, prepared=None):
     """First layer of AugmentedNatureCNN for rollouts (grip_conv1_u8, csrc/grip_policy.hip): uint8 CUDA observations
     [n, 5, 64, 64] -> (relu(conv2d(obs[:, :4] / 255, weight, bias, stride 4)) as a channels-last float32 [n, 32, 15, 15]
     tensor, the two sensor-pad scalars / 255 as [n, 2]) in one launch on the matrix cores (fp32 arithmetic, computed exactly on the bf16 pipe:
-    csrc/grip_policy.hip). No autograd."""
+    csrc/grip_policy.hip). No autograd. prepared: conv1_prep(weight) of the SAME weight values (the split is then not repeated)."""
     import torch
     rows = obs if isinstance(obs, RecordRows) else None
     idx = obs if isinstance(obs, IndexedRows) else None
@@ -269,13 +282,15 @@ def conv1_u8(obs, weight, bias, with_mask=False):
     n = rows.n if rows is not None else idx.n if idx is not None else int(obs.shape[0])
     out = torch.empty((n, 32, 15, 15), dtype=torch.float32, device=obs.device, memory_format=torch.channels_last)
     other = torch.empty((n, 2), dtype=torch.float32, device=obs.device)
-    scratch = torch.empty(12288, dtype=torch.float32, device=obs.device)
+    if prepared is not None:
+        assert prepared.is_cuda and prepared.dtype == torch.float32 and prepared.numel() == 12288 and prepared.is_contiguous()
+    scratch = prepared if prepared is not None else torch.empty(12288, dtype=torch.float32, device=obs.device)
     strides = (C.c_int64 * 4)(*weight.stride())
     stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
     # with_mask (the update's forward): also the layer's ReLU mask, int32 [n, 225], bit c of word (image, position) = channel c is active
     mask = torch.empty((n, 225), dtype=torch.int32, device=obs.device) if with_mask else None
     _chk(lib().grip_conv1_u8_train(C.c_void_p(obs.data_ptr()), None if rows is None else C.c_void_p(rows.row0.data_ptr()),
-                                   None if idx is None else C.c_void_p(idx.index.data_ptr()), n, 5, C.c_void_p(weight.data_ptr()), strides,
+                                   None if idx is None else C.c_void_p(idx.index.data_ptr()), n, 5, None if prepared is not None else C.c_void_p(weight.data_ptr()), strides,
                                    C.c_void_p(bias.data_ptr()), C.c_void_p(scratch.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(other.data_ptr()),
                                    None if mask is None else C.c_void_p(mask.data_ptr()), stream))
     return (out, other, mask) if with_mask else (out, other)

@@ -111,6 +111,7 @@ class AugmentedNatureCNN(BaseFeaturesExtractor):
     _wl_nhwc = None
     _b23 = None             # second / third convolution's weights as grip_conv23's GEMM operands (fixed addresses)
     _b23_store = None
+    _c1_terms = None        # the first convolution's weight as grip_conv1_u8's B operand (three bf16 terms), split once per refresh
 
     @th.no_grad()
     def refresh_rollout_cache(self):
@@ -122,6 +123,12 @@ class AugmentedNatureCNN(BaseFeaturesExtractor):
         self._wl_nhwc.copy_(lw.view(lw.shape[0], c3, hw, hw).permute(0, 2, 3, 1).reshape(lw.shape[0], -1))
         c2, c3m = self.cnn[2], self.cnn[4]
         self._b23 = None
+        c0 = self.cnn[0]
+        if lw.is_cuda and tuple(c0.weight.shape) == (32, 4, 8, 8) and c0.weight.dtype == th.float32:
+            from ..engine import conv1_prep
+            self._c1_terms = conv1_prep(c0.weight, self._c1_terms if (self._c1_terms is not None and self._c1_terms.device == c0.weight.device) else None)
+        else:
+            self._c1_terms = None
         if (lw.is_cuda and tuple(c2.weight.shape) == (64, 32, 4, 4) and c2.stride == (2, 2) and c2.padding == (0, 0) and tuple(c3m.weight.shape) == (64, 64, 3, 3)
                 and c3m.stride == (1, 1) and c3m.padding == (0, 0) and c2.weight.dtype == th.float32):
             from ..engine import conv23_prep
@@ -137,14 +144,14 @@ class AugmentedNatureCNN(BaseFeaturesExtractor):
                 and not th.is_autocast_enabled()):
             return None
         from ..engine import conv1_u8
-        x, other = conv1_u8(obs.contiguous(), c0.weight, c0.bias)      # (a tensor, or engine.RecordRows: the tick's record rows, read in place)
+        x, other = conv1_u8(obs.contiguous(), c0.weight, c0.bias, prepared=self._c1_terms)      # (a tensor, or engine.RecordRows: the tick's record rows, read in place)
         if self._b23 is not None:                                   # both remaining convolutions + ReLUs as one f32-MFMA launch
             from ..engine import conv23
             x = conv23(x, self._b23[0], self.cnn[2].bias, self._b23[1], self.cnn[4].bias)
         else:
             x = th.relu_(self.cnn[2](x)); x = th.relu_(self.cnn[4](x))
         xf = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)          # a view: the tensor is channels_last
-        return th.cat((th.relu_(th.addmm(self.linear[0].bias, xf, self._wl_nhwc.t())), other), dim=1)
+        return th.cat((th._addmm_activation(self.linear[0].bias, xf, self._wl_nhwc.t()), other), dim=1)      # (the ReLU in the GEMM's epilogue)
 
     def forward(self, observations, num_direct_features: int = 2) -> th.Tensor:
         obs = observations["observation"]

@@ -143,11 +143,12 @@ class AsyncRollout:
         """Zero the statistics a benchmark reads over a timed region (keeps the slice ladder's bookkeeping consistent with them)."""
         self.substeps_total.zero_(); self._sub_seen = 0
 
-    def set_slice_ladder(self, ladder=((0, 96, 2000), (215, 144, 3000), (270, 192, 4000))):
+    def set_slice_ladder(self, ladder=((0, 96, 2000), (215, 120, 2500), (270, 192, 4000))):
         """Let the slice length / wall-clock budget follow the measured mean number of physics.step() calls per macro step: after
         every rollout the rung with the largest threshold below that mean is taken (10 % hysteresis); a change re-captures the
         tick graph. Measured on the bench workload: 96 / 2000 us is best at ~180 calls per macro step (fresh episodes), 144-192 /
-        3000-4000 us at ~300 (steady state of training): +9 % there, -16 % if used on the former."""
+        3000-4000 us at ~300 (steady state of training): +9 % there, -16 % if used on the former. (Round 4: the middle rung 144 / 3000 -> 120 / 2500 -- the
+        decision phase a tick pays for got 40 % shorter, and at ~236 calls per macro step 120 / 2500 and 96 / 2000 now measure +0.7 ... +1 % over 144 / 3000.)"""
         self.ladder = tuple(sorted((int(a), int(b), int(c)) for a, b, c in ladder))
 
     def _retune(self, done_n):

@@ -219,7 +219,7 @@ def test_slice_ladder_follows_the_macro_step_length():
     eng.budget_us = 2000
     ro = AsyncRollout(eng, fake_policy, target=8, capacity=4, slice_len=96, gamma=0.99, gae_lambda=0.95)
     ro.set_slice_ladder()
-    assert ro.ladder == ((0, 96, 2000), (215, 144, 3000), (270, 192, 4000))
+    assert ro.ladder == ((0, 96, 2000), (215, 120, 2500), (270, 192, 4000))
 
     def feed(mean, n=100):
         ro._graph = "captured"
@@ -229,8 +229,8 @@ def test_slice_ladder_follows_the_macro_step_length():
 
     assert feed(180) == (96, 2000, "captured")                 # stays on the first rung, graph kept
     assert feed(225) == (96, 2000, "captured")                 # within 10 % of the 215 threshold: no move
-    assert feed(250) == (144, 3000, None)                      # clearly above: second rung, graph dropped
-    assert feed(262) == (144, 3000, "captured")                # within 10 % of 270
+    assert feed(250) == (120, 2500, None)                      # clearly above: second rung, graph dropped
+    assert feed(262) == (120, 2500, "captured")                # within 10 % of 270
     assert feed(320) == (192, 4000, None)
     assert feed(255) == (192, 4000, "captured")                # hysteresis on the way down too
     assert feed(150) == (96, 2000, None)
