@@ -553,7 +553,11 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
     const float tanh_ = tanf(0.5f * m.cam_fovy * 0.017453292519943295f);
     auto ray_x = [&](int px) { return (2.0f * (px + 0.5f) / RW - 1.0f) * tanh_; };       // the ray caster's expressions: the same floats
     auto ray_y = [&](int py) { return (1.0f - 2.0f * (py + 0.5f) / RH) * tanh_; };
-    auto hull_of = [&](const int *adr, int i) { int g = 1; for (int h = 2; h < GN_GEOM; h++) g = (gnum[h] && i >= adr[h]) ? h : g; return g; };   // (the first visible hull starts at 0)
+    // (the first visible hull starts at 0. The tables are read through laundered pointers: hoisted out of the loops below -- one or two trips per thread -- the 20 loop-invariant
+    // words were registers held across the whole per-face pass, i.e. spills)
+    auto hull_of = [&](const int *adr, int i) {
+        const int *gn = gnum; asm volatile("" : "+v"(adr), "+v"(gn));
+        int g = 1; for (int h = 2; h < GN_GEOM; h++) g = (gn[h] && i >= adr[h]) ? h : g; return g; };
     // ---- vertices of the visible hulls -> camera coordinates: Mx^T (v - ol)
     {
         const int nv = gvadr[GN_GEOM];

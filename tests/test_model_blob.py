@@ -44,3 +44,70 @@ def test_model_facts(obj):
         pl = m["hull_planes"][m["hull_padr"][h]:m["hull_padr"][h] + m["hull_pnum"][h]]
         assert (v @ pl[:, :3].T - pl[:, 3]).max() < 1e-9
     assert m["hull_pairs"].tolist() == [[1, 3], [1, 5], [1, 6], [2, 4], [2, 5], [2, 6], [3, 4], [3, 5], [3, 6], [4, 6], [5, 6]]
+
+
+def _cyrus_beck(P, co, Rc, dc):
+    """entering depth of rays t * (Rc dc) from co against the convex hull {n.x <= d} (float64): (hit mask, t)"""
+    A = P[:, :3] @ Rc; B = P[:, 3] - P[:, :3] @ co
+    den = dc @ A.T; front = B < 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = B[None, :] / den
+    tin = np.where(front[None, :] & (den < 0), t, -np.inf)
+    never = (front[None, :] & (den >= 0)).any(1)
+    tb = tin.max(1)
+    ok = (~never) & np.isfinite(tb) & ((B[None, :] - tb[:, None] * den) >= -1e-12).all(1)
+    return ok, tb, A, B, den
+
+
+@pytest.mark.parametrize("obj", OBJECTS)
+def test_face_polygons_are_the_hulls_faces(obj):
+    """hull_ladr / hull_loops (the observation kernel's rasteriser reads them): every listed plane's corner loop lies in its plane, is convex and
+    counter-clockwise seen from outside; a duplicate of an earlier plane of the same flat face has an empty loop; and drawing the loops -- a ray hits a
+    camera-facing face iff dc . (v_i x v_{i+1}) <= 0 for every edge, depth B / (A.dc) -- gives the image a float64 Cyrus-Beck over the planes gives
+    (identical hit masks, depths to 1e-6), from six random viewpoints per hull."""
+    m = blob.read_blob(os.path.join(ASSETS, f"{obj}_env.grpm"))
+    ladr, loops = m["hull_ladr"], m["hull_loops"]
+    assert ladr[0] == 0 and ladr[-1] == len(loops) and len(ladr) == len(m["hull_planes"]) + 1 and (np.diff(ladr) >= 0).all()
+    rng = np.random.default_rng(3)
+    for h in range(6):
+        V = m["hull_verts"][m["hull_vadr"][h]:m["hull_vadr"][h] + m["hull_vnum"][h]]
+        p0, pn = m["hull_padr"][h], m["hull_pnum"][h]
+        P = m["hull_planes"][p0:p0 + pn]
+        L = [loops[ladr[p0 + j]:ladr[p0 + j + 1]] for j in range(pn)]
+        size = np.abs(V - V.mean(0)).max()
+        seen = set()
+        for j, lp in enumerate(L):
+            if len(lp) == 0:
+                continue
+            assert len(lp) >= 3 and lp.min() >= 0 and lp.max() < len(V) and len(set(lp.tolist())) == len(lp)
+            key = tuple(sorted(lp.tolist())); assert key not in seen; seen.add(key)           # one loop per geometric face
+            n = P[j, :3] / np.linalg.norm(P[j, :3])
+            v = V[lp]
+            assert np.abs(v @ P[j, :3] - P[j, 3]).max() < 1e-6 * max(size, 1e-3) * 10            # in the plane
+            e = np.roll(v, -1, 0) - v
+            turn = np.cross(e, np.roll(e, -1, 0)) @ n                                            # counter-clockwise about the outward normal, convex
+            assert turn.min() >= -1e-9 * size * size and turn.max() > 0
+        assert len(seen) >= 4
+        # drawing the loops = clipping rays against the planes
+        for _ in range(6):
+            ctr = V.mean(0)
+            d = rng.normal(size=3); d /= np.linalg.norm(d)
+            co = ctr + d * size * rng.uniform(1.5, 6.0)
+            z = (co - ctr) / np.linalg.norm(co - ctr)
+            x = np.cross([0.0, 0.0, 1.0], z); x = x / np.linalg.norm(x) if np.linalg.norm(x) > 1e-6 else np.array([1.0, 0, 0])
+            Rc = np.stack([x, np.cross(z, x), z], 1)
+            th = np.tan(np.deg2rad(30.0)); g = (2 * (np.arange(32) + 0.5) / 32 - 1) * th
+            X, Y = np.meshgrid(g, -g)
+            dc = np.stack([X, Y, -np.ones_like(X)], -1).reshape(-1, 3)
+            ok, tb, A, B, den = _cyrus_beck(P, co, Rc, dc)
+            Vc = (V - co) @ Rc
+            t_r = np.full(len(dc), np.inf)
+            for j, lp in enumerate(L):
+                if len(lp) == 0 or not B[j] < 0:
+                    continue
+                a, b = Vc[lp], Vc[np.roll(lp, -1)]
+                inside = ((dc @ np.cross(a, b).T) <= 0).all(1) & (den[:, j] < 0)
+                t_r[inside] = np.minimum(t_r[inside], B[j] / den[inside, j])
+            hit = np.isfinite(t_r)
+            assert (hit == ok).all(), (obj, h, int((hit != ok).sum()))
+            assert ok.sum() > 20 and np.abs(t_r[ok] - tb[ok]).max() <= 1e-6 * tb[ok].max()
