@@ -371,6 +371,7 @@ def main():
             # source makes a macro step cost: ~232 for the synthetic U(-1,1) stream, ~312 for actions sampled from the learning policy)
             "action_source": a.actions, "mj_substeps_per_s": total_sub / dt, "mean_substeps_per_env_step": total_sub / max(total_env_steps, 1.0),
             "replicas_identical": replicas_identical,
+            "update_path": "explicit launch sequence (sb3/fused_update.py)" if getattr(model, "_fused", None) is not None else "autograd",
             # N > 1: device time of the one collective per optimiser step (the flat 4 MB fp32 gradient bucket over RCCL), rank 0's view
             "allreduce_ms_per_optimizer_step": ar_ms, "allreduce_steps_timed": ar_n, "env_steps_counted": total_env_steps, "env_steps_nominal": a.envs * world * a.steps, "short_rollouts": short_rollouts,
             "roofline": {"bound": "hbm", "kernel": "k_macro_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

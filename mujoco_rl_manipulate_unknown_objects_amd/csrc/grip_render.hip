@@ -498,7 +498,7 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
                                                     int n, int e, uint8_t *obs, uint8_t *obs2, const long long *row2, int nverts_max, const int RS_EDGES, const int RS_ITEMS) {
     __shared__ Frames fr;
     __shared__ float gmx[GN_GEOM][12];          // plane / vertex transform of a hull: Rg^T Rc (row-major), Rg^T (co - pg)
-    __shared__ int gadr[GN_GEOM + 1], gvadr[GN_GEOM + 1], gnum[GN_GEOM];      // visible hulls: prefix sums of their planes / vertices; planes (0 = not visible)
+    __shared__ int gnum[GN_GEOM];               // a hull's planes if it can be seen, else 0
     __shared__ int nfaces, nedges, nitems;
     // the z-buffer (32 KB) while the faces are drawn; afterwards the composed observation (20 KB) and the two reductions' scratch
     __shared__ __align__(16) unsigned char pool[8 * RPIX];
@@ -510,6 +510,17 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
     float4 *en = reinterpret_cast<float4 *>(frec + RS_FACES);                             // edge normals of the recorded faces (one 16-byte read per edge and item)
     unsigned short *items = reinterpret_cast<unsigned short *>(en + RS_EDGES);            // record << 8 | quad (RS_QUAD = 0: record << 6 | tile)
     const int tid = threadIdx.x;
+    // vertices and planes are numbered over all six hulls as the model lists them (uniform offsets, scalar compares): no per-env table of the visible ones, and
+    // the vertices' global loads are issued before anything else -- they do not depend on the pose, so their latency hides behind the frames
+    const int nvert_all = m.hull_vadr[GN_HULL - 1] + m.hull_vnum[GN_HULL - 1], nplane_all = m.hull_padr[GN_HULL - 1] + m.hull_pnum[GN_HULL - 1];
+    auto hull_of_vertex = [&](int i) { int g = 1; for (int h = 2; h < GN_GEOM; h++) g = i >= m.hull_vadr[h - 1] ? h : g; return g; };
+    auto hull_of_plane = [&](int i) { int g = 1; for (int h = 2; h < GN_GEOM; h++) g = i >= m.hull_padr[h - 1] ? h : g; return g; };
+    constexpr int VPT = 2;                                              // vertices per thread held in registers over the prologue (more: loaded late, below)
+    float4 vearly[VPT];
+    {   const float4 *vb = reinterpret_cast<const float4 *>(m.hull_blob);
+#pragma unroll
+        for (int k = 0; k < VPT; k++) { const int i = tid + k * RTHREADS; vearly[k] = i < nvert_all ? vb[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
     if (tid < 7) frame_role(m, qpos, n, e, cfg.state_half, tid, fr);
     if (tid == 0) { nfaces = 0; nedges = 0; nitems = 0; }
     for (int i = tid; i < RPIX; i += RTHREADS) zb[i] = ~0ull;
@@ -544,31 +555,23 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
         gnum[g] = vis ? m.hull_pnum[g - 1] : 0;
     }
     __syncthreads();
-    if (tid == 0) {
-        int a = 0, v = 0;
-        for (int g = 1; g < GN_GEOM; g++) { gadr[g] = a; gvadr[g] = v; if (gnum[g]) { a += gnum[g]; v += m.hull_vnum[g - 1]; } }
-        gadr[GN_GEOM] = a; gvadr[GN_GEOM] = v;
-    }
-    __syncthreads();
     const float tanh_ = tanf(0.5f * m.cam_fovy * 0.017453292519943295f);
     auto ray_x = [&](int px) { return (2.0f * (px + 0.5f) / RW - 1.0f) * tanh_; };       // the ray caster's expressions: the same floats
     auto ray_y = [&](int py) { return (1.0f - 2.0f * (py + 0.5f) / RH) * tanh_; };
-    // (the first visible hull starts at 0. The tables are read through laundered pointers: hoisted out of the loops below -- one or two trips per thread -- the 20 loop-invariant
-    // words were registers held across the whole per-face pass, i.e. spills)
-    auto hull_of = [&](const int *adr, int i) {
-        const int *gn = gnum; asm volatile("" : "+v"(adr), "+v"(gn));
-        int g = 1; for (int h = 2; h < GN_GEOM; h++) g = (gn[h] && i >= adr[h]) ? h : g; return g; };
     // ---- vertices of the visible hulls -> camera coordinates: Mx^T (v - ol)
     {
-        const int nv = gvadr[GN_GEOM];
         const float4 *vb = reinterpret_cast<const float4 *>(m.hull_blob);
-        for (int i = tid; i < nv; i += RTHREADS) {
-            const int g = hull_of(gvadr, i);
-            const float4 v = vb[m.hull_vadr[g - 1] + (i - gvadr[g])];
+        auto to_camera = [&](int i, float4 v) {
+            const int g = hull_of_vertex(i);
+            const int *gn = gnum; asm volatile("" : "+v"(gn));          // (read where it is used: hoisted, the table is registers held across the loops)
+            if (!gn[g]) return;
             const M3 Mx = ldm(gmx[g]);
             const V3 c = multv(Mx, v3(v.x - gmx[g][9], v.y - gmx[g][10], v.z - gmx[g][11]));
             cv[3 * i] = c.x; cv[3 * i + 1] = c.y; cv[3 * i + 2] = c.z;
-        }
+        };
+#pragma unroll
+        for (int k = 0; k < VPT; k++) if (tid + k * RTHREADS < nvert_all) to_camera(tid + k * RTHREADS, vearly[k]);
+        for (int i = tid + VPT * RTHREADS; i < nvert_all; i += RTHREADS) to_camera(i, vb[i]);
     }
     __syncthreads();
     // ---- one thread per face: set-up, and the small ones drawn on the spot
@@ -576,9 +579,10 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
 #define RS_STOP 0          // diagnostic builds: 1 = leave after the vertex transform, 2 = after the per-face pass (tools/render_ab.py times the difference)
 #endif
     if (RS_STOP != 1) {
-        const int np = gadr[GN_GEOM];
-        for (int i = tid; i < np; i += RTHREADS) {
-            const int g = hull_of(gadr, i), j = i - gadr[g], jg = m.hull_padr[g - 1] + j;
+        // (from the last plane down: the object and the fingers first -- the gripper base, whose 770 planes lead the list, is out of sight and its threads leave at once)
+        for (int i = tid; i < nplane_all; i += RTHREADS) {
+            const int jg = nplane_all - 1 - i, g = hull_of_plane(jg), j = jg - m.hull_padr[g - 1];
+            {   const int *gn = gnum; asm volatile("" : "+v"(gn)); if (!gn[g]) continue; }
             const int l0 = m.hull_ladr[jg], K = m.hull_ladr[jg + 1] - l0;
             if (K < 3) continue;                                        // a duplicate of an earlier plane of the same face
             const float *pl = m.hull_planes + 4 * jg;
@@ -587,7 +591,7 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
             const V3 A = multv(Mx, nn);
             const float B = pl[3] - dot(nn, v3(gmx[g][9], gmx[g][10], gmx[g][11]));
             if (!(B < 0.f)) continue;                                   // the camera is not outside this plane: no ray enters through it
-            const float *cvg = cv + 3 * gvadr[g];
+            const float *cvg = cv + 3 * m.hull_vadr[g - 1];
             const int *lp = m.hull_loops + l0;
             // screen box of the part of the loop beyond the near plane z = -znear (nothing nearer is drawn: t > znear): its corners there and the points where
             // its edges cross the plane. Conservative by a hundredth of a pixel; the edge tests below decide, and they need no projection or clipping.
@@ -690,20 +694,34 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
     if (RS_STOP != 1 && RS_STOP != 2) {
         const int ni = min(nitems, RS_ITEMS), wv = tid >> 6, ln = tid & 63;
 #if RS_QUAD
-        for (int it0 = 4 * wv; it0 < ni; it0 += 4 * (RTHREADS / 64)) {
+        // (the next pass's item and face record are requested while this pass works, and the edge normals come four at a time: one LDS round trip per
+        // dependent step -- item -> record -> edge -> edge ... -- was most of this loop's time)
+        auto fetch = [&](int it0, unsigned &item, RsFace &f) {
             const int it = it0 + (ln >> 4);
-            const unsigned item = it < ni ? (unsigned)items[it] : 0xffffu;
-            const bool live = item != 0xffffu;                          // (0xffff: past the end, or the hole a refused allocation leaves)
-            const RsFace f = frec[live ? (item >> 8) : 0];
+            item = it < ni ? (unsigned)items[it] : 0xffffu;                // (0xffff: past the end, or the hole a refused allocation leaves)
+            f = frec[item != 0xffffu ? (item >> 8) : 0];
+        };
+        unsigned item, item_n = 0xffffu; RsFace f, f_n;
+        fetch(4 * wv, item, f);
+        for (int it0 = 4 * wv; it0 < ni; it0 += 4 * (RTHREADS / 64)) {
+            if (it0 + 4 * (RTHREADS / 64) < ni) fetch(it0 + 4 * (RTHREADS / 64), item_n, f_n);
+            const bool live = item != 0xffffu;
             const int K = live ? f.k : 0;
             const int quad = item & 255, px = (quad & 15) * 4 + (ln & 3), py = (quad >> 4) * 4 + ((ln >> 2) & 3);
             const float x = ray_x(px), y = ray_y(py);
             bool in = live;
             const float4 *ep = en + f.ebase;
-            for (int k = 0; __any(k < K); k++) if (k < K) { const float4 c = ep[k]; in &= !(fmaf(c.x, x, fmaf(c.y, y, -c.z)) > 0.f); }
+            for (int k0 = 0; __any(k0 < K); k0 += 4) {
+                float4 c[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) c[j] = ep[max(min(k0 + j, K - 1), 0)];       // (past the loop's end: its last edge again)
+#pragma unroll
+                for (int j = 0; j < 4; j++) in &= !(fmaf(c[j].x, x, fmaf(c[j].y, y, -c[j].z)) > 0.f);
+            }
             const float den = fmaf(f.P.y, y, fmaf(f.P.x, x, -f.P.z));
             const float t = f.P.w * rcp(den);
             if (in && den < 0.f && t > 0.f && t > m.znear) rs_claim(zb, py * RW + px, t, f.id);
+            item = item_n; f = f_n; item_n = 0xffffu;
         }
 #else
         for (int it = wv; it < ni; it += RTHREADS / 64) {
@@ -751,7 +769,8 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
     asm volatile("" : "+v"(frl));
     const V3 co = ldv(frl->cam_o); const M3 Rc = ldm(frl->cam_R);
     float lmin = 3.0e38f;
-    unsigned cb[3][TPX];
+    // (a pixel's three bytes go to the image as soon as they exist and the four pixels are kept apart -- sched_barrier -- so that one pixel's shading is live at a time:
+    // held in cb[3][4] and interleaved, the tail was most of the kernel's spilled registers)
 #pragma unroll
     for (int q = 0; q < TPX; q++) {
         const float x = xs[q % TW], y = ys[q / TW];
@@ -776,19 +795,17 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
             }
             lit_colour(m, hit, b0, b1, b2, Pw, nrm, co, c0, c1, c2);
         }
-        cb[0][q] = to_u8(c0); cb[1][q] = to_u8(c1); cb[2][q] = to_u8(c2);
+        {   const int px = (TW * ty + q / TW) * RW + TW * tx + q % TW;
+            img[px] = to_u8(c0); img[RPIX + px] = to_u8(c1); img[2 * RPIX + px] = to_u8(c2); }
         lmin = fminf(lmin, best[q]);
+        __builtin_amdgcn_sched_barrier(0);
     }
     auto put2 = [&](int ch, int r, unsigned lo, unsigned hi) {
         const int px = (TW * ty + r) * RW + TW * tx;
         *reinterpret_cast<uint16_t *>(img + ch * RPIX + px) = (uint16_t)(lo | (hi << 8));
     };
 #pragma unroll
-    for (int r = 0; r < TW; r++) {
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) put2(ch, r, cb[ch][2 * r], cb[ch][2 * r + 1]);
-        put2(nch - 1, r, 0u, 0u);
-    }
+    for (int r = 0; r < TW; r++) put2(nch - 1, r, 0u, 0u);
     // transform_depth (utils.py:11-19), as above
     red[tid] = lmin; __syncthreads();
     for (int s = RTHREADS / 2; s > 0; s >>= 1) { if (tid < s) red[tid] = fminf(red[tid], red[tid + s]); __syncthreads(); }
@@ -817,7 +834,7 @@ __device__ __forceinline__ void observe_body_raster(const DevModel &m, const Dev
     }
     __syncthreads();
 #ifdef RS_DEBUG_COUNTS          // diagnostic build: the row starts with the env's table counts (faces, edges, items, visible planes) instead of pixels
-    if (tid == 0) { int *d = reinterpret_cast<int *>(img); d[0] = nfaces; d[1] = nedges; d[2] = nitems; d[3] = gadr[GN_GEOM]; }
+    if (tid == 0) { int *d = reinterpret_cast<int *>(img); d[0] = nfaces; d[1] = nedges; d[2] = nitems; d[3] = gnum[1] + gnum[2] + gnum[3] + gnum[4] + gnum[5] + gnum[6]; }
     __syncthreads();
 #endif
     const uint4 *src = reinterpret_cast<const uint4 *>(img);

@@ -28,7 +28,7 @@ def test_two_ranks_over_rccl_stay_bit_identical():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["replicas_identical"] is True
-    assert d["env_steps_counted"] == 2 * 512 * 4 and d["short_rollouts"] == 0
+    assert d["env_steps_counted"] == 2 * 512 * 4 and d["short_rollouts"] == 0 and d["update_path"].startswith("explicit")
 
 
 def test_two_ranks_rehearsed_on_one_gpu_with_gloo():
@@ -47,3 +47,4 @@ def test_two_ranks_rehearsed_on_one_gpu_with_gloo():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["replicas_identical"] is True and d["env_steps_counted"] == 2 * 1024 * 6 and d["short_rollouts"] == 0
+    assert d["update_path"].startswith("explicit")          # the flat gradient buffer of sb3/fused_update.py is the all-reduce's bucket
