@@ -134,6 +134,14 @@ class PPO:
         self.optimizer = th.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5, capturable=self.graph_update,
                                        fused=True if self.graph_update else None)
         self._upd = None
+        # The explicit update sequence (sb3/fused_update.py) keeps the parameters in one flat buffer. They are laid out HERE, before anything can hold their
+        # addresses -- the rollout copy below, and above all the captured rollout tick, which reads biases straight from the parameters: laid out at the first
+        # update instead, the tick graph kept reading the freed old storage (NaN losses from the second rollout on; tools/train_probe.py found it).
+        self._fused = None
+        if self.explicit_update and self.device.type == "cuda":
+            from .fused_update import FusedUpdate
+            if FusedUpdate.applies(self):
+                self._fused = FusedUpdate(self)
         obs_shape = env.observation_space["observation"].shape
         self.rollout_buffer = None if (async_slice and async_slice > 0) else RolloutBuffer(n_steps, self.n_envs, obs_shape, self.policy.action_dim, self.device)
         self._async = None
@@ -169,7 +177,8 @@ class PPO:
         self.num_timesteps = 0
         self._last_obs = None
         self._last_dones = None
-        self._flat_grad = None
+        if self._fused is None:
+            self._flat_grad = None
         self.logger = {}
 
     # ------------------------------------------------------------------ rollouts
@@ -344,8 +353,20 @@ class PPO:
             if FusedUpdate.applies(self):
                 self._fused = FusedUpdate(self)
                 self._upd = None
+                self._parameters_moved()
             else:
                 self._fused_declined = True
+
+    def _parameters_moved(self):
+        """the parameters have new addresses: whatever captured or cached the old ones must let go -- the rollout's tick graphs (they read biases straight
+        from the parameters) and the merged rollout weights"""
+        ar = self._async
+        if ar is not None:
+            ar._graph = None
+            if getattr(ar, "_side_graph", None) is not None:
+                ar._side_graph = [None, None]
+        if self.policy_rollout is self.policy and getattr(self.policy_rollout, "_rollout_cache", None) is not None:
+            self.policy_rollout.refresh_rollout_cache()
 
     def _fresh_grads(self, to_none):
         """what a backward pass needs of .grad beforehand"""

@@ -347,3 +347,36 @@ def test_permlane32_swap_hands_each_half_of_a_wave_to_the_other(torch):
         subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-w", "-o", exe, src], check=True, capture_output=True, timeout=300)
         r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "t_swap: ok" in r.stdout, (r.stdout, r.stderr)
+
+
+def test_rollout_tick_graph_follows_the_parameters_through_updates():
+    """The captured rollout tick reads the extractor's biases straight from the parameters. The explicit update sequence keeps the parameters in one flat
+    buffer (sb3/fused_update.py); laid out at the first update, the tick graph of the first rollout went on reading the freed old storage -- garbage biases,
+    NaN losses from the second rollout on (tools/train_probe.py found it; a single collect + train, as the other tests do, did not). Now they are laid out at
+    construction. Here: three rollouts with two updates between them, ticks replayed from the graph; the values the LAST rollout recorded must be the
+    current policy's values of the recorded observations (eager forward, 1e-4), and the losses finite."""
+    import numpy as np, torch
+    from mujoco_rl_manipulate_unknown_objects_amd.simulation.environment.robot_env import BatchedRobotEnv, default_config
+    from mujoco_rl_manipulate_unknown_objects_amd.sb3 import PPO, GpuVecEnv
+    from mujoco_rl_manipulate_unknown_objects_amd.models.feature_extractor import AugmentedNatureCNN
+    env = BatchedRobotEnv(default_config(sim_env="/xmls/sand_ball_env.xml", time_horizon=50), n_envs=256, auto_reset=True)
+    model = PPO("MultiInputPolicy", GpuVecEnv(env), n_steps=4, batch_size=256, n_epochs=1, seed=2, async_slice=48, async_capacity=128, async_budget_us=1000,
+                policy_kwargs=dict(features_extractor_class=AugmentedNatureCNN, share_features_extractor=True, net_arch=[256, 256]))
+    assert model._fused is not None
+    ar = model._async
+    for it in range(3):
+        model.collect_rollouts()
+        if it < 2:
+            st = model.train()
+            assert np.isfinite(float(st["loss"])) and np.isfinite(float(st["value_loss"])), (it, st)
+    torch.cuda.synchronize()
+    assert ar._graph is not None and ar.total_ticks > 3 * ar.graph_after            # the ticks were replays
+    assert model._fused is not None and model._fused.intact() and all(torch.isfinite(p).all() for p in model.policy.parameters())
+    rows = torch.arange(ar.tick0, ar.tick0 + ar.tick * ar.C, device=ar.dev)     # this rollout's own decisions (the carry rows before them were decided before the last update)
+    rows = rows[ar.is_rec[rows]][:512]
+    assert rows.numel() >= 256
+    with torch.no_grad():
+        v = model.policy.predict_values({"observation": ar.obs[rows]})
+    err = (v - ar.values[rows]).abs().max().item()
+    assert err < 1e-4 * max(1.0, ar.values[rows].abs().max().item()), err
+    env.close()

@@ -223,7 +223,10 @@ def test_explicit_update_gradients_match_the_autograd_path(n):
     idx = th.randperm(1500, device="cuda")[:n].contiguous()
     before = {k: v.clone() for k, v in pol.state_dict().items()}
     strides = {k: v.stride() for k, v in pol.named_parameters()}
+    assert model._fused is not None and model._fused.intact()      # laid out at construction, before anything can capture the parameters' addresses
     model.explicit_update = False
+    model._select_update_path(src, idx)
+    assert model._fused is None
     pol.zero_grad(set_to_none=True)
     pl0, vl0, loss0 = (float(x) for x in model._loss_backward(src, idx))
     ref = {k: p.grad.clone() for k, p in pol.named_parameters()}
