@@ -323,6 +323,11 @@ def main():
         lo, hi = cs.clone(), cs.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         replicas_identical = bool(torch.equal(lo, hi))
+    # a number measured while the policy had diverged is not a measurement of training: the parameters must be finite after the timed region (round 4: an update path
+    # that left the rollout graph reading freed parameter storage produced NaN losses at full speed, and only a training probe noticed)
+    policy_finite = bool(all(torch.isfinite(p).all() for p in model.policy.parameters()))
+    if not policy_finite:
+        raise RuntimeError("bench.py: the policy's parameters are not finite after the timed region -- the update diverged; no benchmark line for this run")
     ev_ms, ev_n = batch.kernel_time(reset=True)          # host events: the eager launches only (a replayed graph's launches cannot be bracketed)
     k_ms, k_n = ev_ms, ev_n
     if ar is not None and hasattr(batch, "device_time"):
@@ -370,7 +375,7 @@ def main():
             # the workload-independent companion of `value`: physics.step() calls per second (env-steps/s depends on how many calls the action
             # source makes a macro step cost: ~232 for the synthetic U(-1,1) stream, ~312 for actions sampled from the learning policy)
             "action_source": a.actions, "mj_substeps_per_s": total_sub / dt, "mean_substeps_per_env_step": total_sub / max(total_env_steps, 1.0),
-            "replicas_identical": replicas_identical,
+            "replicas_identical": replicas_identical, "policy_finite_after_run": policy_finite,
             "update_path": "explicit launch sequence (sb3/fused_update.py)" if getattr(model, "_fused", None) is not None else "autograd",
             # N > 1: device time of the one collective per optimiser step (the flat 4 MB fp32 gradient bucket over RCCL), rank 0's view
             "allreduce_ms_per_optimizer_step": ar_ms, "allreduce_steps_timed": ar_n, "env_steps_counted": total_env_steps, "env_steps_nominal": a.envs * world * a.steps, "short_rollouts": short_rollouts,
