@@ -1,14 +1,16 @@
 // grip_render.hip -- observation kernel: RobotEnv.get_observation (robot_env.py:275-293).
 //
-// One 1024-thread workgroup per environment, a 2 x 2 pixel tile per thread. Rays from `gripper_camera`
-// (robot xml :60) are clipped against the floor plane and the six convex hulls (Cyrus-Beck over
-// the hull face planes, read with workgroup-uniform indices, after a per-ray bounding-sphere
-// test); the materials and lights of the scene (lit_colour) give RGB (sensor.py:64-66), the distance along the optical axis
+// One 1024-thread workgroup per environment. What the camera `gripper_camera` (robot xml :60) sees of the floor plane and the six convex hulls,
+// the materials and lights of the scene (lit_colour) give RGB (sensor.py:64-66), the distance along the optical axis
 // gives depth (sensor.py:69-72), which goes through transform_depth (utils.py:11-19) with its
 // two whole-image reductions done in LDS. The uint8 CHW observation (5 x 64 x 64 = 20 480 B per
 // env, 98 % of the macro step's algorithmic HBM bytes) is written once, coalesced, together with
 // the sensor pad scalars pad[0,0] = check_grasp, pad[0,1] = pheromone_level (robot_env.py:281-283)
 // that the step kernel left in pad_grasp / pad_pher.
+// Two kernels find the visible surface: k_observe (observe_body_raster, the shipped one since round 4) RASTERISES the hulls' faces -- every camera-facing
+// face tests the pixels of its own screen box, hits meet in a 64-bit LDS z-buffer; k_observe_rays (observe_body, rounds 1-4, GRIP_OBSERVE_RAYS=1) CLIPS every
+// pixel's ray against the planes of every hull in its way (Cyrus-Beck), a 2 x 2 pixel tile per thread. Both shade, reduce and store alike; they agree up to
+// the pixels whose ray passes within rounding of a face's edge (tools/render_ab.py, tests/test_gpu_parity.py).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
