@@ -67,6 +67,34 @@ class RolloutBuffer:
         self.pos = 0
 
 
+_GEMM_CHOICES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "assets", "tunableop_gfx950.csv")
+
+
+def _use_recorded_gemm_choices():
+    """The tensor library's GEMMs of the update (a dozen fp32 problems with [4096 x 256..1024] operands) through the kernels a TunableOp search picked for them on MI355X
+    -- rocBLAS for about half of them, hipBLASLt's non-default solutions for the rest: -3.8 % on the captured update (tools/update_time.py find tune). The search's result
+    is a committed file (assets/tunableop_gfx950.csv, written by `tools/update_time.py find tune`); nothing is tuned at run time and the file is never written. TunableOp
+    ignores it when the library versions in its header are not the running ones, and shapes it does not list take the default path. GRIP_TUNABLEOP=0 switches it off."""
+    if os.environ.get("GRIP_TUNABLEOP") == "0" or not os.path.exists(_GEMM_CHOICES):
+        return
+    try:
+        t = th.cuda.tunable
+        if t.is_enabled():                       # a caller's own TunableOp set-up (tools/update_time.py tune) stays as it is
+            return
+        grow = os.environ.get("GRIP_TUNABLEOP_TUNE")        # maintenance: search the shapes the file lacks into a COPY of it at this path (then copy it back by hand)
+        if grow:
+            import shutil
+            shutil.copyfile(_GEMM_CHOICES, grow)
+            t.set_max_tuning_duration(30); t.set_max_tuning_iterations(20)
+            t.tuning_enable(True); t.set_filename(grow); t.enable(True)
+            return
+        t.tuning_enable(False)                   # nothing is searched, so nothing is ever written to the file either
+        t.set_filename(os.path.abspath(_GEMM_CHOICES)); t.enable(True)
+    except Exception as ex:                      # noqa: BLE001 -- an optimisation only
+        import warnings
+        warnings.warn(f"recorded GEMM choices not used ({ex})")
+
+
 class _FusedPPOLoss(th.autograd.Function):
     """The minibatch loss below and its gradients as one kernel launch (engine.ppo_loss -> grip_ppo_loss, csrc/grip_policy.hip) instead of
     ~60 elementwise / reduction launches of 4096 elements: the same arithmetic in fp32 (tests/test_gpu_env_api.py). The gradients are
@@ -134,6 +162,8 @@ class PPO:
         self.optimizer = th.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5, capturable=self.graph_update,
                                        fused=True if self.graph_update else None)
         self._upd = None
+        if self.device.type == "cuda":
+            _use_recorded_gemm_choices()
         # The explicit update sequence (sb3/fused_update.py) keeps the parameters in one flat buffer. They are laid out HERE, before anything can hold their
         # addresses -- the rollout copy below, and above all the captured rollout tick, which reads biases straight from the parameters: laid out at the first
         # update instead, the tick graph kept reading the freed old storage (NaN losses from the second rollout on; tools/train_probe.py found it).
@@ -407,7 +437,10 @@ class PPO:
         return self._minibatch_update_impl(src, idx)
 
     def _minibatch_update_impl(self, src, idx):
-        self._select_update_path(src, idx)
+        u = self._upd
+        key = tuple(t.data_ptr() for t in src) + (idx.numel(),)
+        if not self.graph_update or u is None or u["key"] != key or u["fwd"] is None:
+            self._select_update_path(src, idx)          # (not per replay: the checks are ~50 us of host time, and the update is not far from launch-bound)
         if not self.graph_update:
             if self._fused is not None:
                 self._fused.bind()
@@ -418,8 +451,7 @@ class PPO:
                 self._allreduce_grads()
             self._apply()
             return out
-        u = self._upd
-        key = tuple(t.data_ptr() for t in src) + (idx.numel(),)
+        u = self._upd                                    # (_select_update_path may have dropped it)
         if u is None or u["key"] != key:
             u = self._upd = {"key": key, "idx": th.zeros_like(idx), "warm": 0, "fwd": None, "apply": None, "out": None}
         u["idx"].copy_(idx)
