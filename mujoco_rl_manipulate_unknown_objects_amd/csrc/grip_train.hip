@@ -9,7 +9,7 @@
 //   k_trunk_bwd          g3 (gradient at the third layer's ReLU output) -> masked g3, masked g2 (the operands of the library's two remaining weight
 //                        gradients), the first layer's weight gradient straight from the observation bytes and all three bias gradients, in ONE launch:
 //                        both data gradients as scatter GEMMs whose column blocks are summed into an LDS tile, g2 and g1 never leaving LDS, the ReLU
-//                        masks (bits written by the forward kernels) folded into the passes. 283 us.
+//                        masks (bits written by the forward kernels) folded into the passes. 283 us; 214 us since the first layer's weight gradient runs on the bf16 pipe.
 //   k_wgrad1_reduce      the workgroups' partial sums -> the gradient tensors (fixed order, no atomics).
 //   k_gradnorm, k_clip_adam   clip_grad_norm_ + Adam.step() on the optimiser's own state tensors, two launches.
 //   k_tanh_bwd_colsum, k_colsum_reduce   activation derivative + bias gradient of a dense layer in one pass (tanh: the policy | value MLPs; ReLU: the
@@ -24,6 +24,7 @@
 int grip_fail(const char *msg);                     // grip_sim.hip
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_trunk_bwd. Shapes (NHWC): y1 [n, 15, 15, 32], y2 [n, 6, 6, 64], y3 [n, 4, 4, 64] (post-ReLU activations of the forward), g3 [n, 4, 4, 64] = d loss / d y3,
@@ -43,7 +44,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // within a wave one block's rows are distinct pixels and blocks follow in program order.
 // The first layer's weight gradient never sees g1 in memory: the masked tile stays in LDS and is the B operand of v_mfma_f32_32x32x2_f32 against the
 // image bytes (A, converted on the fly; the planes of one image take the place of the dead g2 tile): M = 256 patch elements (wave w = plane w, two 32-row
-// tiles = ky 0..3 / 4..7), N = 32 channels, K = 225 positions per image, accumulated in registers over all of the workgroup's images.
+// tiles = ky 0..3 / 4..7), N = 32 channels, K = 225 positions per image, accumulated in registers over all of the workgroup's images. (Round 4: on the bf16 pipe, exactly -- a byte
+// is a bf16, the gradient three bf16 terms: see wgrad_image.)
 #define DG 2
 #define D_PS1 34                            // floats per g1 pixel in LDS
 #define D_PS2 68                            // floats per g2 / g3 row in LDS
@@ -255,6 +257,40 @@ __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ 
         if (gnext < ngroups)
             group_in_load(gi, tl, gnext * DG, min(DG, n_img - gnext * DG), g3, reinterpret_cast<const uint16_t *>(m3), reinterpret_cast<const unsigned long long *>(m2), m1);
     };
+#ifndef WGRAD1_F32
+    // K loop over an image's 225 positions on the bf16 pipe, EXACTLY as k_conv1_u8 computes the forward (grip_policy.hip): a pixel 0..255 is a bf16, the fp32 gradient is the
+    // sum of three bf16 terms (nearest bf16, exact remainder, twice: what is left is below its 25th bit), a byte times a bf16 is exact in the fp32 accumulator -- three
+    // v_mfma_f32_32x32x16_bf16 per tile and 16 positions where the fp32 instruction needed eight v_mfma_f32_32x32x2_f32 (96 against 512 matrix-pipe cycles). A chunk of 16
+    // positions = one row oy of the image's 15 x 15: lanes 0..31 hold ox 0..7, lanes 32..63 ox 8..15 (ox = 15 does not exist: its B operand is forced to zero, its A bytes are
+    // whatever follows the row -- finite). The gradient's split is redone by every wave (the four planes share it; LDS has no room for the three terms of a tile): the loop
+    // is bound by those ~70 VALU and 24 LDS instructions per chunk, not by its six MFMAs. Measured: k_trunk_bwd 310 -> 214 us per 4096 samples, the captured update 1.055 ->
+    // 0.992 ms per minibatch (same box; -DWGRAD1_F32 keeps the fp32 loop for the comparison).
+    auto wgrad_image = [&](int g) {
+        const uint8_t *ap = U + w * 4096 + (m32 >> 3) * 64 + (m32 & 7) + half * 32;          // + oy * 256 + 4 j; second tile (ky + 4): + 256
+        const float *bp = T1 + (g * 225 + half * 8) * D_PS1 + m32;                            // + (oy * 15 + j) * D_PS1
+#pragma unroll 1
+        for (int oy = 0; oy < 15; oy++) {
+            bf16x8 b0, b1, b2;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float x = (j == 7 && half) ? 0.f : bp[j * D_PS1];
+                const __bf16 h = (__bf16)x; const float r = x - (float)h;
+                const __bf16 md = (__bf16)r; const float r2 = r - (float)md;
+                b0[j] = h; b1[j] = md; b2[j] = (__bf16)r2;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                bf16x8 a;
+#pragma unroll
+                for (int j = 0; j < 8; j++) a[j] = (__bf16)(float)ap[4 * j + 256 * t];
+                cw[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, cw[t], 0, 0, 0);
+                cw[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, cw[t], 0, 0, 0);
+                cw[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b2, cw[t], 0, 0, 0);
+            }
+            ap += 256; bp += 15 * D_PS1;
+        }
+    };
+#else
     // K loop over an image's 225 positions, two per instruction: lanes 0..31 walk rows 0..7, lanes 32..63 rows 8..15 (row 15 does not exist: its B operand
     // is forced to zero; 120 k-steps instead of 113, but every address is the row base plus an instruction offset -- with positions 2 j and 2 j + 1 in
     // the two halves the (oy, ox) bookkeeping was a dozen dependent VALU instructions per k-step, and the loop ran at 70 % of the MFMA rate)
@@ -278,6 +314,7 @@ __global__ void __launch_bounds__(256, 2) k_trunk_bwd(const float *__restrict__ 
             cw[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((float)ap[4 * ox + 256], b, cw[1], 0, 0, 0);
         }
     };
+#endif
     if (obs) {
         uint4 *Uq = reinterpret_cast<uint4 *>(U) + tl;
         Uq[0] = pa; Uq[256] = pb; Uq[512] = pc; Uq[768] = pd;
