@@ -343,6 +343,125 @@ extern "C" int grip_ppo_loss(const float *mean_dev, const float *log_std_dev, co
     return 0;
 }
 
+// The HEADS loss over several workgroups (the one-workgroup kernel above is 31 us for 4096 rows: four dependent passes of a single workgroup, latency all the way). Every
+// workgroup forms the advantages' mean and deviation itself, over all n rows and in the same order (16 KB from L2: cheaper than a second launch or a grid barrier), takes its share
+// of the rows, leaves its partial sums in `part`, and the workgroup that arrives last adds them in workgroup order (fixed order: the result does not depend on timing) and resets
+// the ticket. One launch of the loss at a time per device (the ticket is a module variable): the update's single stream.
+#define PLM_THREADS 256
+#define PLM_BLOCKS 16
+#define PLM_SUMS (2 * PL_MAXA + 4)
+__device__ unsigned plm_ticket = 0u;
+__device__ __forceinline__ float plm_block_sum(float v, float *red) {           // 4 waves
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(PLM_THREADS) k_ppo_loss_heads_mb(const float *__restrict__ o, const float *__restrict__ log_std, const float *__restrict__ actions,
+                                                                   const float *__restrict__ old_logp, const float *__restrict__ adv, const float *__restrict__ ret, int n, int A,
+                                                                   float clip, float ent_coef, float vf_coef, float *__restrict__ out, float *__restrict__ go,
+                                                                   float *__restrict__ g_log_std, const float *__restrict__ head_bias, float *__restrict__ g_head_bias,
+                                                                   float *__restrict__ part) {
+    __shared__ float red[PLM_THREADS / 64];
+    __shared__ float redm[PLM_THREADS / 64][PLM_SUMS];
+    __shared__ unsigned last;
+    const int tid = threadIdx.x;
+    float s = 0.f;
+    for (int i = tid; i < n; i += PLM_THREADS) s += adv[i];
+    const float am = plm_block_sum(s, red) / (float)n;
+    s = 0.f;
+    for (int i = tid; i < n; i += PLM_THREADS) { const float d = adv[i] - am; s += d * d; }
+    const float asd = sqrtf(plm_block_sum(s, red) / (float)(n - 1));
+    const float ainv = 1.0f / (asd + 1e-8f), invn = 1.0f / (float)n;
+    float ls[PL_MAXA], isig[PL_MAXA], gls[PL_MAXA], gms[PL_MAXA], hb[PL_MAXA], lsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < PL_MAXA; k++) {
+        ls[k] = k < A ? log_std[k] : 0.f; isig[k] = expf(-ls[k]); gls[k] = 0.f; gms[k] = 0.f; lsum += k < A ? ls[k] : 0.f;
+        hb[k] = k < A ? head_bias[k] : 0.f;
+    }
+    const float hbv = head_bias[PL_MAXA];
+    const float *values = o + (size_t)n * PL_MAXA;
+    float *g_values = go + (size_t)n * PL_MAXA;
+    float sobj = 0.f, sv = 0.f, gvs = 0.f;
+    const int per = (n + PLM_BLOCKS - 1) / PLM_BLOCKS, i0 = blockIdx.x * per, i1 = min(n, i0 + per);
+    for (int i = i0 + tid; i < i1; i += PLM_THREADS) {
+        float z[PL_MAXA], lp = 0.f;
+#pragma unroll
+        for (int k = 0; k < PL_MAXA; k++) {
+            const float mu = k < A ? o[(size_t)i * PL_MAXA + k] + hb[k] : 0.f;
+            z[k] = k < A ? (actions[(size_t)i * A + k] - mu) * isig[k] : 0.f;
+            lp += k < A ? -0.5f * z[k] * z[k] - ls[k] - 0.9189385332046727f : 0.f;
+        }
+        const float lr_raw = lp - old_logp[i];
+        const float lr = fminf(fmaxf(lr_raw, -20.f), 20.f);
+        const float ratio = expf(lr), Ai = (adv[i] - am) * ainv;
+        const float lo = 1.f - clip, hi = 1.f + clip;
+        const float s1 = Ai * ratio, s2 = Ai * fminf(fmaxf(ratio, lo), hi);
+        sobj += fminf(s1, s2);
+        const bool inside = ratio >= lo && ratio <= hi;
+        const float w1 = s1 < s2 ? 1.f : (s1 == s2 ? 0.5f : 0.f), w2 = (s2 < s1 ? 1.f : (s1 == s2 ? 0.5f : 0.f)) * (inside ? 1.f : 0.f);
+        const float pass = (lr_raw >= -20.f && lr_raw <= 20.f) ? 1.f : 0.f;
+        const float coef = -invn * Ai * (w1 + w2) * ratio * pass;
+        float gm[PL_MAXA];
+#pragma unroll
+        for (int k = 0; k < PL_MAXA; k++) {
+            gm[k] = k < A ? coef * z[k] * isig[k] : 0.f;
+            gms[k] += gm[k];
+            gls[k] += k < A ? coef * (z[k] * z[k] - 1.f) : 0.f;
+        }
+        float4 *gp = reinterpret_cast<float4 *>(go + (size_t)i * PL_MAXA);
+        gp[0] = make_float4(gm[0], gm[1], gm[2], gm[3]); gp[1] = make_float4(gm[4], gm[5], gm[6], gm[7]);
+        const float dv = values[(size_t)i * PL_MAXA] + hbv - ret[i];
+        sv += dv * dv;
+        const float gv = vf_coef * 2.f * dv * invn;
+        float4 *gq = reinterpret_cast<float4 *>(g_values + (size_t)i * PL_MAXA);
+        gq[0] = make_float4(gv, 0.f, 0.f, 0.f); gq[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gvs += gv;
+    }
+    auto wsum = [](float v) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+        return v;
+    };
+    const int w = tid >> 6;
+    const bool lead = (tid & 63) == 0;
+    { const float v = wsum(sobj); if (lead) redm[w][0] = v; }
+    { const float v = wsum(sv); if (lead) redm[w][1] = v; }
+    { const float v = wsum(gvs); if (lead) redm[w][2] = v; }
+#pragma unroll
+    for (int k = 0; k < PL_MAXA; k++) {
+        { const float v = wsum(gls[k]); if (lead) redm[w][4 + k] = v; }
+        { const float v = wsum(gms[k]); if (lead) redm[w][4 + PL_MAXA + k] = v; }
+    }
+    __syncthreads();
+    if (tid < PLM_SUMS) part[blockIdx.x * PLM_SUMS + tid] = (redm[0][tid] + redm[1][tid]) + (redm[2][tid] + redm[3][tid]);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) last = atomicAdd(&plm_ticket, 1u);
+    __syncthreads();
+    if (last != PLM_BLOCKS - 1) return;
+    __threadfence();
+    float tot = 0.f;
+    if (tid < PLM_SUMS) {
+#pragma unroll
+        for (int b = 0; b < PLM_BLOCKS; b++) tot += __builtin_nontemporal_load(part + b * PLM_SUMS + tid);
+    }
+    if (tid >= 4 && tid < 4 + A) g_log_std[tid - 4] = tot - ent_coef;
+    if (tid >= 4 + PL_MAXA && tid < 4 + 2 * PL_MAXA) { const int k = tid - 4 - PL_MAXA; g_head_bias[k] = k < A ? tot : 0.f; if (k > 0) g_head_bias[PL_MAXA + k] = 0.f; }
+    if (tid == 2) g_head_bias[PL_MAXA] = tot;
+    __shared__ float fin[2];
+    if (tid < 2) fin[tid] = tot;
+    __syncthreads();
+    if (tid == 0) {
+        const float pl = -fin[0] * invn, vl = fin[1] * invn;
+        const float el = -((float)A * (0.5f + 0.9189385332046727f) + lsum);
+        out[0] = pl + ent_coef * el + vf_coef * vl; out[1] = pl; out[2] = vl;
+        plm_ticket = 0u;
+    }
+}
+
 // rows idx[0..n) of the rollout's sample arrays into one packed block: samples = actions [n, A] | old_log_prob [n] | advantages [n] | returns [n]  (one launch for
 // the four gathers of a minibatch)
 __global__ void __launch_bounds__(256) k_gather_samples(const float *__restrict__ actions, const float *__restrict__ logp, const float *__restrict__ adv,
@@ -365,8 +484,14 @@ extern "C" int grip_ppo_loss_heads(const float *heads_out_dev, const float *head
     hipLaunchKernelGGL(k_gather_samples, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, actions_dev, old_log_prob_dev, advantages_dev, returns_dev, rows_dev, n, A,
                        samples_dev);
     float *sa = samples_dev, *sl = samples_dev + (size_t)n * A, *sd = sl + n, *sr = sd + n;
+#ifdef PLM_OFF            // comparison build: the one-workgroup kernel
     hipLaunchKernelGGL(k_ppo_loss<true>, dim3(1), dim3(PL_THREADS), 0, (hipStream_t)stream, heads_out_dev, log_std_dev, heads_out_dev + (size_t)n * PL_MAXA, sa, sl, sd, sr, n, A,
                        clip_range, ent_coef, vf_coef, out_dev, grad_heads_out_dev, grad_heads_out_dev + (size_t)n * PL_MAXA, grad_log_std_dev, head_bias_dev, grad_head_bias_dev);
+#else
+    // (samples_dev is followed by the workgroups' partial sums: n * (A + 3) + 16 * 20 floats in all)
+    hipLaunchKernelGGL(k_ppo_loss_heads_mb, dim3(PLM_BLOCKS), dim3(PLM_THREADS), 0, (hipStream_t)stream, heads_out_dev, log_std_dev, (const float *)sa, (const float *)sl, (const float *)sd,
+                       (const float *)sr, n, A, clip_range, ent_coef, vf_coef, out_dev, grad_heads_out_dev, grad_log_std_dev, head_bias_dev, grad_head_bias_dev, sr + n);
+#endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { char buf[160]; snprintf(buf, sizeof buf, "grip_ppo_loss_heads: %s", hipGetErrorString(e)); return grip_fail(buf); }
     return 0;

@@ -501,7 +501,7 @@ def ppo_loss_heads(heads_out, head_bias, log_std, actions, old_log_prob, advanta
     assert f32(grad_head_bias, None) and grad_head_bias.numel() == 16 and f32(grad_log_std, None) and grad_log_std.numel() >= A
     dev = heads_out.device
     out = torch.empty(3, dtype=torch.float32, device=dev); go = torch.empty_like(heads_out)
-    samples = torch.empty(n * (A + 3), dtype=torch.float32, device=dev)
+    samples = torch.empty(n * (A + 3) + 320, dtype=torch.float32, device=dev)     # the gathered samples, then the loss kernel's partial sums
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr())
     _chk(lib().grip_ppo_loss_heads(p(heads_out), p(head_bias), p(log_std), p(actions), p(old_log_prob), p(advantages), p(returns), p(rows), n, A, float(clip_range), float(ent_coef),
