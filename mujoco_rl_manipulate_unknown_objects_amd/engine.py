@@ -43,8 +43,11 @@ def build_library(force=False, verbose=False):
         # (tools/physics_rate.py); every oracle-parity tolerance holds unchanged. -amdgpu-sched-strategy=iterative-ilp: the physics kernel is
         # latency-bound (two waves per SIMD, long dependent chains through LDS): the ILP-first instruction scheduler gives +4.1 % physics rate
         # over the default one (max-ilp +-0, max-memory-clause -0.4 %, -O2 +0.3 %; round 3, tools/physics_rate.py on one box).
+        # -fno-signed-zeros -freciprocal-math (round 4): x / y may become x * (1 / y), -0 need not be kept apart from +0: +0.6 % physics rate on the same box, 371 against
+        # 372 of 379 exactly matching contact-fixture lanes, every parity test unchanged. -fassociative-math is NOT harmless: the solver's compensated sums break (43 M
+        # physics.step()/s and 1 % of the macro steps faulting).
         cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-fno-strict-aliasing", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
-               "-fgpu-flush-denormals-to-zero", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-shared", "-fPIC"] + extra + ["-o", tmp,
+               "-fno-signed-zeros", "-freciprocal-math", "-fgpu-flush-denormals-to-zero", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-shared", "-fPIC"] + extra + ["-o", tmp,
                os.path.join(CSRC, "grip_sim.hip"), os.path.join(CSRC, "grip_render.hip"), os.path.join(CSRC, "grip_rollout.hip"),
                os.path.join(CSRC, "grip_policy.hip"), os.path.join(CSRC, "grip_train.hip")]
         procs.append((path, tmp, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))

@@ -9,7 +9,7 @@ CSRC = os.path.join(ROOT, "mujoco_rl_manipulate_unknown_objects_amd", "csrc")
 name, extra = sys.argv[1], sys.argv[2:]
 out = os.path.join(CSRC, f"libgrip_sim_{name}.so")
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-slp-vectorize", "-fno-strict-aliasing", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
-       "-fgpu-flush-denormals-to-zero", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-shared", "-fPIC"] + extra + ["-o", out] + \
+       "-fno-signed-zeros", "-freciprocal-math", "-fgpu-flush-denormals-to-zero", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-shared", "-fPIC"] + extra + ["-o", out] + \
       [os.path.join(CSRC, f) for f in ("grip_sim.hip", "grip_render.hip", "grip_rollout.hip", "grip_policy.hip", "grip_train.hip")]
 subprocess.run(cmd, check=True)
 print(out)
