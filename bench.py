@@ -95,16 +95,19 @@ def cpu_baseline(obj, seconds_target=15.0):
     b = orc.BatchOracle(m, n)
     rng = np.random.default_rng(0)
     obs = np.zeros((n, 5, 64, 64), np.uint8)
-    b.step(np.clip(rng.normal(size=(n, 6)), -1, 1), obs=obs)        # warm-up
+    # the GPU leg's input: every env from the deterministic reset state, actions a ~ U(-1, 1)^6. The oracle envs are young (a bounded sample:
+    # 1 + <= 64 macro steps per env, i.e. fresh episodes, mostly free motion), so its macro steps are SHORTER than the GPU leg's stationary mix -- the line
+    # carries its own mean_substeps_per_env_step and the workload-independent mj_substeps_per_s to compare by
+    b.step(rng.uniform(-1, 1, size=(n, 6)), obs=obs)        # warm-up
     t0 = time.time(); steps = 0; sub = 0
     while time.time() - t0 < seconds_target and steps < 64:
-        sub += b.step(np.clip(rng.normal(size=(n, 6)), -1, 1), obs=obs); steps += 1
+        sub += b.step(rng.uniform(-1, 1, size=(n, 6)), obs=obs); steps += 1
     dt = time.time() - t0
     # one env on one thread (the analogue of BASELINE.json configs[0], the reference's own single-env run)
     e = orc.EnvOracle(m); e.reset(); e.step(np.zeros(6, np.float32)); e.observation()
     t1 = time.time(); k1 = 0
     while time.time() - t1 < 3.0 and k1 < 200:
-        o = e.step(np.clip(rng.normal(size=6), -1, 1).astype(np.float32)); e.observation(); k1 += 1
+        o = e.step(rng.uniform(-1, 1, size=6).astype(np.float32)); e.observation(); k1 += 1
         if o.done:
             e.reset()
     dt1 = time.time() - t1
@@ -117,7 +120,8 @@ def cpu_baseline(obj, seconds_target=15.0):
             "with_policy": (None if not pol.get("fwd_samples_per_s") else
                             {"value": 1.0 / (1.0 / sim_rate + 1.0 / pol["fwd_samples_per_s"] + 2.0 / pol["fwd_bwd_samples_per_s"]), "unit": "env-steps/s",
                              "what": "serial sum on the same cores: simulation + observation, one policy forward, 2 epochs of forward + backward per env step"}),
-            "sample": f"{n} envs x {steps} macro steps incl. observation render (value: no policy; with_policy: + the policy legs); {sub / dt:.0f} mj-substeps/s",
+            "action_source": "U(-1,1)^6 (numpy generator, seed 0): the GPU leg's stream", "mj_substeps_per_s": sub / dt, "mean_substeps_per_env_step": sub / max(1, n * steps),
+            "sample": f"{n} envs x {steps} macro steps from the reset state incl. observation render (value: no policy; with_policy: + the policy legs); {sub / dt:.0f} mj-substeps/s",
             "single_env_single_thread": {"value": k1 / dt1, "unit": "env-steps/s", "sample": f"1 env x {k1} macro steps incl. observation render"},
             "note": "reference dm_control+SB3 stack cannot be installed here; its recorded whole-training rate is 3.95-12.97 env-steps/s (BASELINE.md)"}
 
@@ -379,7 +383,9 @@ def main():
             "update_path": "explicit launch sequence (sb3/fused_update.py)" if getattr(model, "_fused", None) is not None else "autograd",
             # N > 1: device time of the one collective per optimiser step (the flat 4 MB fp32 gradient bucket over RCCL), rank 0's view
             "allreduce_ms_per_optimizer_step": ar_ms, "allreduce_steps_timed": ar_n, "env_steps_counted": total_env_steps, "env_steps_nominal": a.envs * world * a.steps, "short_rollouts": short_rollouts,
-            "roofline": {"bound": "hbm", "kernel": "k_macro_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `achieved` / `peak` / `frac` are the HBM view the contract asks for (SURVEY.md 8(d) bytes / launch duration against 8 TB/s); `bound` names what binds
+            # the kernel: instruction issue (roofline.valu: `frac` there is the issue-slot figure, the lane figure beside it)
+            "roofline": {"bound": "valu-issue", "kernel": "k_macro_step", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms_avg": k_ms, "launches": k_n,
                          "launch_timing": ("device wall-clock stamps of every launch of the timed region (first workgroup's start to the last wave's end, 100 MHz), "
                                            "graph replays included" if k_n != ev_n or k_ms != ev_ms else "HIP events around the launch on its stream"),
@@ -387,7 +393,9 @@ def main():
                          "algorithmic_bytes_per_launch": macro_bytes, "overhead_bytes_per_launch": overhead_bytes,
                          "bytes_definition": "SURVEY.md 8(d): physics state in + out (348 B f32 per env and launch) + action / outputs of the macro steps that end in the launch; "
                                              "overhead = suspended macro-step context + narrow-phase pair memory of the time-sliced schedule (not counted in achieved)",
-                         "note": "the macro-step kernel is VALU-issue-bound (the SIMD's vector ALU is busy ~93 % of the time with two waves on it), not HBM-bound (DESIGN.md §4)"},
+                         "note": "the macro-step kernel is bound by instruction issue, not by HBM (7e-5 of the HBM roofline by construction: SURVEY.md 8(d)); round 5 measured what a "
+                                 "SIMD issues (tools/hiptests/t_simd_rate.hip): a wave issues at most one instruction per ~4.5-5 cycles (scalar, compare and cross-lane instructions ~8.5), two "
+                                 "waves of pure vector streams one per 2.4 (VOP2) ... 3.5 (VOP3) cycles per SIMD; this kernel's two waves issue one VALU instruction per ~4 (DESIGN.md)"},
         }
         if ar is not None:
             out["ticks"] = ar.total_ticks - ticks0
@@ -395,11 +403,18 @@ def main():
             # passes of THIS command at THIS configuration (profiles/r03_pmc_summary.json: separate passes, gfx950 FETCH_SIZE
             # correction) and are attached only when the run is that configuration; otherwise traffic stays null.
             try:
-                pmc_file = next(f for f in ("r04_pmc_summary.json", "r03_pmc_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                from mujoco_rl_manipulate_unknown_objects_amd import engine as _eng
+                pmc_file = next(f for f in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
                 pmj = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
                 same_cfg = (pmj.get("config") == {"object": a.object, "envs": a.envs, "state_dtype": a.state_dtype, "mixed": bool(a.mixed)})
                 pm = pmj["kernels"]["k_macro_step"]
-                if same_cfg and not a.lockstep:
+                # counters of ANOTHER build say nothing about this one: the summary records the fingerprint of the sources it was collected on
+                # (engine.source_fingerprint(), tools/pmc_run.sh) and is attached only when the running tree has the same one
+                same_src = pmj.get("csrc_sha16") == _eng.source_fingerprint()
+                if same_cfg and not a.lockstep and not same_src:
+                    out["roofline"]["traffic_note"] = (f"profiles/{pmc_file} was collected on sources {pmj.get('csrc_sha16')}, this run is {_eng.source_fingerprint()}: "
+                                                       "counter-derived fields (traffic, valu) left out")
+                if same_cfg and not a.lockstep and same_src:
                     rf = out["roofline"]
                     rf["traffic"] = pm["hbm_bytes_per_launch_fetch_doubled"]
                     rf["traffic_source"] = (f"profiles/{pmc_file}, same command and configuration: (2 x FETCH_SIZE + WRITE_SIZE) per launch; raw "
@@ -409,7 +424,13 @@ def main():
                     # the bound that really binds this kernel: VALU issue. Lane-operations of one launch from the PMC pass (SQ_INSTS_VALU x 64
                     # lanes, same command and configuration) / the LIVE launch duration of this run -- formed like the HBM figure above
                     lane_ops = pm["SQ_INSTS_VALU"] * 64.0 / (k_ms * 1e-3) if k_ms > 0 else 0.0
-                    rf["valu"] = {"achieved": lane_ops, "peak": VALU_PEAK_LANE_OPS, "unit": "fp32 lane-ops/s", "frac": lane_ops / VALU_PEAK_LANE_OPS,
+                    # `frac`: VALU instructions the SIMD's two waves issue per quad-cycle (2 x SQ_INSTS_VALU / SQ_WAVE_CYCLES; SQ_ACTIVE_INST_VALU counts exactly one
+                    # quad-cycle per instruction) -- the issue-slot figure. Calibration on pure streams, two waves per SIMD (profiles/r05_simd_issue_rates.txt): VOP2
+                    # 1.7, VOP3 1.15 per quad-cycle, so 1.0 is not a ceiling of the hardware but ~0.9 is where this instruction mix (15 % scalar, compares,
+                    # cross-lane, LDS) saturates two waves. The lane view (64 lanes x instructions / time against the fp32 peak) is `lane_frac`.
+                    rf["valu"] = {"frac": min(1.0, 2.0 * pm["active_inst_valu_frac"]), "frac_is": "VALU instructions issued per quad-cycle and SIMD (two waves)",
+                                  "achieved": lane_ops, "peak": VALU_PEAK_LANE_OPS, "unit": "fp32 lane-ops/s", "lane_frac": lane_ops / VALU_PEAK_LANE_OPS,
+                                  "wave_issue_frac": pm.get("active_inst_any_frac"),
                                   "lane_ops_per_launch": pm["SQ_INSTS_VALU"] * 64.0, "lane_ops_per_env_substep": pm.get("valu_lane_ops_per_env_substep"),
                                   "valu_active_frac": pm["active_inst_valu_frac"], "wait_frac": pm["wait_any_frac"],
                                   # how much of an issued wave instruction's 64 lanes can do anything: two envs x 16 lanes own a wave; lanes 32..63

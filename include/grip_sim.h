@@ -276,12 +276,12 @@ int grip_ppo_loss(const float *mean_dev, const float *log_std_dev, const float *
                   const float *advantages_dev, const float *returns_dev, int n, int action_dim, float clip_range, float ent_coef, float vf_coef,
                   float *out_dev, float *grad_mean_dev, float *grad_values_dev, float *grad_log_std_dev, void *stream);
 /* The same loss for the update's explicit launch sequence (sb3/fused_update.py), two launches: (1) the minibatch's rows rows_dev[0..n) (int64) of the rollout's
- * sample arrays actions_dev [R, action_dim], old_log_prob_dev / advantages_dev / returns_dev [R] are gathered into samples_dev (n * (action_dim + 3) + 320 floats:
- * actions | old_log_prob | advantages | returns | the loss kernel's 16 x 20 partial sums); (2) the loss reads mean and value in the layout of the merged heads' last batch-of-two GEMM --
+ * sample arrays actions_dev [R, action_dim], old_log_prob_dev / advantages_dev / returns_dev [R] are gathered into samples_dev (n * (action_dim + 3) + 321 words:
+ * actions | old_log_prob | advantages | returns | the loss kernel's 16 x 20 partial sums | its arrival counter, which the gather launch zeroes); (2) the loss reads mean and value in the layout of the merged heads' last batch-of-two GEMM --
  * heads_out_dev float32 [2, n, 8] WITHOUT the heads' biases, head_bias_dev [2, 8] beside it: [0, i, :action_dim] + bias[0] = mean_i, [1, i, 0] + bias[1][0] =
  * value_i -- and writes grad_heads_out_dev [2, n, 8] in that layout (padding = 0),
  * grad_head_bias_dev [2, 8] = its column sums (the action / value heads' bias gradients) and grad_log_std_dev [action_dim]; out_dev as above. The loss runs on 16 workgroups
- * whose partial sums the last one to finish adds in a fixed order; one call at a time per device (its ticket is a module variable). */
+ * whose partial sums the last one to finish adds in a fixed order; the arrival counter is part of the call's own samples_dev, so calls on different streams do not interfere. */
 int grip_ppo_loss_heads(const float *heads_out_dev, const float *head_bias_dev, const float *log_std_dev, const float *actions_dev, const float *old_log_prob_dev, const float *advantages_dev,
                         const float *returns_dev, const int64_t *rows_dev, int n, int action_dim, float clip_range, float ent_coef, float vf_coef, float *samples_dev,
                         float *out_dev, float *grad_heads_out_dev, float *grad_head_bias_dev, float *grad_log_std_dev, void *stream);

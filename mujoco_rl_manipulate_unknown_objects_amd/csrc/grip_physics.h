@@ -112,7 +112,17 @@ static_assert(ES_QPOS % 4 == 0 && ENV_FLOATS % 4 == 0 && ES_KIN % 4 == 0, "state
 #define LR_OFF(hull_words) (((hull_words) + GT_FLOATS + 3) & ~3)             // 16-byte aligned
 #define LDS_ENV_BASE(hull_words) (LR_OFF(hull_words) + LR_FLOATS)             // float offset of the first env region (16-byte aligned)
 
-#define NEWTON_MAXIT 20
+#define NEWTON_MAXIT 30
+// A solve that is STALLED after this many iterations from qacc_warmstart -- its last exact line search ended at a step length below NEWTON_STALL_ALPHA -- starts again
+// from qacc_smooth. What gets there (one physics.step() in ~5e7 of the bench workload, all of them objects squeezed between the fingers: tools/newton_cap_probe.py,
+// profiles/r05_newton_cap/) is a warm start inside the wrong facet of the friction cones: the line search ends at the next kink of the piecewise-quadratic cost, step
+// lengths of 1e-2 .. 1e-4 from the third iteration on, the gradient does not move for 15 .. 100 iterations -- the fp64 oracle, which runs MuJoCo's own iteration (100
+// iterations, tolerance 1e-10), needs 5 .. 100 from the same warm start and 5 .. 8 from qacc_smooth. The problem is strictly convex: both starts end at the same qacc.
+// (A healthy solve takes steps of length ~1; the few that need 10 .. 15 iterations do so from either start and are left alone.)
+#ifndef NEWTON_RESTART
+#define NEWTON_RESTART 6
+#endif
+#define NEWTON_STALL_ALPHA 0.02f
 #ifndef NEWTON_TOL
 #define NEWTON_TOL 1e-5f
 #endif
@@ -159,6 +169,16 @@ struct Stamps { int dummy; };
 #define DBG_COUNT(i, n) do { } while (0)
 struct Stamps { int dummy; };
 #define STAMP(st, i) do { } while (0)
+#endif
+
+// diagnostic build only (-DGRIP_CAPDUMP, tools/newton_cap_probe.py): every solve that runs into NEWTON_MAXIT leaves a record -- the state the step started
+// from (qpos, qvel, ctrl, qacc_warmstart as the env's LDS vectors hold them while the solver runs), the last iterate, and per Newton iteration the scaled
+// gradient, the step length, the cost and the line search's evaluations -- to be replayed on the oracle. Never in the shipped library.
+#ifdef GRIP_CAPDUMP
+#define CAPDUMP_RECORDS 256
+#define CAPDUMP_WORDS 256                // 0 ncon, 1 iters, 2 coupled | grip << 1, 3 took the warm start, 4 kind (1 capped, 2 restarted from qacc_smooth and finished); 8.. qpos[14], 24.. qvel[13], 40.. ctrl[7], 48.. warm[13], 64.. last iterate[13], 80.. qacc_smooth[13], 96.. + 4 it: scaled gradient, alpha, cost, line-search evaluations
+__device__ float g_capdump[CAPDUMP_RECORDS][CAPDUMP_WORDS];
+__device__ unsigned g_capdump_n, g_capdump_restarts;
 #endif
 
 // ---------------------------------------------------------------- cross-lane primitives (16-lane rows)
@@ -1827,7 +1847,10 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
     }
     STAMP(st, 14);
     // ---- both starts priced at once (their residuals jar = J x - aref and M (x - a_s) come from make_constraints)
-    float xi, Mdi, jtfi, hdiag, cost; Cone cn; bool gconv;
+    float xi, Mdi, jtfi, hdiag, cost; Cone cn; bool gconv, warm_taken;
+#ifdef GRIP_CAPDUMP
+    int cd_took_w = 0;
+#endif
 #ifdef HAVE_DBG_HIST
     bool take_w_dbg = false; float g2w_dbg = 0.f, g2s_dbg = 0.f;
 #endif
@@ -1846,8 +1869,11 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
 #ifdef HAVE_DBG_HIST
         take_w_dbg = take_w; g2w_dbg = g2w; g2s_dbg = g2s;
 #endif
+#ifdef GRIP_CAPDUMP
+        cd_took_w = take_w ? 1 : 0;
+#endif
         xi = take_w ? warmi : qsi; Mdi = take_w ? Md_w : 0.f; jtfi = take_w ? jt_w : jt_s; hdiag = take_w ? hd_w : hd_s;
-        cost = take_w ? cost_w : cost_s; gconv = take_w ? conv_w : conv_s;
+        cost = take_w ? cost_w : cost_s; gconv = take_w ? conv_w : conv_s; warm_taken = take_w;
         cone_sel(cn, take_w, cn_w);
 #pragma unroll
         for (int r = 0; r < 4; r++) c.jar[r] = take_w ? lc.jar_w[r] : lc.jar_s[r];
@@ -1855,6 +1881,11 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
     STAMP(st, 6);
     bool done = gconv;
     iters = 0;
+#ifdef GRIP_CAPDUMP
+    float cd_hist[4 * NEWTON_MAXIT]; int cd_dump = 0;          // 1: ran into the cap, 2: restarted from qacc_smooth (and finished)
+#pragma unroll
+    for (int i = 0; i < 4 * NEWTON_MAXIT; i++) cd_hist[i] = 0.f;
+#endif
 #ifdef HAVE_DBG_HIST
     auto zone_of = [&](const float (&jar)[4]) {
         const float mu = c.fs * rsqrtf(m.impratio);
@@ -1947,8 +1978,14 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
                 gtol = LS_GTOL * fabsf(dp) + 1e-30f;
                 if (!lsdone) alpha = -dp * rcp(fmaxf(hp, 1e-30f));
             }
+#ifdef GRIP_CAPDUMP
+            int cd_ls = 0;
+#endif
             for (int ls = 1; ls <= LS_MAXIT; ls++) {
                 if (!__any(!lsdone)) break;
+#ifdef GRIP_CAPDUMP
+                if (!lsdone) cd_ls++;
+#endif
                 if (!lsdone) {
                     float dp, hp;
                     line_eval(m, lsgn, lD, laref, xi, pi, c, live, alpha, g0, g1, dp, hp, cn, wlim);
@@ -1986,12 +2023,41 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
                 // ... and a solve that is still going after four iterations is allowed to stop on the measured difference too: what it gains
                 // per iteration is then at the rounding level of the cost anyway (rare: ~0.3 % of the solves get this far)
                 {   const float newcost = sum16(0.5f * Mdi * (xi - qsi) + lcst);
-                    if (iters >= 4 && scale * (cost - newcost) < tol) stop = true;
+                    if (iters >= 4 && scale * fabsf(cost - newcost) < tol) stop = true;      // (a cost that ROSE is no stall: one of 512 restarted solves of round 5's probe ended that way, gradient 6.9)
                     cost = newcost; }
 #ifdef HAVE_DBG_HIST
                 if (cx.sub == 0 && iters <= 4) { const float sg = scale * sqrtf(g2); int b = 0; for (float t = 1e-7f; b < 7 && sg >= t; t *= 10.f) b++; DBG_HIST(32 + 8 * (iters - 1) + b, 1); }
 #endif
+#ifdef GRIP_CAPDUMP
+#pragma unroll
+                for (int q = 0; q < NEWTON_MAXIT; q++) if (q == iters - 1) { cd_hist[4 * q] = scale * sqrtf(g2); cd_hist[4 * q + 1] = alpha; cd_hist[4 * q + 2] = cost; cd_hist[4 * q + 3] = (float)cd_ls; }
+                if (!stop && iters >= NEWTON_MAXIT) cd_dump = 1;
+#endif
                 if (!stop && iters >= NEWTON_MAXIT) { stop = true; env_fault_or(cx, 4); }
+                if (!stop && iters >= NEWTON_RESTART && alpha < NEWTON_STALL_ALPHA && warm_taken) {
+                    warm_taken = false;                     // once
+#ifdef GRIP_CAPDUMP
+                    if (cx.sub == 0 && cx.lane < 32) atomicAdd(&g_capdump_restarts, 1u);
+                    cd_dump = 2;
+#endif
+                    // ---- cold restart (NEWTON_RESTART above): one step of length 1 along qacc_smooth - x, through the machinery of an ordinary step -- the direction
+                    // goes to EF_P (every lane its own component, lanes 13..15 the padding words), jar += J (a_s - x), the cones at the new residuals, one pricing
+                    const int lsub = local_sub(cx);
+                    cx.envl[EF_P + (lsub < 7 ? lsub : lsub < 13 ? lsub + 1 : lsub == 13 ? 7 : lsub)] = lsub < 13 ? qsi - xi : 0.f;
+                    wave_sync();
+                    float jd[4] = {0.f, 0.f, 0.f, 0.f};
+                    contact_jp(cx, live, jd);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) c.jar[r] += jd[r];
+                    xi = qsi; Mdi = 0.f;
+                    if (live) cone_eval(c.jar, c.D0, m.impratio, c.fs, c.ft, cn);
+                    wave_sync();                            // EF_P is read; the pricing below reuses the staging area
+                    const float lcs = price_constraints(m, cx, lsgn, lD, laref, xi, ncon, c, live, cn, jtfi, hdiag, wlim);
+                    cost = sum16(lcs);                                          // M (x - a_s) = 0 at x = a_s
+                    const float g2r = sum16(jtfi * jtfi);
+                    stop = scale * sqrtf(g2r) < tol;
+                    iters++;
+                }
                 done = stop;
                 STAMP(st, 6);
             }
@@ -2015,6 +2081,22 @@ DEVI void solve_newton(const DevModel &m, const Ctx &cx, const LaneCon &lc, Cont
                 if (MI(cx, 13) == curZ && mM == 0 && mS != 0) DBG_HIST(92, 1);   //     ... and the start classification was wrong (what the guess would have saved)
             }
             MI(cx, 13) = curZ; MI(cx, 14) = curI;
+        }
+    }
+#endif
+#ifdef GRIP_CAPDUMP
+    if (cd_dump) {                          // (the restarted solves share the buffer with the capped ones: the first CAPDUMP_RECORDS of either kind are kept)
+        unsigned slot = 0;
+        if (cx.sub == 0 && cx.lane < 32) slot = atomicAdd(&g_capdump_n, 1u);
+        slot = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (cx.lane & 16), (int)slot);     // lane 0 of the env's lower row hands the record number to the row (the clones do not write)
+        if (slot < CAPDUMP_RECORDS && cx.lane < 32) {
+            float *r = g_capdump[slot]; const float *S = cx.envl;
+            if (cx.sub == 0) { r[0] = (float)ncon; r[1] = (float)iters; r[2] = (float)((lc.coupled ? 1 : 0) | (lc.grip ? 2 : 0)); r[3] = (float)cd_took_w; r[4] = (float)cd_dump;
+#pragma unroll
+                for (int q = 0; q < 4 * NEWTON_MAXIT; q++) r[96 + q] = cd_hist[q]; }
+            if (cx.sub < 14) r[8 + cx.sub] = S[ES_QPOS + cx.sub];
+            if (cx.sub < 13) { r[24 + cx.sub] = S[ES_QVEL + cx.sub]; r[48 + cx.sub] = S[ES_WARM + cx.sub]; r[64 + cx.sub] = xi; r[80 + cx.sub] = S[ES_QS + cx.sub]; }
+            if (cx.sub < 7) r[40 + cx.sub] = S[ES_CTRL + cx.sub];
         }
     }
 #endif

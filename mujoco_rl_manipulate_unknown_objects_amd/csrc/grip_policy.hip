@@ -350,7 +350,8 @@ extern "C" int grip_ppo_loss(const float *mean_dev, const float *log_std_dev, co
 #define PLM_THREADS 256
 #define PLM_BLOCKS 16
 #define PLM_SUMS (2 * PL_MAXA + 4)
-__device__ unsigned plm_ticket = 0u;
+// (the arrival counter of the last-workgroup reduction is a word of the CALL's scratch, zeroed by the gather launch in front of it on the same stream: two loss
+// launches in flight on one device, or one that died half-way, cannot disturb each other)
 __device__ __forceinline__ float plm_block_sum(float v, float *red) {           // 4 waves
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
@@ -363,7 +364,7 @@ __global__ void __launch_bounds__(PLM_THREADS) k_ppo_loss_heads_mb(const float *
                                                                    const float *__restrict__ old_logp, const float *__restrict__ adv, const float *__restrict__ ret, int n, int A,
                                                                    float clip, float ent_coef, float vf_coef, float *__restrict__ out, float *__restrict__ go,
                                                                    float *__restrict__ g_log_std, const float *__restrict__ head_bias, float *__restrict__ g_head_bias,
-                                                                   float *__restrict__ part) {
+                                                                   float *__restrict__ part, unsigned *__restrict__ ticket) {
     __shared__ float red[PLM_THREADS / 64];
     __shared__ float redm[PLM_THREADS / 64][PLM_SUMS];
     __shared__ unsigned last;
@@ -439,7 +440,7 @@ __global__ void __launch_bounds__(PLM_THREADS) k_ppo_loss_heads_mb(const float *
     if (tid < PLM_SUMS) part[blockIdx.x * PLM_SUMS + tid] = (redm[0][tid] + redm[1][tid]) + (redm[2][tid] + redm[3][tid]);
     __threadfence();
     __syncthreads();
-    if (tid == 0) last = atomicAdd(&plm_ticket, 1u);
+    if (tid == 0) last = atomicAdd(ticket, 1u);
     __syncthreads();
     if (last != PLM_BLOCKS - 1) return;
     __threadfence();
@@ -458,15 +459,15 @@ __global__ void __launch_bounds__(PLM_THREADS) k_ppo_loss_heads_mb(const float *
         const float pl = -fin[0] * invn, vl = fin[1] * invn;
         const float el = -((float)A * (0.5f + 0.9189385332046727f) + lsum);
         out[0] = pl + ent_coef * el + vf_coef * vl; out[1] = pl; out[2] = vl;
-        plm_ticket = 0u;
     }
 }
 
 // rows idx[0..n) of the rollout's sample arrays into one packed block: samples = actions [n, A] | old_log_prob [n] | advantages [n] | returns [n]  (one launch for
 // the four gathers of a minibatch)
 __global__ void __launch_bounds__(256) k_gather_samples(const float *__restrict__ actions, const float *__restrict__ logp, const float *__restrict__ adv,
-                                                       const float *__restrict__ ret, const int64_t *__restrict__ idx, int n, int A, float *__restrict__ out) {
+                                                       const float *__restrict__ ret, const int64_t *__restrict__ idx, int n, int A, float *__restrict__ out, unsigned *__restrict__ ticket) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && ticket) *ticket = 0u;              // the loss kernel's arrival counter (per call)
     if (i >= n) return;
     const int64_t r = idx[i];
     for (int k = 0; k < A; k++) out[(size_t)i * A + k] = actions[r * A + k];
@@ -482,15 +483,15 @@ extern "C" int grip_ppo_loss_heads(const float *heads_out_dev, const float *head
         return grip_fail("grip_ppo_loss_heads: need n >= 2 rows, 1..8 action dimensions and every array");
     const int A = action_dim;
     hipLaunchKernelGGL(k_gather_samples, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, actions_dev, old_log_prob_dev, advantages_dev, returns_dev, rows_dev, n, A,
-                       samples_dev);
+                       samples_dev, reinterpret_cast<unsigned *>(samples_dev + (size_t)n * (A + 3) + PLM_BLOCKS * PLM_SUMS));
     float *sa = samples_dev, *sl = samples_dev + (size_t)n * A, *sd = sl + n, *sr = sd + n;
 #ifdef PLM_OFF            // comparison build: the one-workgroup kernel
     hipLaunchKernelGGL(k_ppo_loss<true>, dim3(1), dim3(PL_THREADS), 0, (hipStream_t)stream, heads_out_dev, log_std_dev, heads_out_dev + (size_t)n * PL_MAXA, sa, sl, sd, sr, n, A,
                        clip_range, ent_coef, vf_coef, out_dev, grad_heads_out_dev, grad_heads_out_dev + (size_t)n * PL_MAXA, grad_log_std_dev, head_bias_dev, grad_head_bias_dev);
 #else
-    // (samples_dev is followed by the workgroups' partial sums: n * (A + 3) + 16 * 20 floats in all)
+    // (samples_dev is followed by the workgroups' partial sums and the arrival counter: n * (A + 3) + 16 * 20 + 1 words in all)
     hipLaunchKernelGGL(k_ppo_loss_heads_mb, dim3(PLM_BLOCKS), dim3(PLM_THREADS), 0, (hipStream_t)stream, heads_out_dev, log_std_dev, (const float *)sa, (const float *)sl, (const float *)sd,
-                       (const float *)sr, n, A, clip_range, ent_coef, vf_coef, out_dev, grad_heads_out_dev, grad_log_std_dev, head_bias_dev, grad_head_bias_dev, sr + n);
+                       (const float *)sr, n, A, clip_range, ent_coef, vf_coef, out_dev, grad_heads_out_dev, grad_log_std_dev, head_bias_dev, grad_head_bias_dev, sr + n, reinterpret_cast<unsigned *>(sr + n + PLM_BLOCKS * PLM_SUMS));
 #endif
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { char buf[160]; snprintf(buf, sizeof buf, "grip_ppo_loss_heads: %s", hipGetErrorString(e)); return grip_fail(buf); }

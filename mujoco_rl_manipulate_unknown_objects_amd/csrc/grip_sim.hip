@@ -1525,6 +1525,18 @@ extern "C" int grip_debug_counters(unsigned long long *out8) {   // 16 collide()
 }
 #endif
 
+#ifdef GRIP_CAPDUMP
+extern "C" int grip_debug_capdump(float *out, unsigned *count) {   // records of the solves that hit NEWTON_MAXIT (grip_physics.h: g_capdump), reset on read
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(count, HIP_SYMBOL(g_capdump_n), sizeof(unsigned)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_capdump), sizeof(float) * CAPDUMP_RECORDS * CAPDUMP_WORDS) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(count + 1, HIP_SYMBOL(g_capdump_restarts), sizeof(unsigned)) != hipSuccess) return -1;       // count[1]: solves restarted from qacc_smooth
+    const unsigned zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_capdump_restarts), &zero, sizeof zero) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_capdump_n), &zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+#endif
+
 // ---- self-test hook of the lane-distributed Cholesky (tests only): x = A^-1 b for n SPD 13x13 systems
 __global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_test_chol(const float *A, const float *b, float *x, int n) {
     bool act_; int e = blockIdx.x * EPB + wg_env_slot(act_), sub = threadIdx.x & (KL - 1);

@@ -62,6 +62,21 @@ def build_library(force=False, verbose=False):
     return LIB_PATH
 
 
+def source_fingerprint():
+    """sha256 (first 16 hex digits) over the sources the library is built from -- csrc/*.hip, csrc/*.h, include/grip_sim.h, names and contents in sorted order.
+    tools/pmc_run.sh records it beside the counters it collects; bench.py attaches a committed counter summary to its line only when the running tree has the same
+    fingerprint (round 4's summary had been taken two commits before the shipped build)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.normpath(os.path.join(_HERE, "..", "include", "grip_sim.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode()); h.update(b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def select_library(cold_portal=False):
     """Choose the build of the library for this process -- before the first call into it. cold_portal: the comparison build whose
     narrow phase starts every portal refinement from scratch, as libccd / MuJoCo do (the shipped build starts a touching pair's
@@ -505,7 +520,7 @@ def ppo_loss_heads(heads_out, head_bias, log_std, actions, old_log_prob, advanta
     assert f32(grad_head_bias, None) and grad_head_bias.numel() == 16 and f32(grad_log_std, None) and grad_log_std.numel() >= A
     dev = heads_out.device
     out = torch.empty(3, dtype=torch.float32, device=dev); go = torch.empty_like(heads_out)
-    samples = torch.empty(n * (A + 3) + 320, dtype=torch.float32, device=dev)     # the gathered samples, then the loss kernel's partial sums
+    samples = torch.empty(n * (A + 3) + 324, dtype=torch.float32, device=dev)     # the gathered samples, the loss kernel's 16 x 20 partial sums, its arrival counter (one word, per call)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr())
     _chk(lib().grip_ppo_loss_heads(p(heads_out), p(head_bias), p(log_std), p(actions), p(old_log_prob), p(advantages), p(returns), p(rows), n, A, float(clip_range), float(ent_coef),

@@ -228,8 +228,9 @@ class AsyncRollout:
         with th.cuda.stream(self.side):
             self.side.wait_event(ev)
             if self.use_graph and self._side_graph[p] is None and self.total_ticks >= 2 * self.graph_after:
+                from .gemm_choices import recorded_gemm_choices
                 g = th.cuda.CUDAGraph()
-                with th.cuda.graph(g, stream=self.side, capture_error_mode="thread_local"):
+                with recorded_gemm_choices(), th.cuda.graph(g, stream=self.side, capture_error_mode="thread_local"):
                     self._decide(out, self.lst2[p], self.cnt2[p], self.obs_stage2[p], self.slot_act2[p], p)
                 self._side_graph[p] = g
             if self._side_graph[p] is not None:
@@ -331,8 +332,9 @@ class AsyncRollout:
         refuses the capture the rollout goes on eagerly (slower, same results)."""
         th.cuda.synchronize(self.dev)
         try:
+            from .gemm_choices import recorded_gemm_choices
             g = th.cuda.CUDAGraph()
-            with th.cuda.graph(g, capture_error_mode="thread_local"):
+            with recorded_gemm_choices(), th.cuda.graph(g, capture_error_mode="thread_local"):
                 self._tick_body()
             self._graph = g
         except Exception as ex:                                   # noqa: BLE001 -- any capture failure means "no graph"

@@ -67,32 +67,7 @@ class RolloutBuffer:
         self.pos = 0
 
 
-_GEMM_CHOICES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "assets", "tunableop_gfx950.csv")
-
-
-def _use_recorded_gemm_choices():
-    """The tensor library's GEMMs of the update (a dozen fp32 problems with [4096 x 256..1024] operands) through the kernels a TunableOp search picked for them on MI355X
-    -- rocBLAS for about half of them, hipBLASLt's non-default solutions for the rest: -3.8 % on the captured update (tools/update_time.py find tune). The search's result
-    is a committed file (assets/tunableop_gfx950.csv, written by `tools/update_time.py find tune`); nothing is tuned at run time and the file is never written. TunableOp
-    ignores it when the library versions in its header are not the running ones, and shapes it does not list take the default path. GRIP_TUNABLEOP=0 switches it off."""
-    if os.environ.get("GRIP_TUNABLEOP") == "0" or not os.path.exists(_GEMM_CHOICES):
-        return
-    try:
-        t = th.cuda.tunable
-        if t.is_enabled():                       # a caller's own TunableOp set-up (tools/update_time.py tune) stays as it is
-            return
-        grow = os.environ.get("GRIP_TUNABLEOP_TUNE")        # maintenance: search the shapes the file lacks into a COPY of it at this path (then copy it back by hand)
-        if grow:
-            import shutil
-            shutil.copyfile(_GEMM_CHOICES, grow)
-            t.set_max_tuning_duration(30); t.set_max_tuning_iterations(20)
-            t.tuning_enable(True); t.set_filename(grow); t.enable(True)
-            return
-        t.tuning_enable(False)                   # nothing is searched, so nothing is ever written to the file either
-        t.set_filename(os.path.abspath(_GEMM_CHOICES)); t.enable(True)
-    except Exception as ex:                      # noqa: BLE001 -- an optimisation only
-        import warnings
-        warnings.warn(f"recorded GEMM choices not used ({ex})")
+from .gemm_choices import recorded_gemm_choices      # the library GEMMs of a captured graph through the kernels a recorded TunableOp search picked (scoped to the capture)
 
 
 class _FusedPPOLoss(th.autograd.Function):
@@ -162,8 +137,6 @@ class PPO:
         self.optimizer = th.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5, capturable=self.graph_update,
                                        fused=True if self.graph_update else None)
         self._upd = None
-        if self.device.type == "cuda":
-            _use_recorded_gemm_choices()
         # The explicit update sequence (sb3/fused_update.py) keeps the parameters in one flat buffer. They are laid out HERE, before anything can hold their
         # addresses -- the rollout copy below, and above all the captured rollout tick, which reads biases straight from the parameters: laid out at the first
         # update instead, the tick graph kept reading the freed old storage (NaN losses from the second rollout on; tools/train_probe.py found it).
@@ -427,11 +400,13 @@ class PPO:
 
     def _minibatch_update(self, src, idx):
         """One optimiser step. Eager on CPU; on a GPU two captured graphs with the (eager) gradient all-reduce between them."""
-        if self.graph_update and (self._upd is None or self._upd.get("fwd") is None) and self.miopen_find:
-            prev = th.backends.cudnn.benchmark                   # find mode for the eager steps and the capture only
-            th.backends.cudnn.benchmark = True
+        if self.graph_update and (self._upd is None or self._upd.get("fwd") is None):
+            # the eager warm-up steps and the capture: MIOpen's find mode and the recorded GEMM choices are on for these only (both are process-global switches)
+            prev = th.backends.cudnn.benchmark
+            th.backends.cudnn.benchmark = prev or self.miopen_find
             try:
-                return self._minibatch_update_impl(src, idx)
+                with recorded_gemm_choices():
+                    return self._minibatch_update_impl(src, idx)
             finally:
                 th.backends.cudnn.benchmark = prev
         return self._minibatch_update_impl(src, idx)
@@ -535,6 +510,13 @@ class PPO:
     def _train_on(self, src, sel, total):
         bs = min(self.batch_size, total)
         stats = {}
+        # once per train() (~50 us of host time), not per replay: are the parameters still where the captured update reads and writes them? A caller who moved or
+        # re-assigned one (policy.to(), p.data = ...) would otherwise train the old flat buffer while the live module stands still.
+        if self._fused is not None and self._upd is not None and not self._fused.intact():
+            self._fused = None; self._flat_grad = None; self._upd = None
+            for p in self.policy.parameters():
+                p.grad = None
+            self._parameters_moved()
         for _ in range(self.n_epochs):
             perm = th.randperm(total, device=self.device)
             if sel is not None:

@@ -114,10 +114,11 @@ def test_sugar_cube_16384_envs_f16_state_full_size(engine, torch):
         st = b.get_state(); b.close()
         return st, finished.cpu().numpy(), fault.cpu().numpy()
     (q, v, c, w), fin, fault = run(1500, 60)                     # the bench's mode: slices capped by wall-clock time
-    # no env diverged (bit 1) or overflowed its contact slots (bit 2). Bit 4 -- the Newton solver stopped at its 20-iteration limit and the step went on with
-    # the last iterate -- happens in 2-3 of a million macro steps (tools/physics_rate.py counts it: 10 of 5.6 M on sugar_cube, 14 of 5.0 M on acorn; round 3's
-    # kernel 7 of 5.1 M / 10 of 4.4 M): this run makes ~0.3 M, so a hit or two is within that rate and is not a failure of the storage mode under test
-    assert ((fault & 3) == 0).all() and int(((fault & 4) != 0).sum()) <= 3, np.unique(fault, return_counts=True)
+    # no fault bit at all: nobody diverged (1), overflowed its contact slots (2) or ran the Newton solver into its iteration limit (4). Round 4 had to tolerate a hit
+    # or two of bit 4 here; round 5 replayed every such solve on the oracle (tools/newton_cap_probe.py, profiles/r05_newton_cap/): warm starts stalled inside a wrong
+    # cone facet, which the oracle's own (MuJoCo's) iteration needs up to 100 iterations for -- the solver now restarts a stalled solve from qacc_smooth
+    # (csrc/grip_physics.h NEWTON_RESTART) and no capped solve is left in 2e9 physics.step() calls
+    assert (fault == 0).all(), np.unique(fault, return_counts=True)
     assert np.isfinite(q).all() and np.isfinite(v).all() and np.isfinite(w).all()
     assert np.abs(np.linalg.norm(q[:, 10:14], axis=1) - 1).max() < 2e-3          # half resolves 5e-4 near 1
     for a in (q, v, c):

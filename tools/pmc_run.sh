@@ -5,6 +5,7 @@ set -e
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/pmc_$tag
+python3 -c "from mujoco_rl_manipulate_unknown_objects_amd import engine; print(engine.source_fingerprint())" > gpurun_out/pmc_$tag/csrc_sha16.txt
 i=0
 for ctrs in "SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
   name=$(echo $ctrs | cut -d' ' -f1)

@@ -28,6 +28,12 @@ def main(src, out_path, prev_path=None):
                      "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) "
                      "streaming reads and is uncalibrated for other widths -- these kernels read 4 B per lane, so both the raw and the doubled figure are given"],
            "kernels": k}
+    sha = os.path.join(src, "csrc_sha16.txt")
+    if os.path.exists(sha):                    # the tree the counters were collected on (engine.source_fingerprint(), written by tools/pmc_run.sh on the GPU box)
+        out["csrc_sha16"] = open(sha).read().strip()
+        psha = os.path.join(src, "probe_csrc_sha16.txt")
+        if os.path.exists(psha) and open(psha).read().strip() != out["csrc_sha16"]:
+            raise SystemExit("the physics-only probe and the bench passes were taken on different sources: " + open(psha).read().strip() + " / " + out["csrc_sha16"])
     probe_csv, probe_json = os.path.join(src, "probe_SQ.csv"), os.path.join(src, "probe.json")
     if os.path.exists(probe_csv) and os.path.exists(probe_json):          # tools/pmc_probe.sh: the physics-only probe of THIS kernel, measured, not carried over
         c = {r["counter"]: (float(r["sum"]), int(r["dispatches"])) for r in csv.DictReader(open(probe_csv))}
