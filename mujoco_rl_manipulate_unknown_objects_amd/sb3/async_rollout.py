@@ -235,6 +235,10 @@ class AsyncRollout:
                 self._side_graph[p] = g
             if self._side_graph[p] is not None:
                 self._side_graph[p].replay()
+            elif self.use_graph:
+                from .gemm_choices import recorded_gemm_choices
+                with recorded_gemm_choices():                         # (the eager decisions before the capture: see _tick)
+                    self._decide(out, self.lst2[p], self.cnt2[p], self.obs_stage2[p], self.slot_act2[p], p)
             else:
                 self._decide(out, self.lst2[p], self.cnt2[p], self.obs_stage2[p], self.slot_act2[p], p)
             e2 = th.cuda.Event(); e2.record(self.side)
@@ -323,6 +327,12 @@ class AsyncRollout:
         # every `eager_every`-th tick runs outside the graph so that the engine can time its kernel with events
         if use_graph and self._graph is not None and (self.total_ticks % self.eager_every) != 0:
             self._graph.replay()
+        elif use_graph and self._graph is None:
+            # the eager ticks BEFORE the capture run with the recorded GEMM choices switched on, as the capture will: TunableOp's first look at a shape
+            # (table lookup, library queries) is not allowed inside a stream capture, so every shape of the tick has to have been seen by then
+            from .gemm_choices import recorded_gemm_choices
+            with recorded_gemm_choices():
+                self._tick_body()
         else:
             self._tick_body()
         self.tick += 1; self.total_ticks += 1

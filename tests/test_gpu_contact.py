@@ -159,8 +159,10 @@ def test_macro_step_parity_in_contact(engine, orc, torch, contact, obj):
     # (the floor on exact lanes below holds whatever the explanation), and none that is stable at EVERY amplitude of the sweep
     assert len(unexplained) <= 0.03 * len(allrecs), unexplained
     assert all(level[r["row"]] < len(NOISE_LEVELS) for r in differing), [(r["row"], r["cat"]) for r in differing if level[r["row"]] >= len(NOISE_LEVELS)]
+    # (round 5: the rule every other differing lane is held to -- at or below the DISCRIMINATING level; round 4 let these rows fall back to the fixture's own
+    # filter level, at which 10-19 % of the matching lanes flip too)
     for direction, cat, rows_ in pending:
-        assert all(level[i] <= max(disc, NOISE_LEVELS.index((5e-7, 3e-5))) for i in rows_), (obj, direction, cat, [lvl_name(level[i]) for i in rows_])
+        assert all(level[i] <= disc for i in rows_), (obj, direction, cat, [lvl_name(level[i]) for i in rows_], lvl_name(disc))
     assert frac >= 0.92, (frac, bad)
     assert med["drew"] < 1e-4 and med["dgrip"] < 2e-5 and med["dobj"] < 2e-5, med
     # (the reward is 30 x the object's travel along the target line, reward.py:41: its bound is the line-distance bound's image, not a tighter one --
@@ -227,6 +229,12 @@ def oracle_trajectory(orc, m, z, obj, i):
     return pre, post, cons, margins
 
 
+# one-step qvel error allowed on a state whose hull contact (geom pair) is resolved on another facet than the oracle's: per object and pair, from what is
+# measured (round 4: sugar_cube (3, 5) 8.4e-2 over 22 states -- the face-to-face squeeze; acorn 9.8e-3 over 26 states -- grazing pads); everything else 0.015
+OTHER_FACET_QVEL = {"sugar_cube": {(3, 5): 0.1}}
+OTHER_FACET_QVEL_DEFAULT = 0.015
+
+
 @pytest.mark.parametrize("obj", OBJECTS)
 def test_one_step_parity_along_contact_trajectories(engine, orc, torch, contact, obj):
     """a4 where it matters: physics.step() in contact. Every pre-step state of the oracle's own macro steps through pushes, one-finger and
@@ -237,9 +245,11 @@ def test_one_step_parity_along_contact_trajectories(engine, orc, torch, contact,
     are all more than 2 um away from the 1 mm margin. States whose hull contacts all sit on the oracle's facet (normals within 1 degree; 98-100 %
     of the states): qpos error median < 1e-7, p99 < 2e-6, MAX < 2e-5 (m, rad); qvel error median < 2e-6, p99 < 5e-4, MAX < 1e-2 (m/s, rad/s) --
     measured p99 5e-6 ... 2e-4, max 6e-5 ... 5e-3, the largest on sugar_cube, where pad and cube meet face to face and the contact POINT (same
-    normal) lies up to 1.4 mm apart inside the contact patch. States with a hull contact on ANOTHER facet (<= 2 % of the states, round 3 found
-    what they are: flat finger pads pressed 2-3 mm into each other or into a flat face; two facets of the Minkowski difference within 0.2 mm in
-    depth, normals 18-22 degrees apart): qvel error < 0.15 m/s."""
+    normal) lies up to 1.4 mm apart inside the contact patch. States with a hull contact on ANOTHER facet (<= 2 % of the states; finger pad against finger
+    pad or against the object, by geom ids): on sugar_cube the closed gripper's flat pads pressed >= 1.3 mm into each other -- two facets of the Minkowski
+    difference within 0.2 mm in depth, normals 18-22 degrees apart, qvel error < 0.1 m/s (measured 8.4e-2); on acorn GRAZING pad contacts 0.03-0.1 mm deep, two
+    nearly coplanar pad facets <= 12 degrees apart, qvel error < 0.015 (measured 9.8e-3); none on sand_ball and bread_crumb. The bound is per geom pair
+    (OTHER_FACET_QVEL), what is measured, not one number for all."""
     z = contact; m = orc.Model(obj)
     cat = z[f"{obj}/category"]
     pick = []
@@ -267,6 +277,7 @@ def test_one_step_parity_along_contact_trajectories(engine, orc, torch, contact,
     # angle between this path's and the oracle's normal, worst hull contact of the state (pairs that occur once: a pair with two contacts is a floor pair)
     ang = np.zeros(n)
     off_pairs = {}                              # (geom 1, geom 2) -> [count, shallowest penetration] of the hull contacts resolved on another facet
+    off_of_state = {}                           # state -> the geom pairs it has on another facet
     for k in range(n):
         for c in range(dbg["ncon"][k]):
             g = dbg["con"][k, c]
@@ -277,6 +288,7 @@ def test_one_step_parity_along_contact_trajectories(engine, orc, torch, contact,
                 if a_ >= 1.0 and same[k]:
                     rec_ = off_pairs.setdefault((int(g[7]), int(g[8])), [0, 1.0])
                     rec_[0] += 1; rec_[1] = min(rec_[1], 1e-3 - float(g[6]))
+                    off_of_state.setdefault(k, set()).add((int(g[7]), int(g[8])))
     eq = np.abs(gq - nq).max(1); ev = np.abs(gv - nv).max(1)
     facet = same & (ang < 1.0)                  # same contact pairs, every hull contact resolved on the oracle's facet (normals within a degree)
     other = same & ~facet
@@ -289,10 +301,17 @@ def test_one_step_parity_along_contact_trajectories(engine, orc, torch, contact,
     # Where both sides resolve every hull contact on the same facet of the Minkowski difference, the step is held tightly, maximum included.
     assert np.median(eq[facet]) < 1e-7 and np.quantile(eq[facet], .99) < 2e-6 and eq[facet].max() < 2e-5
     assert np.median(ev[facet]) < 2e-6 and np.quantile(ev[facet], .99) < 5e-4 and ev[facet].max() < 1e-2
-    # The rest are flat-pad contacts penetrating 2-3 mm (the closed fingers against each other, a finger pad against a flat face of the object):
-    # two facets of the Minkowski difference lie within 0.2 mm of each other in depth with normals ~20 deg apart, and MPR ends on one or the other
-    # by the last bits of its support values (fp32 here, fp64 in the oracle; libccd has the same ambiguity). Rare and bounded:
-    assert other.sum() <= 0.02 * n and (not other.any() or ev[other].max() < 0.15)
+    # The rest: two facets of the Minkowski difference lie within 0.2 mm of each other in depth and MPR ends on one or the other by the last bits of its
+    # support values (fp32 here, fp64 in the oracle; libccd has the same ambiguity) -- the closed fingers' flat pads squeezed against each other (sugar_cube's
+    # trajectories: normals ~20 deg apart) or grazing pad contacts (acorn's: <= 12 deg). Rare, and bounded PER GEOM PAIR by what is measured (OTHER_FACET_QVEL):
+    assert other.sum() <= 0.02 * n
+    per_pair = {}
+    for k in np.where(other)[0]:
+        bound = max(OTHER_FACET_QVEL.get(obj, {}).get(pr, OTHER_FACET_QVEL_DEFAULT) for pr in off_of_state[k])
+        for pr in off_of_state[k]:
+            per_pair[pr] = max(per_pair.get(pr, 0.0), float(ev[k]))
+        assert ev[k] < bound, (obj, int(k), sorted(off_of_state[k]), float(ev[k]), bound)
+    print(f"[one-step parity] {obj}: largest qvel error of the states with a hull contact on another facet, by geom pair: " + str({k_: float('%.2e' % v_) for k_, v_ in sorted(per_pair.items())}))
     # ... and they ARE that class by geom ids, not only by count: the contact resolved on another facet is finger pad against finger pad
     # (geoms 3 and 5: left / right inner finger) or a finger pad against the object (geom 6). Their depth is printed, not asserted: on sugar_cube
     # they penetrate the margin-inflated hulls by > 1.3 mm (the face-to-face squeeze described above); on acorn the class also holds GRAZING pad
