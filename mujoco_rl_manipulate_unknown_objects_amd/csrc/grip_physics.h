@@ -262,6 +262,11 @@ struct Ctx {
 // whole launch (a dozen such addresses were the kernel's last spilled registers).
 DEVI int local_sub(const Ctx &cx) { int s_ = cx.sub; asm volatile("" : "+v"(s_)); return s_; }
 
+// A constant the optimiser cannot see through, for the same purpose: an LDS base address `cx.envl + CONSTANT` is loop-invariant, so it was hoisted out of the step loop,
+// held in a register across everything and -- the kernel sits at 256 registers -- spilled to scratch and RELOADED inside the Newton loop (two scratch loads and an
+// s_waitcnt vmcnt(0) per pricing: a memory round trip where one v_lshl_add would do). An offset that went through local_const() is a value of the current trip.
+DEVI int local_const(int c) { asm volatile("" : "+v"(c)); return c; }
+
 constexpr DEVI int pidx(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
 // N floats of a 16-byte aligned LDS vector (padded to a multiple of 4) into registers: ceil(N / 4) ds_read_b128, all lanes of an env read
@@ -1403,30 +1408,41 @@ DEVI float impedance(const float *si, float pos, float margin) {
 //   H = diag(w) + ka a a^T - kb b b^T      (top zone: all zero; bottom zone: w = D, ka = kb = 0)
 struct Cone { float cost, grad[4], w[4], a[4], b[4], ka, kb; };
 DEVI void cone_eval(const float (&jar)[4], float D0, float impratio, float fs, float ft, Cone &c) {
-    float mu = fs * rsqrtf(impratio);
-    float D1 = D0 * impratio, D3 = D1 * ft * ft / fmaxf(1e-30f, fs * fs);
-    float S[4] = {mu, fs, fs, ft}, U[4];
+    // (one exit, every field written once on each of the three paths: the early-return form zeroed all 19 fields up front and the compiler repeated those moves at every
+    // nesting level of the zone tests -- ~50 v_mov per evaluation, a dozen evaluations per wave trip. Same expressions, same bits: +0.6 % physics rate, same box.
+    // Splitting the record by consumer instead -- pricing: cost + gradient, line search: phi' / phi'' only, Hessian: the rank structure re-evaluated once per Newton
+    // iteration -- removes the joins altogether and was measured at -2 %: the extra zone evaluations cost more than the moves they save. profiles/r05_physics_levers.txt)
+    const float mu = fs * rsqrtf(impratio);
+    const float D1 = D0 * impratio, D3 = D1 * ft * ft / fmaxf(1e-30f, fs * fs);
+    const float S[4] = {mu, fs, fs, ft};
+    float U[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) { U[i] = S[i] * jar[i]; c.grad[i] = 0.f; c.w[i] = 0.f; c.a[i] = 0.f; c.b[i] = 0.f; }
-    c.cost = 0.f; c.ka = 0.f; c.kb = 0.f;
-    float N = U[0], T = sqrtf(U[1] * U[1] + U[2] * U[2] + U[3] * U[3]);
-    if (N >= mu * T || (T <= 0.f && N >= 0.f)) return;
-    if (mu * N + T <= 0.f || (T <= 0.f && N < 0.f)) {
-        float D[4] = {D0, D1, D1, D3};
+    for (int i = 0; i < 4; i++) U[i] = S[i] * jar[i];
+    const float N = U[0], T = sqrtf(U[1] * U[1] + U[2] * U[2] + U[3] * U[3]);
+    const bool top = N >= mu * T || (T <= 0.f && N >= 0.f);
+    const bool bottom = mu * N + T <= 0.f || (T <= 0.f && N < 0.f);
+    if (top) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) { c.cost += 0.5f * D[i] * jar[i] * jar[i]; c.grad[i] = D[i] * jar[i]; c.w[i] = D[i]; }
-        return;
+        for (int i = 0; i < 4; i++) { c.grad[i] = 0.f; c.w[i] = 0.f; c.a[i] = 0.f; c.b[i] = 0.f; }
+        c.cost = 0.f; c.ka = 0.f; c.kb = 0.f;
+    } else if (bottom) {
+        const float D[4] = {D0, D1, D1, D3};
+        float cost = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { cost += 0.5f * D[i] * jar[i] * jar[i]; c.grad[i] = D[i] * jar[i]; c.w[i] = D[i]; c.a[i] = 0.f; c.b[i] = 0.f; }
+        c.cost = cost; c.ka = 0.f; c.kb = 0.f;
+    } else {
+        const float kap = D0 / fmaxf(1e-30f, mu * mu), s1 = rsqrtf(1.f + mu * mu);
+        const float dist = (mu * T - N) * s1, invT = rcp(T);
+        const float c2 = dist * mu * s1 * invT;
+        c.a[0] = -s1 * S[0]; c.b[0] = 0.f; c.w[0] = 0.f;
+#pragma unroll
+        for (int i = 1; i < 4; i++) { const float t = U[i] * invT; c.a[i] = mu * s1 * t * S[i]; c.b[i] = t * S[i]; c.w[i] = kap * c2 * S[i] * S[i]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) c.grad[i] = kap * dist * c.a[i];
+        c.ka = kap; c.kb = kap * c2;
+        c.cost = 0.5f * kap * dist * dist;
     }
-    float kap = D0 / fmaxf(1e-30f, mu * mu), s1 = rsqrtf(1.f + mu * mu);
-    float dist = (mu * T - N) * s1, invT = rcp(T);
-    float c2 = dist * mu * s1 * invT;
-    c.a[0] = -s1 * S[0];
-#pragma unroll
-    for (int i = 1; i < 4; i++) { float t = U[i] * invT; c.a[i] = mu * s1 * t * S[i]; c.b[i] = t * S[i]; c.w[i] = kap * c2 * S[i] * S[i]; }
-#pragma unroll
-    for (int i = 0; i < 4; i++) c.grad[i] = kap * dist * c.a[i];
-    c.ka = kap; c.kb = kap * c2;
-    c.cost = 0.5f * kap * dist * dist;
 }
 // jv^T H jv for the structured Hessian
 DEVI float cone_quad(const Cone &c, const float (&jv)[4]) {
@@ -1613,10 +1629,10 @@ DEVI float price_constraints(const DevModel &m, const Ctx &cx, float lsgn, float
         hdiag = lact ? lD : 0.f;
     }
     wave_sync();
-    const int isub = UPOS(min(local_sub(cx), 12));
+    const int isub = UPOS(min(local_sub(cx), 12)) + local_const(EF_U), fo_ = local_const(EF_FORCE);
     for (int k = 0; k < ncon; k++) {
-        const float4 f = *reinterpret_cast<const float4 *>(cx.envl + EF_FORCE + 4 * k);
-        const float *u = cx.envl + EF_U + k * 6 * U_STRIDE + isub;
+        const float4 f = *reinterpret_cast<const float4 *>(cx.envl + fo_ + 4 * k);
+        const float *u = cx.envl + k * 6 * U_STRIDE + isub;
         jt = fmaf(u[0], f.x, jt); jt = fmaf(u[U_STRIDE], f.y, jt); jt = fmaf(u[2 * U_STRIDE], f.z, jt); jt = fmaf(u[3 * U_STRIDE], f.w, jt);
     }
     jtfi = cx.sub < 13 ? jt : 0.f;
@@ -1804,11 +1820,11 @@ DEVI void price_two_starts(const DevModel &m, const Ctx &cx, float lsgn, float l
             jt_w = la ? -lD * lj * lsgn : 0.f; lc_w += la ? 0.5f * lD * lj * lj : 0.f; hd_w = la ? lD : 0.f; }
     }
     wave_sync();
-    const int isub = UPOS(min(local_sub(cx), 12));
+    const int isub = UPOS(min(local_sub(cx), 12)) + local_const(EF_U), fo_ = local_const(EF_FORCE);
     for (int k = 0; k < ncon; k++) {
-        const float4 f = *reinterpret_cast<const float4 *>(cx.envl + EF_FORCE + 4 * k);
-        const float4 g = *reinterpret_cast<const float4 *>(cx.envl + EF_FORCE2 + 4 * k);
-        const float *u = cx.envl + EF_U + k * 6 * U_STRIDE + isub;
+        const float4 f = *reinterpret_cast<const float4 *>(cx.envl + fo_ + 4 * k);
+        const float4 g = *reinterpret_cast<const float4 *>(cx.envl + fo_ + (EF_FORCE2 - EF_FORCE) + 4 * k);
+        const float *u = cx.envl + k * 6 * U_STRIDE + isub;
         const float u0 = u[0], u1 = u[U_STRIDE], u2 = u[2 * U_STRIDE], u3 = u[3 * U_STRIDE];
         jt_s = fmaf(u0, f.x, jt_s); jt_s = fmaf(u1, f.y, jt_s); jt_s = fmaf(u2, f.z, jt_s); jt_s = fmaf(u3, f.w, jt_s);
         jt_w = fmaf(u0, g.x, jt_w); jt_w = fmaf(u1, g.y, jt_w); jt_w = fmaf(u2, g.z, jt_w); jt_w = fmaf(u3, g.w, jt_w);

@@ -17,7 +17,7 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 #define R(i) a[IND ? (i) : 0]
 #define Q(i) a[IND ? (((i) + 5) & 15) : 1]
 enum { FMA_VOP3_SGPR, FMA_VOP3_VGPR, FMAC_E32, ADD_E32, MUL_E32_SGPR, MOV_E32, CND_VCC_E32, CND_SGPR_E64, BFI, MAX_E32, AND_E32, LSHL_ADD, CMP_VCC, CMP_SGPR, CMP_CND_PAIR, RCP, SQRT, DPP_MOV, DPP_ADD, READLANE, WRITELANE,
-       READFIRST, SWAP32, DS_SWIZZLE, DS_BPERMUTE, DS_READ_B32, DS_READ_B128, DS_WRITE_B32, SALU_MOV, FMA_MOV_MIX, CVT, MAD_U32, CMP1_CND15, SAND1_CND15, CMPS1_CNDS15, S_MOV32, S_AND64, S_SAVEEXEC, S_WAITCNT, S_NOP, S_CBR_NT, VADD_SADD, VADD3_SADD1, VADD_SNOP, VADD_WAIT, CMP1_CND3, CMP1_CND1_ADD2, CMP1_CND3_E64VCC, CMPS1_CNDS3, CND_E64_VCC, CMP1_CND2_INTERLEAVED, NKIND };
+       READFIRST, SWAP32, DS_SWIZZLE, DS_BPERMUTE, DS_READ_B32, DS_READ_B128, DS_WRITE_B32, SALU_MOV, FMA_MOV_MIX, CVT, MAD_U32, CMP1_CND15, SAND1_CND15, CMPS1_CNDS15, S_MOV32, S_AND64, S_SAVEEXEC, S_WAITCNT, S_NOP, S_CBR_NT, VADD_SADD, VADD3_SADD1, VADD_SNOP, VADD_WAIT, CMP1_CND3, CMP1_CND1_ADD2, CMP1_CND3_E64VCC, CMPS1_CNDS3, CND_E64_VCC, CMP1_CND2_INTERLEAVED, DS_WRITE_B32_SAME, DS_WRITE_B128_SAME, DS_WRITE_B128, DS_READ_B128_BCAST, DS_WRITE_B128_ROWSAME, NKIND };
 template <int KIND, int IND> __global__ void __launch_bounds__(1024) k(float *out, unsigned long long *cyc, int iters) {
     extern __shared__ float lds[];
     for (int i = threadIdx.x; i < 4096; i += blockDim.x) lds[i] = (float)i;
@@ -26,7 +26,7 @@ template <int KIND, int IND> __global__ void __launch_bounds__(1024) k(float *ou
     for (int i = 0; i < 16; i++) a[i] = threadIdx.x * 0.001f + i;
     const float s = out[0];
     const unsigned long long msk = ((unsigned long long *)out)[1] | 0x5555555555555555ull;
-    const int ldsa = (threadIdx.x & 63) * 16;
+    const int ldsa = (threadIdx.x & 63) * 16, rowa = ((threadIdx.x & 63) >> 4) * 7296 * 4;
     unsigned long long t0 = __builtin_amdgcn_s_memtime();
     asm volatile("s_mov_b64 vcc, %0" :: "s"(msk) : "vcc");
     for (int it = 0; it < iters; it++) {
@@ -243,6 +243,31 @@ template <int KIND, int IND> __global__ void __launch_bounds__(1024) k(float *ou
 #define I(i) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %1\n v_add_f32_e32 %2, %2, %1\n v_cndmask_b32_e32 %0, %0, %1, vcc\n v_add_f32_e32 %3, %3, %1\n v_cndmask_b32_e32 %2, %2, %1, vcc\n v_add_f32_e32 %3, %3, %1\n v_add_f32_e32 %3, %3, %1\n v_add_f32_e32 %3, %3, %1" : "+v"(R(i)), "+v"(Q(i)), "+v"(R((i + 1) & 15)), "+v"(R((i + 2) & 15)) :: "vcc");
             I(0) I(1) I(2) I(3) I(4) I(5) I(6) I(7)
 #undef I
+        } else if (KIND == DS_WRITE_B32_SAME) {      // every lane writes the SAME address (the value is the same too: what an unguarded "lane 0 stores" would be)
+#define I(i) asm volatile("ds_write_b32 %1, %0 offset:%2" :: "v"(a[3]), "v"(0), "n"(4 * (i)));
+            X64(I)
+#undef I
+            asm volatile("s_waitcnt lgkmcnt(0)");
+        } else if (KIND == DS_WRITE_B128_SAME) {
+#define I(i) { f4v t_ = {a[0], a[1], a[2], a[3]}; asm volatile("ds_write_b128 %1, %0 offset:%2" :: "v"(t_), "v"(0), "n"(16 * (i))); }
+            X64(I)
+#undef I
+            asm volatile("s_waitcnt lgkmcnt(0)");
+        } else if (KIND == DS_WRITE_B128) {          // every lane its own 16 bytes
+#define I(i) { f4v t_ = {a[0], a[1], a[2], a[3]}; asm volatile("ds_write_b128 %1, %0 offset:%2" :: "v"(t_), "v"(ldsa), "n"(1024 * ((i) & 15))); }
+            X64(I)
+#undef I
+            asm volatile("s_waitcnt lgkmcnt(0)");
+        } else if (KIND == DS_READ_B128_BCAST) {     // all 64 lanes read the same 16 bytes
+#define I(i) { f4v t_; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t_) : "v"(0), "n"(16 * (i))); asm volatile("" :: "v"(t_)); }
+            X64(I)
+#undef I
+            asm volatile("s_waitcnt lgkmcnt(0)");
+        } else if (KIND == DS_WRITE_B128_ROWSAME) {  // the 16 lanes of a row write the same 16 bytes, the four rows different ones (the kernel's "env's lanes store the env's vector")
+#define I(i) { f4v t_ = {a[0], a[1], a[2], a[3]}; asm volatile("ds_write_b128 %1, %0 offset:%2" :: "v"(t_), "v"(rowa), "n"(16 * (i))); }
+            X64(I)
+#undef I
+            asm volatile("s_waitcnt lgkmcnt(0)");
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -289,5 +314,7 @@ int main() {
     run<VADD_WAIT, 1>("v_add + s_waitcnt alternating", d, c);
     run<CMP1_CND3, 1>("1 v_cmp vcc + 3 v_cndmask vcc", d, c); run<CMP1_CND1_ADD2, 1>("1 v_cmp vcc + 1 v_cndmask + 2 v_add", d, c); run<CMP1_CND3_E64VCC, 1>("1 v_cmp vcc + 3 v_cndmask_e64 vcc", d, c);
     run<CMPS1_CNDS3, 1>("1 v_cmp sgpr + 3 v_cndmask sgpr", d, c); run<CND_E64_VCC, 1>("v_cndmask_b32_e64 .., vcc", d, c); run<CMP1_CND2_INTERLEAVED, 1>("cmp add cnd add cnd add add add", d, c);
+    run<DS_WRITE_B32_SAME, 1>("ds_write_b32, all lanes one address", d, c); run<DS_WRITE_B128_SAME, 1>("ds_write_b128, all lanes one address", d, c); run<DS_WRITE_B128, 1>("ds_write_b128, own 16 B per lane", d, c);
+    run<DS_READ_B128_BCAST, 1>("ds_read_b128, all lanes one address", d, c); run<DS_WRITE_B128_ROWSAME, 1>("ds_write_b128, one address per row", d, c);
     return 0;
 }
