@@ -1,6 +1,6 @@
 // grip_device.h -- device-side model layout and small fp32 vector algebra for the gfx950 kernels.
 //
-// One environment is worked on by 16 lanes (4 envs per wavefront). The articulated system of
+// One environment is worked on by 16 lanes (two envs and their clone lanes per wavefront: grip_physics.h). The articulated system of
 // xmls/<object>_env.xml (reference robot xml :58-99) is folded, at model-load time on the host,
 // into FOUR rigid groups -- G = ee + welded base, L = left knuckle + welded finger, R = right
 // knuckle + finger, O = object -- because welded bodies never move relative to each other.

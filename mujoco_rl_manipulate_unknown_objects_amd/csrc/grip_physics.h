@@ -3,11 +3,10 @@
 // What one `physics.step()` of the reference computes (robot_env.py:100,119,142,157 -> dm_control
 // Physics.step -> mj_step2 + mj_step1), laid out for CDNA4:
 //
-//   * the shipped mapping (GRIP_EPW = 2): a wavefront holds TWO environments -- env A in lanes 0..15, env B in lanes 16..31 -- and lanes
+//   * the mapping: a wavefront holds TWO environments -- env A in lanes 0..15, env B in lanes 16..31 -- and lanes
 //     32..63 are CLONES of lanes 0..31 (the same env, the same values, the same LDS addresses, no global writes). A 512-thread workgroup
 //     holds 16 environments in 8 waves; 4096 envs are 2048 waves = TWO per SIMD of the chip, each covering the other's LDS round trips
-//     (needs the kernel inside 256 registers: the env's state lives in LDS, not in registers). -DGRIP_EPW=4 builds round 2's mapping for
-//     comparison: four envs x 16 lanes per wave, 256-thread workgroups, one wave per SIMD, no clones;
+//     (needs the kernel inside 256 registers: the env's state lives in LDS, not in registers);
 //   * where ONE instruction stream can serve two data sets the clones take the second one and v_permlane32_swap hands the results across
 //     (halves_f / halves_i): the support searches of a hull pair's two hulls, the two halves of the cooperative vertex scan, two of a
 //     contact's four constraint rows, the odd-numbered contacts of a Hessian row. Everywhere else they repeat the lower half's arithmetic
@@ -29,14 +28,11 @@
 #include "grip_device.h"
 
 #define KL 16                           // lanes per environment
-// Environments a wave works on. 4: every 16-lane row of the wave is an env, 1024 waves for 4096 envs = ONE per SIMD. 2: only the
-// lower two rows are envs (the upper 32 lanes idle, a wave instruction costs the same for 32 or 64 lanes), 2048 waves = TWO per SIMD:
-// a gfx950 SIMD issues a lone wave's VALU stream at one instruction per 4 cycles but two waves' streams at one per 2 cycles each
-// way, and each wave covers the other's LDS / s_waitcnt stalls. Needs the kernel inside 256 registers.
-#ifndef GRIP_EPW
-#define GRIP_EPW 2
-#endif
-#define EPW GRIP_EPW                    // environments per wave
+// Environments a wave works on: two -- rows 0 and 1 of the wave are envs, rows 2 and 3 their clones (a wave instruction costs the same for 32 or 64 lanes). 4096
+// envs are 2048 waves = TWO per SIMD, each covering the other's LDS round trips and issue gaps; needs the kernel inside 256 registers. (Rounds 2-4 kept round 2's
+// mapping -- four envs per wave, 256-thread workgroups, one wave per SIMD, no clones -- behind -DGRIP_EPW=4 for comparison; it lost every A/B since round 3
+// (86.4 against 93.9 M physics.step()/s then, before the clones took second halves of the work) and was retired in round 5: git history has it.)
+#define EPW 2                           // environments per wave
 #define EPB 16                          // environments per workgroup
 #define WG_THREADS (EPB / EPW * WAVE)
 #define WG_WAVES_PER_SIMD (WG_THREADS / 256)
@@ -214,7 +210,6 @@ DEVI void gather13(float xi, float (&v)[13]) {
 DEVI void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 // 16-bit group of a 64-bit ballot that belongs to this lane's environment
 DEVI unsigned group_bits(unsigned long long b, int lane) { return (unsigned)(b >> (lane & 48)) & 0xFFFFu; }
-#if EPW == 2
 // Lanes 32..63 of a two-env wave are bit-identical clones of lanes 0..31: the same env, the same values, the same LDS traffic, no global
 // writes. Where ONE instruction stream can serve two data sets (the support searches of a pair's two hulls, the two halves of a
 // cooperative vertex scan, the two halves of a slot loop) the clones take the second set, and v_permlane32_swap hands each half's result
@@ -225,7 +220,6 @@ DEVI void halves_u(unsigned x, unsigned &lo, unsigned &hi) { auto r_ = __builtin
 DEVI void halves_f(float x, float &lo, float &hi) { unsigned a_, b_; halves_u(__float_as_uint(x), a_, b_); lo = __uint_as_float(a_); hi = __uint_as_float(b_); }
 DEVI void halves_i(int x, int &lo, int &hi) { unsigned a_, b_; halves_u((unsigned)x, a_, b_); lo = (int)a_; hi = (int)b_; }
 #define UPPER_HALF(cx) ((cx).lane >= 32)
-#endif
 
 struct Kin {
     V3 pe; M3 Re; V3 a4;
@@ -233,13 +227,11 @@ struct Kin {
     V3 po; M3 Ro;
     V3 c[4];
     float Ic[4][6];
-#if EPW == 2
     // the finger chain THIS half of the wave works on (lanes 0..31: left, s = 0; clones 32..63: right, s = 1): c[1 + s], Ic[1 + s], its mass.
     // c[1], c[2], Ic[1], Ic[2] are not filled in this mapping: bias_forces() and mass_matrix() take the own chain and swap results.
     V3 c_own; float Ic_own[6]; float m_own;
     // ... and the big body of the half: the ee + base group (lanes 0..31) or the object (clones): c[0] / c[3], Ic[0] / Ic[3], its mass (c[0], c[3], Ic[0], Ic[3] are not filled)
     V3 c_go; float Ic_go[6]; float m_go;
-#endif
 };
 
 // tables staged in LDS, shared by the workgroup
@@ -379,11 +371,7 @@ DEVI void kinematics(const DevModel &m, float (&qpos)[14], Kin &k, const Ctx &cx
     // along the tree), and every LDS store in ONE block at the end: the whole tree is straight-line code for the instruction scheduler
     float sr, cr, sy, cy, sq[2], cq[2];
     sincos_joint(qpos[3], sr, cr); sincos_joint(qpos[4], sy, cy);
-#if EPW == 2
     sincos_joint(UPPER_HALF(cx) ? qpos[6] : qpos[5], sq[0], cq[0]); sq[1] = sq[0]; cq[1] = cq[0];      // the half's own knuckle angle
-#else
-    sincos_joint(qpos[5], sq[0], cq[0]); sincos_joint(qpos[6], sq[1], cq[1]);
-#endif
     // Re = Rx(roll) * Rz(yaw)
     k.Re.m[0] = cy;      k.Re.m[1] = -sy;     k.Re.m[2] = 0.f;
     k.Re.m[3] = cr * sy; k.Re.m[4] = cr * cy; k.Re.m[5] = -sr;
@@ -391,7 +379,6 @@ DEVI void kinematics(const DevModel &m, float (&qpos)[14], Kin &k, const Ctx &cx
     k.a4 = v3(0.f, -sr, cr);
     const V3 pb = k.pe + mulv(k.Re, ldv(m.base_pos));
     const M3 Rb = mulm(k.Re, ldm(m.base_R));
-#if EPW == 2
     // One finger chain per half of the wave: lanes 0..31 the left knuckle + finger, their clones 32..63 the right ones, the same instructions on
     // constants read by lane from the workgroup's table (stage_tables); pk / ak change hands (the constraint rows and the wrench projection want
     // both), the chain's COM and inertia stay with the half (bias_forces, mass_matrix).
@@ -419,24 +406,8 @@ DEVI void kinematics(const DevModel &m, float (&qpos)[14], Kin &k, const Ctx &cx
         halves_f(pk_o.x, k.pk[0].x, k.pk[1].x); halves_f(pk_o.y, k.pk[0].y, k.pk[1].y); halves_f(pk_o.z, k.pk[0].z, k.pk[1].z);
         halves_f(ak_o.x, k.ak[0].x, k.ak[1].x); halves_f(ak_o.y, k.ak[0].y, k.ak[1].y); halves_f(ak_o.z, k.ak[0].z, k.ak[1].z);
     }
-#else
-    V3 pf[2]; M3 Rk[2], Rf[2];
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-        const V3 pk = pb + mulv(Rb, ldv(m.kn_pos[s]));
-        const M3 Rk0 = mulm(Rb, ldm(m.kn_R[s]));
-        k.pk[s] = pk; k.ak[s] = col(Rk0, 1);
-        M3 Ry; Ry.m[0] = cq[s]; Ry.m[1] = 0; Ry.m[2] = sq[s]; Ry.m[3] = 0; Ry.m[4] = 1; Ry.m[5] = 0; Ry.m[6] = -sq[s]; Ry.m[7] = 0; Ry.m[8] = cq[s];
-        Rk[s] = mulm(Rk0, Ry);
-        pf[s] = pk + mulv(Rk[s], ldv(m.fin_pos[s]));
-        Rf[s] = mulm(Rk[s], ldm(m.fin_R[s]));
-        k.c[1 + s] = pk + mulv(Rk[s], ldv(m.grp_com[1 + s]));
-        rot_sym(Rk[s], m.grp_inertia[1 + s], k.Ic[1 + s]);
-    }
-#endif
     k.po = v3(qpos[7], qpos[8], qpos[9]);
     k.Ro = quat_mat(qpos[10], qpos[11], qpos[12], qpos[13]);
-#if EPW == 2
     {   // the ee + base group in lanes 0..31, the object in the clones: one COM and one rotated inertia per half, constants by lane from the table
         const float4 *G4 = reinterpret_cast<const float4 *>(cx.T.lr + (up ? 3 : 2) * LR_STRIDE + 24);
         const float4 g0 = G4[0], g1 = G4[1], g2 = G4[2];
@@ -449,20 +420,9 @@ DEVI void kinematics(const DevModel &m, float (&qpos)[14], Kin &k, const Ctx &cx
         k.c_go = ps + mulv(Rs, v3(g0.x, g0.y, g0.z));
         rot_sym(Rs, inertia, k.Ic_go);
     }
-#else
-    k.c[0] = k.pe + mulv(k.Re, ldv(m.grp_com[0]));
-    rot_sym(k.Re, m.grp_inertia[0], k.Ic[0]);
-    k.c[3] = k.po + mulv(k.Ro, ldv(m.grp_com[3]));
-    rot_sym(k.Ro, m.grp_inertia[3], k.Ic[3]);
-#endif
     if (store && cx.sub == 0) {                     // one lane of the env publishes the geom frames, what the constraint rows need, the state's quaternion
         store_frame(cx.envl, 1, pb, Rb);
-#if EPW == 2
         store_frame(cx.envl, up ? 4 : 2, pk_o, Rk_o); store_frame(cx.envl, up ? 5 : 3, pf_o, Rf_o);       // each half publishes its own chain's frames
-#else
-        store_frame(cx.envl, 2, k.pk[0], Rk[0]); store_frame(cx.envl, 3, pf[0], Rf[0]);
-        store_frame(cx.envl, 4, k.pk[1], Rk[1]); store_frame(cx.envl, 5, pf[1], Rf[1]);
-#endif
         store_frame(cx.envl, 6, k.po, k.Ro);
         kinc_store(cx.envl, k.pe, k.a4, k.pk, k.ak, k.po, k.Ro);
         // the normalised quaternion is the state's (mj_kinematics normalises qpos in place)
@@ -492,7 +452,6 @@ DEVI void mass_matrix(const DevModel &m, const Kin &k, float (&Mg)[28], float (&
 #pragma unroll
     for (int i = 0; i < 6; i++) Mo[pidx(i, i)] = m.armature[7 + i];
     const V3 ex = v3(1, 0, 0), ey = v3(0, 1, 0), ez = v3(0, 0, 1), z0 = v3(0, 0, 0);
-#if EPW == 2
     {   // the half's big body as a 6 x 6 block: the ee + base group over (ee dofs 0..4, a zero sixth axis) in lanes 0..31, the object over its six dofs in the
         // clones; the halves swap blocks, the gripper's matrix takes the lower half's (first, as in the one-stream form: G, L, R), the object's the upper half's
         const int dofs[6] = {0, 1, 2, 3, 4, 5};
@@ -514,14 +473,6 @@ DEVI void mass_matrix(const DevModel &m, const Kin &k, float (&Mg)[28], float (&
                 Mo[pidx(a, b)] += hi;
             }
     }
-#else
-    {   const int dofs[5] = {0, 1, 2, 3, 4};
-        V3 r = k.c[0] - k.pe;
-        const V3 jp[5] = {ex, ey, ez, cross(ex, r), cross(k.a4, r)};
-        const V3 jr[5] = {z0, z0, z0, ex, k.a4};
-        add_body<5, 28>(Mg, dofs, jp, jr, m.grp_mass[0], k.Ic[0]); }
-#endif
-#if EPW == 2
     {   // the half's own finger body as a 6 x 6 block over (ee dofs 0..4, own knuckle), the same expressions as add_body on the full matrix;
         // the halves swap blocks and both add left, then right, in the order of the one-stream form (G, L, R): the same sums
         const int dofs[6] = {0, 1, 2, 3, 4, 5};
@@ -542,26 +493,6 @@ DEVI void mass_matrix(const DevModel &m, const Kin &k, float (&Mg)[28], float (&
                 else { Mg[pidx(5, b)] += lo; Mg[pidx(6, b == 5 ? 6 : b)] += hi; }
             }
     }
-#else
-    {   const int dofs[6] = {0, 1, 2, 3, 4, 5};
-        V3 r = k.c[1] - k.pe, rk = k.c[1] - k.pk[0];
-        const V3 jp[6] = {ex, ey, ez, cross(ex, r), cross(k.a4, r), cross(k.ak[0], rk)};
-        const V3 jr[6] = {z0, z0, z0, ex, k.a4, k.ak[0]};
-        add_body<6, 28>(Mg, dofs, jp, jr, m.grp_mass[1], k.Ic[1]); }
-    {   const int dofs[6] = {0, 1, 2, 3, 4, 6};
-        V3 r = k.c[2] - k.pe, rk = k.c[2] - k.pk[1];
-        const V3 jp[6] = {ex, ey, ez, cross(ex, r), cross(k.a4, r), cross(k.ak[1], rk)};
-        const V3 jr[6] = {z0, z0, z0, ex, k.a4, k.ak[1]};
-        add_body<6, 28>(Mg, dofs, jp, jr, m.grp_mass[2], k.Ic[2]); }
-#endif
-#if EPW != 2
-    {   const int dofs[6] = {0, 1, 2, 3, 4, 5};
-        V3 r = k.c[3] - k.po;
-        V3 c0 = col(k.Ro, 0), c1 = col(k.Ro, 1), c2 = col(k.Ro, 2);
-        const V3 jp[6] = {ex, ey, ez, cross(c0, r), cross(c1, r), cross(c2, r)};
-        const V3 jr[6] = {z0, z0, z0, c0, c1, c2};
-        add_body<6, 21>(Mo, dofs, jp, jr, m.grp_mass[3], k.Ic[3]); }
-#endif
 }
 
 // y = M x with the block-diagonal mass matrix
@@ -646,7 +577,6 @@ DEVI void bias_forces(const DevModel &m, const Kin &k, const float (&qvel)[13], 
     V3 alG = cross(v3(qvel[3], 0, 0), k.a4 * qvel[4]);
     Wrench w; wrench_zero(w);
     V3 grav = v3(0, 0, m.gravity_z);
-#if EPW == 2
     {   // the half's own finger body (left in lanes 0..31, right in the clones), the expressions of the one-stream form; force and torque
         // about the knuckle change hands
         const V3 pk_o = up ? k.pk[1] : k.pk[0], ak_o = up ? k.ak[1] : k.ak[0], w_o = up ? t.wR : t.wL;
@@ -662,14 +592,6 @@ DEVI void bias_forces(const DevModel &m, const Kin &k, const float (&qvel)[13], 
         halves_f(F.x, w.FL.x, w.FR.x); halves_f(F.y, w.FL.y, w.FR.y); halves_f(F.z, w.FL.z, w.FR.z);
         halves_f(T.x, w.TL.x, w.TR.x); halves_f(T.y, w.TL.y, w.TR.y); halves_f(T.z, w.TL.z, w.TR.z);
     }
-#else
-    V3 sL = k.pk[0] - k.pe, sR = k.pk[1] - k.pe;
-    V3 aL = cross(alG, sL) + cross(t.wG, cross(t.wG, sL));
-    V3 aR = cross(alG, sR) + cross(t.wG, cross(t.wG, sR));
-    V3 alL = alG + cross(t.wG, k.ak[0] * qvel[5]);
-    V3 alR = alG + cross(t.wG, k.ak[1] * qvel[6]);
-#endif
-#if EPW == 2
     {   // the half's big body (ee + base group | object): the one-stream expressions with the object's zero angular acceleration written out
         const V3 ref = up ? k.po : k.pe, w_ = up ? t.wO : t.wG, al_ = up ? v3(0, 0, 0) : alG;
         const V3 rc = k.c_go - ref;
@@ -680,28 +602,6 @@ DEVI void bias_forces(const DevModel &m, const Kin &k, const float (&qvel)[13], 
         halves_f(F.x, w.FG.x, w.FO.x); halves_f(F.y, w.FG.y, w.FO.y); halves_f(F.z, w.FG.z, w.FO.z);
         halves_f(T.x, w.TG.x, w.TO.x); halves_f(T.y, w.TG.y, w.TO.y); halves_f(T.z, w.TG.z, w.TO.z);
     }
-#else
-    {   V3 rc = k.c[0] - k.pe;
-        V3 ac = cross(alG, rc) + cross(t.wG, cross(t.wG, rc)) - grav;
-        V3 tau = symv(k.Ic[0], alG) + cross(t.wG, symv(k.Ic[0], t.wG));
-        wrench_add(k, w, GRP_G, k.c[0], ac * m.grp_mass[0], tau, 1.f); }
-#endif
-#if EPW != 2
-    {   V3 rc = k.c[1] - k.pk[0];
-        V3 ac = aL + cross(alL, rc) + cross(t.wL, cross(t.wL, rc)) - grav;
-        V3 tau = symv(k.Ic[1], alL) + cross(t.wL, symv(k.Ic[1], t.wL));
-        wrench_add(k, w, GRP_L, k.c[1], ac * m.grp_mass[1], tau, 1.f); }
-    {   V3 rc = k.c[2] - k.pk[1];
-        V3 ac = aR + cross(alR, rc) + cross(t.wR, cross(t.wR, rc)) - grav;
-        V3 tau = symv(k.Ic[2], alR) + cross(t.wR, symv(k.Ic[2], t.wR));
-        wrench_add(k, w, GRP_R, k.c[2], ac * m.grp_mass[2], tau, 1.f); }
-#endif
-#if EPW != 2
-    {   V3 rc = k.c[3] - k.po;
-        V3 ac = cross(t.wO, cross(t.wO, rc)) - grav;
-        V3 tau = cross(t.wO, symv(k.Ic[3], t.wO));
-        wrench_add(k, w, GRP_O, k.c[3], ac * m.grp_mass[3], tau, 1.f); }
-#endif
     wrench_project(k, w, bias);
 }
 
@@ -952,12 +852,8 @@ DEVI void coop_support2(const Tables &T, int baseA, int nA, V3 dA, int baseB, in
     float av = -3.0e38f, bv = -3.0e38f; int ai = 0x7fffffff, bi = 0x7fffffff;
     const float4 *vA = reinterpret_cast<const float4 *>(T.v) + baseA, *vB = reinterpret_cast<const float4 *>(T.v) + baseB;
     const int nmax = max(nA, nB);
-#if EPW == 2
     // the env's clone lanes 32..63 scan too: 32 lanes per env, vertices s, s + 32, ... (s = 0..31), the two halves' winners meet at the end
     const int first = sub + ((int)(threadIdx.x & 32) >> 1), stride = 2 * KL;
-#else
-    const int first = sub, stride = KL;
-#endif
     for (int i = first; i < nmax; i += 2 * stride) {
         int ja[2], jb[2]; float4 a[2], b[2];
 #pragma unroll
@@ -980,12 +876,10 @@ DEVI void coop_support2(const Tables &T, int baseA, int nA, V3 dA, int baseB, in
         bool ta = oa > av || (oa == av && oia < ai); av = ta ? oa : av; ai = ta ? oia : ai; bool tb = ob > bv || (ob == bv && oib < bi); bv = tb ? ob : bv; bi = tb ? oib : bi; }
     COOP_STEP2(8) COOP_STEP2(4) COOP_STEP2(2) COOP_STEP2(1)
 #undef COOP_STEP2
-#if EPW == 2
     {   float al, ah, bl, bh; int ail, aih, bil, bih;
         halves_f(av, al, ah); halves_i(ai, ail, aih); halves_f(bv, bl, bh); halves_i(bi, bil, bih);
         ai = (ah > al || (ah == al && aih < ail)) ? aih : ail;
         bi = (bh > bl || (bh == bl && bih < bil)) ? bih : bil; }
-#endif
     ia = ai; ib = bi;
 }
 
@@ -1217,7 +1111,6 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, PairMemo &memo,
             STAMP(st, 21);
             if (!coop && mine) {
                 const bool rem = phase == 6;
-#if EPW == 2
                 // the two hulls of a pair side by side: lanes 0..31 climb hull 2, their clones 32..63 hull 1 -- one hill-climb loop per trip
                 // instead of two (floor items have one hull: the clones repeat it)
                 const bool h1 = UPPER_HALF(cx) && !plane;
@@ -1229,11 +1122,6 @@ DEVI int collide(const DevModel &m, const Ctx &cx, Contact &con, PairMemo &memo,
                 int i_hi; halves_i(vio, vi2, i_hi);
                 V3 v_hi; halves_f(vo.x, vl.x, v_hi.x); halves_f(vo.y, vl.y, v_hi.y); halves_f(vo.z, vl.z, v_hi.z);
                 if (!plane) { vi1 = i_hi; vl1 = v_hi; }
-#else
-                vi2 = support_vertex(T, g2 - 1, base2, multv(R2, plane ? dir : -dir), vl, rem ? memo.h2 : -1, adj2);
-                STAMP(st, 22);
-                if (!plane) vi1 = support_vertex(T, g1 - 1, base1, multv(R1, dir), vl1, rem ? memo.h1 : -1);
-#endif
             }
             STAMP(st, 23);
             if (mine) {
@@ -1561,7 +1449,6 @@ DEVI void make_constraints(const DevModel &m, const Ctx &cx, Contact &c, int nco
             j[5] = sL * dot(k.ak[0], cross(rL, e)); j[6] = sR * dot(k.ak[1], cross(rR, e));
             j[7] = sO * e.x; j[8] = sO * e.y; j[9] = sO * e.z; j[10] = sO * al.x; j[11] = sO * al.y; j[12] = sO * al.z;
         };
-#if EPW == 2
         // The four rows in two passes of ONE instruction stream: lanes 0..31 build the normal row and the first tangent, their clones 32..63 the
         // second tangent and the torsion row (the same expressions per row as the one-row-at-a-time form below; the angular row takes e itself
         // where a linear row takes the lever arm's cross product, and has no translational part). Each half stores its rows to the contact's
@@ -1592,16 +1479,6 @@ DEVI void make_constraints(const DevModel &m, const Ctx &cx, Contact &c, int nco
             halves_f(sA, lc.jar_s[0], lc.jar_s[2]); halves_f(wA, lc.jar_w[0], lc.jar_w[2]);
             halves_f(sB, lc.jar_s[1], lc.jar_s[3]); halves_f(wB, lc.jar_w[1], lc.jar_w[3]);
         }
-#else
-        {   float j[13]; linear_row(j, c.n); finish_row(0, j, m.k_con * imp * (c.dist - m.margin)); }
-        {   float j[13]; linear_row(j, t1); finish_row(1, j, 0.f); }
-        {   float j[13]; linear_row(j, t2); finish_row(2, j, 0.f); }
-        {   const V3 al = multv(k.Ro, c.n);               // torsion: relative angular velocity about the normal
-            float j[13];
-            j[0] = j[1] = j[2] = 0.f; j[3] = sG * c.n.x; j[4] = sG * dot(k.a4, c.n); j[5] = sL * dot(k.ak[0], c.n); j[6] = sR * dot(k.ak[1], c.n);
-            j[7] = j[8] = j[9] = 0.f; j[10] = sO * al.x; j[11] = sO * al.y; j[12] = sO * al.z;
-            finish_row(3, j, 0.f); }
-#endif
     }
 }
 
@@ -1699,7 +1576,6 @@ DEVI void assemble_rows(const Ctx &cx, int ncon, float hdiag, float (&row)[13]) 
 #pragma unroll
         for (int j = 0; j < 13; j++) row[j] = fmaf(wi, u[j], row[j]);
     };
-#if EPW == 2
     // the SAME order of summation as assemble_rows_block -- contacts 0, 2, 4, ... on top of the mass matrix' row in lanes 0..31, contacts
     // 1, 3, 5, ... on top of zeros in the clones, lo + hi -- so that an uncoupled env gets the same bits whether or not a wave-mate forces
     // the full rows on it (time-sliced == lock-step, mixed == single: the wave-mates differ)
@@ -1714,10 +1590,6 @@ DEVI void assemble_rows(const Ctx &cx, int ncon, float hdiag, float (&row)[13]) 
     }
 #pragma unroll
     for (int j = 0; j < 13; j++) { float lo, hi; halves_f(row[j], lo, hi); row[j] = lo + hi; }
-#else
-#pragma unroll 4
-    for (int s = 0; s < 6 * ncon; s++) slot(s);
-#endif
     if (__any(hdiag != 0.f)) {
 #pragma unroll
         for (int j = 0; j < 13; j++) row[j] += cx.sub == j ? hdiag : 0.f;
@@ -1746,7 +1618,6 @@ DEVI void assemble_rows_block(const Ctx &cx, int ncon, const float (&mrow7)[7], 
         row[0] = fmaf(wi, a.x, row[0]); row[1] = fmaf(wi, a.y, row[1]); row[2] = fmaf(wi, a.z, row[2]); row[3] = fmaf(wi, a.w, row[3]);
         row[4] = fmaf(wi, b.x, row[4]); row[5] = fmaf(wi, b.y, row[5]); row[6] = fmaf(wi, b.z, row[6]);
     };
-#if EPW == 2
     // contacts 0, 2, 4, ... in lanes 0..31 (on top of the mass matrix' row), contacts 1, 3, 5, ... in their clones 32..63 (on top of zeros);
     // the two partial rows meet through v_permlane32_swap: half the loop trips per lane, lo + hi in both halves (clones again)
     const bool up = UPPER_HALF(cx);
@@ -1760,12 +1631,6 @@ DEVI void assemble_rows_block(const Ctx &cx, int ncon, const float (&mrow7)[7], 
     }
 #pragma unroll
     for (int j = 0; j < 7; j++) { float lo, hi; halves_f(row[j], lo, hi); row[j] = lo + hi; }
-#else
-    for (int k = 0; k < ncon; k++) {
-        slot(6 * k); slot(6 * k + 1); slot(6 * k + 2); slot(6 * k + 3);
-        if ((midmask >> k) & 1u) { slot(6 * k + 4); slot(6 * k + 5); }
-    }
-#endif
     if (__any(hdiag != 0.f)) {                          // an active joint limit's term on the diagonal (rare)
         const int own = cx.sub < 7 ? cx.sub : cx.sub - 7;
 #pragma unroll

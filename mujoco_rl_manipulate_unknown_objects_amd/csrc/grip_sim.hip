@@ -439,7 +439,7 @@ enum { PH_MOVE = 0, PH_RETURN, PH_OPEN, PH_CLOSE, PH_FINAL, PH_DONE };
 #define CP_CLASSES 16       // work-order classes of k_compact: cost 0..14 of running envs, 15 = idle
 
 // ------------------------------------------------------------------------------------------------
-// kernels: 256-thread workgroups = 16 environments x 16 cooperating lanes (grip_physics.h)
+// kernels: 512-thread workgroups = 16 environments x (16 cooperating lanes + 16 clone lanes) (grip_physics.h)
 // ------------------------------------------------------------------------------------------------
 extern __shared__ float lds_dyn[];
 #ifndef GRIP_COLD_PORTAL
@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(WG_THREADS, WG_WAVES_PER_SIMD) k_reset(const D
     if (out.fault) out.fault[e] = fault;
 }
 
-// RobotEnv.step (robot_env.py:77-241): 4 envs per wave, 16 lanes per env
+// RobotEnv.step (robot_env.py:77-241): 2 envs (+ their clone lanes) per wave, 16 lanes per env
 //
 // slice <= 0: lock-step -- every env starts a macro step with actions[e] and the launch returns when the slowest is done.
 // slice  > 0: time slice of grip_batch_advance -- an env in flight resumes from its MacroCtx, a waiting env that holds a

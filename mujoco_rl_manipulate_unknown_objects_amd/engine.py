@@ -40,8 +40,9 @@ def build_library(force=False, verbose=False):
         tmp = path + f".tmp{os.getpid()}"
         # -fno-hip-fp32-correctly-rounded-divide-sqrt: `/` and sqrtf as v_rcp / v_sqrt + one Newton step (<= 2.5 ulp) instead of the
         # ~10-instruction correctly rounded sequences; -fgpu-flush-denormals-to-zero: no denormal fix-ups. Together +2.6 % physics rate
-        # (tools/physics_rate.py); every oracle-parity tolerance holds unchanged. -amdgpu-sched-strategy=iterative-ilp: the physics kernel is
-        # latency-bound (two waves per SIMD, long dependent chains through LDS): the ILP-first instruction scheduler gives +4.1 % physics rate
+        # (tools/physics_rate.py); every oracle-parity tolerance holds unchanged. -amdgpu-sched-strategy=iterative-ilp: the physics kernel is bound by
+        # instruction issue (two waves per SIMD, each issuing at most one instruction per ~5 cycles: DESIGN.md), and the ILP-first scheduler's order leaves
+        # fewer s_waitcnt / s_nop slots in the long dependent chains through LDS: +4.1 % physics rate
         # over the default one (max-ilp +-0, max-memory-clause -0.4 %, -O2 +0.3 %; round 3, tools/physics_rate.py on one box; round 4 on the final kernel: default / max-ilp /
         # max-memory-clause -2.5 %, iterative-maxocc -0.8 %, iterative-minreg -7.5 %).
         # -fno-signed-zeros -freciprocal-math (round 4): x / y may become x * (1 / y), -0 need not be kept apart from +0: +0.6 % physics rate on the same box, 371 against
