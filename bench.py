@@ -334,6 +334,7 @@ def main():
         raise RuntimeError("bench.py: the policy's parameters are not finite after the timed region -- the update diverged; no benchmark line for this run")
     ev_ms, ev_n = batch.kernel_time(reset=True)          # host events: the eager launches only (a replayed graph's launches cannot be bracketed)
     k_ms, k_n = ev_ms, ev_n
+    d_ms, d_n = None, 0
     if ar is not None and hasattr(batch, "device_time"):
         # every launch of the timed region, replayed graphs' included: start / end stamps the kernel takes with the device's wall clock
         # (grip_batch_device_time, include/grip_sim.h) on the stream it runs on
@@ -389,7 +390,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launch_ms_avg": k_ms, "launches": k_n,
                          "launch_timing": ("device wall-clock stamps of every launch of the timed region (first workgroup's start to the last wave's end, 100 MHz), "
                                            "graph replays included" if k_n != ev_n or k_ms != ev_ms else "HIP events around the launch on its stream"),
-                         "launch_ms_avg_events": ev_ms, "launches_events": ev_n,
+                         # both timings always, under fixed names (launch_ms_avg above is the device figure when there is one: `launch_timing` says which)
+                         "launch_ms_avg_device": d_ms if d_n else None, "launches_device": int(d_n), "launch_ms_avg_events": ev_ms, "launches_events": ev_n,
                          "algorithmic_bytes_per_launch": macro_bytes, "overhead_bytes_per_launch": overhead_bytes,
                          "bytes_definition": "SURVEY.md 8(d): physics state in + out (348 B f32 per env and launch) + action / outputs of the macro steps that end in the launch; "
                                              "overhead = suspended macro-step context + narrow-phase pair memory of the time-sliced schedule (not counted in achieved)",

@@ -1234,9 +1234,11 @@ extern "C" int grip_batch_device_time(GripBatch *b, int reset, double *ms_avg, l
     HIPCHK(hipSetDevice(b->device));
     hipStream_t s = (hipStream_t)stream;
     unsigned long long acc[2] = {0ULL, 0ULL};
-    HIPCHK(hipMemcpyAsync(acc, b->mc_t0 + 2, sizeof acc, hipMemcpyDeviceToHost, s));
-    if (reset) HIPCHK(hipMemsetAsync(b->mc_t0 + 2, 0, sizeof acc, s));
-    HIPCHK(hipStreamSynchronize(s));
+    // (no early return between the asynchronous copy into this stack frame and the synchronisation: the errors are looked at afterwards)
+    const hipError_t e1 = hipMemcpyAsync(acc, b->mc_t0 + 2, sizeof acc, hipMemcpyDeviceToHost, s);
+    const hipError_t e2 = (reset && e1 == hipSuccess) ? hipMemsetAsync(b->mc_t0 + 2, 0, sizeof acc, s) : hipSuccess;
+    const hipError_t e3 = hipStreamSynchronize(s);
+    HIPCHK(e1); HIPCHK(e2); HIPCHK(e3);
     if (ms_avg) *ms_avg = acc[1] ? (double)acc[0] / (double)acc[1] * 1e-5 : 0.0;       // 100 MHz ticks -> ms
     if (launches) *launches = (long long)acc[1];
     return 0;

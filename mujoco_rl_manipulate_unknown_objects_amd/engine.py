@@ -907,8 +907,11 @@ class MixedBatch:
         return self.parts[0].kernel_time(reset)
 
     def device_time(self, reset=True):
-        """the same from the device's clock stamps, every launch (the first group's stamps bracket the set's one launch)"""
-        return self.parts[0].device_time(reset)
+        """the same from the device's clock stamps, every launch. Every group stamps the window of ITS workgroups (first start to last end) inside the set's one launch;
+        the groups run side by side, so the LONGEST group's mean window is reported as the launch's (a lower bound of first-start-to-last-end over all groups)."""
+        per = [p.device_time(reset) for p in self.parts]
+        ms, n = max(per, key=lambda t: t[0])
+        return ms, n
 
     def close(self):
         if getattr(self, "ptr", None) and _lib is not None:

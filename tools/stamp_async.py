@@ -35,6 +35,8 @@ for g_, ids in grp.items():
         print(f"   {names[i]:62s} {100 * out[i] / tot:5.1f} %")
 print("wave-cycles per lane-0 env-substep:", tot / max(1, out[11]))
 print("mean envs at work per wave loop trip: %.2f of 2;  wave-cycles per loop trip: %.0f" % (out[12] / max(1, out[13]), tot / max(1, out[13])))
+if not any(hist):          # the plain -DGRIP_STAMPS build keeps no per-step histograms (GRIP_STAMPS_LIB=hist does): nothing more to print
+    sys.exit(0)
 steps = max(1, hist[16])
 print("per env and physics.step(): Newton iterations 0..6, 7+ :", " ".join(f"{100 * hist[i] / steps:.1f}%" for i in range(8)),
       "| mean %.2f" % (sum(i * hist[i] for i in range(8)) / steps))
