@@ -316,13 +316,17 @@ def conv1_u8(obs, weight, bias, with_mask=False, prepared=None):
     return (out, other, mask) if with_mask else (out, other)
 
 
+CONV23_B2_ROWS, CONV23_B3_ROWS = 1024 + 768, 1152 + 864        # include/grip_sim.h, grip_conv23_prep
+
+
 def conv23_prep(w2, w3, b2_mat=None, b3_mat=None):
-    """The weights of AugmentedNatureCNN's second and third convolutions as the GEMM operands grip_conv23 / grip_trunk_backward read (float32
-    [2 x 512, 64] and [2 x 576, 64]: k-major then channel-major); pass the previous pair to rewrite it in place (fixed addresses for a captured rollout tick)."""
+    """The weights of AugmentedNatureCNN's second and third convolutions as the GEMM operands grip_conv23 / grip_trunk_backward read: float32 [CONV23_B2_ROWS, 64]
+    and [CONV23_B3_ROWS, 64] -- the matrix k-major, then channel-major (2 x 512 / 2 x 576 rows), then the bf16 kernel's operand fragments (three bf16 terms per weight:
+    196 608 / 221 184 bytes = 768 / 864 rows); pass the previous pair to rewrite it in place (fixed addresses for a captured rollout tick)."""
     import torch
     assert w2.is_cuda and w2.dtype == torch.float32 and tuple(w2.shape) == (64, 32, 4, 4) and w3.dtype == torch.float32 and tuple(w3.shape) == (64, 64, 3, 3)
     if b2_mat is None:
-        b2_mat = torch.empty((1024, 64), dtype=torch.float32, device=w2.device); b3_mat = torch.empty((1152, 64), dtype=torch.float32, device=w2.device)
+        b2_mat = torch.empty((CONV23_B2_ROWS, 64), dtype=torch.float32, device=w2.device); b3_mat = torch.empty((CONV23_B3_ROWS, 64), dtype=torch.float32, device=w2.device)
     s2 = (C.c_int64 * 4)(*w2.stride()); s3 = (C.c_int64 * 4)(*w3.stride())
     stream = C.c_void_p(torch.cuda.current_stream(w2.device).cuda_stream)
     _chk(lib().grip_conv23_prep(C.c_void_p(w2.data_ptr()), s2, C.c_void_p(w3.data_ptr()), s3, C.c_void_p(b2_mat.data_ptr()), C.c_void_p(b3_mat.data_ptr()), stream))
@@ -335,7 +339,7 @@ def conv23(y1, b2_mat, bias2, b3_mat, bias3, train=False):
     import torch
     n = int(y1.shape[0])
     assert y1.is_cuda and y1.dtype == torch.float32 and tuple(y1.shape[1:]) == (32, 15, 15) and y1.is_contiguous(memory_format=torch.channels_last)
-    assert tuple(b2_mat.shape) == (1024, 64) and tuple(b3_mat.shape) == (1152, 64) and bias2.is_contiguous() and bias3.is_contiguous()
+    assert tuple(b2_mat.shape) == (CONV23_B2_ROWS, 64) and tuple(b3_mat.shape) == (CONV23_B3_ROWS, 64) and bias2.is_contiguous() and bias3.is_contiguous()
     out = torch.empty((n, 64, 4, 4), dtype=torch.float32, device=y1.device, memory_format=torch.channels_last)
     stream = C.c_void_p(torch.cuda.current_stream(y1.device).cuda_stream)
     # train (the update's forward): also y2 (channels-last [n, 64, 6, 6]) and the two layers' ReLU masks, int64 [n, 36] / [n, 16], bit c = channel c is active
@@ -365,7 +369,7 @@ def trunk_backward(g3, mask3, mask2, mask1, obs, b3_mat, b2_mat, w1=None, want_g
     assert _nhwc(g3, 64, 4)
     for m, shape, dt in ((mask3, (n, 16), torch.int64), (mask2, (n, 36), torch.int64), (mask1, (n, 225), torch.int32)):
         assert m.is_cuda and m.dtype == dt and tuple(m.shape) == shape and m.is_contiguous()
-    assert tuple(b2_mat.shape) == (1024, 64) and tuple(b3_mat.shape) == (1152, 64) and b2_mat.is_contiguous() and b3_mat.is_contiguous()
+    assert tuple(b2_mat.shape) == (CONV23_B2_ROWS, 64) and tuple(b3_mat.shape) == (CONV23_B3_ROWS, 64) and b2_mat.is_contiguous() and b3_mat.is_contiguous()
     g3m = torch.empty_like(g3)
     g2m = torch.empty((n, 64, 6, 6), dtype=torch.float32, device=g3.device, memory_format=torch.channels_last)
     g1m = torch.empty((n, 32, 15, 15), dtype=torch.float32, device=g3.device, memory_format=torch.channels_last) if want_g1m or obs is None else None
