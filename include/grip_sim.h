@@ -243,6 +243,16 @@ int grip_trunk_backward(const float *g3_dev, const uint64_t *mask3_dev, const ui
                         const float *b3_mat_dev, const float *b2_mat_dev, int n, float *g3m_dev, float *g2m_dev, float *g1m_dev, float *partials_dev,
                         float *grad_w1_dev, const int64_t *grad_w1_strides, float *grad_b1_dev, float *grad_b2_dev, float *grad_b3_dev, void *stream);
 
+/* The weight gradients of the second and third convolution (csrc/grip_train.hip, k_wgrad23_b3): what convolution_backward's weight output computes for
+ * Conv2d(32, 64, 4, 2) and Conv2d(64, 64, 3, 1) of models/feature_extractor.py:14-22 in stable_baselines3's PPO.train / SAC.train.
+ * y1_dev [n, 15, 15, 32] and y2_dev [n, 6, 6, 64]: the layers' inputs (post-ReLU activations of the training forward, NHWC float32); g2m_dev [n, 6, 6, 64] and
+ * g3m_dev [n, 4, 4, 64]: d loss / d (pre-activation) of the two layers (grip_trunk_backward). grad_w2_dev = float32 [64, 32, 4, 4] and grad_w3_dev = [64, 64, 3, 3]
+ * with element strides grad_w?_strides[4]. scratch_dev: grip_wgrad23_scratch_floats(n) floats (-1: no device). fp32-equivalent arithmetic on the bf16 matrix
+ * pipe (both operands as three bf16 terms, six products); sums in a fixed order that depends on n and the device's CU count only. */
+long long grip_wgrad23_scratch_floats(int n);
+int grip_wgrad23(const float *y1_dev, const float *g2m_dev, const float *y2_dev, const float *g3m_dev, int n, float *scratch_dev, float *grad_w2_dev,
+                 const int64_t *grad_w2_strides, float *grad_w3_dev, const int64_t *grad_w3_strides, void *stream);
+
 /* Gradient clipping + Adam for a list of float32 tensors in two launches: what torch.nn.utils.clip_grad_norm_(parameters, max_norm) followed by
  * torch.optim.Adam.step() (no weight decay, no amsgrad) do in stable_baselines3's PPO.train for the reference's train_agent.py:33-47. Host arrays of
  * n_tensors (<= 48) device addresses: parameters, gradients (scaled in place by min(1, max_norm / (||g|| + 1e-6))), exp_avg, exp_avg_sq, and the step

@@ -433,6 +433,362 @@ extern "C" int grip_trunk_backward(const float *g3_dev, const uint64_t *mask3_de
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// k_wgrad23_b3: the weight gradients of the second and third convolution on the bf16 matrix pipe (round 5; until then the tensor library's two kernels, 95 + 55 us per 4096
+// samples and a kernel search in the warm-up).
+//   dW2[co][ci][ky][kx] = sum_(img, oy, ox) g2m[img, oy, ox, co] * y1[img, 2 oy + ky, 2 ox + kx, ci]        (6 x 6 positions per image)
+//   dW3[co][ci][ky][kx] = sum_(img, oy, ox) g3m[img, oy, ox, co] * y2[img, oy + ky, ox + kx, ci]            (4 x 4)
+// Each is a GEMM out[m = (tap, ci)][n = co] whose REDUCTION index is the position -- both operands lie in memory position-major ([position][channel], NHWC), the matrix
+// instruction wants a lane to hold eight consecutive k of one row / column. gfx950's ds_read_b64_tr_b16 is that transpose: per 16 lanes it reads a block of 4 rows
+// (positions; any four addresses) x 16 columns (channels) and hands lane i column i. fp32-equivalent arithmetic as in k_conv23_b3 (grip_policy.hip): both operands split
+// into three bf16 terms when they are staged into LDS, six products per k-step, smallest first, fp32 accumulators (v_mfma_f32_32x32x16_bf16).
+// One persistent workgroup per CU (8 waves, two per SIMD: while one stages -- 5.5 VALU instructions per value to split, and a wave issues one per ~5 cycles -- or waits for
+// LDS, the other's MFMAs run), in one of two ROLES by workgroup index -- the two gradients share no input:
+//   role 2 (the first n_wg2 workgroups): a trip = one image PAIR: 72 positions = 4.5 k-chunks of 16 (the last half chunk multiplies zeros). Wave w owns tap row ky = w & 3,
+//          columns kx = 2 (w >> 2), + 1: 2 m-tiles (32 input channels each) x 2 n-tiles = 64 accumulator registers. y1 in LDS as [image][pixel row][pixel][term 3][32 ci] bf16, 224-byte pixels,
+//          3392-byte rows; g2m as [slot 80][term 3][64 co], 448-byte slots.
+//   role 3 (the rest): a trip = four images, one k-chunk each. Wave w owns output channels 32 (w & 1) .., input channels 32 ((w >> 1) & 1) .., taps 0..4 (w < 4) or 5..8.
+//          y2 as [image][pixel 36][term 3][64 ci] and g3m as [image][slot 16][term 3][64 co], 448-byte pixels / slots.
+// The ORDER of the positions inside a chunk is free (a sum), and chosen so that no transposed read has a bank conflict: a 32-lane half reads 4 positions x 64 bytes, which
+// must fall into the four different 64-byte quarters of the 256-byte bank row -- the positions of a 2 x 2 square do (pixel strides = -64, row strides = 128 mod 256), so a
+// block of four k is a 2 x 2 square of positions, and the gradient rows are STORED in that order (slot = 4 block + 2 dy + dx). The next trip's operands are requested
+// into registers before the MFMA loop. Every workgroup writes its partial sums; k_wgrad23_reduce adds them in a fixed order (no atomics) into the gradient tensors.
+#define W2_PS 224
+#define W2_RSY (15 * W2_PS + 32)
+#define W2_IMG (15 * W2_RSY)
+#define W2_GOFF (2 * W2_IMG)
+#define W_RS 448
+#define W2_LDS (W2_GOFF + 80 * W_RS)
+#define W3_NI 4
+#define W3_IMG (36 * W_RS)
+#define W3_GOFF (W3_NI * W3_IMG)
+#define W3_GIMG (16 * W_RS)
+#define W3_LDS (W3_GOFF + W3_NI * W3_GIMG)
+#define W2_PART (512 * 64)
+#define W3_PART (576 * 64)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+// eight consecutive k of the lane's row / column: two transposed reads (4 positions each)
+__device__ __forceinline__ bf16x8 wg_tr8(lds_byte *p0, lds_byte *p1, int off) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(p0 + off));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(p1 + off));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ f32x16 wg_mac6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+    return c;
+}
+// four fp32 values -> three bf16 terms each (nearest, exact remainder, twice), written as three 8-byte words `stride` bytes apart
+__device__ __forceinline__ void wg_split_store(unsigned char *dst, int stride, const float4 v) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    bf16x4 h, m, l;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const __bf16 a = (__bf16)x[i]; const float r = x[i] - (float)a;
+        const __bf16 b = (__bf16)r; const float r2 = r - (float)b;
+        h[i] = a; m[i] = b; l[i] = (__bf16)r2;
+    }
+    *reinterpret_cast<bf16x4 *>(dst) = h; *reinterpret_cast<bf16x4 *>(dst + stride) = m; *reinterpret_cast<bf16x4 *>(dst + 2 * stride) = l;
+}
+
+#ifdef WG_STAMPS                 // diagnostic build only (tools/wgrad23_stamps.py): per role, cycles of wave 0 of the role's first workgroup per phase; every workgroup's start / end
+__device__ unsigned long long g_wg_stamps[2][4];       // [role][prologue, staging (wait + split + store), barrier + requests, MFMA loop + barrier]
+__device__ unsigned long long g_wg_span[512][2];
+#define WG_STAMP(role, i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); if (first_of_role && threadIdx.x == 0) g_wg_stamps[role][i] += n_ - wg_t; wg_t = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int grip_debug_wg_stamps(unsigned long long *out8, unsigned long long *span1024) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wg_stamps), sizeof(unsigned long long) * 8) != hipSuccess || hipMemcpyFromSymbol(span1024, HIP_SYMBOL(g_wg_span), sizeof(unsigned long long) * 1024) != hipSuccess) return -1;
+    static const unsigned long long zero[8] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wg_stamps), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+#else
+#define WG_STAMP(role, i) do { } while (0)
+#endif
+__global__ void __launch_bounds__(512, 1) k_wgrad23_b3(const float *__restrict__ y1, const float *__restrict__ g2m, const float *__restrict__ y2, const float *__restrict__ g3m, int n_img,
+                                                       int n_wg2, float *__restrict__ part2, float *__restrict__ part3) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wl[];
+#ifdef WG_STAMPS
+    unsigned long long wg_t = __builtin_amdgcn_s_memtime();
+    const bool first_of_role = blockIdx.x == 0 || (int)blockIdx.x == n_wg2;
+    if (threadIdx.x == 0 && blockIdx.x < 512) g_wg_span[blockIdx.x][0] = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    const int hf = l >> 5, gsel = (l >> 4) & 1, q = (l & 15) >> 2, p = l & 3;           // the lane in a transposed read: k-half, column half, the block's row it addresses, its 8-byte piece
+    // zeros everywhere once: the padding slots of role 2's last half chunk stay zero, and nothing that is not a number is ever multiplied by them
+    for (int i = tid; i < W2_LDS / 16; i += 512) reinterpret_cast<uint4 *>(wl)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    lds_byte *L = (lds_byte *)wl;
+    if ((int)blockIdx.x < n_wg2) {
+        const int npair = (n_img + 1) / 2, ky = w & 3, kx0 = 2 * (w >> 2);
+        // the lane's addresses in y1 for chunk c, half-fragment h: block b = 4 c + 2 hf + h = (image, 2 x 2 square), row q of it = position (2 sy + (q >> 1), 2 sx + (q & 1))
+        lds_byte *pa[5][2];
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                int b = 4 * c + 2 * hf + h;
+                if (b >= 18) b = 0;                                     // the half chunk of padding: any real pixels (their gradient rows are zero)
+                const int g = b / 9, sq = b - 9 * g, oy = 2 * (sq / 3) + (q >> 1), ox = 2 * (sq % 3) + (q & 1);
+                pa[c][h] = L + g * W2_IMG + (2 * oy + ky) * W2_RSY + (2 * ox + kx0) * W2_PS + 32 * gsel + 8 * p;
+            }
+        lds_byte *pb = L + W2_GOFF + (8 * hf + q) * W_RS + 32 * gsel + 8 * p;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+        // a pair's operands: 3600 + 1152 float4 = 8 + 3 requests per thread, issued in five parts between the chunks of the MFMA loop (the address path takes ~16 cycles
+        // per request and wave: issued in one piece they held the matrix pipe up for 1.8 k cycles per trip)
+        float4 pre[8], preg[3];
+        auto request = [&](int pair, int part) {
+            const int img0 = pair * 2, nimg = min(2, n_img - img0);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (u * 5 / 8 == part) {
+                    const int qq = u * 512 + tid;
+                    pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (qq < nimg * 1800) pre[u] = *reinterpret_cast<const float4 *>(y1 + (size_t)img0 * 7200 + (size_t)qq * 4);
+                }
+#pragma unroll
+            for (int u = 0; u < 3; u++)
+                if (u + 2 == part) {
+                    const int qq = u * 512 + tid;
+                    preg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (qq < nimg * 576) preg[u] = *reinterpret_cast<const float4 *>(g2m + (size_t)img0 * 2304 + (size_t)qq * 4);
+                }
+        };
+        int pair = blockIdx.x;
+        if (pair < npair) {
+#pragma unroll
+            for (int part = 0; part < 5; part++) request(pair, part);
+        }
+        WG_STAMP(0, 0);
+        for (; pair < npair; pair += n_wg2) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int qq = u * 512 + tid;
+                if (qq < 3600) {
+                    const int g = qq >= 1800, rem = qq - 1800 * g, pix = rem >> 3, c4 = (rem & 7) * 4, Y = pix / 15, X = pix - 15 * Y;
+                    wg_split_store(wl + g * W2_IMG + Y * W2_RSY + X * W2_PS + 2 * c4, 64, pre[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                const int qq = u * 512 + tid;
+                if (qq < 1152) {
+                    const int pos = qq >> 4, c4 = (qq & 15) * 4, g = pos >= 36, pp = pos - 36 * g, oy = pp / 6, ox = pp - 6 * oy;
+                    const int slot = (g * 9 + (oy >> 1) * 3 + (ox >> 1)) * 4 + (oy & 1) * 2 + (ox & 1);
+                    wg_split_store(wl + W2_GOFF + slot * W_RS + 2 * c4, 128, preg[u]);
+                }
+            }
+            WG_STAMP(0, 1);
+            __syncthreads();
+            WG_STAMP(0, 2);
+            const bool more = pair + n_wg2 < npair;
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                if (more) request(pair + n_wg2, c);
+                bf16x8 bfr[2][3];
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                    for (int t = 0; t < 3; t++) bfr[nt][t] = wg_tr8(pb, pb + 4 * W_RS, 16 * c * W_RS + nt * 64 + t * 128);
+#pragma unroll
+                for (int kx = 0; kx < 2; kx++) {
+                    bf16x8 afr[3];
+#pragma unroll
+                    for (int t = 0; t < 3; t++) afr[t] = wg_tr8(pa[c][0], pa[c][1], kx * W2_PS + 64 * t);
+                    acc[kx][0] = wg_mac6(afr, bfr[0], acc[kx][0]);
+                    acc[kx][1] = wg_mac6(afr, bfr[1], acc[kx][1]);
+                }
+            }
+            __syncthreads();                                            // before the next trip's staging overwrites the planes
+            WG_STAMP(0, 3);
+        }
+        float *P = part2 + (size_t)blockIdx.x * W2_PART;
+#pragma unroll
+        for (int kx = 0; kx < 2; kx++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) P[((ky * 4 + kx0 + kx) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf) * 64 + nt * 32 + (l & 31)] = acc[kx][nt][r];
+    } else {
+        const int wg = blockIdx.x - n_wg2, n_wg3 = gridDim.x - n_wg2, ngrp = (n_img + W3_NI - 1) / W3_NI;
+        const int nt = w & 1, cih = (w >> 1) & 1, tap0 = 5 * (w >> 2), ntap = 5 - (w >> 2);     // waves 0-3: taps 0..4, waves 4-7 (the same SIMDs): taps 5..8
+        lds_byte *pa[5][2];
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int tap = min(tap0 + i, 8), b = 2 * hf + h, oy = 2 * (b >> 1) + (q >> 1) + tap / 3, ox = 2 * (b & 1) + (q & 1) + tap % 3;
+                pa[i][h] = L + (oy * 6 + ox) * W_RS + 64 * cih + 32 * gsel + 8 * p;
+            }
+        lds_byte *pb = L + W3_GOFF + (8 * hf + q) * W_RS + 64 * nt + 32 * gsel + 8 * p;
+        f32x16 acc[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+        float4 pre[5], preg[2];                                          // four images' operands: 2304 + 1024 float4
+        auto request = [&](int grp, int part) {
+            const int img0 = grp * W3_NI, nimg = min(W3_NI, n_img - img0);
+#pragma unroll
+            for (int u = 0; u < 5; u++)
+                if (u * 4 / 5 == part) {
+                    const int qq = u * 512 + tid;
+                    pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (qq < nimg * 576) pre[u] = *reinterpret_cast<const float4 *>(y2 + (size_t)img0 * 2304 + (size_t)qq * 4);
+                }
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+                if (u + 2 == part) {
+                    const int qq = u * 512 + tid;
+                    preg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (qq < nimg * 256) preg[u] = *reinterpret_cast<const float4 *>(g3m + (size_t)img0 * 1024 + (size_t)qq * 4);
+                }
+        };
+        int grp = wg;
+        if (grp < ngrp) {
+#pragma unroll
+            for (int part = 0; part < 4; part++) request(grp, part);
+        }
+        WG_STAMP(1, 0);
+        for (; grp < ngrp; grp += n_wg3) {
+#pragma unroll
+            for (int u = 0; u < 5; u++) {
+                const int qq = u * 512 + tid;
+                if (qq < 2304) {
+                    const int g = qq / 576, rem = qq - 576 * g, pix = rem >> 4, c4 = (rem & 15) * 4;
+                    wg_split_store(wl + g * W3_IMG + pix * W_RS + 2 * c4, 128, pre[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int qq = u * 512 + tid, g = qq >> 8, pos = (qq & 255) >> 4, c4 = (qq & 15) * 4, oy = pos >> 2, ox = pos & 3;
+                const int slot = ((oy >> 1) * 2 + (ox >> 1)) * 4 + (oy & 1) * 2 + (ox & 1);
+                wg_split_store(wl + W3_GOFF + g * W3_GIMG + slot * W_RS + 2 * c4, 128, preg[u]);
+            }
+            WG_STAMP(1, 1);
+            __syncthreads();
+            WG_STAMP(1, 2);
+            const bool more = grp + n_wg3 < ngrp;
+#pragma unroll
+            for (int g = 0; g < W3_NI; g++) {
+                if (more) request(grp + n_wg3, g);
+                bf16x8 bfr[3];
+#pragma unroll
+                for (int t = 0; t < 3; t++) bfr[t] = wg_tr8(pb, pb + 4 * W_RS, g * W3_GIMG + 128 * t);
+#pragma unroll
+                for (int i = 0; i < 5; i++)
+                    if (i < ntap) {                                      // (wave-uniform: the transposed reads need every lane)
+                        bf16x8 afr[3];
+#pragma unroll
+                        for (int t = 0; t < 3; t++) afr[t] = wg_tr8(pa[i][0], pa[i][1], g * W3_IMG + 128 * t);
+                        acc[i] = wg_mac6(afr, bfr, acc[i]);
+                    }
+            }
+            __syncthreads();
+            WG_STAMP(1, 3);
+        }
+        float *P = part3 + (size_t)wg * W3_PART;
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+            if (i < ntap) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) P[((tap0 + i) * 64 + 32 * cih + (r & 3) + 8 * (r >> 2) + 4 * hf) * 64 + 32 * nt + (l & 31)] = acc[i][r];
+            }
+    }
+#ifdef WG_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 512) g_wg_span[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+// the workgroups' partial sums -> the two gradient tensors (their strides), added in a fixed order: 32 outputs per block, 32 slices of the partials each
+__global__ void __launch_bounds__(1024) k_wgrad23_reduce(const float *__restrict__ part2, int n2, const float *__restrict__ part3, int n3, float *__restrict__ gw2, long long so2, long long sc2,
+                                                          long long sy2, long long sx2, float *__restrict__ gw3, long long so3, long long sc3, long long sy3, long long sx3) {
+    __shared__ float red[32][32];
+    const int o = blockIdx.x * 32 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
+    const bool second = o < W2_PART;
+    const float *base = second ? part2 + o : part3 + (o - W2_PART);
+    const size_t sz = second ? W2_PART : W3_PART;
+    const int np = second ? n2 : n3;
+    float s = 0.f;
+    for (int pi = sl; pi < np; pi += 32) s += base[(size_t)pi * sz];
+    red[sl][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (sl == 0) {
+        float t = red[0][threadIdx.x];
+#pragma unroll
+        for (int i = 1; i < 32; i++) t += red[i][threadIdx.x];
+        if (second) {
+            const int m = o >> 6, co = o & 63, tap = m >> 5, ci = m & 31;
+            gw2[co * so2 + ci * sc2 + (tap >> 2) * sy2 + (tap & 3) * sx2] = t;
+        } else {
+            const int oo = o - W2_PART, m = oo >> 6, co = oo & 63, tap = m >> 6, ci = m & 63;
+            gw3[co * so3 + ci * sc3 + (tap / 3) * sy3 + (tap % 3) * sx3] = t;
+        }
+    }
+}
+
+// How the CUs are divided between the two roles: a trip of role 2 (an image pair) costs ~W_COST2, of role 3 (four images) ~W_COST3 cycles (tools/wgrad23_ab.py prints
+// the measured trips); the split that minimises the slower role's trips x cost. The sums' order, and with it the last bits of the result, depends on it -- a function of
+// (n, CU count) only.
+#define W_COST2 1150
+#define W_COST3 940
+static void wgrad23_split(int n, int n_cu, int &w2, int &w3) {
+    const int pairs = (n + 1) / 2, grps = (n + W3_NI - 1) / W3_NI;
+    long best = -1; w2 = 1; w3 = 1;
+    for (int a = 1; a < n_cu; a++) {
+        const int b = n_cu - a;
+        const long t = std::max((long)((pairs + a - 1) / a) * W_COST2, (long)((grps + b - 1) / b) * W_COST3);
+        if (best < 0 || t < best) { best = t; w2 = a; w3 = b; }
+    }
+    w2 = std::min(w2, pairs); w3 = std::min(w3, grps);
+}
+static int wgrad23_cus(int &n_cu) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return grip_fail("grip_wgrad23: no current device");
+    static std::atomic<int> cus[64];
+    int c = cus[dev & 63].load(std::memory_order_acquire);
+    if (c <= 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 1) return grip_fail("grip_wgrad23: cannot read the CU count");
+        cus[dev & 63].store(c, std::memory_order_release);
+    }
+    n_cu = c;
+    return 0;
+}
+extern "C" long long grip_wgrad23_scratch_floats(int n) {
+    int n_cu = 0, w2, w3;
+    if (n <= 0 || wgrad23_cus(n_cu)) return -1;
+    wgrad23_split(n, n_cu, w2, w3);
+    return (long long)w2 * W2_PART + (long long)w3 * W3_PART;
+}
+extern "C" int grip_wgrad23(const float *y1_dev, const float *g2m_dev, const float *y2_dev, const float *g3m_dev, int n, float *scratch_dev, float *grad_w2_dev, const int64_t *grad_w2_strides,
+                            float *grad_w3_dev, const int64_t *grad_w3_strides, void *stream) {
+    if (!y1_dev || !g2m_dev || !y2_dev || !g3m_dev || !scratch_dev || !grad_w2_dev || !grad_w2_strides || !grad_w3_dev || !grad_w3_strides || n <= 0)
+        return grip_fail("grip_wgrad23: need y1 [n, 15, 15, 32], g2m [n, 6, 6, 64], y2 [n, 6, 6, 64], g3m [n, 4, 4, 64] (NHWC float32), the scratch of grip_wgrad23_scratch_floats(n) "
+                         "floats and the two gradient tensors with their strides");
+    int n_cu = 0, w2, w3;
+    if (wgrad23_cus(n_cu)) return -1;
+    wgrad23_split(n, n_cu, w2, w3);
+    static std::atomic<unsigned long long> mask{0ULL};
+    if (set_dyn_lds((const void *)k_wgrad23_b3, (size_t)W2_LDS, mask, "grip_wgrad23")) return -1;
+    float *part2 = scratch_dev, *part3 = scratch_dev + (size_t)w2 * W2_PART;
+    hipLaunchKernelGGL(k_wgrad23_b3, dim3(w2 + w3), dim3(512), W2_LDS, (hipStream_t)stream, y1_dev, g2m_dev, y2_dev, g3m_dev, n, w2, part2, part3);
+    hipLaunchKernelGGL(k_wgrad23_reduce, dim3((W2_PART + W3_PART) / 32), dim3(1024), 0, (hipStream_t)stream, (const float *)part2, w2, (const float *)part3, w3, grad_w2_dev,
+                       (long long)grad_w2_strides[0], (long long)grad_w2_strides[1], (long long)grad_w2_strides[2], (long long)grad_w2_strides[3], grad_w3_dev,
+                       (long long)grad_w3_strides[0], (long long)grad_w3_strides[1], (long long)grad_w3_strides[2], (long long)grad_w3_strides[3]);
+    return launch_check("grip_wgrad23");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Gradient clipping + Adam for the whole parameter list in two launches (stable_baselines3 PPO.train: clip_grad_norm_(max_grad_norm) then Adam.step(), as
 // the reference's train_agent.py:33-47 configures them; torch.optim.Adam without weight decay / amsgrad). As tensor-library calls the pair is ~20 launches,
 // ~105 us per optimiser step of 1.4 M parameters in 21 tensors (multi-tensor norm, its clean-up, six scalar kernels, the in-place scaling, the step counters,

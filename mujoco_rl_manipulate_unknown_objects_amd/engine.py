@@ -127,7 +127,7 @@ EXPORTS = ["grip_last_error", "grip_model_load", "grip_model_free", "grip_model_
            "grip_batch_kernel_time", "grip_batch_device_time", "grip_selftest_cholesky", "grip_batch_advance", "grip_batch_observe_list", "grip_rollout_tick", "grip_rollout_gae", "grip_intrinsic_reward", "grip_obs_preprocess",
            "grip_batch_set_state_storage", "grip_batchset_create", "grip_batchset_destroy", "grip_batchset_refresh", "grip_batchset_num_envs",
            "grip_batchset_step", "grip_batchset_advance", "grip_batchset_observe", "grip_batchset_observe_list", "grip_conv1_u8", "grip_conv1_u8_rows", "grip_batch_render_camera", "grip_ppo_loss", "grip_conv23_prep", "grip_conv23",
-           "grip_trunk_backward", "grip_trunk_backward_parts", "grip_conv1_u8_train", "grip_conv23_train", "grip_clip_adam", "grip_clip_adam_chunks", "grip_tanh_backward_colsum", "grip_relu_backward_colsum", "grip_ppo_loss_heads", "grip_bias_tanh", "grip_conv1_prep"]
+           "grip_trunk_backward", "grip_trunk_backward_parts", "grip_conv1_u8_train", "grip_conv23_train", "grip_clip_adam", "grip_clip_adam_chunks", "grip_tanh_backward_colsum", "grip_relu_backward_colsum", "grip_ppo_loss_heads", "grip_bias_tanh", "grip_conv1_prep", "grip_wgrad23", "grip_wgrad23_scratch_floats"]
 
 
 def lib():
@@ -190,6 +190,8 @@ def lib():
     L.grip_conv1_u8_train.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int64), vp, vp, vp, vp, vp, vp]
     L.grip_trunk_backward.argtypes = [vp] * 6 + [C.c_int, vp, vp, C.c_int] + [vp] * 5 + [C.POINTER(C.c_int64), vp, vp, vp, vp]
     L.grip_trunk_backward_parts.argtypes = [C.c_int]
+    L.grip_wgrad23_scratch_floats.argtypes = [C.c_int]; L.grip_wgrad23_scratch_floats.restype = C.c_longlong
+    L.grip_wgrad23.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, C.POINTER(C.c_int64), vp, C.POINTER(C.c_int64), vp]
     L.grip_clip_adam_chunks.argtypes = [C.c_int, C.POINTER(C.c_int64)]
     L.grip_relu_backward_colsum.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp]
     L.grip_tanh_backward_colsum.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, vp, vp, vp]
@@ -392,6 +394,25 @@ def trunk_backward(g3, mask3, mask2, mask1, obs, b3_mat, b2_mat, w1=None, want_g
     _chk(lib().grip_trunk_backward(vp(g3), vp(mask3), vp(mask2), vp(mask1), vp(obs), vp(obs_rows), 5, vp(b3_mat), vp(b2_mat), n, vp(g3m), vp(g2m), vp(g1m), vp(part), vp(gw), strides,
                                    *([vp(t) for t in gb] if gb else [None] * 3), stream))
     return g3m, g2m, gw, gb, g1m
+
+
+def conv23_weight_gradients(y1, g2m, y2, g3m, gw2_out=None, gw3_out=None):
+    """d loss / d w2 [64, 32, 4, 4] and d loss / d w3 [64, 64, 3, 3] of AugmentedNatureCNN's second and third convolution (grip_wgrad23, csrc/grip_train.hip:
+    k_wgrad23_b3 on the bf16 matrix pipe in fp32-equivalent arithmetic) from the layers' inputs y1 [n, 32, 15, 15], y2 [n, 64, 6, 6] and the gradients at their
+    pre-activations g2m [n, 64, 6, 6], g3m [n, 64, 4, 4] (trunk_backward) -- all channels-last float32. gw?_out: write there (any strides) instead of into fresh tensors."""
+    import torch
+    n = int(y1.shape[0])
+    assert _nhwc(y1, 32, 15) and _nhwc(g2m, 64, 6) and _nhwc(y2, 64, 6) and _nhwc(g3m, 64, 4) and all(int(t.shape[0]) == n for t in (g2m, y2, g3m))
+    gw2 = torch.empty((64, 32, 4, 4), dtype=torch.float32, device=y1.device) if gw2_out is None else gw2_out
+    gw3 = torch.empty((64, 64, 3, 3), dtype=torch.float32, device=y1.device) if gw3_out is None else gw3_out
+    assert tuple(gw2.shape) == (64, 32, 4, 4) and tuple(gw3.shape) == (64, 64, 3, 3) and gw2.dtype == torch.float32 and gw3.dtype == torch.float32 and gw2.is_cuda and gw3.is_cuda
+    words = int(lib().grip_wgrad23_scratch_floats(n))
+    assert words > 0, "grip_wgrad23_scratch_floats: no device"
+    scratch = torch.empty(words, dtype=torch.float32, device=y1.device)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream(y1.device).cuda_stream)
+    _chk(lib().grip_wgrad23(vp(y1), vp(g2m), vp(y2), vp(g3m), n, vp(scratch), vp(gw2), (C.c_int64 * 4)(*gw2.stride()), vp(gw3), (C.c_int64 * 4)(*gw3.stride()), stream))
+    return gw2, gw3
 
 
 def tanh_backward_colsum(g, h, batch_major_to_rows=False, gb_out=None):

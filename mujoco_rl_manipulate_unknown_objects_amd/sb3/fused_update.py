@@ -20,10 +20,13 @@ captured update's 1.19 ms (profiles/r03_update_path.txt). Here (1.19 -> 1.11 ms 
 
 The arithmetic is that of the autograd path (the same kernels on the same operands; tests/test_gpu_train_kernels.py compares every gradient). Anything
 else -- another extractor or net_arch, autocast, CPU -- keeps the autograd path (``PPO._loss_backward``)."""
+import os
 import torch as th
 from torch import nn
 
 from .policies import ActorCriticPolicy
+
+_WGRAD23_LIBRARY = os.environ.get("GRIP_WGRAD23_LIBRARY", "0") == "1"      # comparison switch: convolution_backward instead of grip_wgrad23
 
 
 class FusedUpdate:
@@ -128,7 +131,7 @@ class FusedUpdate:
 
     @th.no_grad()
     def loss_backward(self, src, idx):
-        from ..engine import conv1_u8, conv23_prep, conv23, trunk_backward, tanh_backward_colsum, relu_backward_colsum, ppo_loss_heads, bias_tanh_, IndexedRows
+        from ..engine import conv1_u8, conv23_prep, conv23, trunk_backward, conv23_weight_gradients, tanh_backward_colsum, relu_backward_colsum, ppo_loss_heads, bias_tanh_, IndexedRows
         obs, actions, old_logp, adv, ret = src
         ppo, p, g = self.ppo, self.p, self.g
         n, A, H0, H, L = int(idx.numel()), self.A, self.H0, self.H, self.L
@@ -173,9 +176,12 @@ class FusedUpdate:
         g3 = th.mm(gz, self.wl_nhwc).view(n, 4, 4, 64).permute(0, 3, 1, 2)                       # d loss / d y3, channels-last
         # ---- the three convolutions
         g3m, g2m, _, _, _ = trunk_backward(g3, m3, m2, m1, rows, b3m, b2m, c0.weight, gw_out=c0.weight.grad, gb_out=(c0.bias.grad, c2.bias.grad, c4.bias.grad))
-        cb = th.ops.aten.convolution_backward
-        c4.weight.grad.copy_(cb(g3m, y2, c4.weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1])
-        c2.weight.grad.copy_(cb(g2m, y1, c2.weight, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1])
+        if _WGRAD23_LIBRARY:                 # the comparison path: the tensor library's two weight-gradient kernels (until round 5 the only one)
+            cb = th.ops.aten.convolution_backward
+            c4.weight.grad.copy_(cb(g3m, y2, c4.weight, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1])
+            c2.weight.grad.copy_(cb(g2m, y1, c2.weight, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1])
+        else:
+            conv23_weight_gradients(y1, g2m, y2, g3m, gw2_out=c2.weight.grad, gw3_out=c4.weight.grad)
         if fork:
             cur.wait_stream(self.side)
         # (every intermediate stays referenced up to here: nothing the side stream reads is handed back to the allocator before the join)

@@ -83,6 +83,34 @@ def test_trunk_backward_matches_autograd(n):
     assert th.equal(c[2], gw) and all(th.equal(x, y) for x, y in zip(c[3], gb))
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 64, 257, 1031, 4096])
+def test_second_and_third_weight_gradients_match_the_tensor_library(n):
+    """grip_wgrad23 (k_wgrad23_b3: bf16 matrix pipe, both operands as three bf16 terms) against convolution_backward in fp64 on the same operands, beside the
+    tensor library's own fp32 kernels: fp32-equivalent means the kernel's error is of the fp32 library's size (sums over n x 36 / n x 16 positions in another order)."""
+    from mujoco_rl_manipulate_unknown_objects_amd.engine import conv23_weight_gradients
+    g = th.Generator(device="cuda").manual_seed(100 + n)
+    rnd = lambda *s: th.randn(*s, device="cuda", generator=g)
+    cl = lambda t: t.contiguous(memory_format=th.channels_last)
+    y1, y2 = cl(th.relu(rnd(n, 32, 15, 15))), cl(th.relu(rnd(n, 64, 6, 6)))
+    g2m, g3m = cl(rnd(n, 64, 6, 6) * (rnd(n, 64, 6, 6) > 0)), cl(rnd(n, 64, 4, 4) * (rnd(n, 64, 4, 4) > 0))         # masked gradients: about half zeros
+    w2, w3 = cl(rnd(64, 32, 4, 4)), cl(rnd(64, 64, 3, 3))
+    cb = th.ops.aten.convolution_backward
+    ref = lambda gm, y, w, st, dt: cb(gm.to(dt), y.to(dt), w.to(dt), None, [st, st], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    r2, r3 = ref(g2m, y1, w2, 2, th.float64), ref(g3m, y2, w3, 1, th.float64)
+    l2, l3 = ref(g2m, y1, w2, 2, th.float32), ref(g3m, y2, w3, 1, th.float32)
+    gw2, gw3 = conv23_weight_gradients(y1, g2m, y2, g3m)
+    th.cuda.synchronize()
+    for name, mine, lib32, r in (("w2", gw2, l2, r2), ("w3", gw3, l3, r3)):
+        scale = r.abs().max().item()
+        e_mine, e_lib = (mine.double() - r).abs().max().item() / scale, (lib32.double() - r).abs().max().item() / scale
+        print(f"n {n} d{name}: max |error| / max |gradient|: kernel {e_mine:.2e}, tensor library fp32 {e_lib:.2e}")
+        assert e_mine <= max(2.0 * e_lib, 2e-6), (name, e_mine, e_lib)
+    # into given tensors of other strides (the update's flat gradient buffer holds channels-last views), and run-to-run bit-identical
+    o2, o3 = cl(th.empty(64, 32, 4, 4, device="cuda")), cl(th.empty(64, 64, 3, 3, device="cuda"))
+    conv23_weight_gradients(y1, g2m, y2, g3m, gw2_out=o2, gw3_out=o3)
+    assert th.equal(o2, gw2) and th.equal(o3, gw3) and o2.stride() != gw2.stride()
+
+
 def test_extractor_trains_the_same_through_the_fused_trunk():
     """AugmentedNatureCNN.forward under autograd: the hand-written trunk (_CnnTrunk + the NHWC linear layer) against the tensor library's modules on
     the same parameters and uint8 observations -- features to 2e-5, every parameter's gradient under a random linear loss to 2e-4 of its largest
