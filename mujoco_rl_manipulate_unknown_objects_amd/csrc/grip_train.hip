@@ -737,11 +737,11 @@ __global__ void __launch_bounds__(1024) k_wgrad23_reduce(const float *__restrict
     }
 }
 
-// How the CUs are divided between the two roles: a trip of role 2 (an image pair) costs ~W_COST2, of role 3 (four images) ~W_COST3 cycles (tools/wgrad23_ab.py prints
-// the measured trips); the split that minimises the slower role's trips x cost. The sums' order, and with it the last bits of the result, depends on it -- a function of
+// How the CUs are divided between the two roles: a trip of role 2 (an image pair) costs ~W_COST2, of role 3 (four images) ~W_COST3 (x 10 cycles; tools/wgrad23_stamps.py
+// prints the measured trips); the split that minimises the slower role's trips x cost. The sums' order, and with it the last bits of the result, depends on it -- a function of
 // (n, CU count) only.
-#define W_COST2 1150
-#define W_COST3 940
+#define W_COST2 1286
+#define W_COST3 1177
 static void wgrad23_split(int n, int n_cu, int &w2, int &w3) {
     const int pairs = (n + 1) / 2, grps = (n + W3_NI - 1) / W3_NI;
     long best = -1; w2 = 1; w3 = 1;
