@@ -208,9 +208,9 @@ int grip_conv1_u8_rows(const uint8_t *obs_dev, const int64_t *row0_dev, int n, i
  * (v_mfma_f32_16x16x4_f32: fp32 products and sums): y1_nhwc_dev float32 [n, 15, 15, 32] (grip_conv1_u8's output) ->
  * out_nhwc_dev float32 [n, 4, 4, 64] = relu(conv2d(relu(conv2d(y1, w2, b2, stride 2)), w3, b3, stride 1)), i.e. a channels-last
  * [n, 64, 4, 4] tensor. The weights are passed as the GEMMs' B matrices, which grip_conv23_prep writes from w2 float32 [64, 32, 4, 4]
- * and w3 float32 [64, 64, 3, 3] (element strides w*_strides[4], any layout) into b2_mat_dev (1792 x 64 floats: the matrix k-major, 512 x 64, then
- * channel-major, then 196 608 bytes of operand fragments for the bf16 kernel -- every weight as three bf16 terms) and b3_mat_dev (2016 x 64 floats:
- * 576 x 64 twice, then 221 184 bytes of fragments): call it again whenever the weights change. No autograd (the update's variant: grip_conv23_train). */
+ * and w3 float32 [64, 64, 3, 3] (element strides w*_strides[4], any layout) into b2_mat_dev (2560 x 64 floats: the matrix k-major, 512 x 64, then
+ * channel-major, then twice 196 608 bytes of operand fragments for the bf16 kernels -- every weight as three bf16 terms; the forward's, then the
+ * data gradient's transposed ones) and b3_mat_dev (2880 x 64 floats: 576 x 64 twice, then twice 221 184 bytes of fragments): call it again whenever the weights change. No autograd (the update's variant: grip_conv23_train). */
 int grip_conv23_prep(const float *w2_dev, const int64_t *w2_strides, const float *w3_dev, const int64_t *w3_strides, float *b2_mat_dev, float *b3_mat_dev,
                      void *stream);
 int grip_conv23(const float *y1_nhwc_dev, int n, const float *b2_mat_dev, const float *bias2_dev, const float *b3_mat_dev, const float *bias3_dev,

@@ -548,6 +548,22 @@ __global__ void __launch_bounds__(256) k_conv23_prep(const float *__restrict__ w
             for (int t = 0; t < 3; t++) { const unsigned h = bf16_rne_bits(r); dst[t * 64 * 8 + j] = (uint16_t)h; r -= __uint_as_float(h << 16); }
         }
     }
+    // ... and the fragments of the TRANSPOSED products the backward's data-gradient GEMMs take (k_trunk_bwd_b3, grip_train.hip: reduction over the output channels):
+    //   B2d [tap 16][input-channel half 2][k-step 2][term 3][lane 64][8] behind B2f, B3d [tap 9][input-channel quarter 4][k-step 2][term 3][lane 64][8] behind B3f;
+    //   lane l holds input channel 16 block + (l & 15), output channels 32 k-step + 8 (l >> 4) .. + 7
+    if (i < (16 * 2 * 2 + 9 * 4 * 2) * 64) {
+        const bool second = i >= 16 * 2 * 2 * 64;
+        const int q = second ? i - 16 * 2 * 2 * 64 : i, lane = q & 63, gd = q >> 6, ks = gd & 1, blk = second ? (gd >> 1) & 3 : (gd >> 1) & 1, tap = second ? gd >> 3 : gd >> 2;
+        const int ci = 16 * blk + (lane & 15), o0 = 32 * ks + 8 * (lane >> 4);
+        const int ky = second ? tap / 3 : tap >> 2, kx = second ? tap - 3 * (tap / 3) : tap & 3;
+        uint16_t *dst = reinterpret_cast<uint16_t *>(second ? B3 + (2 * 576 + 864) * 64 : B2 + (2 * 512 + 768) * 64) + ((size_t)gd * 3 * 64 + lane) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float r = second ? w3[(o0 + j) * s3o + ci * s3c + ky * s3y + kx * s3x] : w2[(o0 + j) * s2o + ci * s2c + ky * s2y + kx * s2x];
+#pragma unroll
+            for (int t = 0; t < 3; t++) { const unsigned h = bf16_rne_bits(r); dst[t * 64 * 8 + j] = (uint16_t)h; r -= __uint_as_float(h << 16); }
+        }
+    }
     if (i < 512 * 64) {
         const int n = i & 63, k = i >> 6, ci = k & 31, kx = (k >> 5) & 3, ky = k >> 7;
         const float v = w2[n * s2o + ci * s2c + ky * s2y + kx * s2x];

@@ -407,6 +407,19 @@ static int launch_check(const char *who) {
     return 0;
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define E_RS 416                                       // bytes of a gradient row in the bf16 planes of k_trunk_bwd_b3: [term 3][64 channels] + 32
+#define E_T2 (DG * 225 * D_PS1 * 4)
+#define E_A3 (E_T2 + DG * 36 * D_PS2 * 4)
+#define E_A2 (E_A3 + DG * 16 * E_RS)
+#define E_LDS (E_A2 + 80 * E_RS)
+#define E_U E_T2
+#define E_G1P (E_T2 + 16384)
+static_assert(E_G1P + 15 * 16 * 192 <= E_A2 + 72 * E_RS, "the first layer's split gradient must end before the padding rows of the g2m planes");
+__global__ void k_trunk_bwd_b3(const float *__restrict__ g3, const uint64_t *__restrict__ m3, const uint64_t *__restrict__ m2, const uint32_t *__restrict__ m1, const uint8_t *__restrict__ obs,
+                               const long long *__restrict__ obs_rows, int channels, const u32x4 *__restrict__ B3d, const u32x4 *__restrict__ B2d, int n_img, float *__restrict__ g3m_out,
+                               float *__restrict__ g2m_out, float *__restrict__ g1m_out, float *__restrict__ part);
+
 extern "C" int grip_trunk_backward_parts(int n) { const int groups = (n + DG - 1) / DG; return groups < 512 ? groups : 512; }
 
 extern "C" int grip_trunk_backward(const float *g3_dev, const uint64_t *mask3_dev, const uint64_t *mask2_dev, const uint32_t *mask1_dev, const uint8_t *obs_dev,
@@ -420,12 +433,31 @@ extern "C" int grip_trunk_backward(const float *g3_dev, const uint64_t *mask3_de
         return grip_fail("grip_trunk_backward: with observations (uint8 [n, 5, 64, 64]) the partial-sum scratch (grip_trunk_backward_parts(n) x 8352 floats) and the "
                          "first layer's gradient outputs are needed");
     if (!obs_dev && !g1m_dev) return grip_fail("grip_trunk_backward: nothing to do with the first layer's gradient (neither observations nor g1m)");
-    static std::atomic<unsigned long long> mask{0ULL};
-    const size_t lds = (size_t)D_LDS_FLOATS * sizeof(float);
-    if (set_dyn_lds((const void *)k_trunk_bwd, lds, mask, "grip_trunk_backward")) return -1;
-    const int parts = grip_trunk_backward_parts(n);
-    hipLaunchKernelGGL(k_trunk_bwd, dim3(parts), dim3(256), lds, (hipStream_t)stream, g3_dev, mask3_dev, mask2_dev, mask1_dev, obs_dev, (const long long *)obs_rows_dev, channels, b3_mat_dev, b2_mat_dev, n, g3m_dev, g2m_dev,
-                       g1m_dev, obs_dev ? partials_dev : (float *)nullptr);
+    // GRIP_TRUNK_F32=1 (read once): round 4's kernel -- the data gradients on the fp32 matrix instructions, two 4-wave workgroups per CU -- instead of k_trunk_bwd_b3
+    static const bool f32_kernel = [] { const char *e = getenv("GRIP_TRUNK_F32"); return e && e[0] == '1'; }();
+    int parts = grip_trunk_backward_parts(n);
+    if (f32_kernel) {
+        static std::atomic<unsigned long long> mask{0ULL};
+        const size_t lds = (size_t)D_LDS_FLOATS * sizeof(float);
+        if (set_dyn_lds((const void *)k_trunk_bwd, lds, mask, "grip_trunk_backward")) return -1;
+        hipLaunchKernelGGL(k_trunk_bwd, dim3(parts), dim3(256), lds, (hipStream_t)stream, g3_dev, mask3_dev, mask2_dev, mask1_dev, obs_dev, (const long long *)obs_rows_dev, channels, b3_mat_dev, b2_mat_dev, n, g3m_dev, g2m_dev,
+                           g1m_dev, obs_dev ? partials_dev : (float *)nullptr);
+    } else {
+        static std::atomic<unsigned long long> mask{0ULL};
+        static std::atomic<int> cus[64];
+        if (set_dyn_lds((const void *)k_trunk_bwd_b3, (size_t)E_LDS, mask, "grip_trunk_backward")) return -1;
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return grip_fail("grip_trunk_backward: no current device");
+        n_cu = cus[dev & 63].load(std::memory_order_acquire);
+        if (n_cu <= 0) {
+            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) return grip_fail("grip_trunk_backward: cannot read the CU count");
+            cus[dev & 63].store(n_cu, std::memory_order_release);
+        }
+        parts = std::min(parts, n_cu);                   // one persistent 8-wave workgroup per CU
+        hipLaunchKernelGGL(k_trunk_bwd_b3, dim3(parts), dim3(512), E_LDS, (hipStream_t)stream, g3_dev, mask3_dev, mask2_dev, mask1_dev, obs_dev, (const long long *)obs_rows_dev, channels,
+                           reinterpret_cast<const u32x4 *>(b3_mat_dev + (2 * 576 + 864) * 64), reinterpret_cast<const u32x4 *>(b2_mat_dev + (2 * 512 + 768) * 64), n, g3m_dev, g2m_dev, g1m_dev,
+                           obs_dev ? partials_dev : (float *)nullptr);
+    }
     if (obs_dev)
         hipLaunchKernelGGL(k_wgrad1_reduce, dim3(TB_PART / 32), dim3(1024), 0, (hipStream_t)stream, (const float *)partials_dev, parts, grad_w1_dev, (long long)grad_w1_strides[0],
                            (long long)grad_w1_strides[1], (long long)grad_w1_strides[2], (long long)grad_w1_strides[3], grad_b1_dev, grad_b2_dev, grad_b3_dev);
@@ -708,6 +740,306 @@ __global__ void __launch_bounds__(512, 1) k_wgrad23_b3(const float *__restrict__
 #ifdef WG_STAMPS
     if (threadIdx.x == 0 && blockIdx.x < 512) g_wg_span[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_trunk_bwd_b3 (round 5): k_trunk_bwd with the two data-gradient GEMMs on the bf16 matrix pipe -- gradient tile and (transposed) weights as three bf16 terms, six products
+// per k-step, fp32 accumulators: 2 x 6 v_mfma_f32_16x16x32_bf16 (16 cycles each) per 16 x 16 tile and column block where the fp32 kernel issues 16 v_mfma_f32_16x16x4_f32
+// (32 cycles each): 2.7 x less matrix-pipe time, which was 58 % of that kernel. What changes around them:
+//   * one persistent workgroup of EIGHT waves per CU (two per SIMD, as the two 4-wave workgroups were). GEMM 1: wave = (input-channel quarter, image); GEMM 2: wave =
+//     (parity class of the target pixel, input-channel half) -- as before no two waves ever add into the same word of the tile below;
+//   * the masked gradient tiles are split ONCE, by the mask passes, into [row][term 3][64 channels] bf16 planes (416-byte rows: the A fragments' ds_read_b128 are free of bank
+//     conflicts), GEMM 1's A fragments stay in registers, GEMM 2's five tiles are re-read per column block; the weights' fragments (k_conv23_prep: B3d, B2d) come from L2,
+//     one column block ahead; the scatter into the fp32 tile below is k_trunk_bwd's (same accumulator layout), between the two k-steps of the next block;
+//   * the first layer's weight gradient: the masked g1 of ONE image is split once into [row of 16 positions][term][32 channels] planes (in the space of the dead g2 tile and
+//     planes) and every wave reads its B fragments from there with the transposed read (ds_read_b64_tr_b16: positions x channels -> channels x positions) -- the fp32
+//     kernel's waves each re-split the tile, ~70 VALU instructions per 16 positions, the bound of that loop. Wave = (byte plane, half of the 8 x 8 patch): one 32 x 32 tile.
+__device__ __forceinline__ f32x4 tb_mac6(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[2]), __builtin_bit_cast(bf16x8, b[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, b[1]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[2]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, b[0]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[1]), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]), c, 0, 0, 0);
+    return c;
+}
+// MT row tiles x NB column blocks, K = 64 channels = two k-steps. TA: the A planes (bytes), arow[t] the lane's row of tile t (+ 64 k-step + 128 term); Bf: the lane's
+// fragment pointer, bidx(nb) the block's first fragment ([k-step 2][term 3] follow, 64 lanes apart); T, tgt, live: as scatter_gemm. HOLD: A fragments stay in registers.
+template <int MT, int NB, bool HOLD, int PF, class BIdx, class Tgt, class Live>
+__device__ __forceinline__ void scatter_gemm_b3(const unsigned char *TA, const int (&arow)[MT], const u32x4 *__restrict__ Bf, float *T, BIdx bidx, Tgt tgt, Live live) {
+    // the weights' fragments come from L2 (~1 k cycles away) into a ring PF column blocks deep; the A fragments of a tile are requested a tile ahead of their MFMAs
+    u32x4 ring[PF][2][3], ah[HOLD ? MT : 1][2][3];
+    auto fetch_b = [&](int nb) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+            for (int tm = 0; tm < 3; tm++) ring[nb % PF][ks][tm] = Bf[(size_t)(bidx(nb) + ks * 3 + tm) * 64];
+    };
+    auto fetch_a = [&](int step, u32x4 (&a)[3]) {                          // step = k-step * MT + tile
+#pragma unroll
+        for (int tm = 0; tm < 3; tm++) a[tm] = *reinterpret_cast<const u32x4 *>(TA + arow[step % MT] + 64 * (step / MT) + 128 * tm);
+    };
+#pragma unroll
+    for (int nb = 0; nb < PF && nb < NB; nb++) fetch_b(nb);
+    if (HOLD) {
+#pragma unroll
+        for (int st = 0; st < 2 * MT; st++) fetch_a(st, ah[st % MT][st / MT]);
+    }
+    f32x4 prev[MT];
+#pragma unroll
+    for (int nb = 0; nb <= NB; nb++) {
+        float old[MT][4];
+        u32x4 acur[3], anext[3];
+        if (nb > 0) {
+#pragma unroll
+            for (int t = 0; t < MT; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) old[t][r] = T[tgt(nb - 1, t, r)];
+        }
+        if (!HOLD && nb < NB) fetch_a(0, acur);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[MT];
+#pragma unroll
+        for (int t = 0; t < MT; t++) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 2 * MT; st++) {
+            const int ks = st / MT, t = st % MT;
+            if (nb < NB) {
+                if (HOLD) acc[t] = tb_mac6(ah[t][ks], ring[nb % PF][ks], acc[t]);
+                else {
+                    if (st + 1 < 2 * MT) fetch_a(st + 1, anext);
+                    acc[t] = tb_mac6(acur, ring[nb % PF][ks], acc[t]);
+#pragma unroll
+                    for (int tm = 0; tm < 3; tm++) acur[tm] = anext[tm];
+                }
+            }
+            if (st == MT - 1 && nb > 0) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t2 = 0; t2 < MT; t2++)
+                    if (live(t2)) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) T[tgt(nb - 1, t2, r)] = old[t2][r] + prev[t2][r];
+                    }
+                wave_order();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (nb < NB) {
+            if (nb + PF < NB) fetch_b(nb + PF);
+#pragma unroll
+            for (int t = 0; t < MT; t++) prev[t] = acc[t];
+        }
+    }
+}
+
+#ifdef TB_STAMPS                 // diagnostic build only (tools/trunk_stamps.py): cycles of wave 0 of workgroup 0 per phase
+__device__ unsigned long long g_tb_stamps[8];
+#define TB_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); if (blockIdx.x == 0 && threadIdx.x == 0) g_tb_stamps[i] += n_ - tb_t; tb_t = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int grip_debug_tb_stamps(unsigned long long *out8) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_tb_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    static const unsigned long long zero[8] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tb_stamps), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+#else
+#define TB_STAMP(i) do { } while (0)
+#endif
+struct GroupIn3 { float4 g3; unsigned m3; unsigned long long m2; unsigned m1; };           // a thread's share (of 512) of a group's gradient tile and ReLU masks
+__device__ __forceinline__ void group_in_load3(GroupIn3 &gi, int tl, int img0, int nimg, const float *__restrict__ g3, const uint16_t *__restrict__ m3h,
+                                               const unsigned long long *__restrict__ m2, const uint32_t *__restrict__ m1) {
+    const int row = tl >> 4, c4 = (tl & 15) * 4;
+    gi.g3 = make_float4(0.f, 0.f, 0.f, 0.f); gi.m3 = 0u;
+    if ((row >> 4) < nimg) {
+        gi.g3 = *reinterpret_cast<const float4 *>(g3 + ((size_t)img0 * 16 + row) * 64 + c4);
+        gi.m3 = (unsigned)m3h[((size_t)img0 * 16 + row) * 4 + (c4 >> 4)] >> (c4 & 15);
+    }
+    gi.m1 = tl < nimg * 225 ? m1[(size_t)img0 * 225 + tl] : 0u;
+    gi.m2 = tl < nimg * 36 ? m2[(size_t)img0 * 36 + tl] : 0ULL;
+}
+
+__global__ void __launch_bounds__(512, 1) k_trunk_bwd_b3(const float *__restrict__ g3, const uint64_t *__restrict__ m3, const uint64_t *__restrict__ m2, const uint32_t *__restrict__ m1,
+                                                         const uint8_t *__restrict__ obs, const long long *__restrict__ obs_rows, int channels, const u32x4 *__restrict__ B3d,
+                                                         const u32x4 *__restrict__ B2d, int n_img, float *__restrict__ g3m_out, float *__restrict__ g2m_out, float *__restrict__ g1m_out,
+                                                         float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char e_lds[];
+    float *T1 = reinterpret_cast<float *>(e_lds), *T2 = reinterpret_cast<float *>(e_lds + E_T2);
+    unsigned char *A3 = e_lds + E_A3, *A2 = e_lds + E_A2, *U = e_lds + E_U, *G1P = e_lds + E_G1P;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, r16 = l & 15, kq = l >> 4;
+    const int half = l >> 5, m32 = l & 31, gsel = (l >> 4) & 1, q4 = (l & 15) >> 2, p4 = l & 3;      // lane roles in the 32 x 32 x 16 instruction and in its transposed read
+    f32x16 cw;
+#pragma unroll
+    for (int r = 0; r < 16; r++) cw[r] = 0.f;
+    float4 bs1 = make_float4(0.f, 0.f, 0.f, 0.f), bs2 = bs1, bs3 = bs1;      // bias gradients: the thread's four channels of each layer, over its rows
+    const int ngroups = (n_img + DG - 1) / DG;
+    // rows 72..79 of the g2m planes (the half tile of padding) are zeros for the whole launch: nothing else is ever written there
+    for (int i = tid; i < 8 * E_RS / 16; i += 512) reinterpret_cast<uint4 *>(A2 + 72 * E_RS)[i] = make_uint4(0u, 0u, 0u, 0u);
+#ifdef TB_STAMPS
+    unsigned long long tb_t = __builtin_amdgcn_s_memtime();
+#endif
+    GroupIn3 gi;
+    if ((int)blockIdx.x < ngroups) group_in_load3(gi, tid, blockIdx.x * DG, min(DG, n_img - (int)blockIdx.x * DG), g3, reinterpret_cast<const uint16_t *>(m3),
+                                                  reinterpret_cast<const unsigned long long *>(m2), m1);
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int img0 = grp * DG, nimg = min(DG, n_img - img0);
+    const u32x4 *B3g = B3d, *B2g = B2d;                                    // (hidden from the optimiser, as in k_trunk_bwd: loop-invariant loads and addresses would be hoisted and spilled)
+    asm volatile("" : "+s"(B3g), "+s"(B2g));
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    // ---- g3m = g3 * mask3 -> memory (the third layer's weight gradient reads it) and, split, the A planes of GEMM 1; zero T2
+    {
+        const int row = tl >> 4, c4 = (tl & 15) * 4;
+        const float4 v = bit_mask(gi.m3, gi.g3);
+        bs3.x += v.x; bs3.y += v.y; bs3.z += v.z; bs3.w += v.w;
+        if (g3m_out && (row >> 4) < nimg) *reinterpret_cast<float4 *>(g3m_out + ((size_t)img0 * 16 + row) * 64 + c4) = v;
+        wg_split_store(A3 + row * E_RS + 2 * c4, 128, v);
+    }
+#pragma unroll 1
+    for (int i = tl; i < D_T2 / 4; i += 512) reinterpret_cast<float4 *>(T2)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (tl < DG * 36) *reinterpret_cast<unsigned long long *>(T2 + tl * D_PS2 + 64) = gi.m2;      // the rows' ReLU masks ride in their padding words
+    TB_STAMP(0);            // g3m pass, zero fill, barrier (+ loop top)
+    // ---- GEMM 1: this wave's image (16 positions = one row tile), 9 column blocks (taps) of its 16 input channels
+    {
+        const int cb = w & 3, img = w >> 2;
+        const int arow[1] = {(img * 16 + r16) * E_RS + 16 * kq};
+        const int tb = kq * 6 * D_PS2 + 16 * cb + r16;                      // the lane holds rows 4 kq + r: (oy, ox) = (kq, r)
+        scatter_gemm_b3<1, 9, true, 1>(A3, arow, B3g + l, T2, [&](int c) { return ((c * 4 + cb) * 2) * 3; },
+                                    [&](int c, int, int r) { return tb + (img * 36 + (c / 3) * 6 + r + (c % 3)) * D_PS2; }, [](int) { return true; });
+    }
+    __syncthreads();
+    TB_STAMP(1);            // GEMM 1 + barrier
+    // ---- g2m = g2 * mask2: to memory (the second layer's weight gradient reads it) and, split, the A planes of GEMM 2; zero T1
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+        const int i = tl + 512 * u, row = i >> 4, c4 = (i & 15) * 4;
+        if (i < DG * 36 * 16) {
+            const unsigned bits = reinterpret_cast<const unsigned *>(T2)[row * D_PS2 + 64 + (c4 >> 5)] >> (c4 & 31);
+            const float4 v = bit_mask(bits, *reinterpret_cast<float4 *>(T2 + row * D_PS2 + c4));
+            bs2.x += v.x; bs2.y += v.y; bs2.z += v.z; bs2.w += v.w;
+            if (row < nimg * 36) *reinterpret_cast<float4 *>(g2m_out + ((size_t)img0 * 36 + row) * 64 + c4) = v;
+            wg_split_store(A2 + row * E_RS + 2 * c4, 128, v);
+        }
+    }
+#pragma unroll 1
+    for (int i = tl; i < D_T1 / 4; i += 512) reinterpret_cast<float4 *>(T1)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    if (tl < DG * 225) reinterpret_cast<unsigned *>(T1)[tl * D_PS1 + 32] = gi.m1;
+    TB_STAMP(2);            // g2m pass, zero fill, barrier
+    // ---- GEMM 2: rows m = image * 36 + position (80 = 5 tiles, rows 72.. are zeros), this wave's 4 taps (one parity class) of its 16 input channels
+    {
+        const int par = w & 3, py = par >> 1, px = par & 1, chh = w >> 2;
+        int arow[5], base[5][4];
+#pragma unroll
+        for (int t = 0; t < 5; t++) {
+            arow[t] = (t * 16 + r16) * E_RS + 16 * kq;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int mo = min(t * 16 + 4 * kq + r, DG * 36 - 1), g = mo / 36, p = mo - g * 36, oy = p / 6, ox = p - oy * 6;
+                base[t][r] = (g * 225 + (2 * oy + py) * 15 + 2 * ox + px) * D_PS1 + 16 * chh + r16;
+            }
+        }
+        const bool pad_ok = kq < 2;                     // tile 4: rows 64 + 4 kq + r exist for kq < 2 only
+        // column block a: tap (ky, kx) = (py + 2 (a >> 1), px + 2 (a & 1))
+        scatter_gemm_b3<5, 4, false, 1>(A2, arow, B2g + l, T1, [&](int a) { return ((((py + 2 * (a >> 1)) * 4 + px + 2 * (a & 1)) * 2 + chh) * 2) * 3; },
+                                     [&](int a, int t, int r) { return base[t][r] + ((a >> 1) * 30 + 2 * (a & 1)) * D_PS1; }, [&](int t) { return t < 4 || pad_ok; });
+    }
+    __syncthreads();                                                        // T1 complete; T2 and the planes are free
+    TB_STAMP(3);            // GEMM 2 + barrier
+    // ---- g1m = g1 * mask1 (to memory when asked for). With observations the masked tile is consumed on chip, image by image, while the byte planes are on their way:
+    // the first layer's weight gradient, K = an image's 225 positions in 15 chunks of 16 (one row oy; position 15 of a row does not exist: zeros), A = the image bytes
+    // (a pixel 0..255 is a bf16), B = the masked gradient as three bf16 terms, split ONCE per image into planes every wave reads by the transposed read
+    const int gnext = grp + gridDim.x;
+    auto next_group = [&]() {
+        if (gnext < ngroups)
+            group_in_load3(gi, tl, gnext * DG, min(DG, n_img - gnext * DG), g3, reinterpret_cast<const uint16_t *>(m3), reinterpret_cast<const unsigned long long *>(m2), m1);
+    };
+    auto masked = [&](int pix, int c4) {                                    // four channels of a pixel of the g1 tile, masked; db1 takes them (c4 is the same in every pass: 512 % 8 == 0)
+        const float2 *tp = reinterpret_cast<const float2 *>(T1 + pix * D_PS1 + c4);
+        const float2 v0 = tp[0], v1 = tp[1];
+        const float4 v = bit_mask(reinterpret_cast<const unsigned *>(T1)[pix * D_PS1 + 32] >> c4, make_float4(v0.x, v0.y, v1.x, v1.y));
+        bs1.x += v.x; bs1.y += v.y; bs1.z += v.z; bs1.w += v.w;
+        return v;
+    };
+    if (obs) {
+        uint4 pa, pb;
+        {   const uint4 *src = reinterpret_cast<const uint4 *>(obs + (size_t)(obs_rows ? obs_rows[img0] : img0) * channels * 4096) + tl;
+            pa = src[0]; pb = src[512]; }
+        const int plane = w & 3, tile = w >> 2;
+        const uint8_t *ap0 = U + plane * 4096 + ((m32 >> 3) + 4 * tile) * 64 + (m32 & 7) + half * 32;       // + oy * 256 + 4 j
+        lds_byte *bp0 = (lds_byte *)G1P + (8 * half + q4) * 192 + 32 * gsel + 8 * p4;                       // + oy * 3072 + 64 term; the second four positions: + 768
+#pragma unroll 1
+        for (int g = 0; g < nimg; g++) {
+            if (g > 0) __syncthreads();                                     // every wave is done with the last image's planes
+#pragma unroll 1
+            for (int i = tl; i < 225 * 8; i += 512) {
+                const int pix = i >> 3, c4 = (i & 7) * 4, oy = pix / 15, ox = pix - 15 * oy;
+                const float4 v = masked(g * 225 + pix, c4);
+                if (g1m_out) *reinterpret_cast<float4 *>(g1m_out + ((size_t)(img0 + g) * 225 + pix) * 32 + c4) = v;
+                wg_split_store(G1P + (oy * 16 + ox) * 192 + 2 * c4, 64, v);
+            }
+            if (tl < 15 * 12) reinterpret_cast<uint4 *>(G1P + ((tl / 12) * 16 + 15) * 192)[tl % 12] = make_uint4(0u, 0u, 0u, 0u);
+            uint4 *Uq = reinterpret_cast<uint4 *>(U) + tl;
+            Uq[0] = pa; Uq[512] = pb;
+            __syncthreads();
+            TB_STAMP(4);        // barrier, the image's mask + split pass, byte planes -> LDS, barrier
+            // requests that fly during the K loop: the next image's planes, or the next group's gradient tile and masks
+            if (g + 1 < nimg) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(obs + (size_t)(obs_rows ? obs_rows[img0 + g + 1] : img0 + g + 1) * channels * 4096) + tl;
+                pa = src[0]; pb = src[512];
+            } else next_group();
+            const uint8_t *ap = ap0;
+            lds_byte *bp = bp0;
+#pragma unroll 3
+            for (int oy = 0; oy < 15; oy++) {
+                bf16x8 b[3], a;
+#pragma unroll
+                for (int tm = 0; tm < 3; tm++) b[tm] = wg_tr8(bp, bp + 768, 64 * tm);
+#pragma unroll
+                for (int j = 0; j < 8; j++) a[j] = (__bf16)(float)ap[4 * j];
+                cw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[2], cw, 0, 0, 0);
+                cw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[1], cw, 0, 0, 0);
+                cw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[0], cw, 0, 0, 0);
+                ap += 256; bp += 3072;
+            }
+            TB_STAMP(5);        // requests + the K loop
+        }
+    } else {
+#pragma unroll 2
+        for (int i = tl; i < DG * 225 * 8; i += 512) {
+            const float4 v = masked(i >> 3, (i & 7) * 4);
+            if (g1m_out && i < nimg * 225 * 8) *reinterpret_cast<float4 *>(g1m_out + (size_t)img0 * 7200 + (size_t)i * 4) = v;
+        }
+        next_group();
+    }
+    __syncthreads();                                                        // before the next group's staging
+  }
+    if (part) {
+        float *P = part + (size_t)blockIdx.x * TB_PART;
+        const int plane = w & 3, tile = w >> 2;
+#pragma unroll
+        for (int r = 0; r < 16; r++) P[(plane * 64 + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + m32] = cw[r];
+        // db1: thread tid holds channels 4 (tid & 7) .. + 3 summed over its pixels: 64 threads per channel group, added in a fixed order through LDS
+        float *red = reinterpret_cast<float *>(e_lds);
+        __syncthreads();
+        *reinterpret_cast<float4 *>(red + tid * 4) = bs1;
+        __syncthreads();
+        if (tid < 32) {
+            float t = 0.f;
+            for (int k = 0; k < 64; k++) t += red[((tid >> 2) + 8 * k) * 4 + (tid & 3)];
+            P[256 * 32 + tid] = t;
+        }
+        // db2, db3: channels 4 (tid & 15) .. + 3, 32 threads per channel group
+        __syncthreads();
+        *reinterpret_cast<float4 *>(red + tid * 4) = bs2; *reinterpret_cast<float4 *>(red + 2048 + tid * 4) = bs3;
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, co = tid & 63;
+            float t = 0.f;
+            for (int k = 0; k < 32; k++) t += red[which * 2048 + ((co >> 2) + 16 * k) * 4 + (co & 3)];
+            P[256 * 32 + 32 + tid] = t;
+        }
+    }
 }
 
 // the workgroups' partial sums -> the two gradient tensors (their strides), added in a fixed order: 32 outputs per block, 32 slices of the partials each

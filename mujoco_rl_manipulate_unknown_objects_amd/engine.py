@@ -318,7 +318,7 @@ def conv1_u8(obs, weight, bias, with_mask=False, prepared=None):
     return (out, other, mask) if with_mask else (out, other)
 
 
-CONV23_B2_ROWS, CONV23_B3_ROWS = 1024 + 768, 1152 + 864        # include/grip_sim.h, grip_conv23_prep
+CONV23_B2_ROWS, CONV23_B3_ROWS = 1024 + 768 + 768, 1152 + 864 + 864     # fp32 operand in both layouts + the bf16 fragments of the forward + those of the data gradients (k_conv23_prep)
 
 
 def conv23_prep(w2, w3, b2_mat=None, b3_mat=None):
