@@ -29,11 +29,12 @@ echo pmc-done
 if [ -f mujoco_rl_manipulate_unknown_objects_amd/csrc/libgrip_sim_stamps.so ]; then python tools/stamp_async.py acorn 3000 > $out/phase_shares.txt 2>&1 || true; fi
 if [ -f mujoco_rl_manipulate_unknown_objects_amd/csrc/libgrip_sim_hist.so ]; then GRIP_STAMPS_LIB=hist python tools/stamp_async.py acorn 3000 > $out/phase_hist.txt 2>&1 || true; fi
 python tools/update_time.py find > $out/update_time.txt 2>&1 || true
-GRIP_WGRAD23_LIBRARY=1 GRIP_CONV23_F32=1 python tools/update_time.py find > $out/update_time_round4_kernels.txt 2>&1 || true
+GRIP_WGRAD23_LIBRARY=1 GRIP_CONV23_F32=1 GRIP_TRUNK_F32=1 python tools/update_time.py find > $out/update_time_round4_kernels.txt 2>&1 || true
 python tools/conv23_ab.py > $out/conv23_ab.txt 2>&1 || true
 python tools/wgrad23_ab.py > $out/wgrad23_ab.txt 2>&1 || true
 if [ -f mujoco_rl_manipulate_unknown_objects_amd/csrc/libgrip_sim_cbst.so ]; then python tools/conv23_stamps.py > $out/conv23_phases.txt 2>&1 || true; fi
 if [ -f mujoco_rl_manipulate_unknown_objects_amd/csrc/libgrip_sim_wgst.so ]; then python tools/wgrad23_stamps.py > $out/wgrad23_phases.txt 2>&1 || true; fi
+if [ -f mujoco_rl_manipulate_unknown_objects_amd/csrc/libgrip_sim_tbst.so ]; then python tools/trunk_stamps.py > $out/trunk_bwd_phases.txt 2>&1 || true; fi
 python tools/update_kernels.py 512 > $out/update_kernels.txt 2>&1 || true
 python tools/render_ab.py rays - > $out/render_ab_acorn.txt 2>&1 || true
 if [ -f mujoco_rl_manipulate_unknown_objects_amd/csrc/libgrip_sim_capdump.so ]; then
