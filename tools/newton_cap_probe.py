@@ -35,7 +35,7 @@ rc = engine.lib().grip_debug_capdump(buf, cnt2)
 cnt_c = C.c_uint(cnt2[0]); restarts = int(cnt2[1])
 assert rc == 0, rc
 recs = np.ctypeslib.as_array(buf).reshape(REC, WORDS)[: min(cnt_c.value, REC)].copy()
-print(f"{obj}: {int(total.item())} macro steps, {int(subs.item())} physics.step() calls, {int(f4.item())} finished macro steps with fault bit 4, {cnt_c.value} capped solves recorded, {restarts} solves restarted from qacc_smooth", flush=True)
+print(f"{obj}: {int(total.item())} macro steps, {int(subs.item())} physics.step() calls, {int(f4.item())} finished macro steps with fault bit 4, {cnt_c.value} solves recorded (capped or restarted; the first {REC} kept), {restarts} solves restarted from qacc_smooth", flush=True)
 
 m = orc.Model(obj)
 h = m.scalar("timestep") if hasattr(m, "scalar") else 2e-3
