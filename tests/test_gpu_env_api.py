@@ -475,14 +475,15 @@ def test_fused_ppo_loss_matches_the_tensor_formula(torch):
 
 
 def test_fused_second_and_third_convolution_match_the_tensor_library(torch):
-    """grip_conv23 (conv2 + ReLU + conv3 + ReLU of AugmentedNatureCNN on f32 MFMA, y2 kept in LDS) against torch.nn.functional on the same
-    weights: contiguous and channels-last weight layouts, batch sizes that are not multiples of the 4 images a workgroup takes, and an
-    exact-integer case that pins the operand / accumulator lane maps. fp32 both ways: 2e-5 relative to the activations' scale."""
+    """grip_conv23 (conv2 + ReLU + conv3 + ReLU of AugmentedNatureCNN, y2 kept in LDS; since round 5 k_conv23_b3: bf16 matrix pipe, both operands as three bf16
+    terms -- fp32-equivalent) against torch.nn.functional on the same weights: contiguous and channels-last weight layouts, batch sizes that are odd, not multiples of
+    the image pair a trip takes, fewer and more pairs than the persistent workgroups (one per CU), and an exact-integer case that pins the operand / accumulator lane
+    maps (small integers split exactly, so the result is bit-exact). 2e-5 relative to the activations' scale."""
     import torch.nn.functional as F
     from mujoco_rl_manipulate_unknown_objects_amd.engine import conv23, conv23_prep
     g = torch.Generator(device="cuda"); g.manual_seed(2)
     rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
-    for n in (1, 3, 4, 130, 1024):
+    for n in (1, 3, 4, 130, 1024, 1537):
         y1 = torch.relu(rnd(n, 32, 15, 15)).contiguous(memory_format=torch.channels_last)
         w2 = rnd(64, 32, 4, 4) / 22.0; b2 = 0.1 * rnd(64); w3 = rnd(64, 64, 3, 3) / 24.0; b3 = 0.1 * rnd(64)
         ref = F.relu(F.conv2d(F.relu(F.conv2d(y1, w2, b2, stride=2)), w3, b3))
