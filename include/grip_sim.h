@@ -205,7 +205,7 @@ int grip_conv1_u8_rows(const uint8_t *obs_dev, const int64_t *row0_dev, int n, i
                        const float *bias_dev, float *scratch_dev, float *out_nhwc_dev, float *other_dev, void *stream);
 
 /* Rollout-side second and third layers of AugmentedNatureCNN (models/feature_extractor.py:17-21) in one launch on the matrix cores
- * (v_mfma_f32_16x16x4_f32: fp32 products and sums): y1_nhwc_dev float32 [n, 15, 15, 32] (grip_conv1_u8's output) ->
+ * (since round 5 v_mfma_f32_16x16x32_bf16 on three-term splits of both operands, fp32-equivalent; GRIP_CONV23_F32=1 keeps v_mfma_f32_16x16x4_f32): y1_nhwc_dev float32 [n, 15, 15, 32] (grip_conv1_u8's output) ->
  * out_nhwc_dev float32 [n, 4, 4, 64] = relu(conv2d(relu(conv2d(y1, w2, b2, stride 2)), w3, b3, stride 1)), i.e. a channels-last
  * [n, 64, 4, 4] tensor. The weights are passed as the GEMMs' B matrices, which grip_conv23_prep writes from w2 float32 [64, 32, 4, 4]
  * and w3 float32 [64, 64, 3, 3] (element strides w*_strides[4], any layout) into b2_mat_dev (2560 x 64 floats: the matrix k-major, 512 x 64, then
@@ -235,8 +235,9 @@ int grip_conv23_train(const float *y1_nhwc_dev, int n, const float *b2_mat_dev, 
  * [n, 15, 15, 32] = d loss / d (first layer's pre-activation) (may be NULL when obs_dev is given: the tile is consumed on chip); grad_w1_dev =
  * d loss / d w1 as float32 [32, 4, 8, 8] with element strides grad_w1_strides[4] (w.r.t. the weight that multiplies obs / 255), grad_b1_dev [32].
  * With obs_dev also the other two layers' bias gradients, grad_b2_dev [64] and grad_b3_dev [64] (sums of g2m / g3m; either may be NULL).
- * partials_dev: scratch of grip_trunk_backward_parts(n) x 8352 floats. fp32 products and sums on the matrix cores; sums in a fixed order (no
- * atomics): bit-identical from run to run. */
+ * partials_dev: scratch of grip_trunk_backward_parts(n) x 8352 floats. fp32-equivalent arithmetic on the matrix cores (since round 5 the two data
+ * gradients on the bf16 pipe: gradient tile and weights as three bf16 terms, six products; GRIP_TRUNK_F32=1 in the environment keeps the fp32 instructions); sums in a
+ * fixed order (no atomics): bit-identical from run to run on one device (the partial sums' grouping follows the CU count). */
 int grip_trunk_backward_parts(int n);
 int grip_trunk_backward(const float *g3_dev, const uint64_t *mask3_dev, const uint64_t *mask2_dev, const uint32_t *mask1_dev, const uint8_t *obs_dev,
                         const int64_t *obs_rows_dev, int channels,

@@ -1,6 +1,7 @@
 // grip_train.hip -- the update side of the policy (PPO / SAC minibatches; reference models/feature_extractor.py:14-22 trained by stable_baselines3 as
-// train_agent.py:33-47 configures it), hand-written where the time went, in fp32 arithmetic throughout (v_mfma_f32_16x16x4_f32 / v_mfma_f32_32x32x2_f32:
-// fp32 products, fp32 sums -- the tensor library's fp32 path up to the order of summation; tests/test_gpu_train_kernels.py).
+// train_agent.py:33-47 configures it), hand-written where the time went, in fp32 or fp32-EQUIVALENT arithmetic throughout (rounds 3-4: v_mfma_f32_16x16x4_f32 /
+// v_mfma_f32_32x32x2_f32; round 5: the bf16 matrix pipe on three-term splits of both operands, six products, <= 2^-24 relative per product -- the tensor library's
+// fp32 path up to the order of summation; tests/test_gpu_train_kernels.py).
 //
 // As tensor-library calls the backward of the three convolutions is, per 4096-sample minibatch on MI355X: data gradients 109 + 306 us (the stride-2 4 x 4
 // layer at 32 TFLOP/s), weight gradients 55 + 93 + 211 us, three ReLU-mask passes (16 + 16 + 49 us), three bias-gradient reductions
@@ -10,6 +11,9 @@
 //                        gradients), the first layer's weight gradient straight from the observation bytes and all three bias gradients, in ONE launch:
 //                        both data gradients as scatter GEMMs whose column blocks are summed into an LDS tile, g2 and g1 never leaving LDS, the ReLU
 //                        masks (bits written by the forward kernels) folded into the passes. 283 us; 214 us since the first layer's weight gradient runs on the bf16 pipe.
+//   k_trunk_bwd_b3       (round 5, the shipped one) the same with both data-gradient GEMMs on the bf16 pipe, one 8-wave workgroup per CU: 176-191 us.
+//   k_wgrad23_b3         (round 5) the weight gradients of the second and third layer on the bf16 pipe (transposed LDS reads), + k_wgrad23_reduce: 92 us for
+//                        the tensor library's 152.
 //   k_wgrad1_reduce      the workgroups' partial sums -> the gradient tensors (fixed order, no atomics).
 //   k_gradnorm, k_clip_adam   clip_grad_norm_ + Adam.step() on the optimiser's own state tensors, two launches.
 //   k_tanh_bwd_colsum, k_colsum_reduce   activation derivative + bias gradient of a dense layer in one pass (tanh: the policy | value MLPs; ReLU: the
